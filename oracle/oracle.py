@@ -1,0 +1,195 @@
+"""ctypes front-end of the CPU oracle (oracle/psfm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of psfm_oracle.c.  Imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package.
+
+Function names follow the reference (paths relative to the reference root):
+  flow_check      point_trajectory/utils.py:94-105
+  grid_sample     point_trajectory/trajectory.py:25-37
+  track           point_trajectory/track.py:24-50
+  track_optimize  point_trajectory/track_optimize.py:24-53
+  optimize_location  point_trajectory/optimize/src/trajectory_optimize.cpp:30-96
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "libpsfm_oracle.so")
+_lib = None
+
+
+class SolveStats(ctypes.Structure):
+    _fields_ = [
+        ("iterations", ctypes.c_int32),
+        ("successful_steps", ctypes.c_int32),
+        ("termination", ctypes.c_int32),
+        ("dogleg_nonGN", ctypes.c_int32),
+        ("initial_cost", ctypes.c_double),
+        ("final_cost", ctypes.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class _Result(ctypes.Structure):
+    _fields_ = [
+        ("n_traj", ctypes.c_int64),
+        ("n_points", ctypes.c_int64),
+        ("birth", ctypes.POINTER(ctypes.c_int32)),
+        ("len", ctypes.POINTER(ctypes.c_int32)),
+        ("off", ctypes.POINTER(ctypes.c_int64)),
+        ("xy", ctypes.POINTER(ctypes.c_double)),
+        ("n_solves", ctypes.c_int32),
+        ("solves", ctypes.POINTER(SolveStats)),
+    ]
+
+
+def build(force=False):
+    """Compile the C restatement (gcc, seconds).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "psfm_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        c_p = ctypes.c_void_p
+        L.orc_grid_sample.argtypes = [c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_p, ctypes.c_int64, c_p]
+        L.orc_grid_sample.restype = None
+        L.orc_flow_check.argtypes = [c_p, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_p, c_p]
+        L.orc_flow_check.restype = None
+        L.orc_optimize_location.argtypes = [c_p, c_p, c_p, c_p, c_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                            c_p, ctypes.POINTER(SolveStats)]
+        L.orc_optimize_location.restype = ctypes.c_int
+        L.orc_track.argtypes = [c_p, c_p, c_p, c_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_track.restype = ctypes.POINTER(_Result)
+        L.orc_result_free.argtypes = [ctypes.POINTER(_Result)]
+        L.orc_result_free.restype = None
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def grid_sample(map_hwc, xy):
+    """trajectory.py:25-37 on an HWC map.  map_hwc: (H,W,C) or (H,W); xy: (N,2) f64 -> (N,C) f32."""
+    m = _f32(map_hwc)
+    if m.ndim == 2:
+        m = m[:, :, None]
+    H, W, C = m.shape
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    out = np.empty((xy.shape[0], C), np.float32)
+    lib().orc_grid_sample(_ptr(m), C, H, W, _ptr(xy), xy.shape[0], _ptr(out))
+    return out
+
+
+def flow_check(flows, flows_b, thres):
+    """utils.py:94-105 -> (error_maps, occ_maps) lists of (H,W) f32 / bool arrays."""
+    errs, occs = [], []
+    for f, b in zip(flows, flows_b):
+        f, b = _f32(f), _f32(b)
+        H, W = f.shape[:2]
+        occ = np.empty((H, W), np.uint8)
+        err = np.empty((H, W), np.float32)
+        lib().orc_flow_check(_ptr(f), _ptr(b), H, W, ctypes.c_float(thres), _ptr(occ), _ptr(err))
+        errs.append(err)
+        occs.append(occ.astype(bool))
+    return errs, occs
+
+
+def optimize_location(uv12, ref1, ref2, scale, flow12_map, total_num=None, width=None, height=None,
+                      return_stats=False):
+    """trajectory_optimize.cpp:30-96 (same argument order as the pybind entry)."""
+    uv12 = np.ascontiguousarray(uv12, np.float64).reshape(-1, 4)
+    n = uv12.shape[0] if total_num is None else int(total_num)
+    ref1 = np.ascontiguousarray(ref1, np.float64).reshape(-1, 2)
+    ref2 = np.ascontiguousarray(ref2, np.float64).reshape(-1, 2)
+    scale = np.ascontiguousarray(scale, np.float64).reshape(-1)
+    fm = _f32(flow12_map)
+    H, W = fm.shape[:2]
+    if width is not None:
+        assert (int(width), int(height)) == (W, H)
+    out = np.empty((n, 4), np.float64)
+    st = SolveStats()
+    rc = lib().orc_optimize_location(_ptr(uv12), _ptr(ref1), _ptr(ref2), _ptr(scale), _ptr(fm), n, W, H,
+                                     _ptr(out), ctypes.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle optimize_location: solver failure")
+    return (out, st.as_dict()) if return_stats else out
+
+
+class TrackResult:
+    """All trajectories in full_trajs order (index == saved id) as CSR arrays."""
+
+    def __init__(self, birth, length, off, xy, solves=None):
+        self.birth, self.length, self.off, self.xy, self.solves = birth, length, off, xy, solves or []
+
+    @property
+    def n_traj(self):
+        return int(self.birth.shape[0])
+
+    @property
+    def n_points(self):
+        return int(self.xy.shape[0])
+
+    def traj(self, i):
+        return self.birth[i], self.xy[self.off[i]:self.off[i + 1]]
+
+
+def _run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio):
+    fl = [_f32(f) for f in flows]
+    oc = [np.ascontiguousarray(o, dtype=np.uint8) for o in occ_maps]
+    n = len(fl)
+    H, W = fl[0].shape[:2]
+    PA = ctypes.c_void_p * n
+    fp = PA(*[f.ctypes.data for f in fl])
+    op = PA(*[o.ctypes.data for o in oc])
+    keep = [fl, oc]
+    f2p = o2p = None
+    if flows_f2 is not None:
+        f2 = [_f32(f) for f in flows_f2]
+        o2 = [np.ascontiguousarray(o, dtype=np.uint8) for o in occ_maps_s2]
+        keep += [f2, o2]
+        m = len(f2)
+        PB = ctypes.c_void_p * max(m, 1)
+        f2p = PB(*[f.ctypes.data for f in f2])
+        o2p = PB(*[o.ctypes.data for o in o2])
+    r = lib().orc_track(fp, op, f2p, o2p, n, H, W, int(sample_ratio))
+    try:
+        c = r.contents
+        nt, npnt = c.n_traj, c.n_points
+        birth = np.ctypeslib.as_array(c.birth, (max(nt, 1),))[:nt].copy()
+        length = np.ctypeslib.as_array(c.len, (max(nt, 1),))[:nt].copy()
+        off = np.ctypeslib.as_array(c.off, (nt + 1,)).copy()
+        xy = np.ctypeslib.as_array(c.xy, (max(npnt, 1) * 2,))[:npnt * 2].copy().reshape(-1, 2)
+        solves = [c.solves[i].as_dict() for i in range(c.n_solves)] if flows_f2 is not None else []
+    finally:
+        lib().orc_result_free(r)
+    del keep
+    return TrackResult(birth, length, off, xy, solves)
+
+
+def track(flows, occ_maps, sample_ratio):
+    """track.py:24-50"""
+    return _run_track(flows, occ_maps, None, None, sample_ratio)
+
+
+def track_optimize(flows, flows_f2, occ_maps, occ_maps_s2, sample_ratio):
+    """track_optimize.py:24-53"""
+    return _run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio)

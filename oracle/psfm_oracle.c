@@ -1,0 +1,740 @@
+/*
+ * psfm_oracle.c -- CPU restatement of ParticleSfM's point_trajectory hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the timed CPU baseline.  The product path
+ * (particle-sfm_amd/) never links, imports or falls back to it.
+ *
+ * Plain scalar C, one thread, written from the reference's semantics (SURVEY.md
+ * Appendix A/B).  Every function cites the reference file:line it restates
+ * (paths relative to the reference root).
+ *
+ * Pinning status:
+ *   - sampler / flow_check / track / track_optimize orchestration: PINNED against
+ *     the reference's own Python (torch-CPU grid_sample, SciPy EDT, NumPy) run
+ *     unmodified in the build container; vectors in tests/golden/ (see
+ *     tests/golden/make_golden.py).
+ *   - orc_optimize_location (the Ceres 2.0.0 trust-region/dogleg loop):
+ *     PARITY UNPINNED.  Ceres is a third-party dependency that is absent from
+ *     the reference tree and from this image (pinned 2.0.0 in
+ *     misc/doc/ceres.md:5); the loop below restates its published algorithm
+ *     (trust_region_minimizer.cc, dogleg_strategy.cc,
+ *     trust_region_step_evaluator.cc, cubic_interpolation.h Grid2D) as
+ *     configured at point_trajectory/optimize/src/trajectory_optimize.cpp:74-79.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -- no fused ops except
+ * the explicit fmaf() chains that restate ATen's vectorised kernel).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* A-1  bilinear sampler == point_trajectory/trajectory.py:25-37              */
+/*      (torch F.grid_sample, bilinear, zeros padding, align_corners=True)    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int x0, y0;           /* north-west tap */
+    float nw, ne, sw, se; /* weights */
+} orc_taps_t;
+
+/* trajectory.py:29-35: positions are cast to fp32, divided by (W-1)/2 resp.
+ * (H-1)/2 (true IEEE division by the fp32-rounded scalar), minus 1; ATen then
+ * un-normalises (g+1)*((size-1)/2) and splits into floor + weights. */
+static inline void orc_taps_f32(float x32, float y32, int H, int W, orc_taps_t* t)
+{
+    const float cw = (float)((double)(W - 1) / 2.0);
+    const float ch = (float)((double)(H - 1) / 2.0);
+    float gx = x32 / cw;
+    float gy = y32 / ch;
+    gx = gx - 1.0f;
+    gy = gy - 1.0f;
+    const float ix = (gx + 1.0f) * cw;
+    const float iy = (gy + 1.0f) * ch;
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float w = ix - fx, e = 1.0f - w;
+    const float n = iy - fy, s = 1.0f - n;
+    t->nw = s * e; t->ne = s * w; t->sw = n * e; t->se = n * w;
+    /* clamp before the int conversion so absurd coordinates stay defined;
+     * anything outside [-1, size] has all four taps out of bounds anyway */
+    float cx = fx < -2.0f ? -2.0f : (fx > (float)W + 1.0f ? (float)W + 1.0f : fx);
+    float cy = fy < -2.0f ? -2.0f : (fy > (float)H + 1.0f ? (float)H + 1.0f : fy);
+    if (!(fx == fx)) cx = -2.0f; /* NaN -> all taps out of bounds */
+    if (!(fy == fy)) cy = -2.0f;
+    t->x0 = (int)cx; t->y0 = (int)cy;
+}
+
+static inline int orc_inb(int x, int y, int H, int W)
+{
+    return x >= 0 && x < W && y >= 0 && y < H;
+}
+
+/* ATen blend: ((nw_v*nw + ne_v*ne) + sw_v*sw) + se_v*se, contracted to an
+ * fma chain by the build (probe-verified bit-exact). */
+static inline float orc_blend(float vnw, float vne, float vsw, float vse, const orc_taps_t* t)
+{
+    return fmaf(vse, t->se, fmaf(vsw, t->sw, fmaf(vne, t->ne, vnw * t->nw)));
+}
+
+/* sample an interleaved HWC float map with C channels (C = 1 or 2) */
+static inline void orc_sample_hwc(const float* map, int C, int H, int W, const orc_taps_t* t, float* out)
+{
+    const int x0 = t->x0, y0 = t->y0;
+    const int inw = orc_inb(x0, y0, H, W), ine = orc_inb(x0 + 1, y0, H, W);
+    const int isw = orc_inb(x0, y0 + 1, H, W), ise = orc_inb(x0 + 1, y0 + 1, H, W);
+    for (int c = 0; c < C; ++c) {
+        const float vnw = inw ? map[((int64_t)y0 * W + x0) * C + c] : 0.0f;
+        const float vne = ine ? map[((int64_t)y0 * W + x0 + 1) * C + c] : 0.0f;
+        const float vsw = isw ? map[((int64_t)(y0 + 1) * W + x0) * C + c] : 0.0f;
+        const float vse = ise ? map[((int64_t)(y0 + 1) * W + x0 + 1) * C + c] : 0.0f;
+        out[c] = orc_blend(vnw, vne, vsw, vse, t);
+    }
+}
+
+static inline float orc_sample_u8(const uint8_t* map, int H, int W, const orc_taps_t* t)
+{
+    const int x0 = t->x0, y0 = t->y0;
+    const float vnw = orc_inb(x0, y0, H, W) ? (float)(map[(int64_t)y0 * W + x0] != 0) : 0.0f;
+    const float vne = orc_inb(x0 + 1, y0, H, W) ? (float)(map[(int64_t)y0 * W + x0 + 1] != 0) : 0.0f;
+    const float vsw = orc_inb(x0, y0 + 1, H, W) ? (float)(map[(int64_t)(y0 + 1) * W + x0] != 0) : 0.0f;
+    const float vse = orc_inb(x0 + 1, y0 + 1, H, W) ? (float)(map[(int64_t)(y0 + 1) * W + x0 + 1] != 0) : 0.0f;
+    return orc_blend(vnw, vne, vsw, vse, t);
+}
+
+/* trajectory.py:25-37  grid_sample(data[C,H,W], xy[N,2]) -> [N,C]; here the map
+ * is the file-native HWC interleaved layout (the permute at track.py:39 is a
+ * view change only). */
+ORC_API void orc_grid_sample(const float* map_hwc, int C, int H, int W,
+                             const double* xy, int64_t n, float* out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        orc_taps_t t;
+        orc_taps_f32((float)xy[2 * i], (float)xy[2 * i + 1], H, W, &t);
+        orc_sample_hwc(map_hwc, C, H, W, &t, out + i * C);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A-2  flow_check == point_trajectory/utils.py:58-105                        */
+/* ------------------------------------------------------------------------- */
+/* One frame pair.  F, B: (H,W,2) f32.  occ: (H,W) u8 0/1.  err: (H,W) f32 or NULL. */
+ORC_API void orc_flow_check(const float* F, const float* B, int H, int W, float thres,
+                            uint8_t* occ, float* err)
+{
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            const int64_t p = (int64_t)y * W + x;
+            const float fu = F[2 * p], fv = F[2 * p + 1];
+            /* utils.py:73-78: coord + flow in fp32 */
+            const float X = (float)x + fu, Y = (float)y + fv;
+            orc_taps_t t;
+            orc_taps_f32(X, Y, H, W, &t); /* utils.py:79-82 */
+            float b[2];
+            orc_sample_hwc(B, 2, H, W, &t, b);
+            /* utils.py:87: torch.norm(warp + flow, dim=1) == sqrtf(fma(ev,ev,eu*eu)) */
+            const float eu = b[0] + fu, ev = b[1] + fv;
+            const float e = sqrtf(fmaf(ev, ev, eu * eu));
+            /* utils.py:58-68 oob; :88-91 union */
+            const int oob = (X < 0.0f) || (X > (float)(W - 1)) || (Y < 0.0f) || (Y > (float)(H - 1));
+            occ[p] = (uint8_t)((e > thres) || oob);
+            if (err) err[p] = e;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A-7 / Appendix B   optimize_location                                       */
+/*   == point_trajectory/optimize/src/trajectory_optimize.cpp:30-96           */
+/*   cost functor  path_consistency_cost.h:42-59                              */
+/*   interpolator  linear_interpolation.h:97-123 (+ Ceres Grid2D clamping)    */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    const float* flow; /* (H,W,2) f32; the pybind force-cast to f64 is exact */
+    int H, W;
+} orc_grid_t;
+
+/* ceres::Grid2D<double,2>::GetValue: indices clamped to the image */
+static inline void orc_grid_get(const orc_grid_t* g, int r, int c, double* f)
+{
+    const int rr = r < 0 ? 0 : (r > g->H - 1 ? g->H - 1 : r);
+    const int cc = c < 0 ? 0 : (c > g->W - 1 ? g->W - 1 : c);
+    const float* p = g->flow + ((int64_t)rr * g->W + cc) * 2;
+    f[0] = (double)p[0];
+    f[1] = (double)p[1];
+}
+
+/* linear_interpolation.h:97-123 */
+static inline void orc_bilerp(const orc_grid_t* g, double r, double c,
+                              double* f, double* dfdr, double* dfdc)
+{
+    double fr = floor(r), fc = floor(c);
+    /* keep the int conversion defined for absurd coordinates */
+    if (!(fr > -1.0e9)) fr = -1.0e9; if (fr > 1.0e9) fr = 1.0e9;
+    if (!(fc > -1.0e9)) fc = -1.0e9; if (fc > 1.0e9) fc = 1.0e9;
+    const int row = (int)fr, col = (int)fc;
+    double p00[2], p01[2], p10[2], p11[2];
+    orc_grid_get(g, row, col, p00);
+    orc_grid_get(g, row, col + 1, p01);
+    orc_grid_get(g, row + 1, col, p10);
+    orc_grid_get(g, row + 1, col + 1, p11);
+    const double tc = c - (double)col, tr = r - (double)row;
+    for (int k = 0; k < 2; ++k) {
+        const double f0 = (1.0 - tc) * p00[k] + tc * p01[k];
+        const double f1 = (1.0 - tc) * p10[k] + tc * p11[k];
+        const double d0 = p01[k] - p00[k];
+        const double d1 = p11[k] - p10[k];
+        f[k] = (1.0 - tr) * f0 + tr * f1;
+        if (dfdr) dfdr[k] = f1 - f0;
+        if (dfdc) dfdc[k] = (1.0 - tr) * d0 + tr * d1;
+    }
+}
+
+/* residuals (path_consistency_cost.h:50-57) and the 4 non-trivial Jacobian
+ * entries the Jet evaluation produces:
+ *   row4 = [-1-dfdc_u, -dfdr_u, 1, 0], row5 = [-dfdc_v, -1-dfdr_v, 0, 1]
+ *   rows0..3 = diag(1,1,s,s).  x = (x1,y1,x2,y2). */
+static inline void orc_pc_eval(const orc_grid_t* g, const double* x, const double* ref1,
+                               const double* ref2, double s, double* r, double* jac /*[4]: j40,j41,j50,j51 or NULL*/)
+{
+    double f[2], dr[2], dc[2];
+    orc_bilerp(g, x[1], x[0], f, jac ? dr : NULL, jac ? dc : NULL);
+    r[0] = x[0] - ref1[0];
+    r[1] = x[1] - ref1[1];
+    r[2] = (x[2] - ref2[0]) * s;
+    r[3] = (x[3] - ref2[1]) * s;
+    r[4] = (x[2] - x[0]) - f[0];
+    r[5] = (x[3] - x[1]) - f[1];
+    if (jac) {
+        jac[0] = -1.0 - dc[0]; /* d r4 / d x1 */
+        jac[1] = 0.0 - dr[0];  /* d r4 / d y1 */
+        jac[2] = 0.0 - dc[1];  /* d r5 / d x1 */
+        jac[3] = -1.0 - dr[1]; /* d r5 / d y1 */
+    }
+}
+
+/* 4x4 SPD solve by Cholesky (what the sparse normal Cholesky does on each
+ * independent 4x4 diagonal block).  Returns 0 on success. */
+static inline int orc_chol4(const double A[4][4], const double* b, double* y)
+{
+    double L[4][4];
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[i][j];
+            for (int k = 0; k < j; ++k) sum -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(sum > 0.0)) return 1;
+                L[i][i] = sqrt(sum);
+            } else {
+                L[i][j] = sum / L[j][j];
+            }
+        }
+    }
+    double z[4];
+    for (int i = 0; i < 4; ++i) {
+        double sum = b[i];
+        for (int k = 0; k < i; ++k) sum -= L[i][k] * z[k];
+        z[i] = sum / L[i][i];
+    }
+    for (int i = 3; i >= 0; --i) {
+        double sum = z[i];
+        for (int k = i + 1; k < 4; ++k) sum -= L[k][i] * y[k];
+        y[i] = sum / L[i][i];
+    }
+    return 0;
+}
+
+/* scaled 6x4 Jacobian of one track: Js = J * diag(S) */
+typedef struct { double a[6][4]; } orc_js_t;
+
+static inline void orc_build_js(const double* jac, double s, const double* S, orc_js_t* J)
+{
+    memset(J, 0, sizeof(*J));
+    J->a[0][0] = 1.0 * S[0];
+    J->a[1][1] = 1.0 * S[1];
+    J->a[2][2] = s * S[2];
+    J->a[3][3] = s * S[3];
+    J->a[4][0] = jac[0] * S[0]; J->a[4][1] = jac[1] * S[1]; J->a[4][2] = 1.0 * S[2];
+    J->a[5][0] = jac[2] * S[0]; J->a[5][1] = jac[3] * S[1]; J->a[5][3] = 1.0 * S[3];
+}
+
+/* solver statistics (optional) */
+typedef struct {
+    int32_t iterations;       /* trust-region iterations executed (excluding iteration 0) */
+    int32_t successful_steps;
+    int32_t termination;      /* 0 function tol, 1 parameter tol, 2 gradient tol, 3 max iter, 4 min radius, 5 failure */
+    int32_t dogleg_nonGN;     /* iterations whose step was not the pure Gauss-Newton step */
+    double initial_cost, final_cost;
+} orc_solve_stats_t;
+
+/* trajectory_optimize.cpp:30-96.  flow12 is the (H,W,2) f32 map (exactly what
+ * the reference force-casts to double).  Restates Ceres 2.0.0:
+ * TrustRegionMinimizer::Minimize with DoglegStrategy(TRADITIONAL_DOGLEG),
+ * jacobi_scaling, SPARSE_NORMAL_CHOLESKY, max_num_iterations=200, defaults
+ * otherwise.  All global scalars (cost, norms) run over ALL tracks. */
+ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const double* ref2,
+                                  const double* scale, const float* flow12, int64_t n, int w, int h,
+                                  double* out, orc_solve_stats_t* stats)
+{
+    orc_solve_stats_t st; memset(&st, 0, sizeof(st));
+    if (n <= 0) { if (stats) *stats = st; return 0; }
+    const orc_grid_t grid = { flow12, h, w };
+    const int64_t P = 4 * n;
+
+    double* x = (double*)malloc(sizeof(double) * P);     /* current iterate */
+    double* xc = (double*)malloc(sizeof(double) * P);    /* candidate */
+    double* res = (double*)malloc(sizeof(double) * 6 * n);
+    double* jac = (double*)malloc(sizeof(double) * 4 * n);
+    double* S = (double*)malloc(sizeof(double) * P);     /* jacobi scaling */
+    double* diag = (double*)malloc(sizeof(double) * P);
+    double* ghat = (double*)malloc(sizeof(double) * P);  /* scaled gradient */
+    double* gn = (double*)malloc(sizeof(double) * P);    /* scaled Gauss-Newton step */
+    double* step = (double*)malloc(sizeof(double) * P);
+    double* best = (double*)malloc(sizeof(double) * P);  /* parameters_ (user-visible) */
+    memcpy(x, uv12, sizeof(double) * P);
+
+    /* solver constants (Ceres 2.0.0 defaults unless set at trajectory_optimize.cpp:74-79) */
+    const int max_iter = 200;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double min_relative_decrease = 1e-3, min_radius = 1e-32;
+    const double min_diag = 1e-6, max_diag = 1e32;
+    const double min_mu = 1e-8, max_mu = 1.0, mu_increase = 10.0;
+    const int max_invalid = 5;
+    double radius = 1e4, mu = min_mu, dogleg_step_norm = 0.0, alpha = 0.0;
+    int reuse = 0;
+
+    double x_cost = 0.0, gmax = 0.0, x_norm = 0.0;
+    double cand_cost = 0.0, model_cost_change = 0.0;
+    int n_invalid = 0;
+
+    /* --- EvaluateGradientAndJacobian at iteration 0 (trust_region_minimizer.cc) --- */
+#define EVAL_AT_X(first)                                                              \
+    do {                                                                              \
+        double cs = 0.0, gm = 0.0;                                                    \
+        for (int64_t i = 0; i < n; ++i) {                                             \
+            const double s_ = scale[i];                                               \
+            double* r_ = res + 6 * i; double* j_ = jac + 4 * i;                       \
+            orc_pc_eval(&grid, x + 4 * i, ref1 + 2 * i, ref2 + 2 * i, s_, r_, j_);    \
+            double ss = 0.0;                                                          \
+            for (int k = 0; k < 6; ++k) ss += r_[k] * r_[k];                          \
+            cs += 0.5 * ss;                                                           \
+            /* unscaled gradient g = J^T r */                                         \
+            double g[4];                                                              \
+            g[0] = (r_[0] + j_[0] * r_[4]) + j_[2] * r_[5];                           \
+            g[1] = (r_[1] + j_[1] * r_[4]) + j_[3] * r_[5];                           \
+            g[2] = s_ * r_[2] + r_[4];                                                \
+            g[3] = s_ * r_[3] + r_[5];                                                \
+            if (first) {                                                              \
+                /* jacobian_scaling = 1/(1+sqrt(colnorm^2)), computed ONCE */         \
+                const double c0 = (1.0 + j_[0] * j_[0]) + j_[2] * j_[2];              \
+                const double c1 = (1.0 + j_[1] * j_[1]) + j_[3] * j_[3];              \
+                const double c2 = s_ * s_ + 1.0;                                      \
+                S[4 * i + 0] = 1.0 / (1.0 + sqrt(c0));                                \
+                S[4 * i + 1] = 1.0 / (1.0 + sqrt(c1));                                \
+                S[4 * i + 2] = 1.0 / (1.0 + sqrt(c2));                                \
+                S[4 * i + 3] = 1.0 / (1.0 + sqrt(c2));                                \
+            }                                                                         \
+            /* gradient_max_norm = |x - Plus(x, -g)|_inf */                           \
+            for (int k = 0; k < 4; ++k) {                                             \
+                const double xv = x[4 * i + k];                                       \
+                const double d_ = fabs(xv - (xv + (-g[k])));                          \
+                if (d_ > gm) gm = d_;                                                 \
+            }                                                                         \
+        }                                                                             \
+        x_cost = cs; gmax = gm;                                                       \
+    } while (0)
+
+#define NORM_OF(v, outv)                                                              \
+    do { double a_ = 0.0; for (int64_t q = 0; q < P; ++q) a_ += (v)[q] * (v)[q];      \
+         (outv) = sqrt(a_); } while (0)
+
+    NORM_OF(x, x_norm);            /* Init(): x_norm_ = x_.norm() */
+    EVAL_AT_X(1);                  /* IterationZero() */
+    st.initial_cost = x_cost;
+    memcpy(best, x, sizeof(double) * P);
+    double minimum_cost = x_cost;
+    int iteration = 0;
+    int step_successful = 1;       /* iteration 0 counts as successful */
+    st.termination = 3;
+
+    for (;;) {
+        /* FinalizeIterationAndCheckIfMinimizerCanContinue */
+        if (step_successful && x_cost <= minimum_cost) { /* parameters_ = x_ when cost improved */
+            minimum_cost = x_cost;
+            memcpy(best, x, sizeof(double) * P);
+        }
+        if (iteration >= max_iter) { st.termination = 3; break; }
+        if (step_successful && gmax <= gradient_tolerance) { st.termination = 2; break; }
+        if (radius <= min_radius) { st.termination = 4; break; }
+
+        ++iteration;
+        st.iterations = iteration;
+        step_successful = 0;
+
+        /* ---- DoglegStrategy::ComputeStep ---- */
+        int lin_fail = 0;
+        if (!reuse) {
+            reuse = 1;
+            double g2 = 0.0, jg2 = 0.0;
+            /* diagonal, gradient, Cauchy point (alpha) */
+            for (int64_t i = 0; i < n; ++i) {
+                orc_js_t J; orc_build_js(jac + 4 * i, scale[i], S + 4 * i, &J);
+                const double* r_ = res + 6 * i;
+                double d[4], gt[4], sg[4];
+                for (int c = 0; c < 4; ++c) {
+                    double cn = 0.0, gr = 0.0;
+                    for (int q = 0; q < 6; ++q) { cn += J.a[q][c] * J.a[q][c]; gr += J.a[q][c] * r_[q]; }
+                    cn = cn < min_diag ? min_diag : (cn > max_diag ? max_diag : cn);
+                    d[c] = sqrt(cn);
+                    gt[c] = gr / d[c];
+                    sg[c] = gt[c] / d[c];
+                    diag[4 * i + c] = d[c];
+                    ghat[4 * i + c] = gt[c];
+                    g2 += gt[c] * gt[c];
+                }
+                for (int q = 0; q < 6; ++q) {
+                    double v = 0.0;
+                    for (int c = 0; c < 4; ++c) v += J.a[q][c] * sg[c];
+                    jg2 += v * v;
+                }
+            }
+            alpha = g2 / jg2;
+            /* ComputeGaussNewtonStep: (Js^T Js + mu*diag^2) y = Js^T r, retry with mu*=10 */
+            lin_fail = 1;
+            while (mu < max_mu) {
+                int fail = 0;
+                for (int64_t i = 0; i < n && !fail; ++i) {
+                    orc_js_t J; orc_build_js(jac + 4 * i, scale[i], S + 4 * i, &J);
+                    const double* r_ = res + 6 * i;
+                    double A[4][4], b[4], y[4];
+                    const double smu = sqrt(mu);
+                    for (int a = 0; a < 4; ++a) {
+                        for (int c = 0; c <= a; ++c) {
+                            double v = 0.0;
+                            for (int q = 0; q < 6; ++q) v += J.a[q][a] * J.a[q][c];
+                            A[a][c] = v; A[c][a] = v;
+                        }
+                        const double D = diag[4 * i + a] * smu; /* lm_diagonal */
+                        A[a][a] += D * D;
+                        double br = 0.0;
+                        for (int q = 0; q < 6; ++q) br += J.a[q][a] * r_[q];
+                        b[a] = br;
+                    }
+                    if (orc_chol4(A, b, y)) { fail = 1; break; }
+                    for (int c = 0; c < 4; ++c) {
+                        if (!(y[c] == y[c]) || isinf(y[c])) fail = 1;
+                        gn[4 * i + c] = y[c] * (-diag[4 * i + c]); /* gauss_newton_step *= -diagonal */
+                    }
+                }
+                if (fail) { mu *= mu_increase; continue; }
+                lin_fail = 0;
+                break;
+            }
+        }
+        int step_valid = 0;
+        if (!lin_fail) {
+            /* ComputeTraditionalDoglegStep */
+            double gnorm, gnn;
+            NORM_OF(ghat, gnorm);
+            NORM_OF(gn, gnn);
+            if (gnn <= radius) {
+                for (int64_t q = 0; q < P; ++q) step[q] = gn[q] / diag[q];
+                dogleg_step_norm = gnn;
+            } else if (gnorm * alpha >= radius) {
+                for (int64_t q = 0; q < P; ++q) step[q] = (-(radius / gnorm) * ghat[q]) / diag[q];
+                dogleg_step_norm = radius;
+                st.dogleg_nonGN++;
+            } else {
+                double dot = 0.0;
+                for (int64_t q = 0; q < P; ++q) dot += ghat[q] * gn[q];
+                const double b_dot_a = -alpha * dot;
+                const double a2 = pow(alpha * gnorm, 2.0);
+                const double bma2 = a2 - 2 * b_dot_a + pow(gnn, 2);
+                const double c = b_dot_a - a2;
+                const double d = sqrt(c * c + bma2 * (pow(radius, 2.0) - a2));
+                const double beta = (c <= 0) ? (d - c) / bma2 : (radius * radius - a2) / (d + c);
+                double sn = 0.0;
+                for (int64_t q = 0; q < P; ++q) {
+                    const double v = (-alpha * (1.0 - beta)) * ghat[q] + beta * gn[q];
+                    sn += v * v;
+                    step[q] = v / diag[q];
+                }
+                dogleg_step_norm = sqrt(sn);
+                st.dogleg_nonGN++;
+            }
+            /* model_cost_change = -(J*step)'(f + J*step/2)   (ComputeTrustRegionStep) */
+            double mcc = 0.0;
+            for (int64_t i = 0; i < n; ++i) {
+                orc_js_t J; orc_build_js(jac + 4 * i, scale[i], S + 4 * i, &J);
+                const double* r_ = res + 6 * i;
+                for (int q = 0; q < 6; ++q) {
+                    double m = 0.0;
+                    for (int c = 0; c < 4; ++c) m += J.a[q][c] * step[4 * i + c];
+                    mcc += m * (r_[q] + m / 2.0);
+                }
+            }
+            model_cost_change = -mcc;
+            step_valid = model_cost_change > 0.0;
+        }
+        if (!step_valid) {
+            /* HandleInvalidStep */
+            if (++n_invalid >= max_invalid) { st.termination = 5; break; }
+            mu *= mu_increase; reuse = 0; /* StepIsInvalid */
+            continue;
+        }
+        n_invalid = 0;
+        /* delta = step .* jacobian_scaling ; candidate = x + delta ; cost */
+        {
+            double cs = 0.0, sn2 = 0.0;
+            for (int64_t i = 0; i < n; ++i) {
+                for (int c = 0; c < 4; ++c) {
+                    const double delta = step[4 * i + c] * S[4 * i + c];
+                    xc[4 * i + c] = x[4 * i + c] + delta;
+                    const double dd = x[4 * i + c] - xc[4 * i + c];
+                    sn2 += dd * dd;
+                }
+                double r_[6];
+                orc_pc_eval(&grid, xc + 4 * i, ref1 + 2 * i, ref2 + 2 * i, scale[i], r_, NULL);
+                double ss = 0.0;
+                for (int k = 0; k < 6; ++k) ss += r_[k] * r_[k];
+                cs += 0.5 * ss;
+            }
+            cand_cost = cs;
+            /* ParameterToleranceReached */
+            const double step_norm = sqrt(sn2);
+            if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { st.termination = 1; break; }
+        }
+        /* FunctionToleranceReached */
+        if (fabs(x_cost - cand_cost) <= function_tolerance * x_cost) { st.termination = 0; break; }
+        /* IsStepSuccessful (monotonic step evaluator) */
+        const double rho = (x_cost - cand_cost) / model_cost_change;
+        if (rho > min_relative_decrease) {
+            /* HandleSuccessfulStep */
+            memcpy(x, xc, sizeof(double) * P);
+            NORM_OF(x, x_norm);
+            EVAL_AT_X(0);
+            step_successful = 1;
+            st.successful_steps++;
+            /* DoglegStrategy::StepAccepted */
+            if (rho < 0.25) radius *= 0.5;
+            if (rho > 0.75) radius = fmax(radius, 3.0 * dogleg_step_norm);
+            mu = fmax(min_mu, 2.0 * mu / mu_increase);
+            reuse = 0;
+        } else {
+            /* HandleUnsuccessfulStep -> DoglegStrategy::StepRejected */
+            radius *= 0.5;
+            reuse = 1;
+        }
+    }
+    st.final_cost = minimum_cost;
+    memcpy(out, best, sizeof(double) * P);
+    if (stats) *stats = st;
+    free(x); free(xc); free(res); free(jac); free(S); free(diag); free(ghat); free(gn); free(step); free(best);
+    return st.termination == 5 ? 1 : 0;
+#undef EVAL_AT_X
+#undef NORM_OF
+}
+
+/* ------------------------------------------------------------------------- */
+/* track / track_optimize                                                     */
+/*   == point_trajectory/track.py:24-50, track_optimize.py:24-53,             */
+/*      trajectory.py:45-62 (step_forward), :98-194 (IncrementalTrajectorySet)*/
+/*      optimize/src/trajectory_base.cpp:21-93 (Trajectory)                   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t birth;     /* first time */
+    int32_t len;       /* number of positions (xys + buffer) */
+    int32_t cap;
+    double* pts;       /* len x 2; the last min(len,buffer_size) entries are the buffer deque */
+} orc_traj_t;
+
+typedef struct {
+    orc_traj_t** v; int64_t n, cap;
+} orc_list_t;
+
+static void orc_list_push(orc_list_t* l, orc_traj_t* t)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 1024; l->v = (orc_traj_t**)realloc(l->v, sizeof(void*) * l->cap); }
+    l->v[l->n++] = t;
+}
+
+/* Trajectory(time, xy, buffer_size) + extend  (trajectory_base.cpp:21-24,55-67) */
+static void orc_traj_extend(orc_traj_t* t, double x, double y)
+{
+    if (t->len == t->cap) { t->cap = t->cap ? t->cap * 2 : 8; t->pts = (double*)realloc(t->pts, sizeof(double) * 2 * t->cap); }
+    t->pts[2 * t->len] = x; t->pts[2 * t->len + 1] = y; t->len++;
+}
+
+typedef struct {
+    int64_t n_traj, n_points;
+    int32_t* birth;   /* n_traj */
+    int32_t* len;     /* n_traj */
+    int64_t* off;     /* n_traj+1 */
+    double* xy;       /* n_points x 2 */
+    /* optional per-solve statistics (track_optimize only) */
+    int32_t n_solves;
+    orc_solve_stats_t* solves;
+} orc_result_t;
+
+ORC_API void orc_result_free(orc_result_t* r)
+{
+    if (!r) return;
+    free(r->birth); free(r->len); free(r->off); free(r->xy); free(r->solves); free(r);
+}
+
+/* flows: n_flows pointers to (H,W,2) f32; occ: n_flows pointers to (H,W) u8.
+ * flows_f2 / occ_s2: stride-2 stacks or NULL (-> track()).  The result lists
+ * ALL trajectories in full_trajs order (the index is the saved id,
+ * main_connect_point_trajectories.py:56-60); no min-length filter here. */
+ORC_API orc_result_t* orc_track(const float* const* flows, const uint8_t* const* occ,
+                                const float* const* flows_f2, const uint8_t* const* occ_s2,
+                                int n_flows, int H, int W, int ratio)
+{
+    const int optimize = (flows_f2 != NULL);
+    const int buffer_size = optimize ? 3 : 0;      /* track_optimize.py:30 / track.py:30 */
+    const int GW = (W + ratio - 1) / ratio, GH = (H + ratio - 1) / ratio; /* trajectory.py:110-115 */
+    const int64_t G = (int64_t)GW * GH;
+    orc_list_t active = {0}, next_active = {0}, full = {0};
+    uint8_t* cand = (uint8_t*)malloc(G);           /* sample_candidates as a grid mask */
+    memset(cand, 1, G);                            /* trajectory.py:108: all candidates at start */
+    uint8_t* occupied = (uint8_t*)malloc((size_t)H * W);
+    orc_result_t* R = (orc_result_t*)calloc(1, sizeof(orc_result_t));
+    if (optimize) R->solves = (orc_solve_stats_t*)calloc(n_flows > 0 ? n_flows : 1, sizeof(orc_solve_stats_t));
+    double* nxt = NULL; uint8_t* flag = NULL; int64_t scratch_cap = 0;
+
+    for (int f = 0; f < n_flows; ++f) {
+        /* new_traj_all (trajectory.py:117-120): births in row-major grid order, time = f */
+        for (int64_t g = 0; g < G; ++g) {
+            if (!cand[g]) continue;
+            orc_traj_t* t = (orc_traj_t*)calloc(1, sizeof(orc_traj_t));
+            t->birth = f;
+            orc_traj_extend(t, (double)((g % GW) * ratio), (double)((g / GW) * ratio));
+            orc_list_push(&active, t);
+        }
+        const int64_t A = active.n;
+        if (A > scratch_cap) { scratch_cap = A; nxt = (double*)realloc(nxt, sizeof(double) * 2 * A); flag = (uint8_t*)realloc(flag, A); }
+        /* get_cur_pos + grid_sample(flow) + step_forward  (track.py:38-46, trajectory.py:45-62) */
+        for (int64_t i = 0; i < A; ++i) {
+            const orc_traj_t* t = active.v[i];
+            const double px = t->pts[2 * (t->len - 1)], py = t->pts[2 * (t->len - 1) + 1]; /* get_tail_location */
+            orc_taps_t tp;
+            orc_taps_f32((float)px, (float)py, H, W, &tp);
+            float fl[2];
+            orc_sample_hwc(flows[f], 2, H, W, &tp, fl);
+            const float oc = orc_sample_u8(occ[f], H, W, &tp);
+            const int occ_c = oc > 0.1f;                               /* trajectory.py:50 */
+            const double nx = px + (double)fl[0], ny = py + (double)fl[1]; /* :55 */
+            const int valid = (nx > 0) && (nx < (double)(W - 1)) && (ny > 0) && (ny < (double)(H - 1)); /* :56-57 */
+            nxt[2 * i] = nx; nxt[2 * i + 1] = ny;
+            flag[i] = (uint8_t)(valid && !occ_c);                      /* :61 */
+        }
+        /* extend_all (trajectory.py:129-152) */
+        memset(occupied, 0, (size_t)H * W);
+        int64_t n_occ = 0;
+        next_active.n = 0;
+        for (int64_t i = 0; i < A; ++i) {
+            orc_traj_t* t = active.v[i];
+            if (!flag[i]) {
+                orc_list_push(&full, t);                               /* clear_buffer + append */
+            } else {
+                occupied[(int64_t)((int)nxt[2 * i + 1]) * W + (int)nxt[2 * i]] = 1;
+                n_occ++;
+                orc_traj_extend(t, nxt[2 * i], nxt[2 * i + 1]);
+                orc_list_push(&next_active, t);
+            }
+        }
+        { orc_list_t tmp = active; active = next_active; next_active = tmp; }
+        /* respawn candidates: distance_transform_edt(1-occupied) > ratio on the stride grid
+         * == no occupied pixel with dx^2+dy^2 <= ratio^2 (SURVEY A-5).  With no occupied
+         * pixel at all SciPy measures to a phantom feature at (y=-1,x=0): everything
+         * but grid point (0,0) respawns. */
+        for (int gy = 0; gy < GH; ++gy) {
+            for (int gx = 0; gx < GW; ++gx) {
+                const int cx = gx * ratio, cy = gy * ratio;
+                int free_ = 1;
+                if (n_occ == 0) {
+                    free_ = !((cy + 1) * (cy + 1) + cx * cx <= ratio * ratio);
+                } else {
+                    for (int dy = -ratio; dy <= ratio && free_; ++dy) {
+                        const int yy = cy + dy;
+                        if (yy < 0 || yy >= H) continue;
+                        for (int dx = -ratio; dx <= ratio; ++dx) {
+                            const int xx = cx + dx;
+                            if (xx < 0 || xx >= W) continue;
+                            if (dx * dx + dy * dy > ratio * ratio) continue;
+                            if (occupied[(int64_t)yy * W + xx]) { free_ = 0; break; }
+                        }
+                    }
+                }
+                cand[(int64_t)gy * GW + gx] = (uint8_t)free_;
+            }
+        }
+        /* optimize_buffer (track_optimize.py:49-50, trajectory.py:161-194) */
+        if (optimize && f + 1 >= 2) {
+            int64_t N = 0;
+            for (int64_t i = 0; i < active.n; ++i) if (active.v[i]->len >= buffer_size) N++;
+            if (N > 0) { /* the reference raises on N == 0 (np.stack([])): we skip the solve */
+                double* uv12 = (double*)malloc(sizeof(double) * 4 * N);
+                double* r1 = (double*)malloc(sizeof(double) * 2 * N);
+                double* r2 = (double*)malloc(sizeof(double) * 2 * N);
+                double* sc = (double*)malloc(sizeof(double) * N);
+                double* o = (double*)malloc(sizeof(double) * 4 * N);
+                int64_t k = 0;
+                for (int64_t i = 0; i < active.n; ++i) {
+                    const orc_traj_t* t = active.v[i];
+                    if (t->len < buffer_size) continue;
+                    const double* b0 = t->pts + 2 * (t->len - 3);
+                    orc_taps_t tp;
+                    orc_taps_f32((float)b0[0], (float)b0[1], H, W, &tp);
+                    float f01[2], f02[2];
+                    orc_sample_hwc(flows[f - 1], 2, H, W, &tp, f01);       /* trajectory.py:173-176 */
+                    orc_sample_hwc(flows_f2[f - 1], 2, H, W, &tp, f02);
+                    const float o02 = orc_sample_u8(occ_s2[f - 1], H, W, &tp); /* :177-178 */
+                    /* :179  (1.0 - occ02) * (norm(flow02) < 20): all fp32, numpy norm = sqrt(u*u+v*v) */
+                    const float nrm = sqrtf(f02[0] * f02[0] + f02[1] * f02[1]);
+                    const float s = (1.0f - o02) * (nrm < 20.0f ? 1.0f : 0.0f);
+                    r1[2 * k] = b0[0] + (double)f01[0]; r1[2 * k + 1] = b0[1] + (double)f01[1]; /* :182 */
+                    r2[2 * k] = b0[0] + (double)f02[0]; r2[2 * k + 1] = b0[1] + (double)f02[1]; /* :183 */
+                    sc[k] = (double)s;
+                    uv12[4 * k] = b0[2]; uv12[4 * k + 1] = b0[3]; uv12[4 * k + 2] = b0[4]; uv12[4 * k + 3] = b0[5];
+                    k++;
+                }
+                orc_optimize_location(uv12, r1, r2, sc, flows[f], N, W, H, o, &R->solves[R->n_solves]);
+                R->n_solves++;
+                k = 0;
+                for (int64_t i = 0; i < active.n; ++i) {                    /* :190-194 set_buffer_xy(1|2) */
+                    orc_traj_t* t = active.v[i];
+                    if (t->len < buffer_size) continue;
+                    double* b0 = t->pts + 2 * (t->len - 3);
+                    b0[2] = o[4 * k]; b0[3] = o[4 * k + 1]; b0[4] = o[4 * k + 2]; b0[5] = o[4 * k + 3];
+                    k++;
+                }
+                free(uv12); free(r1); free(r2); free(sc); free(o);
+            }
+        }
+    }
+    /* clear_active (trajectory.py:154-158) */
+    for (int64_t i = 0; i < active.n; ++i) orc_list_push(&full, active.v[i]);
+
+    R->n_traj = full.n;
+    R->birth = (int32_t*)malloc(sizeof(int32_t) * (full.n ? full.n : 1));
+    R->len = (int32_t*)malloc(sizeof(int32_t) * (full.n ? full.n : 1));
+    R->off = (int64_t*)malloc(sizeof(int64_t) * (full.n + 1));
+    int64_t tot = 0;
+    for (int64_t i = 0; i < full.n; ++i) { R->off[i] = tot; tot += full.v[i]->len; }
+    R->off[full.n] = tot;
+    R->n_points = tot;
+    R->xy = (double*)malloc(sizeof(double) * 2 * (tot ? tot : 1));
+    for (int64_t i = 0; i < full.n; ++i) {
+        orc_traj_t* t = full.v[i];
+        R->birth[i] = t->birth; R->len[i] = t->len;
+        memcpy(R->xy + 2 * R->off[i], t->pts, sizeof(double) * 2 * t->len);
+        free(t->pts); free(t);
+    }
+    free(active.v); free(next_active.v); free(full.v); free(cand); free(occupied); free(nxt); free(flag);
+    return R;
+}

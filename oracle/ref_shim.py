@@ -1,0 +1,163 @@
+"""Run the reference's own point_trajectory Python, UNMODIFIED, from /root/reference.
+
+TEST INFRASTRUCTURE ONLY, and only usable where /root/reference exists (the build
+container).  It is what pins oracle/psfm_oracle.c: tests/golden/make_golden.py
+executes the reference through this shim and commits the outputs as fixtures;
+nothing on the GPU box imports this file.
+
+Two import shims are needed:
+  * `cv2` (utils.py:22) is absent; it is only used by load_images/draw_traj.
+  * `point_trajectory.optimize.build.particlesfm` (trajectory.py:23,
+    main_connect_point_trajectories.py:25) is the pybind11/Ceres module that
+    cannot be built here (no Ceres/Eigen/glog).  The stand-in below restates
+    Trajectory / TrajectorySet (optimize/src/trajectory_base.cpp:21-185) in
+    Python and forwards optimize_location to the C restatement in
+    psfm_oracle.c -- so the solver iterate itself stays "parity unpinned".
+
+The reference package is loaded under the alias `psfm_reference_pt` so it cannot
+collide with the product package that mirrors its name.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REFERENCE_ROOT = os.environ.get("PSFM_REFERENCE_ROOT", "/root/reference")
+ALIAS = "psfm_reference_pt"
+
+
+def available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "point_trajectory"))
+
+
+class Trajectory:
+    """trajectory_base.cpp:21-93 (ctor (time, xy, *, buffer_size), extend, clear_buffer, ...)."""
+
+    def __init__(self, time=None, point=None, *, buffer_size=0, times=None, xys=None, labels=None):
+        self._buffer_size = int(buffer_size)
+        self.times, self.labels, self.xys, self.buffer_xys = [], [], [], []
+        if isinstance(time, dict):
+            d = time
+            self.times = [int(t) for t in d.get("frame_ids", [])]
+            self.xys = [np.asarray(p, np.float64) for p in d.get("locations", [])]
+            self.labels = [bool(b) for b in d.get("labels", [])]
+        elif time is not None:
+            self.extend(int(time), point)
+
+    def extend(self, time, xy):
+        xy = np.asarray(xy, dtype=np.float64).copy()
+        self.times.append(int(time))
+        self.labels.append(False)
+        if self._buffer_size == 0:
+            self.xys.append(xy)
+            return
+        self.buffer_xys.append(xy)
+        if len(self.buffer_xys) > self._buffer_size:
+            self.xys.append(self.buffer_xys.pop(0))
+
+    def clear_buffer(self):
+        self.xys.extend(self.buffer_xys)
+        self.buffer_xys = []
+
+    def set_buffer_xy(self, index, xy):
+        if index >= len(self.buffer_xys):
+            raise RuntimeError("Error! Index out of bound for the buffer.")
+        self.buffer_xys[index] = np.asarray(xy, dtype=np.float64).copy()
+
+    def length(self):
+        return len(self.xys) + len(self.buffer_xys)
+
+    def get_tail_location(self):
+        if self.length() == 0:
+            raise RuntimeError("Error! The trajectory is empty!")
+        return self.buffer_xys[-1] if self.buffer_xys else self.xys[-1]
+
+    def as_dict(self):
+        return {"frame_ids": list(self.times), "locations": list(self.xys), "labels": list(self.labels)}
+
+
+class TrajectorySet:
+    """trajectory_base.cpp:95-107 (only what the hot path touches)."""
+
+    def __init__(self, trajs=None):
+        self.trajs = dict(trajs or {})
+
+    def as_dict(self):
+        return {k: v.as_dict() for k, v in sorted(self.trajs.items())}
+
+
+def _optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num, width, height):
+    from . import oracle  # noqa: PLC0415
+    return oracle.optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num, width, height)
+
+
+_loaded = None
+
+
+def load():
+    """Returns a namespace with the reference's flow_check, track, track_optimize, grid_sample, ..."""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    if "tqdm" not in sys.modules:
+        try:
+            importlib.import_module("tqdm")
+        except ImportError:
+            m = types.ModuleType("tqdm")
+            m.tqdm = lambda it, *a, **k: it
+            sys.modules["tqdm"] = m
+    pkg = types.ModuleType(ALIAS)
+    pkg.__path__ = [os.path.join(REFERENCE_ROOT, "point_trajectory")]
+    sys.modules[ALIAS] = pkg
+    opt = types.ModuleType(ALIAS + ".optimize")
+    opt.__path__ = []
+    bld = types.ModuleType(ALIAS + ".optimize.build")
+    bld.__path__ = []
+    standin = types.ModuleType(ALIAS + ".optimize.build.particlesfm")
+    standin.Trajectory = Trajectory
+    standin.TrajectorySet = TrajectorySet
+    standin.optimize_location = _optimize_location
+    bld.particlesfm = standin
+    opt.build = bld
+    pkg.optimize = opt
+    sys.modules[ALIAS + ".optimize"] = opt
+    sys.modules[ALIAS + ".optimize.build"] = bld
+    sys.modules[ALIAS + ".optimize.build.particlesfm"] = standin
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        utils = importlib.import_module(ALIAS + ".utils")
+        trajectory = importlib.import_module(ALIAS + ".trajectory")
+        track = importlib.import_module(ALIAS + ".track")
+        track_optimize = importlib.import_module(ALIAS + ".track_optimize")
+    # silence the progress bars of the frame loops
+    track.tqdm = lambda it, *a, **k: it
+    track_optimize.tqdm = lambda it, *a, **k: it
+    ns = types.SimpleNamespace(
+        utils=utils, trajectory=trajectory,
+        flow_check=utils.flow_check, read_flo=utils.read_flo, load_flows=utils.load_flows,
+        grid_sample=trajectory.grid_sample, step_forward=trajectory.step_forward,
+        IncrementalTrajectorySet=trajectory.IncrementalTrajectorySet,
+        track=track.track, track_optimize=track_optimize.track_optimize,
+        particlesfm=standin,
+    )
+    _loaded = ns
+    return ns
+
+
+def trajs_to_csr(trajs):
+    """List of stand-in Trajectory (full_trajs order) -> (birth, length, off, xy)."""
+    birth = np.array([t.times[0] for t in trajs], np.int32)
+    length = np.array([t.length() for t in trajs], np.int32)
+    off = np.zeros(len(trajs) + 1, np.int64)
+    off[1:] = np.cumsum(length)
+    xy = np.concatenate([np.stack(t.xys + t.buffer_xys, 0) for t in trajs], 0) if trajs else np.zeros((0, 2))
+    for t in trajs:
+        assert t.times == list(range(t.times[0], t.times[0] + t.length()))
+    return birth, length, off, xy.astype(np.float64)

@@ -1,0 +1,116 @@
+"""Deterministic synthetic optical-flow stacks.
+
+The reference ships no data (its examples are fetched by
+scripts/download_examples.sh); every parity / bench input is synthesised here.
+Flows are forward/backward consistent (otherwise every track dies on frame 1):
+
+    F_t(x,y) = A * [ sin(2pi*1.5x/W + p0) cos(2pi*y/H + p1),
+                     cos(2pi*x/W + p2) sin(2pi*1.5y/H + p3) ] + sigma*N(0,1)
+    B_t      = -F_t^clean + sigma*N(0,1)          (inside "occluder" boxes: B = +F)
+    F2_t     = F_t^clean + F_{t+1}^clean(id + F_t^clean) + sigma*N(0,1)   (stride 2)
+
+`synth_sequence` is NumPy (host, bit-reproducible from the seed, used by tests and
+fixtures); `synth_sequence_torch` evaluates the same formula with torch on any
+device (used by bench.py to fill HBM without a PCIe copy; not bit-identical to
+the NumPy version, which does not matter because both paths under test read
+the same tensors).
+"""
+import math
+
+import numpy as np
+
+
+def _clean_np(xx, yy, H, W, amp, ph):
+    u = amp * np.sin(2 * np.pi * 1.5 * xx / W + ph[0]) * np.cos(2 * np.pi * yy / H + ph[1])
+    v = amp * np.cos(2 * np.pi * xx / W + ph[2]) * np.sin(2 * np.pi * 1.5 * yy / H + ph[3])
+    return u, v
+
+
+def synth_sequence(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluders=0, stride2=True):
+    """Returns dict(flows_f, flows_b[, flows_f2, flows_b2]) of lists of (H,W,2) float32 arrays.
+
+    n_frames images -> n_frames-1 stride-1 pairs and n_frames-2 stride-2 pairs."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    n_pairs = n_frames - 1
+    phases = rng.uniform(0, 2 * np.pi, size=(n_pairs + 1, 4))
+
+    def noisy(u, v):
+        out = np.stack([u, v], -1)
+        if sigma > 0:
+            out = out + sigma * rng.standard_normal(out.shape)
+        return out.astype(np.float32)
+
+    def occlude(fb, ff_clean):
+        for _ in range(n_occluders):
+            bh, bw = max(2, H // 8), max(2, W // 8)
+            y0 = int(rng.integers(0, H - bh + 1))
+            x0 = int(rng.integers(0, W - bw + 1))
+            fb[y0:y0 + bh, x0:x0 + bw, :] = ff_clean[y0:y0 + bh, x0:x0 + bw, :]
+        return fb
+
+    out = {"flows_f": [], "flows_b": []}
+    for t in range(n_pairs):
+        u, v = _clean_np(xx, yy, H, W, amp, phases[t])
+        out["flows_f"].append(noisy(u, v))
+        fb = noisy(-u, -v)
+        out["flows_b"].append(occlude(fb, np.stack([u, v], -1).astype(np.float32)))
+    if stride2:
+        out["flows_f2"], out["flows_b2"] = [], []
+        for t in range(n_pairs - 1):
+            u, v = _clean_np(xx, yy, H, W, amp, phases[t])
+            u2, v2 = _clean_np(xx + u, yy + v, H, W, amp, phases[t + 1])
+            out["flows_f2"].append(noisy(u + u2, v + v2))
+            fb = noisy(-(u + u2), -(v + v2))
+            out["flows_b2"].append(occlude(fb, np.stack([u + u2, v + v2], -1).astype(np.float32)))
+    return out
+
+
+def synth_sequence_torch(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluders=0, stride2=False,
+                         device="cuda"):
+    """Same formula evaluated with torch on `device`.  Returns dict of (n,H,W,2) float32 tensors."""
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    host_rng = np.random.default_rng(seed)
+    n_pairs = n_frames - 1
+    phases = host_rng.uniform(0, 2 * np.pi, size=(n_pairs + 1, 4))
+    ys = torch.arange(H, device=device, dtype=torch.float32)[:, None]
+    xs = torch.arange(W, device=device, dtype=torch.float32)[None, :]
+
+    def clean(xx, yy, ph):
+        u = amp * torch.sin(2 * math.pi * 1.5 * xx / W + ph[0]) * torch.cos(2 * math.pi * yy / H + ph[1])
+        v = amp * torch.cos(2 * math.pi * xx / W + ph[2]) * torch.sin(2 * math.pi * 1.5 * yy / H + ph[3])
+        return u, v
+
+    def noisy(dst, u, v):
+        dst[..., 0] = u
+        dst[..., 1] = v
+        if sigma > 0:
+            dst += sigma * torch.randn(dst.shape, generator=gen, device=device, dtype=torch.float32)
+
+    def occlude(fb, ff):
+        for _ in range(n_occluders):
+            bh, bw = max(2, H // 8), max(2, W // 8)
+            y0 = int(host_rng.integers(0, H - bh + 1))
+            x0 = int(host_rng.integers(0, W - bw + 1))
+            fb[y0:y0 + bh, x0:x0 + bw, :] = ff[y0:y0 + bh, x0:x0 + bw, :]
+
+    out = {"flows_f": torch.empty((n_pairs, H, W, 2), device=device, dtype=torch.float32),
+           "flows_b": torch.empty((n_pairs, H, W, 2), device=device, dtype=torch.float32)}
+    if stride2:
+        out["flows_f2"] = torch.empty((max(n_pairs - 1, 0), H, W, 2), device=device, dtype=torch.float32)
+        out["flows_b2"] = torch.empty((max(n_pairs - 1, 0), H, W, 2), device=device, dtype=torch.float32)
+    for t in range(n_pairs):
+        u, v = clean(xs, ys, phases[t])
+        u, v = u.expand(H, W), v.expand(H, W)
+        noisy(out["flows_f"][t], u, v)
+        noisy(out["flows_b"][t], -u, -v)
+        occlude(out["flows_b"][t], torch.stack([u, v], -1))
+        if stride2 and t < n_pairs - 1:
+            u2, v2 = clean(xs + u, ys + v, phases[t + 1])
+            noisy(out["flows_f2"][t], u + u2, v + v2)
+            noisy(out["flows_b2"][t], -(u + u2), -(v + v2))
+            occlude(out["flows_b2"][t], torch.stack([u + u2, v + v2], -1))
+    return out

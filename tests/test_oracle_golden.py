@@ -1,0 +1,110 @@
+"""Pin the CPU oracle (oracle/psfm_oracle.c) against vectors produced by the reference's own
+Python (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from _common import golden, regen_inputs, assert_csr_equal
+import psfm_synth
+
+
+def test_sampler_bit_exact():
+    g = golden("sampler")
+    rng = np.random.default_rng(int(g["seed"]))
+    H, W = int(g["H"]), int(g["W"])
+    m2 = rng.standard_normal((H, W, 2)).astype(np.float32)
+    m1 = (rng.uniform(size=(H, W)) < 0.3)
+    s2 = orc.grid_sample(m2, g["pts"])
+    s1 = orc.grid_sample(m1.astype(np.float32), g["pts"])
+    assert np.array_equal(s2.view(np.uint32), g["s2"].view(np.uint32))
+    assert np.array_equal(s1.view(np.uint32), g["s1"].view(np.uint32))
+
+
+def test_sampler_1080p_bit_exact():
+    g = golden("sampler")
+    rng = np.random.default_rng(int(g["seed"]))
+    H, W = int(g["H"]), int(g["W"])
+    m2 = rng.standard_normal((H, W, 2)).astype(np.float32)
+    m1 = (rng.uniform(size=(H, W)) < 0.3)
+    # the generator consumed the point draws between the maps: replay them
+    rng.uniform([-3, -3], [W + 2, H + 2], size=(4000, 2))
+    Hb, Wb = int(g["Hb"]), int(g["Wb"])
+    mb = rng.standard_normal((Hb, Wb, 2)).astype(np.float32)
+    assert hashlib.sha256(m2.tobytes() + m1.tobytes() + mb.tobytes()).hexdigest() == str(g["map_hash"])
+    sb = orc.grid_sample(mb, g["pb"])
+    assert np.array_equal(sb.view(np.uint32), g["sb"].view(np.uint32))
+
+
+def test_flow_check_bit_exact():
+    g = golden("flow_check")
+    d = psfm_synth.synth_sequence(4, 64, 96, seed=21, sigma=0.4, n_occluders=2, stride2=False)
+    for thres in (1.0, 3.0):
+        err, occ = orc.flow_check(d["flows_f"], d["flows_b"], thres)
+        assert np.array_equal(np.stack(err).view(np.uint32), g["fc_err_%g" % thres].view(np.uint32))
+        assert np.array_equal(np.packbits(np.stack(occ)), g["fc_occ_%g" % thres])
+    dd = psfm_synth.synth_sequence(3, 40, 56, seed=22, amp=9.0, sigma=0.0, stride2=False)
+    err, occ = orc.flow_check(dd["flows_f"], dd["flows_b"], 1.0)
+    assert np.array_equal(np.stack(err).view(np.uint32), g["big_err"].view(np.uint32))
+    assert np.array_equal(np.packbits(np.stack(occ)), g["big_occ"])
+    assert 0.02 < np.stack(occ).mean() < 0.98
+
+
+@pytest.mark.parametrize("name", ["track_48x64_r2", "track_45x70_r1", "track_50x66_r3", "track_52x61_r4"])
+def test_track_bit_exact(name):
+    g = golden(name)
+    d = regen_inputs(g, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    R = orc.track(d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+
+
+def test_track_all_tracks_die():
+    """SciPy's EDT with no background pixel: the reference respawns every grid point but (0,0)."""
+    g = golden("track_alldie_24x30_r2")
+    d = regen_inputs(g, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    occ = [o.copy() for o in occ]
+    occ[1][:] = True
+    R = orc.track(d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+
+
+@pytest.mark.parametrize("name", ["opt_48x64_r2", "opt_45x70_r3"])
+def test_track_optimize_orchestration(name):
+    """Buffer / index / scale semantics are the reference's (pinned); the solver iterate inside is the
+    C restatement on both sides (parity unpinned w.r.t. real Ceres)."""
+    g = golden(name)
+    d = regen_inputs(g, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    R = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+    assert len(R.solves) == int(g["T"]) - 2
+
+
+def test_solver_properties():
+    """Known-answer style checks of the restated Ceres loop that need no Ceres."""
+    rng = np.random.default_rng(5)
+    H, W, n = 30, 40, 500
+    # constant flow: the objective is an exact linear least squares -> one Gauss-Newton step solves it
+    flow = np.zeros((H, W, 2), np.float32)
+    flow[..., 0], flow[..., 1] = 1.5, -0.5
+    p0 = rng.uniform([5, 5], [W - 6, H - 6], size=(n, 2))
+    ref1 = p0 + [1.5, -0.5]
+    ref2 = p0 + [3.0, -1.0]
+    uv = np.concatenate([ref1, ref2], 1) + rng.normal(0, 0.3, size=(n, 4))
+    s = np.ones(n)
+    out, st = orc.optimize_location(uv, ref1, ref2, s, flow, return_stats=True)
+    # (the dogleg's mu=1e-8 regularisation leaves a ~1e-8 relative remainder per step)
+    assert np.abs(out - np.concatenate([ref1, ref2], 1)).max() < 1e-6
+    assert st["successful_steps"] >= 1 and st["final_cost"] < 1e-12 * st["initial_cost"]
+    # scale = 0 removes the stride-2 term; p1 -> ref1, p2 -> p1 + flow
+    out0 = orc.optimize_location(uv, ref1, ref2 + 7.0, np.zeros(n), flow)
+    assert np.abs(out0[:, :2] - ref1).max() < 1e-6
+    assert np.abs(out0[:, 2:] - (ref1 + [1.5, -0.5])).max() < 1e-6
+    # already optimal input: terminates immediately, returns the input bits
+    exact = np.concatenate([ref1, ref2], 1)
+    out1, st1 = orc.optimize_location(exact, ref1, ref2, s, flow, return_stats=True)
+    assert np.abs(out1 - exact).max() < 1e-12
