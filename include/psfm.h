@@ -1,0 +1,144 @@
+/*
+ * psfm.h -- C ABI of libpsfm_hip.so: the MI355X (gfx950) implementation of
+ * ParticleSfM's point-trajectory hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one interface of the
+ * reference (paths relative to the reference root, bytedance/particle-sfm):
+ *
+ *   psfm_flow_check         point_trajectory/utils.py:94-105        flow_check()
+ *   psfm_grid_sample        point_trajectory/trajectory.py:25-37    grid_sample()
+ *   psfm_optimize_location  point_trajectory/optimize/src/trajectory_optimize.cpp:30-96
+ *                           (pybind entry: optimize/src/bindings.cc:31)
+ *   psfm_track              point_trajectory/track.py:24-50          track()
+ *                           point_trajectory/track_optimize.py:24-53 track_optimize()
+ *                           (+ the IncrementalTrajectorySet / Trajectory bookkeeping they
+ *                           drive: trajectory.py:98-194, optimize/src/trajectory_base.cpp:21-93)
+ *   psfm_result_*           the list of Trajectory objects those functions return and the
+ *                           id / min-length rule of main_connect_point_trajectories.py:56-60
+ *
+ * Conventions
+ *   - plain C, no C++/torch types.  Every data pointer is a DEVICE pointer
+ *     (HBM of the context's GPU) unless the name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Kernels are
+ *     enqueued on it; calls that must learn a data-dependent size (psfm_track) synchronise
+ *     that stream before returning.
+ *   - every function returns a psfm_status; on failure psfm_last_error() (thread local)
+ *     describes it.  Nothing throws across this boundary and there is no CPU fallback:
+ *     without a GPU every compute entry point fails with PSFM_ERR_HIP.
+ *   - a psfm_ctx owns the device workspace (trajectory log, lane tables, results); it is
+ *     not thread-safe, use one per host thread / stream.  No hidden global state.
+ */
+#ifndef PSFM_H_
+#define PSFM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSFM_VERSION 100
+
+typedef enum psfm_status {
+    PSFM_OK = 0,
+    PSFM_ERR_ARG = 1,       /* bad argument */
+    PSFM_ERR_HIP = 2,       /* HIP runtime error (no device, OOM, launch failure) */
+    PSFM_ERR_CAPACITY = 3,  /* lane / trajectory tables too small: raise psfm_ctx_set_capacity and retry */
+    PSFM_ERR_SOLVER = 4     /* the trust-region solver reported failure (Ceres would return FAILURE) */
+} psfm_status;
+
+typedef struct psfm_ctx psfm_ctx;
+
+/* Termination codes of the path-consistency solve (Ceres 2.0.0 TerminationType detail). */
+enum {
+    PSFM_TERM_FUNCTION_TOL = 0,
+    PSFM_TERM_PARAMETER_TOL = 1,
+    PSFM_TERM_GRADIENT_TOL = 2,
+    PSFM_TERM_MAX_ITER = 3,
+    PSFM_TERM_MIN_RADIUS = 4,
+    PSFM_TERM_FAILURE = 5
+};
+
+typedef struct psfm_solve_stats {
+    int32_t iterations;        /* trust-region iterations (excluding iteration 0) */
+    int32_t successful_steps;
+    int32_t termination;       /* PSFM_TERM_* */
+    int32_t dogleg_nonGN;      /* iterations whose step was not the pure Gauss-Newton step */
+    double initial_cost;
+    double final_cost;
+} psfm_solve_stats;
+
+typedef struct psfm_track_info {
+    int64_t n_traj;            /* all trajectories, index == id (full_trajs order) */
+    int64_t n_points;          /* sum of their lengths */
+    int64_t n_lanes_peak;      /* peak number of lanes used (<= lane capacity) */
+    int64_t lane_capacity;
+    int64_t solver_iterations; /* total trust-region iterations over all frames (track_optimize) */
+    int32_t n_solves;
+    int32_t reserved;
+} psfm_track_info;
+
+const char* psfm_last_error(void);
+int psfm_version(void);
+
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int psfm_device_count(void);
+
+psfm_status psfm_ctx_create(int device, psfm_ctx** out);
+psfm_status psfm_ctx_destroy(psfm_ctx* ctx);
+
+/* Lane table = lane_factor * (grid points); finished-trajectory table = traj_factor * (grid points).
+ * Defaults 2.0 / 8.0.  psfm_track returns PSFM_ERR_CAPACITY when either overflows. */
+psfm_status psfm_ctx_set_capacity(psfm_ctx* ctx, double lane_factor, double traj_factor);
+
+/* utils.py:94-105.  flows_f, flows_b: (n_pairs,H,W,2) f32 stacks in the .flo-native interleaved
+ * layout.  occ_out: (n_pairs,H,W) u8 0/1.  err_out: (n_pairs,H,W) f32 or NULL (the reference
+ * pipeline never consumes it).  Bit-exact with the reference's torch-CPU arithmetic. */
+psfm_status psfm_flow_check(psfm_ctx* ctx, const float* flows_f, const float* flows_b, int n_pairs, int h,
+                            int w, float thres, uint8_t* occ_out, float* err_out, void* stream);
+
+/* trajectory.py:25-37 on an (H,W,C) f32 map, C in {1,2}; xy: (n,2) f64; out: (n,C) f32. */
+psfm_status psfm_grid_sample(psfm_ctx* ctx, const float* map_hwc, int c, int h, int w, const double* xy,
+                             int64_t n, float* out, void* stream);
+
+/* trajectory_optimize.cpp:30-96.  uv12 (n,4), ref1 (n,2), ref2 (n,2), scale (n), out (n,4): f64;
+ * flow12: (H,W,2) f32 (the f64 force-cast of the reference is exact).  stats_host may be NULL.
+ * Synchronises `stream` (the iteration count is data dependent). */
+psfm_status psfm_optimize_location(psfm_ctx* ctx, const double* uv12, const double* ref1, const double* ref2,
+                                   const double* scale, const float* flow12, int64_t n, int w, int h,
+                                   double* out, psfm_solve_stats* stats_host, void* stream);
+
+/* track.py:24-50 when flows_f2 == NULL, track_optimize.py:24-53 otherwise.
+ *   flows    (n_flows,H,W,2) f32      occ     (n_flows,H,W) u8
+ *   flows_f2 (n_flows-1,H,W,2) f32    occ_s2  (n_flows-1,H,W) u8        (stride-2 stacks)
+ * Runs the whole frame recurrence and the id assignment on the device; the result stays in the
+ * context (HBM) until the next psfm_track on it.  info_host may be NULL.  Synchronises `stream`. */
+psfm_status psfm_track(psfm_ctx* ctx, const float* flows, const uint8_t* occ, const float* flows_f2,
+                       const uint8_t* occ_s2, int n_flows, int h, int w, int sample_ratio,
+                       psfm_track_info* info_host, void* stream);
+
+/* Device-resident result of the last psfm_track: CSR over trajectories in id order.
+ *   birth (n_traj) i32 first frame; len (n_traj) i32; off (n_traj+1) i64; xy (n_points,2) f64.
+ * Trajectory i has times birth[i] .. birth[i]+len[i]-1 and points xy[off[i] .. off[i+1]). */
+psfm_status psfm_result_device(psfm_ctx* ctx, const int32_t** birth, const int32_t** len,
+                               const int64_t** off, const double** xy);
+
+/* Copy the result into caller-provided HOST buffers (any may be NULL to skip). */
+psfm_status psfm_result_copy(psfm_ctx* ctx, int32_t* birth_host, int32_t* len_host, int64_t* off_host,
+                             double* xy_host, void* stream);
+
+/* Per-solve statistics of the last psfm_track (track_optimize mode): up to `max_n` entries. */
+psfm_status psfm_result_solve_stats(psfm_ctx* ctx, psfm_solve_stats* stats_host, int32_t max_n,
+                                    int32_t* n_out);
+
+/* Per-kernel device time of the last psfm_track / psfm_flow_check when profiling is enabled with
+ * psfm_ctx_set_profiling(ctx, 1): HIP events recorded on the launch stream around every launch of
+ * the named kernel family.  kind: 0 flow_check, 1 chain_step, 2 respawn, 3 solver, 4 finalize.
+ * Returns the accumulated milliseconds and the number of launches. */
+psfm_status psfm_ctx_set_profiling(psfm_ctx* ctx, int enable);
+psfm_status psfm_profile_get(psfm_ctx* ctx, int kind, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSFM_H_ */

@@ -1,0 +1,330 @@
+// psfm_api.hip -- the extern "C" boundary declared in include/psfm.h: context, workspace, frame loop.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "psfm_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void psfm_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* psfm_last_error(void) { return g_err; }
+extern "C" int psfm_version(void) { return PSFM_VERSION; }
+
+extern "C" int psfm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+psfm_status PsfmBuf::ensure(size_t need)
+{
+    if (need <= bytes) return PSFM_OK;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    // round up so slightly different sequence lengths do not reallocate
+    size_t want = (need + (size_t)(1 << 20) - 1) & ~((size_t)(1 << 20) - 1);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        psfm_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return PSFM_ERR_HIP;
+    }
+    bytes = want;
+    return PSFM_OK;
+}
+
+void PsfmBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+// ---- profiler: HIP events on the launch stream around each kernel family -----------------------
+hipEvent_t PsfmProfiler::get()
+{
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void PsfmProfiler::begin(int kind, hipStream_t s)
+{
+    if (!enabled) return;
+    Span sp; sp.kind = kind; sp.a = get(); sp.b = get();
+    (void)hipEventRecord(sp.a, s);
+    spans.push_back(sp);
+}
+void PsfmProfiler::end(hipStream_t s)
+{
+    if (!enabled) return;
+    (void)hipEventRecord(spans.back().b, s);
+}
+void PsfmProfiler::collect()
+{
+    for (auto& sp : spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { total_ms[sp.kind] += ms; launches[sp.kind]++; }
+        pool.push_back(sp.a); pool.push_back(sp.b);
+    }
+    spans.clear();
+}
+void PsfmProfiler::reset()
+{
+    for (int k = 0; k < PSFM_PROF_KINDS; ++k) { total_ms[k] = 0; launches[k] = 0; }
+}
+void PsfmProfiler::destroy()
+{
+    collect();
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+}
+
+extern "C" psfm_status psfm_ctx_create(int device, psfm_ctx** out)
+{
+    if (!out) { psfm_set_error("psfm_ctx_create: out is NULL"); return PSFM_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        psfm_set_error("no HIP device available (%s); libpsfm_hip has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return PSFM_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { psfm_set_error("device %d out of range [0,%d)", device, n); return PSFM_ERR_ARG; }
+    PSFM_HIP(hipSetDevice(device));
+    psfm_ctx* c = new psfm_ctx();
+    c->device = device;
+    c->host_pinned_bytes = 512 + sizeof(PsfmShard) * PSFM_NSHARD + 4096;
+    e = hipHostMalloc(&c->host_pinned, c->host_pinned_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { delete c; psfm_set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return PSFM_ERR_HIP; }
+    *out = c;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
+{
+    if (!c) return PSFM_OK;
+    (void)hipSetDevice(c->device);
+    PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
+                       &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
+                       &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
+                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc};
+    for (auto b : bufs) b->release();
+    c->prof.destroy();
+    if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    delete c;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_ctx_set_capacity(psfm_ctx* c, double lane_factor, double traj_factor)
+{
+    if (!c || !(lane_factor >= 1.0) || !(traj_factor >= 1.0)) { psfm_set_error("psfm_ctx_set_capacity: factors must be >= 1"); return PSFM_ERR_ARG; }
+    c->lane_factor = lane_factor;
+    c->traj_factor = traj_factor;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_ctx_set_profiling(psfm_ctx* c, int enable)
+{
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    c->prof.enabled = enable != 0;
+    c->prof.collect();
+    c->prof.reset();
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_profile_get(psfm_ctx* c, int kind, double* total_ms, int64_t* launches)
+{
+    if (!c || kind < 0 || kind >= PSFM_PROF_KINDS) { psfm_set_error("psfm_profile_get: bad argument"); return PSFM_ERR_ARG; }
+    if (total_ms) *total_ms = c->prof.total_ms[kind];
+    if (launches) *launches = c->prof.launches[kind];
+    return PSFM_OK;
+}
+
+#define PSFM_CHECK_CTX(c)                                                     \
+    do {                                                                      \
+        if (!(c)) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }     \
+        PSFM_HIP(hipSetDevice((c)->device));                                  \
+    } while (0)
+
+extern "C" psfm_status psfm_flow_check(psfm_ctx* c, const float* flows_f, const float* flows_b, int n_pairs, int h, int w,
+                                       float thres, uint8_t* occ_out, float* err_out, void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    if (n_pairs < 0 || h < 2 || w < 2 || (n_pairs > 0 && (!flows_f || !flows_b || !occ_out))) {
+        psfm_set_error("psfm_flow_check: bad argument (n_pairs=%d h=%d w=%d)", n_pairs, h, w);
+        return PSFM_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    c->prof.begin(PSFM_PROF_FLOW_CHECK, s);
+    psfm_status st = psfm_launch_flow_check(flows_f, flows_b, n_pairs, h, w, thres, occ_out, err_out, s);
+    c->prof.end(s);
+    return st;
+}
+
+extern "C" psfm_status psfm_grid_sample(psfm_ctx* c, const float* map_hwc, int ch, int h, int w, const double* xy,
+                                        int64_t n, float* out, void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    if ((ch != 1 && ch != 2) || h < 2 || w < 2 || n < 0 || (n > 0 && (!map_hwc || !xy || !out))) {
+        psfm_set_error("psfm_grid_sample: bad argument (c=%d h=%d w=%d n=%lld)", ch, h, w, (long long)n);
+        return PSFM_ERR_ARG;
+    }
+    return psfm_launch_grid_sample(map_hwc, ch, h, w, xy, n, out, (hipStream_t)stream);
+}
+
+extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
+                                              const double* scale, const float* flow12, int64_t n, int w, int h,
+                                              double* out, psfm_solve_stats* stats_host, void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
+        psfm_set_error("psfm_optimize_location: bad argument (n=%lld h=%d w=%d)", (long long)n, h, w);
+        return PSFM_ERR_ARG;
+    }
+    psfm_solve_stats st;
+    memset(&st, 0, sizeof(st));
+    hipStream_t s = (hipStream_t)stream;
+    c->prof.begin(PSFM_PROF_SOLVER, s);
+    psfm_status rc = psfm_solve_batch(c, uv12, ref1, ref2, scale, flow12, n, w, h, out, &st, s);
+    c->prof.end(s);
+    if (stats_host) *stats_host = st;
+    return rc;
+}
+
+extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t* occ, const float* flows_f2,
+                                  const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
+                                  void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    const bool optimize = flows_f2 != nullptr;
+    if (n_flows < 1 || h < 2 || w < 2 || ratio < 1 || !flows || !occ || (optimize && !occ_s2 && n_flows > 1)) {
+        psfm_set_error("psfm_track: bad argument (n_flows=%d h=%d w=%d ratio=%d)", n_flows, h, w, ratio);
+        return PSFM_ERR_ARG;
+    }
+    if (ratio > 64) { psfm_set_error("psfm_track: sample_ratio %d > 64 unsupported", ratio); return PSFM_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    PsfmTrackDims d;
+    d.H = h; d.W = w; d.ratio = ratio; d.n_flows = n_flows;
+    d.GW = (w + ratio - 1) / ratio; d.GH = (h + ratio - 1) / ratio;   // trajectory.py:110-115
+    d.G = (int64_t)d.GW * d.GH;
+    d.cap = (int64_t)(c->lane_factor * (double)d.G);
+    d.cap = ((d.cap + 255) / 256) * 256;
+    const int64_t n_blocks = d.cap / 256;
+    d.free_cap = (int)(((n_blocks + PSFM_NSHARD - 1) / PSFM_NSHARD) * 256);
+    // records are spread over PSFM_NSHARD slices by block index: give every slice head-room
+    d.shard_cap = (int)(((int64_t)(c->traj_factor * (double)d.G) + d.cap) / PSFM_NSHARD) + 1024;
+    d.traj_cap = (int64_t)d.shard_cap * PSFM_NSHARD;
+    if (d.cap > 0x7fffffff / 2 || d.traj_cap > 0x7fffffff / 2) { psfm_set_error("psfm_track: grid too large"); return PSFM_ERR_ARG; }
+    d.shift_b = 1; while ((1ll << d.shift_b) < d.G) ++d.shift_b;
+    int tbits = 1; while ((1ll << tbits) < (long long)n_flows + 2) ++tbits;
+    d.shift_d = d.shift_b + tbits;
+    if (d.shift_d + tbits > 63) { psfm_set_error("psfm_track: key does not fit 64 bits"); return PSFM_ERR_ARG; }
+    d.cw = (float)((double)(w - 1) / 2.0); d.ch = (float)((double)(h - 1) / 2.0);
+
+    psfm_status st;
+    const int64_t P = (int64_t)h * w;
+    if ((st = c->log.ensure(sizeof(double2) * (size_t)(n_flows + 1) * d.cap)) != PSFM_OK) return st;
+    if ((st = c->birth_frame.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
+    if ((st = c->birth_idx.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
+    if ((st = c->free_stack.ensure(sizeof(int) * (size_t)d.free_cap * PSFM_NSHARD)) != PSFM_OK) return st;
+    if ((st = c->shards.ensure(sizeof(PsfmShard) * PSFM_NSHARD)) != PSFM_OK) return st;
+    if ((st = c->fin_keys.ensure(sizeof(unsigned long long) * d.traj_cap)) != PSFM_OK) return st;
+    if ((st = c->fin_lanes.ensure(sizeof(int) * d.traj_cap)) != PSFM_OK) return st;
+    if ((st = c->occupied.ensure((size_t)P)) != PSFM_OK) return st;
+    if ((st = c->counters.ensure(sizeof(PsfmCounters))) != PSFM_OK) return st;
+    if ((st = c->survivors.ensure(sizeof(int) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
+
+    c->solve_stats.clear();
+    c->res_n_traj = c->res_n_points = 0;
+    if ((st = psfm_launch_track_init(c, d, s)) != PSFM_OK) return st;
+    int64_t total_iters = 0;
+    for (int f = 0; f < n_flows; ++f) {
+        // track.py:31-47 / track_optimize.py:31-50, one loop iteration
+        c->prof.begin(PSFM_PROF_CHAIN, s);
+        st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * P, f, s);
+        c->prof.end(s);
+        if (st != PSFM_OK) return st;
+        if (f + 1 < n_flows) {   // births for frame f+1 exist only if another loop iteration follows
+            c->prof.begin(PSFM_PROF_RESPAWN, s);
+            st = psfm_launch_respawn(c, d, f, s);
+            c->prof.end(s);
+            if (st != PSFM_OK) return st;
+        }
+        if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
+            psfm_solve_stats ss;
+            memset(&ss, 0, sizeof(ss));
+            c->prof.begin(PSFM_PROF_SOLVER, s);
+            st = psfm_solve_frame(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
+                                  flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f, &ss, s);
+            c->prof.end(s);
+            if (st != PSFM_OK) return st;
+            c->solve_stats.push_back(ss);
+            total_iters += ss.iterations;
+        }
+    }
+    c->prof.begin(PSFM_PROF_FINALIZE, s);
+    st = psfm_finalize(c, d, s);
+    c->prof.end(s);
+    if (st != PSFM_OK) return st;
+    PSFM_HIP(hipStreamSynchronize(s));
+    c->prof.collect();
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->n_traj = c->res_n_traj;
+        info->n_points = c->res_n_points;
+        info->n_lanes_peak = ((PsfmCounters*)c->host_pinned)->n_lanes;
+        info->lane_capacity = d.cap;
+        info->solver_iterations = total_iters;
+        info->n_solves = (int32_t)c->solve_stats.size();
+    }
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_result_device(psfm_ctx* c, const int32_t** birth, const int32_t** len, const int64_t** off,
+                                          const double** xy)
+{
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    if (birth) *birth = c->res_birth.as<int32_t>();
+    if (len) *len = c->res_len.as<int32_t>();
+    if (off) *off = c->res_off.as<int64_t>();
+    if (xy) *xy = c->res_xy.as<double>();
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_result_copy(psfm_ctx* c, int32_t* birth_host, int32_t* len_host, int64_t* off_host,
+                                        double* xy_host, void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = c->res_n_traj, np = c->res_n_points;
+    if (n > 0) {
+        if (birth_host) PSFM_HIP(hipMemcpyAsync(birth_host, c->res_birth.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+        if (len_host) PSFM_HIP(hipMemcpyAsync(len_host, c->res_len.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+        if (off_host) PSFM_HIP(hipMemcpyAsync(off_host, c->res_off.p, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, s));
+        if (xy_host && np > 0) PSFM_HIP(hipMemcpyAsync(xy_host, c->res_xy.p, sizeof(double) * 2 * np, hipMemcpyDeviceToHost, s));
+    } else if (off_host) {
+        off_host[0] = 0;
+    }
+    PSFM_HIP(hipStreamSynchronize(s));
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_result_solve_stats(psfm_ctx* c, psfm_solve_stats* stats_host, int32_t max_n, int32_t* n_out)
+{
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    const int32_t n = (int32_t)c->solve_stats.size();
+    if (n_out) *n_out = n;
+    if (stats_host) for (int32_t i = 0; i < n && i < max_n; ++i) stats_host[i] = c->solve_stats[i];
+    return PSFM_OK;
+}

@@ -1,0 +1,216 @@
+// psfm_finalize.hip -- K7: trajectory ids, lengths and the id-ordered CSR result.
+//
+// Reference semantics: full_trajs lists, for every step f ascending, the tracks that
+// failed at f in active-list order, then all still-active tracks (trajectory.py:138-147,154-158); the
+// active list is always sorted by (birth_frame, birth grid index).  Hence
+//     id = rank under the key (last_valid_time, birth_frame, birth_grid_index)
+// and the saved id is that rank (main_connect_point_trajectories.py:56-60).  The frame loop recorded one
+// (key, lane) pair per finished track; here the survivors are appended, the pairs are radix-sorted by
+// key (rocPRIM device radix sort on the used key bits only), lengths are scanned into offsets, and the
+// frame-major log is transposed into a track-major (n_points,2) f64 array through LDS tiles so that
+// both the slab reads (consecutive lanes) and the result writes (consecutive times) are coalesced.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "psfm_device.h"
+#include "psfm_internal.h"
+
+#define PSFM_BLOCK 256
+
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_kernel(
+    const int* __restrict__ birth_frame, const int* __restrict__ birth_idx, PsfmCounters* __restrict__ ctr,
+    PsfmShard* __restrict__ shards, unsigned long long* __restrict__ fin_keys, int* __restrict__ fin_lanes, int cap,
+    int shard_cap, int last_time, int shift_b, int shift_d)
+{
+    __shared__ int s_cnt[PSFM_BLOCK / PSFM_WAVE];
+    __shared__ int s_base;
+    const int n_lanes = min(ctr->n_lanes, cap);
+    if ((int)(blockIdx.x * PSFM_BLOCK) >= n_lanes) return;
+    const int i = blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    int bf = -1;
+    if (i < n_lanes) bf = birth_frame[i];
+    const bool alive = bf >= 0;
+    const unsigned long long am = __ballot(alive);
+    const int lane = psfm_lane_id(), wave = threadIdx.x / PSFM_WAVE;
+    if (lane == 0) s_cnt[wave] = __popcll(am);
+    __syncthreads();
+    const int shard = blockIdx.x % PSFM_NSHARD;
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) tot += s_cnt[w];
+        s_base = tot > 0 ? atomicAdd(&shards[shard].fin_cnt, tot) : 0;
+    }
+    __syncthreads();
+    if (alive) {
+        int r = s_base + psfm_rank_in(am);
+        for (int w = 0; w < wave; ++w) r += s_cnt[w];
+        if (r < shard_cap) {
+            const int64_t o = (int64_t)shard * shard_cap + r;
+            fin_keys[o] = ((unsigned long long)last_time << shift_d) | ((unsigned long long)bf << shift_b) |
+                          (unsigned long long)birth_idx[i];
+            fin_lanes[o] = i;
+        } else {
+            atomicOr(&ctr->overflow, 2);
+        }
+    }
+}
+
+// gather the per-shard record slices into one contiguous (key, lane) array for the sort
+struct PsfmShardOffsets { int count[PSFM_NSHARD]; int64_t start[PSFM_NSHARD]; };
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_compact_shards_kernel(
+    const unsigned long long* __restrict__ fin_keys, const int* __restrict__ fin_lanes, int shard_cap,
+    PsfmShardOffsets so, unsigned long long* __restrict__ keys, int* __restrict__ lanes)
+{
+    const int shard = blockIdx.y;
+    const int n = so.count[shard];
+    for (int i = blockIdx.x * PSFM_BLOCK + threadIdx.x; i < n; i += gridDim.x * PSFM_BLOCK) {
+        keys[so.start[shard] + i] = fin_keys[(int64_t)shard * shard_cap + i];
+        lanes[so.start[shard] + i] = fin_lanes[(int64_t)shard * shard_cap + i];
+    }
+}
+
+// sorted record i (== trajectory id) -> birth, length (i32) and length as i64 for the offset scan
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_decode_kernel(const unsigned long long* __restrict__ keys, int64_t n,
+                                                                 int shift_b, int shift_d, int* __restrict__ birth,
+                                                                 int* __restrict__ len, int64_t* __restrict__ len64)
+{
+    const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { len64[i] = 0; return; }
+    const unsigned long long k = keys[i];
+    const int last = (int)(k >> shift_d);
+    const int b = (int)((k >> shift_b) & ((1ull << (shift_d - shift_b)) - 1ull));
+    birth[i] = b;
+    len[i] = last - b + 1;
+    len64[i] = (int64_t)(last - b + 1);
+}
+
+// Transpose gather: a block owns TILE_J consecutive ids and walks time in chunks of TILE_K steps.
+#define TILE_J 64
+#define TILE_K 32
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* __restrict__ log, int64_t cap,
+                                                                 const int* __restrict__ lanes,
+                                                                 const int* __restrict__ birth,
+                                                                 const int* __restrict__ len,
+                                                                 const int64_t* __restrict__ off, int64_t n,
+                                                                 double2* __restrict__ out)
+{
+    __shared__ double2 tile[TILE_J][TILE_K + 1];
+    __shared__ int s_lane[TILE_J], s_birth[TILE_J], s_len[TILE_J];
+    __shared__ int64_t s_off[TILE_J];
+    __shared__ int s_maxlen;
+    const int tid = threadIdx.x;
+    const int64_t id0 = (int64_t)blockIdx.x * TILE_J;
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (tid < TILE_J) {
+        const int64_t id = id0 + tid;
+        const bool ok = id < n;
+        s_lane[tid] = ok ? lanes[id] : 0;
+        s_birth[tid] = ok ? birth[id] : 0;
+        s_len[tid] = ok ? len[id] : 0;
+        s_off[tid] = ok ? off[id] : 0;
+        if (ok) atomicMax(&s_maxlen, s_len[tid]);
+    }
+    __syncthreads();
+    const int maxlen = s_maxlen;
+    const int j = tid & (TILE_J - 1);   // track within the tile (read phase: lanes fastest)
+    const int q = tid / TILE_J;         // 0..3
+    for (int k0 = 0; k0 < maxlen; k0 += TILE_K) {
+        // read: for a fixed time, 64 consecutive ids -> (mostly) consecutive lanes of one slab
+        const int lj = s_len[j];
+        const int64_t col = s_lane[j];
+        const int bj = s_birth[j];
+        for (int k = q; k < TILE_K; k += PSFM_BLOCK / TILE_J) {
+            const int t = k0 + k;
+            if (t < lj) tile[j][k] = log[(int64_t)(bj + t) * cap + col];
+        }
+        __syncthreads();
+        // write: for a fixed track, TILE_K consecutive times -> contiguous run of the result
+        const int kk = tid & (TILE_K - 1);
+        for (int jj = tid / TILE_K; jj < TILE_J; jj += PSFM_BLOCK / TILE_K) {
+            const int t = k0 + kk;
+            if (t < s_len[jj]) out[s_off[jj] + t] = tile[jj][kk];
+        }
+        __syncthreads();
+    }
+}
+
+psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
+{
+    PsfmCounters* ctr = c->counters.as<PsfmCounters>();
+    PsfmShard* shards = c->shards.as<PsfmShard>();
+    // 1. survivors -> records with last_valid_time = n_flows
+    hipLaunchKernelGGL(psfm_collect_alive_kernel, dim3((unsigned)((d.cap + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
+                       0, s, c->birth_frame.as<int>(), c->birth_idx.as<int>(), ctr, shards,
+                       c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), (int)d.cap, d.shard_cap,
+                       d.n_flows, d.shift_b, d.shift_d);
+    PSFM_HIP(hipGetLastError());
+    PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
+    PsfmShard* hs = (PsfmShard*)((char*)c->host_pinned + 512);
+    PSFM_HIP(hipMemcpyAsync(hc, ctr, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipMemcpyAsync(hs, shards, sizeof(PsfmShard) * PSFM_NSHARD, hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    PsfmShardOffsets so;
+    int64_t n = 0;
+    bool over = hc->overflow != 0;
+    for (int k = 0; k < PSFM_NSHARD; ++k) {
+        if (hs[k].fin_cnt > d.shard_cap) over = true;
+        so.count[k] = hs[k].fin_cnt > d.shard_cap ? d.shard_cap : hs[k].fin_cnt;
+        so.start[k] = n;
+        n += so.count[k];
+    }
+    if (over || hc->n_lanes > d.cap) {
+        psfm_set_error("capacity exceeded: lanes used %d of %lld, trajectory records %lld of %lld (%d shards); "
+                       "raise psfm_ctx_set_capacity", hc->n_lanes, (long long)d.cap, (long long)n,
+                       (long long)d.traj_cap, PSFM_NSHARD);
+        return PSFM_ERR_CAPACITY;
+    }
+    c->res_n_traj = n;
+    c->res_n_points = 0;
+    if (n == 0) return PSFM_OK;
+    // 2. compact the shards, then sort (key, lane) by key over the used bits
+    psfm_status st;
+    if ((st = c->sort_keys.ensure(sizeof(unsigned long long) * n * 2)) != PSFM_OK) return st;
+    if ((st = c->sort_lanes.ensure(sizeof(int) * n * 2)) != PSFM_OK) return st;
+    unsigned long long* k_in = c->sort_keys.as<unsigned long long>() + n;
+    unsigned long long* k_out = c->sort_keys.as<unsigned long long>();
+    int* l_in = c->sort_lanes.as<int>() + n;
+    int* l_out = c->sort_lanes.as<int>();
+    hipLaunchKernelGGL(psfm_compact_shards_kernel, dim3(64, PSFM_NSHARD), dim3(PSFM_BLOCK), 0, s,
+                       c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), d.shard_cap, so, k_in, l_in);
+    PSFM_HIP(hipGetLastError());
+    int tbits = 1;
+    while ((1ll << tbits) < (long long)d.n_flows + 2) ++tbits;
+    const unsigned end_bit = (unsigned)(d.shift_d + tbits);
+    size_t tmp_bytes = 0, scan_bytes = 0;
+    PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+    PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
+                                     (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+    if ((st = c->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
+    PSFM_HIP(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+    // 3. decode + offsets
+    if ((st = c->res_birth.ensure(sizeof(int) * n)) != PSFM_OK) return st;
+    if ((st = c->res_len.ensure(sizeof(int) * n)) != PSFM_OK) return st;
+    if ((st = c->res_off.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
+    if ((st = c->scan_tmp.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
+    hipLaunchKernelGGL(psfm_decode_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
+                       c->sort_keys.as<unsigned long long>(), n, d.shift_b, d.shift_d, c->res_birth.as<int>(),
+                       c->res_len.as<int>(), c->scan_tmp.as<int64_t>());
+    PSFM_HIP(hipGetLastError());
+    PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->res_off.as<int64_t>(),
+                                     (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+    int64_t* hn = (int64_t*)((char*)c->host_pinned + 256);   // (counters at +0, shards at +512)
+    PSFM_HIP(hipMemcpyAsync(hn, c->res_off.as<int64_t>() + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    const int64_t npts = *hn;
+    c->res_n_points = npts;
+    // 4. transpose the frame-major log into the id-ordered CSR
+    if ((st = c->res_xy.ensure(sizeof(double2) * (size_t)(npts > 0 ? npts : 1))) != PSFM_OK) return st;
+    hipLaunchKernelGGL(psfm_gather_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
+                       c->log.as<double2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
+                       c->res_len.as<int>(), c->res_off.as<int64_t>(), n, c->res_xy.as<double2>());
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}

@@ -1,0 +1,125 @@
+// psfm_internal.h -- host-side context and launcher prototypes (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/psfm.h"
+
+void psfm_set_error(const char* fmt, ...);
+
+#define PSFM_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            psfm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PSFM_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+// grow-only device buffer
+struct PsfmBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    psfm_status ensure(size_t need);
+    void release();
+    template <class T> T* as() const { return (T*)p; }
+};
+
+// Device-side counters of the frame recurrence (one cache line, zeroed at init).
+struct PsfmCounters {
+    int n_lanes;      // lanes ever handed out (high-water mark); chain_step scans [0, n_lanes)
+    int overflow;     // bit0: lane table full, bit1: trajectory table full
+    int pad[14];
+};
+
+// Death records and free lanes are published through PSFM_NSHARD independent tables so that the
+// per-block atomics land on different words (a single word saturates at ~88 atomics/us on MI355X).
+#define PSFM_NSHARD 64
+struct PsfmShard {
+    int fin_cnt;      // trajectory records written into this shard's slice
+    int pad0[31];
+    int free_top;     // top of this shard's free-lane stack
+    int pad1[31];
+};
+
+enum { PSFM_PROF_FLOW_CHECK = 0, PSFM_PROF_CHAIN = 1, PSFM_PROF_RESPAWN = 2, PSFM_PROF_SOLVER = 3,
+       PSFM_PROF_FINALIZE = 4, PSFM_PROF_KINDS = 5 };
+
+struct PsfmProfiler {
+    bool enabled = false;
+    struct Span { int kind; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    double total_ms[PSFM_PROF_KINDS] = {0};
+    int64_t launches[PSFM_PROF_KINDS] = {0};
+    hipEvent_t get();
+    void begin(int kind, hipStream_t s);
+    void end(hipStream_t s);
+    void collect();  // after a stream sync: fold spans into totals
+    void reset();
+    void destroy();
+};
+
+// Device control block of the path-consistency solver (written by the last block of each kernel).
+struct PsfmSolveCtrl;
+
+struct psfm_ctx {
+    int device = 0;
+    double lane_factor = 2.0, traj_factor = 8.0;
+    // frame recurrence workspace
+    PsfmBuf log;          // (n_flows+1) x cap double2
+    PsfmBuf birth_frame;  // cap i32, -1 = free lane
+    PsfmBuf birth_idx;    // cap i32
+    PsfmBuf free_stack;   // cap i32
+    PsfmBuf fin_keys;     // traj_cap u64
+    PsfmBuf fin_lanes;    // traj_cap i32
+    PsfmBuf occupied;     // H*W u8 (frame-stamped)
+    PsfmBuf counters;     // PsfmCounters
+    PsfmBuf shards;       // PSFM_NSHARD x PsfmShard
+    PsfmBuf survivors;    // (n_flows+1) i32
+    // finalize workspace + result
+    PsfmBuf sort_keys, sort_lanes, sort_tmp, scan_tmp;
+    PsfmBuf res_birth, res_len, res_off, res_xy;
+    int64_t res_n_traj = 0, res_n_points = 0;
+    // solver workspace
+    PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc;
+    std::vector<psfm_solve_stats> solve_stats;
+    PsfmProfiler prof;
+    void* host_pinned = nullptr;  // small pinned staging block
+    size_t host_pinned_bytes = 0;
+};
+
+// ---- launchers (psfm_track.hip) -------------------------------------------------------------
+psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs, int h, int w, float thres,
+                                   uint8_t* occ, float* err, hipStream_t s);
+psfm_status psfm_launch_grid_sample(const float* map, int c, int h, int w, const double* xy, int64_t n,
+                                    float* out, hipStream_t s);
+
+struct PsfmTrackDims {
+    int H, W, ratio, GW, GH, n_flows;
+    int64_t G, cap, traj_cap;
+    int shard_cap;          // trajectory records per shard (traj_cap = PSFM_NSHARD * shard_cap)
+    int free_cap;           // free-lane stack entries per shard
+    int shift_b, shift_d;   // key = death<<shift_d | birth<<shift_b | grid index
+    float cw, ch;
+};
+
+psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
+psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
+                                   int frame, hipStream_t s);
+psfm_status psfm_launch_respawn(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
+
+// ---- finalize (psfm_finalize.hip) -----------------------------------------------------------
+psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
+
+// ---- solver (psfm_solver.hip) ---------------------------------------------------------------
+// In-place solve on the trajectory log for frame index f (positions at f-1, f, f+1).
+psfm_status psfm_solve_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                             const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
+                             hipStream_t s);
+// Batch API form (psfm_optimize_location).
+psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
+                             const double* scale, const float* flow12, int64_t n, int w, int h, double* out,
+                             psfm_solve_stats* st, hipStream_t s);

@@ -1,0 +1,152 @@
+"""ctypes binding of libpsfm_hip.so (include/psfm.h).
+
+The HIP library is the product; there is NO CPU fallback.  If the library is missing, or there is
+no GPU, every compute entry point raises -- loudly -- instead of silently computing elsewhere.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("PSFM_HIP_LIB", os.path.join(_PKG, "lib", "libpsfm_hip.so"))
+
+PSFM_OK, PSFM_ERR_ARG, PSFM_ERR_HIP, PSFM_ERR_CAPACITY, PSFM_ERR_SOLVER = 0, 1, 2, 3, 4
+PROF_KINDS = {"flow_check": 0, "chain_step": 1, "respawn": 2, "solver": 3, "finalize": 4}
+
+EXPORTS = [
+    "psfm_last_error", "psfm_version", "psfm_device_count", "psfm_ctx_create", "psfm_ctx_destroy",
+    "psfm_ctx_set_capacity", "psfm_flow_check", "psfm_grid_sample", "psfm_optimize_location", "psfm_track",
+    "psfm_result_device", "psfm_result_copy", "psfm_result_solve_stats", "psfm_ctx_set_profiling",
+    "psfm_profile_get",
+]
+
+
+class SolveStats(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("successful_steps", ctypes.c_int32),
+                ("termination", ctypes.c_int32), ("dogleg_nonGN", ctypes.c_int32),
+                ("initial_cost", ctypes.c_double), ("final_cost", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class TrackInfo(ctypes.Structure):
+    _fields_ = [("n_traj", ctypes.c_int64), ("n_points", ctypes.c_int64), ("n_lanes_peak", ctypes.c_int64),
+                ("lane_capacity", ctypes.c_int64), ("solver_iterations", ctypes.c_int64),
+                ("n_solves", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class PsfmError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("libpsfm_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load libpsfm_hip.so; raises RuntimeError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libpsfm_hip.so not found at %s -- build it with `python particle-sfm_amd/build.py` "
+            "(the HIP extension is mandatory, there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+    L.psfm_last_error.restype = ctypes.c_char_p
+    L.psfm_last_error.argtypes = []
+    L.psfm_version.restype = i32
+    L.psfm_device_count.restype = i32
+    L.psfm_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.psfm_ctx_destroy.argtypes = [vp]
+    L.psfm_ctx_set_capacity.argtypes = [vp, f64, f64]
+    L.psfm_flow_check.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
+    L.psfm_grid_sample.argtypes = [vp, vp, i32, i32, i32, vp, i64, vp, vp]
+    L.psfm_optimize_location.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, ctypes.POINTER(SolveStats), vp]
+    L.psfm_track.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(TrackInfo), vp]
+    L.psfm_result_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.psfm_result_copy.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.psfm_result_solve_stats.argtypes = [vp, ctypes.POINTER(SolveStats), i32, ctypes.POINTER(ctypes.c_int32)]
+    L.psfm_ctx_set_profiling.argtypes = [vp, i32]
+    L.psfm_profile_get.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(i64)]
+    for name in EXPORTS:
+        if name != "psfm_last_error":
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != PSFM_OK:
+        raise PsfmError(status, lib().psfm_last_error().decode("utf-8", "replace"))
+
+
+class Context:
+    """One psfm_ctx (device workspace).  Not thread-safe; cached per device by `context()`."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        check(lib().psfm_ctx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_capacity(self, lane_factor, traj_factor):
+        check(lib().psfm_ctx_set_capacity(self._h, float(lane_factor), float(traj_factor)))
+
+    def set_profiling(self, enable):
+        check(lib().psfm_ctx_set_profiling(self._h, int(bool(enable))))
+
+    def profile(self):
+        out = {}
+        for name, k in PROF_KINDS.items():
+            ms, n = ctypes.c_double(), ctypes.c_int64()
+            check(lib().psfm_profile_get(self._h, k, ctypes.byref(ms), ctypes.byref(n)))
+            out[name] = {"total_ms": ms.value, "launches": n.value}
+        return out
+
+    def close(self):
+        if self._h:
+            lib().psfm_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def context(device=None):
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("point_trajectory (MI355X build) needs a HIP device: torch.cuda.is_available() is False "
+                           "and there is no CPU fallback")
+    if device is None:
+        device = torch.cuda.current_device()
+    device = int(device)
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())

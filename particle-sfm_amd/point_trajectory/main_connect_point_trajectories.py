@@ -1,0 +1,57 @@
+"""Mirror of point_trajectory/main_connect_point_trajectories.py (reference :27-62): same signature, same
+inputs (flow_dir/{flow_f,flow_b[,flow_f2,flow_b2]}/*.flo) and the same output (traj_dir/track.npy)."""
+import argparse
+import os
+
+import numpy as np
+
+from .utils import load_flows, flow_check_device
+from .trajectory import run_track, _as_device_stack
+
+
+def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_check_thres=1.0, traj_min_len=3,
+                                    skip_path_consistency=False, skip_exists=False):
+    import torch
+    os.makedirs(traj_dir, exist_ok=True)
+    output_npy_fname = os.path.join(traj_dir, "track.npy")
+    if skip_exists and os.path.exists(output_npy_fname):
+        return
+
+    # load data (.flo -> HBM once; the error maps of the reference are never consumed, :39-40)
+    flows_f = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_f")), torch.float32, (1, 1, 2))
+    flows_b = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_b")), torch.float32, (1, 1, 2))
+    n = min(flows_f.shape[0], flows_b.shape[0])
+    _, occ_maps = flow_check_device(flows_f[:n], flows_b[:n], flow_check_thres)
+    del flows_b
+
+    flows_f2 = occ_maps_s2 = None
+    if not skip_path_consistency:
+        flows_f2 = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_f2")), torch.float32, (1, 1, 2))
+        flows_b2 = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_b2")), torch.float32, (1, 1, 2))
+        n2 = min(flows_f2.shape[0], flows_b2.shape[0])
+        _, occ_maps_s2 = flow_check_device(flows_f2[:n2], flows_b2[:n2], flow_check_thres)
+        del flows_b2
+
+    # connect tracks into point trajectories (track.py / track_optimize.py)
+    trajs = run_track(flows_f, occ_maps, flows_f2, occ_maps_s2, sample_ratio)
+
+    # save the outputs (:56-62): ids are indices into the full list, short trajectories dropped
+    trajectories = trajs.to_trajectory_set(traj_min_len)
+    np.save(output_npy_fname, trajectories)
+
+
+def main(args):
+    main_connect_point_trajectories(args.flow_dir, args.traj_dir, sample_ratio=args.sample_ratio,
+                                    flow_check_thres=args.flow_check_thres, traj_min_len=args.traj_min_len,
+                                    skip_path_consistency=args.skip_path_consistency)
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser("Connecting and optimizing point trajectories from pairwise flows")
+    parser.add_argument("--flow_dir", help="path to the folder of optical flows")
+    parser.add_argument("--traj_dir", help="trajectory output")
+    parser.add_argument("--sample_ratio", type=int, default=2, help="sample ratio of trajectories")
+    parser.add_argument("--traj_min_len", type=int, default=3, help="minimum length of the trajectories")
+    parser.add_argument("--flow_check_thres", type=float, default=1.0, help="flow consistency check threshold")
+    parser.add_argument("--skip_path_consistency", action='store_true', help='whether to skip the path consistency optimization or not')
+    main(parser.parse_args())

@@ -1,0 +1,144 @@
+"""Mirror of the reference's point_trajectory/trajectory.py on top of libpsfm_hip.so.
+
+What the reference does per frame with Python lists of pybind objects (IncrementalTrajectorySet,
+trajectory.py:98-194) lives on the device here: lanes + a frame-major position log (csrc/psfm_track.hip).
+This module keeps the reference's *callable surface*: `grid_sample` (:25-37) and the result container that
+`track()` / `track_optimize()` return -- a list-like of Trajectory in full_trajs order.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _hip
+from .optimize.build import particlesfm
+
+
+def grid_sample(data, xy):
+    """trajectory.py:25-37.  data: [C,H,W] torch tensor (C in {1,2}); xy: [N,2] array -> [N,C] float32 ndarray.
+    Bit-exact with the reference's torch-CPU F.grid_sample(bilinear, zeros, align_corners=True)."""
+    import torch
+    ctx = _hip.context()
+    dev = torch.device("cuda", ctx.device)
+    C, H, W = int(data.shape[0]), int(data.shape[1]), int(data.shape[2])
+    m = data.detach().to(dev, torch.float32).permute(1, 2, 0).contiguous()   # HWC, the kernels' native layout
+    pts = torch.from_numpy(np.ascontiguousarray(np.asarray(xy, dtype=np.float64).reshape(-1, 2))).to(dev)
+    out = torch.empty((pts.shape[0], C), dtype=torch.float32, device=dev)
+    _hip.check(_hip.lib().psfm_grid_sample(ctx.handle, _hip.ptr(m), C, H, W, _hip.ptr(pts), pts.shape[0],
+                                           _hip.ptr(out), _hip.current_stream_ptr()))
+    return out.cpu().numpy()
+
+
+class TrajectoryList:
+    """What track()/track_optimize() return: trajectories in full_trajs order (index == saved id,
+    main_connect_point_trajectories.py:56-60), stored as CSR arrays copied once from HBM.
+
+    Behaves like the reference's list of Trajectory objects (len, indexing, iteration; elements expose
+    .length(), .times, .xys, .labels, .as_dict()) without materialising ~5e7 Python objects up front."""
+
+    def __init__(self, birth, length, off, xy, info=None, solve_stats=None):
+        self.birth = birth          # (n,) int32
+        self.length = length        # (n,) int32
+        self.off = off              # (n+1,) int64
+        self.xy = xy                # (n_points, 2) float64
+        self.info = info or {}
+        self.solve_stats = solve_stats or []
+
+    def __len__(self):
+        return int(self.birth.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return particlesfm.Trajectory._from_arrays(self.birth[i], self.xy[self.off[i]:self.off[i + 1]])
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    @property
+    def n_points(self):
+        return int(self.xy.shape[0])
+
+    def to_trajectory_set(self, traj_min_len=3):
+        """main_connect_point_trajectories.py:56-61: ids are list indices, short tracks dropped."""
+        keep = np.nonzero(self.length >= int(traj_min_len))[0]
+        ts = particlesfm.TrajectorySet()
+        ts.trajs = {int(i): self[int(i)] for i in keep}
+        return ts
+
+
+def _result_to_host(ctx, info):
+    n, npnt = int(info.n_traj), int(info.n_points)
+    birth = np.empty(n, np.int32)
+    length = np.empty(n, np.int32)
+    off = np.zeros(n + 1, np.int64)
+    xy = np.empty((npnt, 2), np.float64)
+    _hip.check(_hip.lib().psfm_result_copy(ctx.handle, birth.ctypes.data_as(ctypes.c_void_p),
+                                           length.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p),
+                                           xy.ctypes.data_as(ctypes.c_void_p), _hip.current_stream_ptr()))
+    stats = []
+    if info.n_solves:
+        arr = (_hip.SolveStats * int(info.n_solves))()
+        nout = ctypes.c_int32()
+        _hip.check(_hip.lib().psfm_result_solve_stats(ctx.handle, arr, int(info.n_solves), ctypes.byref(nout)))
+        stats = [arr[i].as_dict() for i in range(nout.value)]
+    return TrajectoryList(birth, length, off, xy, info.as_dict(), stats)
+
+
+def _as_device_stack(maps, dtype, trailing):
+    """list of (H,W[,2]) arrays | (n,H,W[,2]) array/tensor -> contiguous device tensor."""
+    import torch
+    ctx = _hip.context()
+    dev = torch.device("cuda", ctx.device)
+    if isinstance(maps, torch.Tensor):
+        t = maps
+    else:
+        if isinstance(maps, (list, tuple)):
+            if len(maps) and isinstance(maps[0], torch.Tensor):
+                t = torch.stack(list(maps))
+            else:
+                t = torch.from_numpy(np.stack([np.asarray(m) for m in maps])) if len(maps) else torch.zeros((0,) + trailing)
+        else:
+            t = torch.from_numpy(np.asarray(maps))
+    if t.dtype == torch.bool and dtype == torch.uint8:
+        t = t.to(torch.uint8)
+    return t.to(device=dev, dtype=dtype).contiguous()
+
+
+def run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio, return_device=False):
+    """Shared driver of track() / track_optimize(): one psfm_track call (whole frame loop on the device)."""
+    import torch
+    ctx = _hip.context()
+    fl = _as_device_stack(flows, torch.float32, (1, 1, 2))
+    oc = _as_device_stack(occ_maps, torch.uint8, (1, 1))
+    n, H, W = int(fl.shape[0]), int(fl.shape[1]), int(fl.shape[2])
+    if n < 1:
+        raise ValueError("track: need at least one flow field")
+    if oc.shape[0] < n:
+        raise ValueError("track: %d occlusion maps for %d flows" % (oc.shape[0], n))
+    f2 = o2 = None
+    if flows_f2 is not None:
+        f2 = _as_device_stack(flows_f2, torch.float32, (1, 1, 2))
+        o2 = _as_device_stack(occ_maps_s2, torch.uint8, (1, 1))
+        if n > 1 and (f2.shape[0] < n - 1 or o2.shape[0] < n - 1):
+            raise ValueError("track_optimize: need %d stride-2 flows / occlusion maps" % (n - 1))
+        if f2.numel() == 0:   # single-pair sequence: the stride-2 stack is empty but must be non-NULL
+            f2 = torch.zeros((1, H, W, 2), dtype=torch.float32, device=fl.device)
+            o2 = torch.zeros((1, H, W), dtype=torch.uint8, device=fl.device)
+    info = _hip.TrackInfo()
+    lane_f, traj_f = 2.0, 8.0
+    for attempt in range(6):
+        ctx.set_capacity(lane_f, traj_f)
+        st = _hip.lib().psfm_track(ctx.handle, _hip.ptr(fl), _hip.ptr(oc), _hip.ptr(f2), _hip.ptr(o2), n, H, W,
+                                   int(sample_ratio), ctypes.byref(info), _hip.current_stream_ptr())
+        if st != _hip.PSFM_ERR_CAPACITY:
+            break
+        lane_f, traj_f = lane_f * 2.0, traj_f * 4.0   # tables too small for this sequence: grow and rerun
+    _hip.check(st)
+    if return_device:
+        return info
+    return _result_to_host(ctx, info)

@@ -1,0 +1,63 @@
+"""Mirror of point_trajectory/utils.py: .flo reader (reference :26-56) and flow_check (:58-105)."""
+import glob
+import os
+
+import numpy as np
+
+from . import _hip
+
+TAG_FLOAT = 202021.25
+
+
+def read_flo(file):
+    """utils.py:43-56 (Middlebury .flo: f32 magic, i32 w, i32 h, h*w*2 f32 interleaved)."""
+    assert type(file) is str, "file is not str %r" % str(file)
+    assert os.path.isfile(file) is True, "file does not exist %r" % str(file)
+    assert file[-4:] == '.flo', "file ending is not .flo %r" % file[-4:]
+    with open(file, 'rb') as f:
+        flo_number = np.fromfile(f, np.float32, count=1)[0]
+        assert flo_number == TAG_FLOAT, 'Flow number %r incorrect. Invalid .flo file' % flo_number
+        w = int(np.fromfile(f, np.int32, count=1)[0])
+        h = int(np.fromfile(f, np.int32, count=1)[0])
+        data = np.fromfile(f, np.float32, count=2 * w * h)
+    return np.resize(data, (h, w, 2))
+
+
+def write_flo(file, flow):
+    flow = np.ascontiguousarray(flow, dtype=np.float32)
+    with open(file, 'wb') as f:
+        np.array([TAG_FLOAT], np.float32).tofile(f)
+        np.array([flow.shape[1], flow.shape[0]], np.int32).tofile(f)
+        flow.tofile(f)
+
+
+def load_flows(dir):
+    """utils.py:26-32"""
+    return [read_flo(name) for name in sorted(glob.glob(dir + "/*.flo"))]
+
+
+def flow_check_device(flows, flows_b, thres, want_error=False):
+    """flow_check on device tensors: (n,H,W,2) float32 stacks -> (err (n,H,W) f32 | None, occ (n,H,W) uint8)."""
+    import torch
+    ctx = _hip.context()
+    n, H, W = int(flows.shape[0]), int(flows.shape[1]), int(flows.shape[2])
+    occ = torch.empty((n, H, W), dtype=torch.uint8, device=flows.device)
+    err = torch.empty((n, H, W), dtype=torch.float32, device=flows.device) if want_error else None
+    _hip.check(_hip.lib().psfm_flow_check(ctx.handle, _hip.ptr(flows), _hip.ptr(flows_b), n, H, W, float(thres),
+                                          _hip.ptr(occ), _hip.ptr(err), _hip.current_stream_ptr()))
+    return err, occ
+
+
+def flow_check(flows, flows_b, thres):
+    """utils.py:94-105: forward/backward consistency.  Returns (error_maps, occ_maps): lists of (H,W) float32 /
+    bool arrays, bit-identical to the reference's torch-CPU result."""
+    from .trajectory import _as_device_stack
+    import torch
+    n = min(len(flows), len(flows_b))   # zip() semantics of the reference loop
+    if n == 0:
+        return [], []
+    f = _as_device_stack(flows[:n], torch.float32, (1, 1, 2))
+    b = _as_device_stack(flows_b[:n], torch.float32, (1, 1, 2))
+    err, occ = flow_check_device(f, b, thres, want_error=True)
+    err, occ = err.cpu().numpy(), occ.cpu().numpy().astype(bool)
+    return [err[i] for i in range(n)], [occ[i] for i in range(n)]

@@ -1,0 +1,146 @@
+"""GPU parity: the HIP path (through the C ABI, via the point_trajectory mirror) against the CPU oracle and the
+golden vectors produced by the reference's own Python.  Bit-exact for everything fp32/integer."""
+import numpy as np
+import pytest
+
+from _common import golden, regen_inputs, assert_csr_equal
+import psfm_synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import point_trajectory
+    from point_trajectory import utils, trajectory, track, track_optimize, _hip
+    _hip.context()   # fails loudly if libpsfm_hip.so is missing
+    class NS: pass
+    ns = NS()
+    ns.utils, ns.trajectory, ns.track, ns.track_optimize, ns.hip = utils, trajectory, track.track, track_optimize.track_optimize, _hip
+    return ns
+
+
+def test_sampler_golden(pt):
+    import torch
+    g = golden("sampler")
+    rng = np.random.default_rng(int(g["seed"]))
+    H, W = int(g["H"]), int(g["W"])
+    m2 = rng.standard_normal((H, W, 2)).astype(np.float32)
+    m1 = (rng.uniform(size=(H, W)) < 0.3)
+    s2 = pt.trajectory.grid_sample(torch.from_numpy(m2).permute(2, 0, 1), g["pts"])
+    s1 = pt.trajectory.grid_sample(torch.from_numpy(m1.astype(np.float32)).unsqueeze(0), g["pts"])
+    assert np.array_equal(s2.view(np.uint32), g["s2"].view(np.uint32))
+    assert np.array_equal(s1.view(np.uint32), g["s1"].view(np.uint32))
+    rng.uniform([-3, -3], [W + 2, H + 2], size=(4000, 2))
+    mb = rng.standard_normal((int(g["Hb"]), int(g["Wb"]), 2)).astype(np.float32)
+    sb = pt.trajectory.grid_sample(torch.from_numpy(mb).permute(2, 0, 1), g["pb"])
+    assert np.array_equal(sb.view(np.uint32), g["sb"].view(np.uint32))
+
+
+def test_flow_check_golden(pt):
+    g = golden("flow_check")
+    d = psfm_synth.synth_sequence(4, 64, 96, seed=21, sigma=0.4, n_occluders=2, stride2=False)
+    for thres in (1.0, 3.0):
+        err, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], thres)
+        assert np.array_equal(np.stack(err).view(np.uint32), g["fc_err_%g" % thres].view(np.uint32))
+        assert np.array_equal(np.packbits(np.stack(occ)), g["fc_occ_%g" % thres])
+    dd = psfm_synth.synth_sequence(3, 40, 56, seed=22, amp=9.0, sigma=0.0, stride2=False)
+    err, occ = pt.utils.flow_check(dd["flows_f"], dd["flows_b"], 1.0)
+    assert np.array_equal(np.stack(err).view(np.uint32), g["big_err"].view(np.uint32))
+    assert np.array_equal(np.packbits(np.stack(occ)), g["big_occ"])
+
+
+def test_flow_check_vs_oracle_odd_sizes(pt):
+    from oracle import oracle as orc
+    for (H, W, seed) in [(37, 53, 1), (270, 480, 2), (33, 130, 3)]:
+        d = psfm_synth.synth_sequence(3, H, W, seed=seed, sigma=0.5, n_occluders=1, stride2=False)
+        e_o, o_o = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        e_g, o_g = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        for a, b in zip(e_o, e_g):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(o_o, o_g):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["track_48x64_r2", "track_45x70_r1", "track_50x66_r3", "track_52x61_r4"])
+def test_track_golden(pt, name):
+    g = golden(name)
+    d = regen_inputs(g, stride2=False)
+    _, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    R = pt.track(d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+
+
+def test_track_all_tracks_die(pt):
+    g = golden("track_alldie_24x30_r2")
+    d = regen_inputs(g, stride2=False)
+    _, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    occ = [o.copy() for o in occ]
+    occ[1][:] = True
+    R = pt.track(d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+
+
+@pytest.mark.parametrize("H,W,T,r,seed,sigma,nocc", [
+    (270, 480, 12, 2, 41, 0.2, 3),
+    (135, 241, 10, 3, 42, 0.35, 2),
+    (96, 130, 30, 1, 43, 0.1, 2),
+    (200, 300, 300, 4, 44, 0.05, 1),     # > 255 frames: exercises the occupied-stamp wrap
+])
+def test_track_vs_oracle(pt, H, W, T, r, seed, sigma, nocc):
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    O = orc.track(d["flows_f"], occ, r)
+    R = pt.track(d["flows_f"], occ, r)
+    assert R.birth.shape[0] == O.n_traj
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+    assert np.array_equal(R.xy, O.xy)
+    assert (O.length < 3).any() and (O.length > 5).any()
+
+
+def test_track_single_flow(pt):
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(2, 40, 60, seed=9, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    O = orc.track(d["flows_f"], occ, 2)
+    R = pt.track(d["flows_f"], occ, 2)
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+
+
+def test_track_full_size_properties(pt):
+    """1080p, sample_ratio=2 (BASELINE.json configs[1] shape, fewer frames): size-independent invariants."""
+    import torch
+    H, W, T, r = 1080, 1920, 12, 2
+    d = psfm_synth.synth_sequence_torch(T, H, W, seed=0, sigma=0.05, n_occluders=2, stride2=False)
+    _, occ = pt.utils.flow_check_device(d["flows_f"], d["flows_b"], 1.0)
+    R = pt.trajectory.run_track(d["flows_f"], occ, None, None, r)
+    n = len(R)
+    GW, GH = (W + r - 1) // r, (H + r - 1) // r
+    # offsets are the exclusive scan of the lengths
+    assert R.off[0] == 0 and np.array_equal(np.diff(R.off), R.length) and R.off[-1] == R.n_points
+    # every track lives inside [0, T-1]; ids are sorted by (last time, birth) -- full_trajs order
+    last = R.birth + R.length - 1
+    assert R.birth.min() == 0 and last.max() == T - 1 and (R.length >= 1).all()
+    assert (np.diff(last) >= 0).all()
+    same = np.diff(last) == 0
+    assert (np.diff(R.birth)[same] >= 0).all()
+    # frame-0 generation is the full grid; first positions are integer grid points
+    assert int((R.birth == 0).sum()) == GW * GH
+    first = R.xy[R.off[:-1]]
+    assert np.array_equal(first, np.round(first)) and (first[:, 0] % r == 0).all() and (first[:, 1] % r == 0).all()
+    # all later positions strictly inside the image (trajectory.py:56-57)
+    assert (R.xy[:, 0] >= 0).all() and (R.xy[:, 0] <= W - 1).all() and (R.xy[:, 1] >= 0).all() and (R.xy[:, 1] <= H - 1).all()
+    # determinism: a second run gives identical bits although lane assignment is free
+    R2 = pt.trajectory.run_track(d["flows_f"], occ, None, None, r)
+    assert np.array_equal(R.birth, R2.birth) and np.array_equal(R.length, R2.length) and np.array_equal(R.xy, R2.xy)
+    # and the first frames agree with the CPU oracle run on the same tensors
+    from oracle import oracle as orc
+    k = 3
+    ff = d["flows_f"][:k].cpu().numpy()
+    oo = occ[:k].cpu().numpy()
+    O = orc.track(list(ff), list(oo), r)
+    Rk = pt.trajectory.run_track(d["flows_f"][:k], occ[:k], None, None, r)
+    assert np.array_equal(Rk.birth, O.birth) and np.array_equal(Rk.length, O.length) and np.array_equal(Rk.xy, O.xy)
