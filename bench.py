@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the point-trajectory hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one synthetic sequence: BASELINE.json configs[1] =
+100 x (1920x1080) forward/backward flow pairs, sample_ratio=2, chaining + occlusion only, i.e.
+    flow_check(100 pairs) -> track(100 flows) -> finalize (ids, lengths, id-ordered CSR result),
+with the flow stacks already resident in HBM when the timed region starts and the result left in HBM.
+metric  = trajectory points per second (sum over all trajectories of their length / wall time).
+N > 1   = N independent sequences, one per rank/GPU (sequences are the unit the reference's driver
+          loops over, run_particlesfm.py:168-176); no data-path collective, weak scaling.
+The JSON line also carries the roofline of the flow-chaining kernel (HIP events on the launch stream,
+inside the timed region) and the CPU oracle timed on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+H, W, N_FRAMES, RATIO, THRES = 1080, 1920, 101, 2, 1.0
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(flows_f, flows_b, n_pairs):
+    """The CPU oracle ("port": plain scalar C restatement of the reference path, 1 thread) on the first
+    n_pairs frame pairs of the same tensors."""
+    import numpy as np
+    from oracle import oracle as orc
+    ff = [f for f in flows_f[:n_pairs].cpu().numpy()]
+    fb = [f for f in flows_b[:n_pairs].cpu().numpy()]
+    t0 = time.perf_counter()
+    _, occ = orc.flow_check(ff, fb, THRES)
+    R = orc.track(ff, occ, RATIO)
+    dt = time.perf_counter() - t0
+    return {"value": R.n_points / dt, "unit": "trajectory-points/s", "cores": 1, "kind": "port",
+            "sample": "first %d of %d frame pairs at 1080p, sample_ratio=2: flow_check + track + id order; %d points in %.1f s"
+                      % (n_pairs, N_FRAMES - 1, R.n_points, dt)}, R
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=N_FRAMES, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-pairs", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import psfm_synth
+    from point_trajectory import _hip
+    from point_trajectory.utils import flow_check_device
+    from point_trajectory.trajectory import run_track
+
+    n_frames = args.frames
+    n_flows = n_frames - 1
+    # one sequence per rank, different seeds (rank 0 = BASELINE seed 0)
+    d = psfm_synth.synth_sequence_torch(n_frames, H, W, seed=rank, sigma=0.05, n_occluders=2, stride2=False,
+                                        device=dev)
+    flows_f, flows_b = d["flows_f"], d["flows_b"]
+    ctx = _hip.context(local_rank)
+
+    def step():
+        _, occ = flow_check_device(flows_f, flows_b, THRES)
+        return run_track(flows_f, occ, None, None, RATIO, return_device=True)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.set_profiling(False)
+    for _ in range(args.warmup):
+        info = step()
+    # ---- timed region: exactly K steps, HIP events around every kernel family ----
+    ctx.set_profiling(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile()
+    ctx.set_profiling(False)
+
+    points = int(info.n_points)
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    pts = torch.tensor([float(points)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    dt_max = float(t_max.item())
+    total_points = float(pts.item())
+
+    if rank == 0:
+        # ---- roofline of the flow-chaining kernel (K2): algorithmic bytes per launch / avg duration ----
+        # chain_step/frame = min(8P,32A) + min(P,4A) + 16A + 16A + A, A = tracks alive at the step.
+        import ctypes
+        birth = np.empty(int(info.n_traj), np.int32)
+        length = np.empty(int(info.n_traj), np.int32)
+        _hip.check(_hip.lib().psfm_result_copy(ctx.handle, birth.ctypes.data_as(ctypes.c_void_p),
+                                               length.ctypes.data_as(ctypes.c_void_p), None, None,
+                                               _hip.current_stream_ptr()))
+        last = birth.astype(np.int64) + length - 1
+        alive_steps = float(points - int((last == n_flows).sum()))   # sum_t A_t over the n_flows launches
+        A = alive_steps / n_flows
+        P = float(H * W)
+        chain_bytes = min(8 * P, 32 * A) + min(P, 4 * A) + 16 * A + 16 * A + A
+        ch = prof["chain_step"]
+        chain_us = 1e3 * ch["total_ms"] / max(ch["launches"], 1)
+        achieved = chain_bytes / (chain_us * 1e-6) / 1e9 if chain_us > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_chain_step.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        fc = prof["flow_check"]
+        fc_us = 1e3 * fc["total_ms"] / max(fc["launches"], 1)
+        fc_bytes = 17.0 * P * n_flows
+        out = {
+            "metric": "trajectory-points/s", "value": total_points * args.steps / dt_max,
+            "unit": "trajectory-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 sampling + f64 positions", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic %dx(1920x1080) flow pairs, sample_ratio=2, "
+                                   "flow_check + chaining + occlusion + id assignment, 1 sequence per GPU" % n_flows,
+                       "frames": n_frames, "height": H, "width": W, "sample_ratio": RATIO,
+                       "flow_check_thres": THRES, "points_per_sequence": points, "trajectories": int(info.n_traj),
+                       "parallelism": "sequence-per-gpu x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "psfm_chain_step_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "bytes_per_launch": chain_bytes, "avg_launch_us": chain_us,
+                         "avg_alive_tracks": A},
+            "kernels": {
+                "flow_check": {"avg_launch_us": fc_us, "bytes_per_launch": fc_bytes,
+                               "achieved_GBs": fc_bytes / (fc_us * 1e-6) / 1e9 if fc_us > 0 else 0.0,
+                               "frac": fc_bytes / (fc_us * 1e-6) / 1e9 / HBM_PEAK_GBS if fc_us > 0 else 0.0},
+                "respawn_avg_us": 1e3 * prof["respawn"]["total_ms"] / max(prof["respawn"]["launches"], 1),
+                "finalize_avg_us": 1e3 * prof["finalize"]["total_ms"] / max(prof["finalize"]["launches"], 1),
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            cb, Rc = cpu_baseline(flows_f, flows_b, min(args.cpu_pairs, n_flows))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
