@@ -269,8 +269,10 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
                                   flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f, &ss, s);
             c->prof.end(s);
             if (st != PSFM_OK) return st;
-            c->solve_stats.push_back(ss);
-            total_iters += ss.iterations;
+            if (ss.termination >= 0) {   // termination == -1: no track had a full buffer, nothing was solved
+                c->solve_stats.push_back(ss);
+                total_iters += ss.iterations;
+            }
         }
     }
     c->prof.begin(PSFM_PROF_FINALIZE, s);

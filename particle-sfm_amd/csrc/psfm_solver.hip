@@ -1,6 +1,679 @@
-// placeholder -- replaced by the real solver TU in the next milestone
+// psfm_solver.hip -- K5/K6: the path-consistency solve (trajectory.py:161-194 +
+// optimize/src/trajectory_optimize.cpp:30-96) as a device-resident Ceres-compatible trust-region loop.
+//
+// Objective per track (path_consistency_cost.h:42-59), x = (x1,y1,x2,y2):
+//     r = [ p1 - ref1 ; s (p2 - ref2) ; (p2 - p1) - F12(p1) ],   cost = 1/2 sum r^2
+// F12 is the f64 clamp-to-edge bilinear interpolator of linear_interpolation.h:97-123 (NOT the fp32
+// zero-padded sampler).  The Hessian is block diagonal (one 4x4 block per track), but Ceres' trust-region
+// loop is global: ONE cost, ONE radius, ONE accept/reject and ONE termination test over all tracks
+// (SURVEY.md Appendix B).  To land on the same iterate the whole control flow of Ceres 2.0.0
+// (TrustRegionMinimizer + DoglegStrategy/TRADITIONAL_DOGLEG + Jacobi scaling + SPARSE_NORMAL_CHOLESKY,
+// max 200 iterations) is reproduced with its scalars reduced over all tracks:
+//
+//   pc_init   per track: refs/scale (fp32 sampler, trajectory.py:173-183), r, J at x0, Jacobi scaling,
+//             partial sums of {cost, |grad|_inf, |x|^2} and of the Gauss-Newton system
+//   pc_iter   per track, ONE launch per trust-region iteration: dogleg step from the block-local
+//             Cholesky + the global dogleg scalars, model decrease, candidate x+ and its cost, and --
+//             speculatively -- r, J and the Gauss-Newton sums AT x+ so that an accepted step needs no
+//             extra pass.  x lives in a ping-pong pair (log slabs <-> scratch).
+//   pc_ctrl   one block: deterministic tree reduction of the per-block partials + the scalar control
+//             logic (accept / reject / radius / mu / termination), written to a device control block
+//             that the next pc_iter reads.  Nothing returns to the host inside the loop; the host only
+//             polls a `done` word between chunks of launches.
+//
+// All arithmetic f64 without contraction; reductions have a fixed order (bitwise reproducible for a
+// given lane assignment).
+#include <string.h>
+
+#include "psfm_device.h"
 #include "psfm_internal.h"
-psfm_status psfm_solve_frame(psfm_ctx*, const PsfmTrackDims&, const float*, const float*, const float*, const uint8_t*, int,
-                             psfm_solve_stats*, hipStream_t) { psfm_set_error("solver not built"); return PSFM_ERR_SOLVER; }
-psfm_status psfm_solve_batch(psfm_ctx*, const double*, const double*, const double*, const double*, const float*, int64_t, int,
-                             int, double*, psfm_solve_stats*, hipStream_t) { psfm_set_error("solver not built"); return PSFM_ERR_SOLVER; }
+
+#define PC_BLOCK 256
+#define PC_MAX_BLOCKS 2048
+#define PC_NSUM 12
+
+enum { PC_MODE_STEP = 0, PC_MODE_SUMS = 1 };
+
+struct PsfmSolveCtrl {
+    // trust-region state
+    double radius, mu, x_cost, x_norm, gmax, initial_cost;
+    double g2, jg2, gn2, dot;        // Gauss-Newton system sums at the current x (for the current mu)
+    double dl_a, dl_b;               // dogleg step = (dl_a * ghat + dl_b * gn) / diag
+    double dl_norm;                  // scaled norm of that step when known a priori (cases 1, 2); < 0 -> from the kernel
+    int mode, done, termination, iteration;
+    int n_invalid, cur, successful, nonGN;
+    int n_tracks, failed, dl_case, pad;
+};
+
+struct PcParams {
+    // geometry
+    int H, W;
+    float cw, ch;
+    // frame mode: lanes; batch mode: rows
+    const int* birth_frame;   // NULL in batch mode
+    int max_birth;            // track participates iff 0 <= birth_frame <= max_birth
+    const int* n_lanes_ptr;   // device count of lanes (frame mode) or NULL
+    int n_rows;               // upper bound of the index range (cap or batch n)
+    // ping-pong iterate: buffer 0 = (x1a, x2a), buffer 1 = (x1b, x2b)
+    double2 *x1a, *x2a, *x1b, *x2b;
+    const double2* p0;        // frame mode: log slab f-1
+    // per-track constants
+    double2 *ref1, *ref2;
+    double* scale;
+    double2* jscale;          // (S0, S1); S2 = S3 = 1/(1+sqrt(s^2+1))
+    const float2* flow12;
+    // init-only inputs (frame mode)
+    const float2* flow01;
+    const float2* flow02;
+    const uint8_t* occ02;
+    double* partials;         // [PC_MAX_BLOCKS][PC_NSUM]
+    PsfmSolveCtrl* ctrl;
+};
+
+// ---- f64 clamp-to-edge bilinear interpolation (linear_interpolation.h:97-123 over ceres::Grid2D) ----
+__device__ __forceinline__ void pc_bilerp(const float2* __restrict__ flow, int H, int W, double r, double c,
+                                          double f[2], double dr[2], double dc[2])
+{
+    double fr = floor(r), fc = floor(c);
+    fr = fr > -1.0e9 ? fr : -1.0e9; fr = fr < 1.0e9 ? fr : 1.0e9;   // also maps NaN to -1e9
+    fc = fc > -1.0e9 ? fc : -1.0e9; fc = fc < 1.0e9 ? fc : 1.0e9;
+    const int row = (int)fr, col = (int)fc;
+    const int r0 = min(max(row, 0), H - 1), r1 = min(max(row + 1, 0), H - 1);
+    const int c0 = min(max(col, 0), W - 1), c1 = min(max(col + 1, 0), W - 1);
+    const float2 p00 = flow[(int64_t)r0 * W + c0], p01 = flow[(int64_t)r0 * W + c1];
+    const float2 p10 = flow[(int64_t)r1 * W + c0], p11 = flow[(int64_t)r1 * W + c1];
+    const double tc = c - (double)col, tr = r - (double)row;
+    {
+        const double a00 = p00.x, a01 = p01.x, a10 = p10.x, a11 = p11.x;
+        const double f0 = (1.0 - tc) * a00 + tc * a01, f1 = (1.0 - tc) * a10 + tc * a11;
+        f[0] = (1.0 - tr) * f0 + tr * f1;
+        dr[0] = f1 - f0;
+        dc[0] = (1.0 - tr) * (a01 - a00) + tr * (a11 - a10);
+    }
+    {
+        const double a00 = p00.y, a01 = p01.y, a10 = p10.y, a11 = p11.y;
+        const double f0 = (1.0 - tc) * a00 + tc * a01, f1 = (1.0 - tc) * a10 + tc * a11;
+        f[1] = (1.0 - tr) * f0 + tr * f1;
+        dr[1] = f1 - f0;
+        dc[1] = (1.0 - tr) * (a01 - a00) + tr * (a11 - a10);
+    }
+}
+
+// residuals and the four non-trivial Jacobian entries (rows 4,5 wrt x1,y1), path_consistency_cost.h:50-57
+__device__ __forceinline__ void pc_eval(const float2* __restrict__ flow, int H, int W, const double x[4],
+                                        double2 ref1, double2 ref2, double s, double r[6], double jac[4])
+{
+    double f[2], dr[2], dc[2];
+    pc_bilerp(flow, H, W, x[1], x[0], f, dr, dc);
+    r[0] = x[0] - ref1.x;
+    r[1] = x[1] - ref1.y;
+    r[2] = (x[2] - ref2.x) * s;
+    r[3] = (x[3] - ref2.y) * s;
+    r[4] = (x[2] - x[0]) - f[0];
+    r[5] = (x[3] - x[1]) - f[1];
+    jac[0] = -1.0 - dc[0];
+    jac[1] = 0.0 - dr[0];
+    jac[2] = 0.0 - dc[1];
+    jac[3] = -1.0 - dr[1];
+}
+
+// The scaled sparse 6x4 Jacobian Js = J diag(S):  rows 0..3 = diag(a0,a1,a2,a3),
+// row 4 = (b0,b1,b2,0), row 5 = (c0,c1,0,c3).
+struct PcJac { double a0, a1, a2, a3, b0, b1, b2, c0, c1, c3; };
+
+__device__ __forceinline__ PcJac pc_scaled_jac(const double jac[4], double s, const double S[4])
+{
+    PcJac J;
+    J.a0 = 1.0 * S[0]; J.a1 = 1.0 * S[1]; J.a2 = s * S[2]; J.a3 = s * S[3];
+    J.b0 = jac[0] * S[0]; J.b1 = jac[1] * S[1]; J.b2 = 1.0 * S[2];
+    J.c0 = jac[2] * S[0]; J.c1 = jac[3] * S[1]; J.c3 = 1.0 * S[3];
+    return J;
+}
+
+// Gauss-Newton system of one track: diag, scaled gradient ghat, scaled GN step gn; returns false when the
+// Cholesky factorisation of (Js^T Js + mu diag^2) breaks down.  Also the Cauchy-point term |Js (ghat/diag)|^2.
+__device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], double mu, double d[4], double gh[4],
+                                             double gn[4], double* jg2)
+{
+    const double n0 = (J.a0 * J.a0 + J.b0 * J.b0) + J.c0 * J.c0;
+    const double n1 = (J.a1 * J.a1 + J.b1 * J.b1) + J.c1 * J.c1;
+    const double n2 = J.a2 * J.a2 + J.b2 * J.b2;
+    const double n3 = J.a3 * J.a3 + J.c3 * J.c3;
+    const double q[4] = {(J.a0 * r[0] + J.b0 * r[4]) + J.c0 * r[5], (J.a1 * r[1] + J.b1 * r[4]) + J.c1 * r[5],
+                         J.a2 * r[2] + J.b2 * r[4], J.a3 * r[3] + J.c3 * r[5]};
+    const double nn[4] = {n0, n1, n2, n3};
+    double sg[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double cn = fmin(fmax(nn[c], 1e-6), 1e32);   // min/max_lm_diagonal
+        d[c] = sqrt(cn);
+        gh[c] = q[c] / d[c];
+        sg[c] = gh[c] / d[c];
+    }
+    {
+        const double m0 = J.a0 * sg[0], m1 = J.a1 * sg[1], m2 = J.a2 * sg[2], m3 = J.a3 * sg[3];
+        const double m4 = (J.b0 * sg[0] + J.b1 * sg[1]) + J.b2 * sg[2];
+        const double m5 = (J.c0 * sg[0] + J.c1 * sg[1]) + J.c3 * sg[3];
+        *jg2 = ((((m0 * m0 + m1 * m1) + m2 * m2) + m3 * m3) + m4 * m4) + m5 * m5;
+    }
+    // normal equations (lower triangle) + mu * diag^2, dense 4x4 Cholesky
+    const double smu = sqrt(mu);
+    double A[4][4];
+    double D;
+    D = d[0] * smu; A[0][0] = n0 + D * D;
+    D = d[1] * smu; A[1][1] = n1 + D * D;
+    D = d[2] * smu; A[2][2] = n2 + D * D;
+    D = d[3] * smu; A[3][3] = n3 + D * D;
+    A[1][0] = J.b0 * J.b1 + J.c0 * J.c1;
+    A[2][0] = J.b0 * J.b2;
+    A[2][1] = J.b1 * J.b2;
+    A[3][0] = J.c0 * J.c3;
+    A[3][1] = J.c1 * J.c3;
+    A[3][2] = 0.0;
+    double L[4][4];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sum -= L[i][k] * L[j][k];
+            if (i == j) {
+                ok = ok && (sum > 0.0);
+                L[i][i] = sqrt(sum);
+            } else {
+                L[i][j] = sum / L[j][j];
+            }
+        }
+    }
+    double z[4], y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double sum = q[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum -= L[i][k] * z[k];
+        z[i] = sum / L[i][i];
+    }
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        double sum = z[i];
+#pragma unroll
+        for (int k = i + 1; k < 4; ++k) sum -= L[k][i] * y[k];
+        y[i] = sum / L[i][i];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ok = ok && (y[c] == y[c]) && (fabs(y[c]) <= 1.7e308);
+        gn[c] = y[c] * (-d[c]);   // gauss_newton_step *= -diagonal
+    }
+    return ok;
+}
+
+// sums slots
+enum { SUM_MCC = 0, SUM_COST = 1, SUM_STEP2 = 2, SUM_DL2 = 3, SUM_XN2 = 4, SUM_GMAX = 5, SUM_G2 = 6, SUM_JG2 = 7,
+       SUM_GN2 = 8, SUM_DOT = 9, SUM_FAIL = 10, SUM_CNT = 11 };
+
+__device__ __forceinline__ double pc_wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+__device__ __forceinline__ double pc_wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+    return v;
+}
+
+// block reduction of acc[PC_NSUM] (slot SUM_GMAX by max, others by sum) -> partials[blockIdx]
+__device__ __forceinline__ void pc_block_reduce(double acc[PC_NSUM], double* __restrict__ partials)
+{
+    __shared__ double s_red[PC_BLOCK / PSFM_WAVE][PC_NSUM];
+    const int lane = psfm_lane_id(), wave = threadIdx.x / PSFM_WAVE;
+#pragma unroll
+    for (int k = 0; k < PC_NSUM; ++k) {
+        const double v = (k == SUM_GMAX) ? pc_wave_max(acc[k]) : pc_wave_sum(acc[k]);
+        if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PC_NSUM) {
+        const int k = threadIdx.x;
+        double v = s_red[0][k];
+        for (int w = 1; w < PC_BLOCK / PSFM_WAVE; ++w) v = (k == SUM_GMAX) ? fmax(v, s_red[w][k]) : v + s_red[w][k];
+        partials[(int64_t)blockIdx.x * PC_NSUM + k] = v;
+    }
+}
+
+__device__ __forceinline__ bool pc_participates(const PcParams& P, int i, int n)
+{
+    if (i >= n) return false;
+    if (!P.birth_frame) return true;
+    const int bf = P.birth_frame[i];
+    return bf >= 0 && bf <= P.max_birth;
+}
+
+// accumulate the state at a point (cost is NOT included; the caller knows whether it is x or x+)
+__device__ __forceinline__ void pc_accumulate_point(const double x[4], const double r[6], const double jac[4], double s,
+                                                    const double S[4], double mu, double acc[PC_NSUM])
+{
+    // |x - Plus(x,-g)|_inf with g = J^T r unscaled (trust_region_minimizer.cc EvaluateGradientAndJacobian)
+    const double g[4] = {(r[0] + jac[0] * r[4]) + jac[2] * r[5], (r[1] + jac[1] * r[4]) + jac[3] * r[5],
+                         s * r[2] + r[4], s * r[3] + r[5]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc[SUM_GMAX] = fmax(acc[SUM_GMAX], fabs(x[k] - (x[k] + (-g[k]))));
+        acc[SUM_XN2] += x[k] * x[k];
+    }
+    const PcJac J = pc_scaled_jac(jac, s, S);
+    double d[4], gh[4], gn[4], jg2;
+    const bool ok = pc_gn_system(J, r, mu, d, gh, gn, &jg2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc[SUM_G2] += gh[k] * gh[k];
+        acc[SUM_GN2] += gn[k] * gn[k];
+        acc[SUM_DOT] += gh[k] * gn[k];
+    }
+    acc[SUM_JG2] += jg2;
+    if (!ok) acc[SUM_FAIL] += 1.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pc_init: iteration 0.  Frame mode also prepares ref1/ref2/scale (trajectory.py:173-183).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
+{
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    double acc[PC_NSUM];
+#pragma unroll
+    for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
+    const double mu = 1e-8;
+    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
+        if (!pc_participates(P, i, n)) continue;
+        double2 r1, r2;
+        double s;
+        if (P.p0) {
+            const double2 p0 = P.p0[i];
+            const PsfmTaps t = psfm_taps((float)p0.x, (float)p0.y, P.cw, P.ch, P.H, P.W);
+            const float2 f01 = psfm_sample_flow(P.flow01, P.H, P.W, t);
+            const float2 f02 = psfm_sample_flow(P.flow02, P.H, P.W, t);
+            const float o02 = psfm_sample_mask(P.occ02, P.H, P.W, t);
+            // (1.0 - occ02) * (|flow02| < 20) in fp32; numpy's norm = sqrt(u*u + v*v) without fma (trajectory.py:179)
+            const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
+            const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
+            s = (double)sf;
+            r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
+            r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
+            P.ref1[i] = r1; P.ref2[i] = r2; P.scale[i] = s;
+        } else {
+            r1 = P.ref1[i]; r2 = P.ref2[i]; s = P.scale[i];
+        }
+        const double2 p1 = P.x1a[i], p2 = P.x2a[i];
+        const double x[4] = {p1.x, p1.y, p2.x, p2.y};
+        double r[6], jac[4];
+        pc_eval(P.flow12, P.H, P.W, x, r1, r2, s, r, jac);
+        // Jacobi scaling 1/(1+sqrt(colnorm^2)), computed once at iteration 0
+        const double c0 = (1.0 + jac[0] * jac[0]) + jac[2] * jac[2];
+        const double c1 = (1.0 + jac[1] * jac[1]) + jac[3] * jac[3];
+        const double c2 = s * s + 1.0;
+        const double S2 = 1.0 / (1.0 + sqrt(c2));
+        const double S[4] = {1.0 / (1.0 + sqrt(c0)), 1.0 / (1.0 + sqrt(c1)), S2, S2};
+        P.jscale[i] = make_double2(S[0], S[1]);
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ss += r[k] * r[k];
+        acc[SUM_COST] += 0.5 * ss;
+        acc[SUM_CNT] += 1.0;
+        pc_accumulate_point(x, r, jac, s, S, mu, acc);
+    }
+    pc_block_reduce(acc, P.partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pc_iter: one trust-region iteration (MODE_STEP) or a re-evaluation of the Gauss-Newton sums at the
+// current x after mu changed (MODE_SUMS).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
+{
+    const PsfmSolveCtrl C = *P.ctrl;
+    if (C.done) return;
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    const double2* xc1 = C.cur ? P.x1b : P.x1a;
+    const double2* xc2 = C.cur ? P.x2b : P.x2a;
+    double2* xn1 = C.cur ? P.x1a : P.x1b;
+    double2* xn2 = C.cur ? P.x2a : P.x2b;
+    double acc[PC_NSUM];
+#pragma unroll
+    for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
+    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
+        if (!pc_participates(P, i, n)) continue;
+        const double2 r1 = P.ref1[i], r2 = P.ref2[i];
+        const double s = P.scale[i];
+        const double2 js = P.jscale[i];
+        const double S2 = 1.0 / (1.0 + sqrt(s * s + 1.0));
+        const double S[4] = {js.x, js.y, S2, S2};
+        const double2 p1 = xc1[i], p2 = xc2[i];
+        const double x[4] = {p1.x, p1.y, p2.x, p2.y};
+        double r[6], jac[4];
+        pc_eval(P.flow12, P.H, P.W, x, r1, r2, s, r, jac);
+        if (C.mode == PC_MODE_SUMS) {
+            double dummy[PC_NSUM];
+#pragma unroll
+            for (int k = 0; k < PC_NSUM; ++k) dummy[k] = 0.0;
+            pc_accumulate_point(x, r, jac, s, S, C.mu, dummy);
+            acc[SUM_G2] += dummy[SUM_G2]; acc[SUM_JG2] += dummy[SUM_JG2]; acc[SUM_GN2] += dummy[SUM_GN2];
+            acc[SUM_DOT] += dummy[SUM_DOT]; acc[SUM_FAIL] += dummy[SUM_FAIL];
+            continue;
+        }
+        const PcJac J = pc_scaled_jac(jac, s, S);
+        double d[4], gh[4], gn[4], jg2;
+        pc_gn_system(J, r, C.mu, d, gh, gn, &jg2);
+        // dogleg step in the scaled space, then /diag (ComputeTraditionalDoglegStep)
+        double st[4], xp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double v = C.dl_a * gh[k] + C.dl_b * gn[k];
+            acc[SUM_DL2] += v * v;
+            st[k] = v / d[k];
+        }
+        // model_cost_change = -(J step)'(r + J step / 2)
+        {
+            const double m0 = J.a0 * st[0], m1 = J.a1 * st[1], m2 = J.a2 * st[2], m3 = J.a3 * st[3];
+            const double m4 = (J.b0 * st[0] + J.b1 * st[1]) + J.b2 * st[2];
+            const double m5 = (J.c0 * st[0] + J.c1 * st[1]) + J.c3 * st[3];
+            acc[SUM_MCC] += ((((m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0)) + m2 * (r[2] + m2 / 2.0)) +
+                              m3 * (r[3] + m3 / 2.0)) + m4 * (r[4] + m4 / 2.0)) + m5 * (r[5] + m5 / 2.0);
+        }
+        // candidate = x + step .* jacobi_scaling
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xp[k] = x[k] + st[k] * S[k];
+            const double dd = x[k] - xp[k];
+            acc[SUM_STEP2] += dd * dd;
+        }
+        xn1[i] = make_double2(xp[0], xp[1]);
+        xn2[i] = make_double2(xp[2], xp[3]);
+        double rp[6], jp[4];
+        pc_eval(P.flow12, P.H, P.W, xp, r1, r2, s, rp, jp);
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ss += rp[k] * rp[k];
+        acc[SUM_COST] += 0.5 * ss;
+        // speculative: everything the NEXT iteration needs if this candidate is accepted
+        pc_accumulate_point(xp, rp, jp, s, S, C.mu, acc);
+    }
+    pc_block_reduce(acc, P.partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pc_ctrl: reduce the partials in a fixed order and run Ceres' scalar control logic.
+// ------------------------------------------------------------------------------------------------
+__device__ void pc_choose_dogleg(PsfmSolveCtrl& C)
+{
+    // ComputeTraditionalDoglegStep, with alpha = |ghat|^2 / |Js ghat/diag|^2 (ComputeCauchyPoint)
+    const double gnorm = sqrt(C.g2), gnn = sqrt(C.gn2);
+    const double alpha = C.g2 / C.jg2;
+    if (gnn <= C.radius) {
+        C.dl_case = 1; C.dl_a = 0.0; C.dl_b = 1.0; C.dl_norm = gnn;
+    } else if (gnorm * alpha >= C.radius) {
+        C.dl_case = 2; C.dl_a = -(C.radius / gnorm); C.dl_b = 0.0; C.dl_norm = C.radius;
+    } else {
+        const double b_dot_a = -alpha * C.dot;
+        const double a2 = pow(alpha * gnorm, 2.0);
+        const double bma2 = a2 - 2 * b_dot_a + pow(gnn, 2);
+        const double c = b_dot_a - a2;
+        const double dd = sqrt(c * c + bma2 * (pow(C.radius, 2.0) - a2));
+        const double beta = (c <= 0) ? (dd - c) / bma2 : (C.radius * C.radius - a2) / (dd + c);
+        C.dl_case = 3; C.dl_a = -alpha * (1.0 - beta); C.dl_b = beta; C.dl_norm = -1.0;
+    }
+}
+
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_ctrl_kernel(PsfmSolveCtrl* __restrict__ ctrl,
+                                                                const double* __restrict__ partials, int n_blocks,
+                                                                int is_init)
+{
+    __shared__ double s_red[PC_BLOCK];
+    __shared__ double s_tot[PC_NSUM];
+    if (!is_init && ctrl->done) return;
+    for (int k = 0; k < PC_NSUM; ++k) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < n_blocks; b += PC_BLOCK) {
+            const double p = partials[(int64_t)b * PC_NSUM + k];
+            v = (k == SUM_GMAX) ? fmax(v, p) : v + p;
+        }
+        s_red[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = PC_BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o)
+                s_red[threadIdx.x] = (k == SUM_GMAX) ? fmax(s_red[threadIdx.x], s_red[threadIdx.x + o])
+                                                    : s_red[threadIdx.x] + s_red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) s_tot[k] = s_red[0];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    PsfmSolveCtrl C = *ctrl;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double min_relative_decrease = 1e-3, min_radius = 1e-32;
+    const double min_mu = 1e-8, mu_increase = 10.0;
+    const int max_iter = 200, max_invalid = 5;
+    bool need_checks = false, accepted = false;
+    if (is_init) {
+        memset(&C, 0, sizeof(C));
+        C.radius = 1e4; C.mu = min_mu;
+        C.n_tracks = (int)s_tot[SUM_CNT];
+        C.x_cost = s_tot[SUM_COST]; C.initial_cost = C.x_cost;
+        C.x_norm = sqrt(s_tot[SUM_XN2]);
+        C.gmax = s_tot[SUM_GMAX];
+        C.g2 = s_tot[SUM_G2]; C.jg2 = s_tot[SUM_JG2]; C.gn2 = s_tot[SUM_GN2]; C.dot = s_tot[SUM_DOT];
+        C.termination = PSFM_TERM_MAX_ITER;
+        C.mode = PC_MODE_STEP;
+        if (C.n_tracks == 0) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
+        if (s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+        need_checks = true; accepted = true;   // iteration 0 counts as a successful step
+    } else if (C.mode == PC_MODE_SUMS) {
+        C.g2 = s_tot[SUM_G2]; C.jg2 = s_tot[SUM_JG2]; C.gn2 = s_tot[SUM_GN2]; C.dot = s_tot[SUM_DOT];
+        if (s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+        C.mode = PC_MODE_STEP;
+    } else {
+        C.iteration += 1;
+        if (C.dl_case != 1) C.nonGN += 1;
+        const double mcc = -s_tot[SUM_MCC];
+        const double dogleg_step_norm = C.dl_norm >= 0.0 ? C.dl_norm : sqrt(s_tot[SUM_DL2]);
+        if (!(mcc > 0.0)) {
+            // HandleInvalidStep / StepIsInvalid
+            if (++C.n_invalid >= max_invalid) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+            C.mu *= mu_increase;
+            C.mode = PC_MODE_SUMS;
+            need_checks = true;
+        } else {
+            C.n_invalid = 0;
+            const double cand = s_tot[SUM_COST];
+            const double step_norm = sqrt(s_tot[SUM_STEP2]);
+            if (step_norm <= parameter_tolerance * (C.x_norm + parameter_tolerance)) {
+                C.done = 1; C.termination = PSFM_TERM_PARAMETER_TOL;
+            } else if (fabs(C.x_cost - cand) <= function_tolerance * C.x_cost) {
+                C.done = 1; C.termination = PSFM_TERM_FUNCTION_TOL;
+            } else {
+                const double rho = (C.x_cost - cand) / mcc;
+                if (rho > min_relative_decrease) {
+                    // HandleSuccessfulStep + DoglegStrategy::StepAccepted
+                    C.cur ^= 1;
+                    C.x_cost = cand;
+                    C.x_norm = sqrt(s_tot[SUM_XN2]);
+                    C.gmax = s_tot[SUM_GMAX];
+                    C.successful += 1;
+                    if (rho < 0.25) C.radius *= 0.5;
+                    if (rho > 0.75) C.radius = fmax(C.radius, 3.0 * dogleg_step_norm);
+                    const double new_mu = fmax(min_mu, 2.0 * C.mu / mu_increase);
+                    if (new_mu == C.mu) {
+                        C.g2 = s_tot[SUM_G2]; C.jg2 = s_tot[SUM_JG2]; C.gn2 = s_tot[SUM_GN2]; C.dot = s_tot[SUM_DOT];
+                        if (s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+                    } else {
+                        C.mu = new_mu;
+                        C.mode = PC_MODE_SUMS;   // the speculative sums were formed with the old mu
+                    }
+                    accepted = true;
+                } else {
+                    C.radius *= 0.5;   // StepRejected; the Gauss-Newton sums at x stay valid
+                }
+                need_checks = true;
+            }
+        }
+    }
+    if (need_checks && !C.done) {
+        // FinalizeIterationAndCheckIfMinimizerCanContinue
+        if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
+        else if (accepted && C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
+        else if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
+    }
+    if (!C.done && C.mode == PC_MODE_STEP) pc_choose_dogleg(C);
+    *ctrl = C;
+}
+
+// final: if the accepted iterate lives in the scratch pair, copy it back (frame mode: into the log)
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P, double* out_rows)
+{
+    const PsfmSolveCtrl C = *P.ctrl;
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    const double2* xc1 = C.cur ? P.x1b : P.x1a;
+    const double2* xc2 = C.cur ? P.x2b : P.x2a;
+    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
+        if (!pc_participates(P, i, n)) continue;
+        const double2 p1 = xc1[i], p2 = xc2[i];
+        if (out_rows) {
+            out_rows[4 * (int64_t)i + 0] = p1.x; out_rows[4 * (int64_t)i + 1] = p1.y;
+            out_rows[4 * (int64_t)i + 2] = p2.x; out_rows[4 * (int64_t)i + 3] = p2.y;
+        } else if (C.cur) {
+            P.x1a[i] = p1; P.x2a[i] = p2;
+        }
+    }
+}
+
+// batch mode: split (n,4) rows into the (x1, x2) pair and (n,2) refs into double2 arrays
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_load_rows_kernel(const double* __restrict__ uv12, int64_t n,
+                                                                     double2* __restrict__ x1, double2* __restrict__ x2)
+{
+    const int64_t i = (int64_t)blockIdx.x * PC_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    x1[i] = make_double2(uv12[4 * i], uv12[4 * i + 1]);
+    x2[i] = make_double2(uv12[4 * i + 2], uv12[4 * i + 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------------
+static psfm_status pc_run(psfm_ctx* c, PcParams& P, int n_rows_upper, double* out_rows, psfm_solve_stats* st, hipStream_t s)
+{
+    int n_blocks = (n_rows_upper + PC_BLOCK - 1) / PC_BLOCK;
+    if (n_blocks > PC_MAX_BLOCKS) n_blocks = PC_MAX_BLOCKS;
+    if (n_blocks < 1) n_blocks = 1;
+    psfm_status rc;
+    if ((rc = c->sol_partials.ensure(sizeof(double) * PC_MAX_BLOCKS * PC_NSUM)) != PSFM_OK) return rc;
+    if ((rc = c->sol_ctrl.ensure(sizeof(PsfmSolveCtrl))) != PSFM_OK) return rc;
+    P.partials = c->sol_partials.as<double>();
+    P.ctrl = c->sol_ctrl.as<PsfmSolveCtrl>();
+    hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    hipLaunchKernelGGL(psfm_pc_ctrl_kernel, dim3(1), dim3(PC_BLOCK), 0, s, P.ctrl, P.partials, n_blocks, 1);
+    PSFM_HIP(hipGetLastError());
+    PsfmSolveCtrl* hctrl = (PsfmSolveCtrl*)((char*)c->host_pinned + 512 + sizeof(PsfmShard) * PSFM_NSHARD);
+    int launched = 0, chunk = 6;
+    for (;;) {
+        for (int k = 0; k < chunk; ++k) {
+            hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+            hipLaunchKernelGGL(psfm_pc_ctrl_kernel, dim3(1), dim3(PC_BLOCK), 0, s, P.ctrl, P.partials, n_blocks, 0);
+        }
+        launched += chunk;
+        PSFM_HIP(hipGetLastError());
+        PSFM_HIP(hipMemcpyAsync(hctrl, P.ctrl, sizeof(PsfmSolveCtrl), hipMemcpyDeviceToHost, s));
+        PSFM_HIP(hipStreamSynchronize(s));
+        if (hctrl->done) break;
+        if (launched > 2 * 200 + 64) { psfm_set_error("path-consistency solver did not terminate"); return PSFM_ERR_SOLVER; }
+        chunk = chunk < 32 ? chunk * 2 : 32;
+    }
+    hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, out_rows);
+    PSFM_HIP(hipGetLastError());
+    if (st) {
+        st->iterations = hctrl->iteration;
+        st->successful_steps = hctrl->successful;
+        st->termination = hctrl->termination;
+        st->dogleg_nonGN = hctrl->nonGN;
+        st->initial_cost = hctrl->initial_cost;
+        st->final_cost = hctrl->x_cost;
+        if (hctrl->n_tracks == 0) st->termination = -1;   // nothing to solve (the reference would raise here)
+    }
+    if (hctrl->failed) { psfm_set_error("path-consistency solver: FAILURE (invalid steps / Cholesky breakdown)"); return PSFM_ERR_SOLVER; }
+    return PSFM_OK;
+}
+
+static psfm_status pc_workspace(psfm_ctx* c, int64_t rows)
+{
+    psfm_status rc;
+    // x1b, x2b, ref1, ref2, jscale (double2 each) + scale (double)
+    if ((rc = c->sol_x.ensure(sizeof(double2) * rows * 2)) != PSFM_OK) return rc;
+    if ((rc = c->sol_state.ensure(sizeof(double2) * rows * 3 + sizeof(double) * rows)) != PSFM_OK) return rc;
+    return PSFM_OK;
+}
+
+psfm_status psfm_solve_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                             const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st, hipStream_t s)
+{
+    psfm_status rc;
+    if ((rc = pc_workspace(c, d.cap)) != PSFM_OK) return rc;
+    PcParams P;
+    memset(&P, 0, sizeof(P));
+    P.H = d.H; P.W = d.W; P.cw = d.cw; P.ch = d.ch;
+    P.birth_frame = c->birth_frame.as<int>();
+    P.max_birth = frame - 1;    // three buffered positions: times frame-1, frame, frame+1
+    P.n_lanes_ptr = &c->counters.as<PsfmCounters>()->n_lanes;
+    P.n_rows = (int)d.cap;
+    double2* lg = c->log.as<double2>();
+    P.p0 = lg + (int64_t)(frame - 1) * d.cap;
+    P.x1a = lg + (int64_t)frame * d.cap;
+    P.x2a = lg + (int64_t)(frame + 1) * d.cap;
+    P.x1b = c->sol_x.as<double2>();
+    P.x2b = P.x1b + d.cap;
+    P.ref1 = c->sol_state.as<double2>();
+    P.ref2 = P.ref1 + d.cap;
+    P.jscale = P.ref2 + d.cap;
+    P.scale = (double*)(P.jscale + d.cap);
+    P.flow12 = (const float2*)flow12; P.flow01 = (const float2*)flow01; P.flow02 = (const float2*)flow02;
+    P.occ02 = occ02;
+    return pc_run(c, P, (int)d.cap, nullptr, st, s);
+}
+
+psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
+                             const double* scale, const float* flow12, int64_t n, int w, int h, double* out,
+                             psfm_solve_stats* st, hipStream_t s)
+{
+    if (n == 0) return PSFM_OK;
+    if (n > 0x3fffffff) { psfm_set_error("psfm_optimize_location: n too large"); return PSFM_ERR_ARG; }
+    psfm_status rc;
+    if ((rc = pc_workspace(c, n)) != PSFM_OK) return rc;
+    if ((rc = c->sol_misc.ensure(sizeof(double2) * n * 2)) != PSFM_OK) return rc;
+    PcParams P;
+    memset(&P, 0, sizeof(P));
+    P.H = h; P.W = w;
+    P.cw = (float)((double)(w - 1) / 2.0); P.ch = (float)((double)(h - 1) / 2.0);
+    P.n_rows = (int)n;
+    P.x1a = c->sol_misc.as<double2>();
+    P.x2a = P.x1a + n;
+    P.x1b = c->sol_x.as<double2>();
+    P.x2b = P.x1b + n;
+    P.ref1 = c->sol_state.as<double2>();
+    P.ref2 = P.ref1 + n;
+    P.jscale = P.ref2 + n;
+    P.scale = (double*)(P.jscale + n);
+    P.flow12 = (const float2*)flow12;
+    const unsigned nb = (unsigned)((n + PC_BLOCK - 1) / PC_BLOCK);
+    hipLaunchKernelGGL(psfm_pc_load_rows_kernel, dim3(nb), dim3(PC_BLOCK), 0, s, uv12, n, P.x1a, P.x2a);
+    PSFM_HIP(hipMemcpyAsync(P.ref1, ref1, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
+    PSFM_HIP(hipMemcpyAsync(P.ref2, ref2, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
+    PSFM_HIP(hipMemcpyAsync(P.scale, scale, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    rc = pc_run(c, P, (int)n, out, st, s);
+    if (rc != PSFM_OK) return rc;
+    PSFM_HIP(hipStreamSynchronize(s));
+    return PSFM_OK;
+}

@@ -1,0 +1,113 @@
+"""GPU parity of the path-consistency solver (psfm_optimize_location / track_optimize) against the CPU oracle.
+Tolerance: ids / lengths bit-exact, positions within 1e-4 px (north_star); in practice ~1e-10 because both
+sides run the same Ceres-compatible control flow in f64 and differ only in summation order."""
+import numpy as np
+import pytest
+
+from _common import golden, regen_inputs, assert_csr_equal
+import psfm_synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pt():
+    import torch
+    assert torch.cuda.is_available()
+    from point_trajectory import utils, trajectory, _hip
+    from point_trajectory.track_optimize import track_optimize
+    from point_trajectory.optimize.build import particlesfm
+    _hip.context()
+    class NS: pass
+    ns = NS()
+    ns.utils, ns.trajectory, ns.track_optimize, ns.particlesfm = utils, trajectory, track_optimize, particlesfm
+    return ns
+
+
+def _batch(H, W, n, seed, sigma, kink=False):
+    rng = np.random.default_rng(seed)
+    d = psfm_synth.synth_sequence(3, H, W, seed=seed, sigma=sigma, stride2=True)
+    flow12 = d["flows_f"][1]
+    p0 = rng.uniform([-2, -2], [W + 1, H + 1], size=(n, 2)) if kink else rng.uniform([2, 2], [W - 3, H - 3], size=(n, 2))
+    ref1 = p0 + rng.normal(0, 1.0, size=(n, 2))
+    ref2 = ref1 + rng.normal(0, 1.5, size=(n, 2))
+    uv = np.concatenate([ref1 + rng.normal(0, 0.5, (n, 2)), ref2 + rng.normal(0, 0.5, (n, 2))], 1)
+    scale = rng.uniform(0, 1, size=(n, 1)).astype(np.float32).astype(np.float64)
+    scale[rng.uniform(size=n) < 0.2] = 0.0
+    return uv, ref1, ref2, scale, flow12
+
+
+@pytest.mark.parametrize("H,W,n,seed,sigma,kink", [
+    (60, 80, 3000, 1, 0.02, False),
+    (60, 80, 3000, 2, 0.5, False),      # noisy flow: rejected steps, dogleg interpolation
+    (45, 70, 5000, 3, 0.3, True),       # points outside the image: Grid2D clamping
+    (270, 480, 100000, 4, 0.05, False),
+    (33, 47, 1, 5, 0.1, False),         # a single track
+])
+def test_optimize_location_vs_oracle(pt, H, W, n, seed, sigma, kink):
+    from oracle import oracle as orc
+    uv, ref1, ref2, scale, flow12 = _batch(H, W, n, seed, sigma, kink)
+    out_o, st_o = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+    out_g = pt.particlesfm.optimize_location(uv, ref1, ref2, scale, flow12, n, W, H)
+    st_g = pt.particlesfm.optimize_location.last_stats
+    assert st_g["iterations"] == st_o["iterations"], (st_g, st_o)
+    assert st_g["successful_steps"] == st_o["successful_steps"] and st_g["termination"] == st_o["termination"]
+    assert st_g["dogleg_nonGN"] == st_o["dogleg_nonGN"]
+    assert abs(st_g["final_cost"] - st_o["final_cost"]) <= 1e-9 * max(1.0, st_o["final_cost"])
+    assert float(np.abs(out_g - out_o).max()) <= 1e-8
+
+
+def test_optimize_location_exercises_dogleg(pt):
+    """The noisy batch must actually leave the pure Gauss-Newton path, otherwise cases 2/3 are untested."""
+    from oracle import oracle as orc
+    uv, ref1, ref2, scale, flow12 = _batch(60, 80, 3000, 2, 0.5)
+    _, st = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+    assert st["dogleg_nonGN"] > 0 and st["iterations"] > st["successful_steps"]
+
+
+@pytest.mark.parametrize("name", ["opt_48x64_r2", "opt_45x70_r3"])
+def test_track_optimize_golden(pt, name):
+    g = golden(name)
+    d = regen_inputs(g, stride2=True)
+    _, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = pt.utils.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g, tol=TOL)
+    assert float(np.abs(R.xy - g["xy"]).max()) <= 1e-7
+
+
+@pytest.mark.parametrize("H,W,T,r,seed,sigma,nocc", [
+    (120, 200, 9, 2, 51, 0.05, 2),
+    (90, 140, 8, 3, 52, 0.3, 3),
+    (436, 1024, 8, 2, 53, 0.05, 2),    # configs[2] shape (Sintel alley_1), fewer frames
+    (64, 96, 20, 1, 54, 0.15, 1),
+])
+def test_track_optimize_vs_oracle(pt, H, W, T, r, seed, sigma, nocc):
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    assert len(R) == O.n_traj
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+    err = float(np.abs(R.xy - O.xy).max())
+    assert err <= TOL, err
+    assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+    assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
+
+
+def test_track_optimize_two_flows_only(pt):
+    """n_flows = 2: exactly one solve; n_flows = 1: none (the stride-2 stack is empty)."""
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(3, 40, 60, seed=61, sigma=0.05, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+    R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+    assert float(np.abs(R.xy - O.xy).max()) <= TOL and len(R.solve_stats) == 1
+    O1 = orc.track_optimize(d["flows_f"][:1], [], occ[:1], [], 2)
+    R1 = pt.track_optimize(d["flows_f"][:1], [], occ[:1], [], 2)
+    assert np.array_equal(R1.birth, O1.birth) and np.array_equal(R1.xy, O1.xy)
