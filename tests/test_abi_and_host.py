@@ -1,0 +1,162 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/psfm.h declares, fails loudly
+without a GPU (no fallback), and the host-side mirror of the reference's containers behaves like the pybind
+classes (optimize/src/bindings.cc, trajectory_base.cpp)."""
+import ctypes
+import io
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "psfm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(psfm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from point_trajectory import _hip
+    L = _hip.lib()
+    names = _declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(L, n), "libpsfm_hip.so does not export %s" % n
+    assert set(names) == set(_hip.EXPORTS)
+    assert L.psfm_version() == 100
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device every compute path raises; nothing silently routes to the oracle or the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from point_trajectory import _hip
+    from point_trajectory.utils import flow_check
+    from point_trajectory.track import track
+    L = _hip.lib()
+    assert L.psfm_device_count() == 0
+    h = ctypes.c_void_p()
+    assert L.psfm_ctx_create(0, ctypes.byref(h)) == _hip.PSFM_ERR_HIP
+    assert b"no CPU fallback" in L.psfm_last_error()
+    f = [np.zeros((8, 8, 2), np.float32)]
+    with pytest.raises(RuntimeError):
+        flow_check(f, f, 1.0)
+    with pytest.raises(RuntimeError):
+        track(f, [np.zeros((8, 8), bool)], 2)
+    # the product package never imports the oracle
+    pkg = os.path.join(ROOT, "particle-sfm_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in txt.replace("the oracle", "").replace("CPU oracle", ""), os.path.join(dp, fn)
+
+
+def test_flo_roundtrip(tmp_path):
+    from point_trajectory.utils import read_flo, write_flo, load_flows
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        write_flo(str(tmp_path / ("%05d.flo" % i)), rng.standard_normal((7, 11, 2)).astype(np.float32))
+    fl = load_flows(str(tmp_path))
+    assert len(fl) == 3 and fl[0].shape == (7, 11, 2) and fl[0].dtype == np.float32
+    rng = np.random.default_rng(0)
+    assert np.array_equal(fl[0], rng.standard_normal((7, 11, 2)).astype(np.float32))
+    with pytest.raises(AssertionError):
+        read_flo(str(tmp_path / "nope.flo"))
+
+
+def _toy_list():
+    from point_trajectory.trajectory import TrajectoryList
+    birth = np.array([0, 0, 1, 2, 0], np.int32)
+    length = np.array([1, 3, 4, 2, 6], np.int32)
+    off = np.zeros(6, np.int64)
+    off[1:] = np.cumsum(length)
+    xy = np.arange(2 * off[-1], dtype=np.float64).reshape(-1, 2)
+    return TrajectoryList(birth, length, off, xy)
+
+
+def test_trajectory_list_behaves_like_the_reference_list():
+    tl = _toy_list()
+    assert len(tl) == 5
+    t = tl[2]
+    assert t.length() == 4 and t.times == [1, 2, 3, 4] and t.labels == [False] * 4
+    assert all(isinstance(p, np.ndarray) and p.shape == (2,) for p in t.xys)
+    assert np.array_equal(np.array(t.xys), tl.xy[4:8])
+    assert np.array_equal(t.get_tail_location(), tl.xy[7])
+    d = t.as_dict()
+    assert set(d) == {"frame_ids", "locations", "labels"} and d["frame_ids"] == [1, 2, 3, 4]
+    assert [x.length() for x in tl] == [1, 3, 4, 2, 6]
+    # main_connect_point_trajectories.py:56-60: ids are list indices, short ones dropped
+    ts = tl.to_trajectory_set(3)
+    assert sorted(ts.trajs) == [1, 2, 4]
+
+
+def test_trajectory_semantics_match_trajectory_base_cpp():
+    from point_trajectory.optimize.build.particlesfm import Trajectory
+    t = Trajectory(np.int64(3), np.array([4, 6]), buffer_size=3)       # trajectory.py:119 call form
+    for k in range(4):
+        t.extend(4 + k, [k, k])
+    assert t.length() == 5 and len(t.buffer_xys) == 3 and len(t.xys) == 2
+    assert np.array_equal(t.get_tail_location(), [3.0, 3.0])
+    t.set_buffer_xy(1, [9.0, 9.0])
+    with pytest.raises(RuntimeError):
+        t.set_buffer_xy(3, [0, 0])
+    t.clear_buffer()
+    assert len(t.buffer_xys) == 0 and np.array_equal(np.array(t.xys)[3], [9.0, 9.0])
+    assert t.times == [3, 4, 5, 6, 7]
+    t2 = Trajectory([0, 1], [np.zeros(2), np.ones(2)])
+    assert t2.labels == [False, False] and t2.length() == 2
+    t3 = Trajectory(t2.as_dict())
+    assert t3.times == [0, 1] and np.array_equal(np.array(t3.xys), np.array(t2.xys))
+    with pytest.raises(RuntimeError):
+        Trajectory().get_tail_location()
+
+
+def test_track_npy_roundtrip_and_consumers(tmp_path):
+    """np.save / np.load(allow_pickle).item() through the access patterns of the unmodified consumers
+    (sfm/matches_from_flow.py:56-86, motion_seg/load_cut_seq.py:46-79)."""
+    from point_trajectory.optimize.build import particlesfm
+    tl = _toy_list()
+    ts = tl.to_trajectory_set(3)
+    fn = str(tmp_path / "track.npy")
+    np.save(fn, ts)
+    raw = open(fn, "rb").read()
+    assert b"point_trajectory.optimize.build.particlesfm" in raw and b"TrajectorySet" in raw
+    back = np.load(fn, allow_pickle=True).item()
+    assert type(back).__name__ == "TrajectorySet" and sorted(back.trajs) == [1, 2, 4]
+    d = back.as_dict()                                     # matches_from_flow.py:57-58
+    for key in d:
+        traj = d[key]
+        loc, lab, fid = np.array(traj["locations"]), np.array(traj["labels"]), np.array(traj["frame_ids"])
+        assert loc.shape == (len(fid), 2) and lab.shape[0] == len(fid)
+    assert np.array_equal(np.array(d[4]["locations"]), tl.xy[10:16])
+    # the legacy state layout (list of (2,) arrays, as written by the pybind module) loads too
+    legacy = {7: {"frame_ids": [2, 3, 4], "locations": [np.array([1.0, 2.0])] * 3, "labels": [False, True, False]}}
+    ts2 = particlesfm.TrajectorySet.__new__(particlesfm.TrajectorySet)
+    ts2.__setstate__(legacy)
+    assert ts2.trajs[7].labels == [False, True, False] and ts2.trajs[7].length() == 3
+    ts3 = particlesfm.TrajectorySet(legacy)
+    assert ts3.as_dict()[7]["frame_ids"] == [2, 3, 4]
+    with pytest.raises(RuntimeError):
+        ts3.insert(7, ts3.trajs[7])
+    # sample_inside_window (trajectory_base.cpp:127-185)
+    with pytest.raises(RuntimeError):
+        back.sample_inside_window([0, 1, 2])
+    back.build_invert_indexes()
+    out = back.sample_inside_window([1, 2, 3, 4], min_length=3)
+    X, Y = out["locations"]
+    assert out["traj_ids"] == [2, 4] and X.shape == (2, 4) and out["masks"].dtype == np.int32
+    assert out["masks"].tolist() == [[1, 1, 1, 1], [1, 1, 1, 1]]
+    assert np.array_equal(X[0], tl.xy[4:8, 0]) and np.array_equal(Y[1], tl.xy[11:15, 1])
+    out = back.sample_inside_window([0, 1, 2, 9], min_length=3)
+    assert out["traj_ids"] == [1, 4] and out["masks"].tolist() == [[1, 1, 1, 0], [1, 1, 1, 0]]
+    assert out["locations"][0][0, 3] == 0.0
+    out = back.sample_inside_window([0, 1, 2, 3, 4, 5], min_length=1, max_num_tracks=2)
+    assert len(out["traj_ids"]) == 2
