@@ -18,7 +18,10 @@ LIB = os.path.join(LIBDIR, "libpsfm_hip.so")
 SOURCES = ["psfm_api.hip", "psfm_track.hip", "psfm_finalize.hip", "psfm_solver.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+         # counts are aggregated by hand (ballot -> LDS -> one atomic per block); the compiler's own per-wave
+         # atomic aggregation would add a readfirstlane + wait after every atomic and serialise them
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _newer(target, deps):

@@ -63,6 +63,13 @@ void PsfmProfiler::begin(int kind, hipStream_t s)
     (void)hipEventRecord(sp.a, s);
     spans.push_back(sp);
 }
+void PsfmProfiler::kernel_span(int kind, hipEvent_t* a, hipEvent_t* b)
+{
+    if (!enabled) { *a = nullptr; *b = nullptr; return; }
+    Span sp; sp.kind = kind; sp.a = get(); sp.b = get();
+    spans.push_back(sp);
+    *a = sp.a; *b = sp.b;
+}
 void PsfmProfiler::end(hipStream_t s)
 {
     if (!enabled) return;
@@ -237,11 +244,11 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
     if ((st = c->log.ensure(sizeof(double2) * (size_t)(n_flows + 1) * d.cap)) != PSFM_OK) return st;
     if ((st = c->birth_frame.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
     if ((st = c->birth_idx.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
-    if ((st = c->free_stack.ensure(sizeof(int) * (size_t)d.free_cap * PSFM_NSHARD)) != PSFM_OK) return st;
-    if ((st = c->shards.ensure(sizeof(PsfmShard) * PSFM_NSHARD)) != PSFM_OK) return st;
+    if ((st = c->free_stack.ensure(sizeof(int) * (size_t)d.free_cap * PSFM_NSHARD * 2)) != PSFM_OK) return st;
+    if ((st = c->shards.ensure(sizeof(PsfmShard) * PSFM_NSHARD * 2)) != PSFM_OK) return st;
     if ((st = c->fin_keys.ensure(sizeof(unsigned long long) * d.traj_cap)) != PSFM_OK) return st;
     if ((st = c->fin_lanes.ensure(sizeof(int) * d.traj_cap)) != PSFM_OK) return st;
-    if ((st = c->occupied.ensure((size_t)P)) != PSFM_OK) return st;
+    if ((st = c->occupied.ensure((size_t)d.G * 2)) != PSFM_OK) return st;
     if ((st = c->counters.ensure(sizeof(PsfmCounters))) != PSFM_OK) return st;
     if ((st = c->survivors.ensure(sizeof(int) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
 
@@ -251,16 +258,9 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
     int64_t total_iters = 0;
     for (int f = 0; f < n_flows; ++f) {
         // track.py:31-47 / track_optimize.py:31-50, one loop iteration
-        c->prof.begin(PSFM_PROF_CHAIN, s);
+        // one launch: births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
         st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * P, f, s);
-        c->prof.end(s);
         if (st != PSFM_OK) return st;
-        if (f + 1 < n_flows) {   // births for frame f+1 exist only if another loop iteration follows
-            c->prof.begin(PSFM_PROF_RESPAWN, s);
-            st = psfm_launch_respawn(c, d, f, s);
-            c->prof.end(s);
-            if (st != PSFM_OK) return st;
-        }
         if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
             psfm_solve_stats ss;
             memset(&ss, 0, sizeof(ss));

@@ -51,47 +51,80 @@ __device__ __forceinline__ float psfm_blend(float vnw, float vne, float vsw, flo
     return __fmaf_rn(vse, t.se, __fmaf_rn(vsw, t.sw, __fmaf_rn(vne, t.ne, __fmul_rn(vnw, t.nw))));
 }
 
+// Tap addressing: every tap is loaded UNCONDITIONALLY from a clamped (always valid) address and zeroed by a
+// select afterwards (zeros padding).  Branch-free loads let the compiler issue all taps back to back behind a
+// single s_waitcnt; predicated loads compiled to one exec-masked branch + wait per tap (8 serial round trips).
+struct PsfmTapIdx {
+    int nw, ne, sw, se;          // element offsets of the four taps (clamped into the map; H*W < 2^31)
+    bool inw, ine, isw, ise;     // tap inside the map?
+};
+
+__device__ __forceinline__ PsfmTapIdx psfm_tap_idx(int H, int W, const PsfmTaps& t)
+{
+    const int x0 = t.x0, y0 = t.y0, x1 = t.x0 + 1, y1 = t.y0 + 1;
+    const bool xw = (x0 >= 0) & (x0 < W), xe = (x1 >= 0) & (x1 < W);
+    const bool yn = (y0 >= 0) & (y0 < H), ys = (y1 >= 0) & (y1 < H);
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
+    const int rn = min(max(y0, 0), H - 1) * W, rs = min(max(y1, 0), H - 1) * W;
+    PsfmTapIdx k;
+    k.nw = rn + xc0; k.ne = rn + xc1; k.sw = rs + xc0; k.se = rs + xc1;
+    k.inw = xw & yn; k.ine = xe & yn; k.isw = xw & ys; k.ise = xe & ys;
+    return k;
+}
+
 // Two-channel (flow) sample from the .flo-native interleaved (H,W,2) layout: one 8-byte load per tap.
+__device__ __forceinline__ float2 psfm_sample_flow(const float2* __restrict__ map, const PsfmTapIdx& k, const PsfmTaps& t)
+{
+    float2 vnw = map[k.nw], vne = map[k.ne], vsw = map[k.sw], vse = map[k.se];
+    vnw.x = k.inw ? vnw.x : 0.0f; vnw.y = k.inw ? vnw.y : 0.0f;
+    vne.x = k.ine ? vne.x : 0.0f; vne.y = k.ine ? vne.y : 0.0f;
+    vsw.x = k.isw ? vsw.x : 0.0f; vsw.y = k.isw ? vsw.y : 0.0f;
+    vse.x = k.ise ? vse.x : 0.0f; vse.y = k.ise ? vse.y : 0.0f;
+    return make_float2(psfm_blend(vnw.x, vne.x, vsw.x, vse.x, t), psfm_blend(vnw.y, vne.y, vsw.y, vse.y, t));
+}
 __device__ __forceinline__ float2 psfm_sample_flow(const float2* __restrict__ map, int H, int W, const PsfmTaps& t)
 {
-    const int x0 = t.x0, y0 = t.y0;
-    const bool xw = (x0 >= 0) & (x0 < W), xe = (x0 + 1 >= 0) & (x0 + 1 < W);
-    const bool yn = (y0 >= 0) & (y0 < H), ys = (y0 + 1 >= 0) & (y0 + 1 < H);
-    const float2 z = make_float2(0.0f, 0.0f);
-    const int64_t rn = (int64_t)y0 * W, rs = (int64_t)(y0 + 1) * W;
-    const float2 vnw = (xw & yn) ? map[rn + x0] : z;
-    const float2 vne = (xe & yn) ? map[rn + x0 + 1] : z;
-    const float2 vsw = (xw & ys) ? map[rs + x0] : z;
-    const float2 vse = (xe & ys) ? map[rs + x0 + 1] : z;
-    return make_float2(psfm_blend(vnw.x, vne.x, vsw.x, vse.x, t), psfm_blend(vnw.y, vne.y, vsw.y, vse.y, t));
+    return psfm_sample_flow(map, psfm_tap_idx(H, W, t), t);
 }
 
 // One-channel sample of a 0/1 byte map (the occlusion masks), values taken as 0.0f / 1.0f.
+__device__ __forceinline__ float psfm_sample_mask(const uint8_t* __restrict__ map, const PsfmTapIdx& k, const PsfmTaps& t)
+{
+    const uint8_t bnw = map[k.nw], bne = map[k.ne], bsw = map[k.sw], bse = map[k.se];
+    const float vnw = (k.inw & (bnw != 0)) ? 1.0f : 0.0f;
+    const float vne = (k.ine & (bne != 0)) ? 1.0f : 0.0f;
+    const float vsw = (k.isw & (bsw != 0)) ? 1.0f : 0.0f;
+    const float vse = (k.ise & (bse != 0)) ? 1.0f : 0.0f;
+    return psfm_blend(vnw, vne, vsw, vse, t);
+}
 __device__ __forceinline__ float psfm_sample_mask(const uint8_t* __restrict__ map, int H, int W, const PsfmTaps& t)
 {
-    const int x0 = t.x0, y0 = t.y0;
-    const bool xw = (x0 >= 0) & (x0 < W), xe = (x0 + 1 >= 0) & (x0 + 1 < W);
-    const bool yn = (y0 >= 0) & (y0 < H), ys = (y0 + 1 >= 0) & (y0 + 1 < H);
-    const int64_t rn = (int64_t)y0 * W, rs = (int64_t)(y0 + 1) * W;
-    const float vnw = (xw & yn) ? (map[rn + x0] ? 1.0f : 0.0f) : 0.0f;
-    const float vne = (xe & yn) ? (map[rn + x0 + 1] ? 1.0f : 0.0f) : 0.0f;
-    const float vsw = (xw & ys) ? (map[rs + x0] ? 1.0f : 0.0f) : 0.0f;
-    const float vse = (xe & ys) ? (map[rs + x0 + 1] ? 1.0f : 0.0f) : 0.0f;
-    return psfm_blend(vnw, vne, vsw, vse, t);
+    return psfm_sample_mask(map, psfm_tap_idx(H, W, t), t);
 }
 
 // One-channel f32 sample (API parity for psfm_grid_sample with C == 1).
 __device__ __forceinline__ float psfm_sample_f32(const float* __restrict__ map, int H, int W, const PsfmTaps& t)
 {
-    const int x0 = t.x0, y0 = t.y0;
-    const bool xw = (x0 >= 0) & (x0 < W), xe = (x0 + 1 >= 0) & (x0 + 1 < W);
-    const bool yn = (y0 >= 0) & (y0 < H), ys = (y0 + 1 >= 0) & (y0 + 1 < H);
-    const int64_t rn = (int64_t)y0 * W, rs = (int64_t)(y0 + 1) * W;
-    const float vnw = (xw & yn) ? map[rn + x0] : 0.0f;
-    const float vne = (xe & yn) ? map[rn + x0 + 1] : 0.0f;
-    const float vsw = (xw & ys) ? map[rs + x0] : 0.0f;
-    const float vse = (xe & ys) ? map[rs + x0 + 1] : 0.0f;
+    const PsfmTapIdx k = psfm_tap_idx(H, W, t);
+    float vnw = map[k.nw], vne = map[k.ne], vsw = map[k.sw], vse = map[k.se];
+    vnw = k.inw ? vnw : 0.0f; vne = k.ine ? vne : 0.0f; vsw = k.isw ? vsw : 0.0f; vse = k.ise ? vse : 0.0f;
     return psfm_blend(vnw, vne, vsw, vse, t);
+}
+
+// ---- division by a launch-invariant divisor (Granlund-Montgomery): q = (t + ((n - t) >> sh1)) >> sh2 ----
+struct PsfmFastDiv { unsigned m; int sh1, sh2; unsigned d; };
+static inline PsfmFastDiv psfm_fastdiv_make(unsigned d)
+{
+    PsfmFastDiv f; f.d = d;
+    int l = 0; while ((1ull << l) < d) ++l;
+    f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1; f.sh2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ unsigned psfm_fastdiv(unsigned n, const PsfmFastDiv& f)
+{
+    const unsigned t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
 // ---- wavefront (64-lane) helpers ----------------------------------------------------------

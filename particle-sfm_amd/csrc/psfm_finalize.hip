@@ -30,7 +30,12 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_kernel(
     const int i = blockIdx.x * PSFM_BLOCK + threadIdx.x;
     int bf = -1;
     if (i < n_lanes) bf = birth_frame[i];
-    const bool alive = bf >= 0;
+    // bf >= 0: still active at the end (clear_active, trajectory.py:154-158) -> last time = n_flows;
+    // bf <= -2: marked dead by the LAST chain_step launch (record not yet written) -> last time = n_flows - 1
+    const bool pending = bf <= -2;
+    const bool alive = (bf >= 0) | pending;
+    const int my_last = pending ? last_time - 1 : last_time;
+    if (pending) bf = -2 - bf;
     const unsigned long long am = __ballot(alive);
     const int lane = psfm_lane_id(), wave = threadIdx.x / PSFM_WAVE;
     if (lane == 0) s_cnt[wave] = __popcll(am);
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_kernel(
         for (int w = 0; w < wave; ++w) r += s_cnt[w];
         if (r < shard_cap) {
             const int64_t o = (int64_t)shard * shard_cap + r;
-            fin_keys[o] = ((unsigned long long)last_time << shift_d) | ((unsigned long long)bf << shift_b) |
+            fin_keys[o] = ((unsigned long long)my_last << shift_d) | ((unsigned long long)bf << shift_b) |
                           (unsigned long long)birth_idx[i];
             fin_lanes[o] = i;
         } else {

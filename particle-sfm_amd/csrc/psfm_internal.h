@@ -56,6 +56,7 @@ struct PsfmProfiler {
     int64_t launches[PSFM_PROF_KINDS] = {0};
     hipEvent_t get();
     void begin(int kind, hipStream_t s);
+    void kernel_span(int kind, hipEvent_t* a, hipEvent_t* b);  // events for hipExtLaunchKernelGGL (exact kernel begin/end)
     void end(hipStream_t s);
     void collect();  // after a stream sync: fold spans into totals
     void reset();
@@ -72,12 +73,12 @@ struct psfm_ctx {
     PsfmBuf log;          // (n_flows+1) x cap double2
     PsfmBuf birth_frame;  // cap i32, -1 = free lane
     PsfmBuf birth_idx;    // cap i32
-    PsfmBuf free_stack;   // cap i32
+    PsfmBuf free_stack;   // 2 sets x PSFM_NSHARD x free_cap i32 (double-buffered by frame parity)
     PsfmBuf fin_keys;     // traj_cap u64
     PsfmBuf fin_lanes;    // traj_cap i32
-    PsfmBuf occupied;     // H*W u8 (frame-stamped)
+    PsfmBuf occupied;     // 2 x G u8: frame-stamped grid-resolution `blocked` maps
     PsfmBuf counters;     // PsfmCounters
-    PsfmBuf shards;       // PSFM_NSHARD x PsfmShard
+    PsfmBuf shards;       // 2 x PSFM_NSHARD x PsfmShard
     PsfmBuf survivors;    // (n_flows+1) i32
     // finalize workspace + result
     PsfmBuf sort_keys, sort_lanes, sort_tmp, scan_tmp;
@@ -109,7 +110,6 @@ struct PsfmTrackDims {
 psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
                                    int frame, hipStream_t s);
-psfm_status psfm_launch_respawn(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 
 // ---- finalize (psfm_finalize.hip) -----------------------------------------------------------
 psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);

@@ -15,14 +15,34 @@
 //            is free: ids derive from the key (death_step, birth_frame, birth_grid_index) at finalize
 //            (SURVEY.md a-17), so no stable compaction is ever needed.
 #include "psfm_device.h"
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
 #include "psfm_internal.h"
 
 #define PSFM_BLOCK 256
 
 // ------------------------------------------------------------------------------------------------
-// K1  flow_check: one thread per pixel of one frame pair (blockIdx.y = pair).
-// Algorithmic bytes per pair: 8P (F, streamed) + 8P (B, gathered near p+F) + P (occ) = 17P.
+// K1  flow_check (utils.py:58-105).  Algorithmic bytes per pair: 8P (F, streamed) + 8P (B, gathered
+// near p+F) + P (occ) = 17P.  Vector form: a thread owns 4 consecutive pixels -> F arrives as two
+// 16-byte loads, the mask leaves as one 4-byte store; blockIdx.y = frame pair (one launch for all pairs).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t psfm_flow_check_px(const float2* __restrict__ B, int x, int y, float2 f, int H, int W,
+                                                      float cw, float ch, float thres, float* err)
+{
+    // utils.py:73-78: pixel coordinate + flow in fp32
+    const float X = __fadd_rn((float)x, f.x), Y = __fadd_rn((float)y, f.y);
+    const PsfmTaps t = psfm_taps(X, Y, cw, ch, H, W);           // utils.py:79-82
+    const float2 b = psfm_sample_flow(B, H, W, t);
+    // utils.py:87: torch.norm(warp + flow, dim=1) == sqrtf(fma(ev,ev, eu*eu)); sqrtf is correctly rounded
+    const float eu = __fadd_rn(b.x, f.x), ev = __fadd_rn(b.y, f.y);
+    const float e = sqrtf(__fmaf_rn(ev, ev, __fmul_rn(eu, eu)));
+    // utils.py:58-68 (oob) and :88-91 (union)
+    const bool oob = (X < 0.0f) | (X > (float)(W - 1)) | (Y < 0.0f) | (Y > (float)(H - 1));
+    *err = e;
+    return (uint8_t)((e > thres) | oob);
+}
+
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_kernel(
     const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, int H, int W, float cw, float ch,
     float thres, uint8_t* __restrict__ occ_out, float* __restrict__ err_out)
@@ -32,18 +52,40 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_kernel(
     if (p >= P) return;
     const int64_t base = (int64_t)blockIdx.y * P;
     const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
-    const float2 f = flows_f[base + p];
-    // utils.py:73-78: pixel coordinate + flow in fp32
-    const float X = __fadd_rn((float)x, f.x), Y = __fadd_rn((float)y, f.y);
-    const PsfmTaps t = psfm_taps(X, Y, cw, ch, H, W);           // utils.py:79-82
-    const float2 b = psfm_sample_flow(flows_b + base, H, W, t);
-    // utils.py:87: torch.norm(warp + flow, dim=1) == sqrtf(fma(ev,ev, eu*eu))
-    const float eu = __fadd_rn(b.x, f.x), ev = __fadd_rn(b.y, f.y);
-    const float e = sqrtf(__fmaf_rn(ev, ev, __fmul_rn(eu, eu)));   // correctly rounded (hipcc default)
-    // utils.py:58-68 (oob) and :88-91 (union)
-    const bool oob = (X < 0.0f) | (X > (float)(W - 1)) | (Y < 0.0f) | (Y > (float)(H - 1));
-    occ_out[base + p] = (uint8_t)((e > thres) | oob);
+    float e;
+    occ_out[base + p] = psfm_flow_check_px(flows_b + base, x, y, flows_f[base + p], H, W, cw, ch, thres, &e);
     if (err_out) err_out[base + p] = e;
+}
+
+// 4 pixels per thread, strided by the block size: every load/store instruction stays fully coalesced
+// (64 lanes x 8 B contiguous) while each wave keeps 4x more bytes in flight.
+#define PSFM_FC_UNROLL 4
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x4_kernel(
+    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, int H, int W, float cw, float ch,
+    float thres, uint8_t* __restrict__ occ_out, float* __restrict__ err_out, PsfmFastDiv wdiv)
+{
+    const int P = H * W;
+    const int p0 = blockIdx.x * (PSFM_BLOCK * PSFM_FC_UNROLL) + threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.y * P;
+    const float2* __restrict__ F = flows_f + base;
+    const float2* __restrict__ B = flows_b + base;
+    float2 f[PSFM_FC_UNROLL];
+#pragma unroll
+    for (int k = 0; k < PSFM_FC_UNROLL; ++k) {
+        const int p = p0 + k * PSFM_BLOCK;
+        f[k] = p < P ? F[p] : make_float2(0.f, 0.f);
+    }
+    int y = (int)psfm_fastdiv((unsigned)p0, wdiv), x = p0 - y * W;
+#pragma unroll
+    for (int k = 0; k < PSFM_FC_UNROLL; ++k) {
+        const int p = p0 + k * PSFM_BLOCK;
+        if (p >= P) break;
+        float e;
+        occ_out[base + p] = psfm_flow_check_px(B, x, y, f[k], H, W, cw, ch, thres, &e);
+        if (err_out) err_out[base + p] = e;
+        x += PSFM_BLOCK;
+        while (x >= W) { x -= W; ++y; }
+    }
 }
 
 psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs, int h, int w, float thres,
@@ -52,9 +94,15 @@ psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs
     if (n_pairs <= 0) return PSFM_OK;
     const int64_t P = (int64_t)h * w;
     const float cw = (float)((double)(w - 1) / 2.0), ch = (float)((double)(h - 1) / 2.0);
-    dim3 grid((unsigned)((P + PSFM_BLOCK - 1) / PSFM_BLOCK), (unsigned)n_pairs);
-    hipLaunchKernelGGL(psfm_flow_check_kernel, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
-                       h, w, cw, ch, thres, occ, err);
+    if (P >= PSFM_BLOCK * PSFM_FC_UNROLL) {
+        dim3 grid((unsigned)((P + PSFM_BLOCK * PSFM_FC_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_UNROLL)), (unsigned)n_pairs);
+        hipLaunchKernelGGL(psfm_flow_check_x4_kernel, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
+                           h, w, cw, ch, thres, occ, err, psfm_fastdiv_make((unsigned)w));
+    } else {
+        dim3 grid((unsigned)((P + PSFM_BLOCK - 1) / PSFM_BLOCK), (unsigned)n_pairs);
+        hipLaunchKernelGGL(psfm_flow_check_kernel, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
+                           h, w, cw, ch, thres, occ, err);
+    }
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
@@ -101,7 +149,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
 {
     const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
     if (i == 0) { ctr->n_lanes = (int)G; ctr->overflow = 0; }
-    if (i < PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; }
+    if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; }
     if (i >= cap) return;
     if (i < G) {
         birth_frame[i] = 0;
@@ -114,7 +162,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
 
 psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
 {
-    PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.H * d.W, s));
+    PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.G * 2, s));
     PSFM_HIP(hipMemsetAsync(c->survivors.p, 0, sizeof(int) * (size_t)(d.n_flows + 1), s));
     hipLaunchKernelGGL(psfm_track_init_kernel, dim3((unsigned)((d.cap + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
                        0, s, d.cap, d.G, d.GW, d.ratio, c->birth_frame.as<int>(), c->birth_idx.as<int>(),
@@ -124,157 +172,219 @@ psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2  chain_step: one thread per lane.
-//   p = log[t][L];  flow = S(F_t, p), occ = S(occ_t, p) > 0.1     (trajectory.py:25-37, :50)
-//   next = p + flow (f64);  valid = strictly inside               (trajectory.py:55-57)
-//   alive -> log[t+1][L] = next, occupied[int(ny), int(nx)] = stamp   (trajectory.py:144-146)
-//   dead  -> record (key, lane), push the lane on a free stack        (trajectory.py:140-142)
-// Deaths are counted with wavefront ballots, summed per block in LDS and published with ONE atomic per
-// block per table, on the shard blockIdx % PSFM_NSHARD (different words -> no serialisation).
-// Algorithmic bytes per alive lane: 16 (p) + 32 (4 flow taps) + 4 (occ taps) + 16 (next) + 1 (occupied).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(
-    const float2* __restrict__ flow, const uint8_t* __restrict__ occ, int H, int W, float cw, float ch,
-    const double2* __restrict__ log_cur, double2* __restrict__ log_next, int* __restrict__ birth_frame,
-    const int* __restrict__ birth_idx, uint8_t* __restrict__ occupied, uint8_t stamp,
-    const PsfmCounters* __restrict__ ctr, int* __restrict__ overflow, int* __restrict__ survivors_f,
-    PsfmShard* __restrict__ shards, int* __restrict__ free_stack, unsigned long long* __restrict__ fin_keys,
-    int* __restrict__ fin_lanes, int cap, int shard_cap, int free_cap, int frame, int shift_b, int shift_d)
-{
-    __shared__ int s_dead[PSFM_BLOCK / PSFM_WAVE];
-    __shared__ int s_alive_any;
-    __shared__ int s_base_fin, s_base_free;
-    const int n_lanes = min(ctr->n_lanes, cap);
-    if ((int)(blockIdx.x * PSFM_BLOCK) >= n_lanes) return;   // block-uniform
-    const int i = blockIdx.x * PSFM_BLOCK + threadIdx.x;
-    int bf = -1;
-    if (i < n_lanes) bf = birth_frame[i];
-    bool alive = false, dead = false;
-    if (bf >= 0) {
-        const double2 p = log_cur[i];
-        const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, cw, ch, H, W);
-        const float2 fl = psfm_sample_flow(flow, H, W, t);
-        const float oc = psfm_sample_mask(occ, H, W, t);
-        const double nx = p.x + (double)fl.x, ny = p.y + (double)fl.y;
-        const bool valid = (nx > 0.0) & (nx < (double)(W - 1)) & (ny > 0.0) & (ny < (double)(H - 1));
-        alive = valid & !(oc > 0.1f);
-        dead = !alive;
-        if (alive) {
-            log_next[i] = make_double2(nx, ny);
-            occupied[(int64_t)((int)ny) * W + (int)nx] = stamp;
-        }
-    }
-    const unsigned long long am = __ballot(alive);
-    const unsigned long long dm = __ballot(dead);
-    const int lane = psfm_lane_id(), wave = threadIdx.x / PSFM_WAVE;
-    if (threadIdx.x == 0) s_alive_any = 0;
-    if (lane == 0) s_dead[wave] = __popcll(dm);
-    __syncthreads();
-    if (lane == 0 && am != 0ull) s_alive_any = 1;   // benign race: every writer stores 1
-    const int shard = blockIdx.x % PSFM_NSHARD;
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) tot += s_dead[w];
-        if (tot > 0) {
-            s_base_fin = atomicAdd(&shards[shard].fin_cnt, tot);
-            s_base_free = atomicAdd(&shards[shard].free_top, tot);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_alive_any) *survivors_f = 1;   // "some track survived" (respawn's degenerate rule)
-    if (dead) {
-        int r = psfm_rank_in(dm);
-        for (int w = 0; w < wave; ++w) r += s_dead[w];
-        birth_frame[i] = -1;
-        const int fpos = s_base_free + r;
-        if (fpos < free_cap) free_stack[(int64_t)shard * free_cap + fpos] = i;   // cannot overflow by construction
-        const int rpos = s_base_fin + r;
-        if (rpos < shard_cap) {
-            const int64_t o = (int64_t)shard * shard_cap + rpos;
-            fin_keys[o] = ((unsigned long long)frame << shift_d) | ((unsigned long long)bf << shift_b) |
-                          (unsigned long long)birth_idx[i];
-            fin_lanes[o] = i;
-        } else {
-            atomicOr(overflow, 2);
-        }
-    }
-}
-
-psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
-                                   int frame, hipStream_t s)
-{
-    const uint8_t stamp = (uint8_t)((frame % 255) + 1);
-    if (frame > 0 && (frame % 255) == 0) PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.H * d.W, s));
-    double2* lg = c->log.as<double2>();
-    PsfmCounters* ctr = c->counters.as<PsfmCounters>();
-    hipLaunchKernelGGL(psfm_chain_step_kernel, dim3((unsigned)((d.cap + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
-                       0, s, (const float2*)flow, occ, d.H, d.W, d.cw, d.ch, lg + (int64_t)frame * d.cap,
-                       lg + (int64_t)(frame + 1) * d.cap, c->birth_frame.as<int>(), c->birth_idx.as<int>(),
-                       c->occupied.as<uint8_t>(), stamp, ctr, &ctr->overflow, c->survivors.as<int>() + frame,
-                       c->shards.as<PsfmShard>(), c->free_stack.as<int>(), c->fin_keys.as<unsigned long long>(),
-                       c->fin_lanes.as<int>(), (int)d.cap, d.shard_cap, d.free_cap, frame, d.shift_b, d.shift_d);
-    PSFM_HIP(hipGetLastError());
-    return PSFM_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3  respawn: one thread per stride-r grid point.
-//   distance_transform_edt(1 - occupied) > r   (trajectory.py:150-151)
-//     == no occupied pixel inside the integer disc dx^2+dy^2 <= r^2 (SURVEY A-5, pinned by fixtures);
-//   with NO occupied pixel at all SciPy measures to a phantom feature at (y=-1,x=0): every grid point
-//   but (0,0) respawns.  Births are counted per block (ballot + LDS); thread 0 pops that many lanes from
-//   up to PSFM_PROBE free-stack shards (one atomic each) and takes fresh lanes for the remainder.
+// K2+K3  chain_step: ONE launch per frame t = `frame`, organised so that every dependent memory round
+// trip of the bookkeeping overlaps the bilinear gathers.
+//
+//  (A) respawn for this frame -- what the reference computes at the end of the previous extend_all
+//      (trajectory.py:150-152) and instantiates at the top of the loop body (new_traj_all, :117-120):
+//        distance_transform_edt(1 - occupied) > r   on the stride-r grid
+//          == "no survivor's pixel inside the integer disc of radius r around the grid point" (pinned by
+//             tests/golden; SURVEY A-5).  The previous launch scattered every survivor's pixel into a
+//             GRID-resolution `blocked` map (all grid points within distance r of the pixel), so the test is
+//             one byte per grid point.  With NO survivor at all SciPy measures to a phantom feature at
+//             (y=-1,x=0): every grid point but (0,0) respawns.
+//      The newborn's own chain step needs only its grid position, so its gathers are issued together with
+//      (B)'s; its lane (a recycled one popped from the free stack, else a fresh one) is only needed for the
+//      final stores.
+//  (B) chain step of every lane born before t (trajectory.py:25-37,45-62, track.py:38-46, extend_all :129-147):
+//        p = log[t][L];  flow = S(F_t, p);  occ = S(occ_t, p) > 0.1;  next = p + flow (f64);
+//        alive = strictly inside & !occ  -> log[t+1][L] = next, block the grid points around int(next)
+//        dead  -> birth_frame[L] = -2 - birth_frame   ("died at step t", no atomics here)
+//  (C) the deaths marked by the PREVIOUS launch are turned into records (key, lane) and free lanes at the top
+//      of this launch, where the atomics' latency hides under the gathers.  A lane freed at step t-1 becomes
+//      poppable at launch t+1 (free stacks are double-buffered by frame parity, so pops never race pushes).
+//  All counts go through wavefront ballots -> LDS -> ONE atomic per block per table on shard
+//  blockIdx % PSFM_NSHARD.
+//  Algorithmic bytes per alive lane: 16 (p) + 32 (4 flow taps) + 4 (occ taps) + 16 (next) + 1 (occupancy).
 // ------------------------------------------------------------------------------------------------
 #define PSFM_PROBE 8
-__global__ __launch_bounds__(PSFM_BLOCK) void psfm_respawn_kernel(
-    const uint8_t* __restrict__ occupied, uint8_t stamp, int H, int W, int ratio, int GW, int64_t G,
-    const int* __restrict__ survivors_f, int* __restrict__ birth_frame, int* __restrict__ birth_idx,
-    double2* __restrict__ log_next, PsfmCounters* __restrict__ ctr, PsfmShard* __restrict__ shards,
-    const int* __restrict__ free_stack, int cap, int free_cap, int next_frame)
+
+struct PsfmChainArgs {
+    const float2* flow; const uint8_t* occ;
+    int H, W; float cw, ch;
+    int ratio, GW, GH; int G;
+    double2* log_cur; double2* log_next;
+    int* birth_frame; int* birth_idx;
+    const uint8_t* blocked_prev; uint8_t* blocked_cur; uint8_t stamp_prev, stamp_cur;
+    const int* surv_prev; int* surv_cur;
+    PsfmCounters* ctr;
+    PsfmShard* sh_pop; PsfmShard* sh_push; PsfmShard* sh_fin;
+    const int* free_pop; int* free_push;
+    unsigned long long* fin_keys; int* fin_lanes;
+    int cap, shard_cap, free_cap, frame, shift_b, shift_d;
+    PsfmFastDiv gwdiv, rdiv;   // division by GW (grid index -> row/col) and by the sample ratio
+};
+
+struct PsfmStep { bool alive; double2 next; };
+
+// One chain step split in two so that the caller can issue the gathers of several steps back to back:
+// psfm_step_issue() computes the tap geometry and performs the eight raw loads (4 flow taps, 4 mask taps);
+// psfm_step_finish() blends them (fp32, bit-exact op order) and applies trajectory.py:50,55-57.
+struct PsfmStepLoads {
+    PsfmTaps t;
+    PsfmTapIdx k;
+    float2 fnw, fne, fsw, fse;
+    uint8_t onw, one, osw, ose;
+};
+
+__device__ __forceinline__ PsfmStepLoads psfm_step_issue(const PsfmChainArgs& a, double2 p)
 {
-    __shared__ int s_births[PSFM_BLOCK / PSFM_WAVE];
-    __shared__ int s_seg_start[PSFM_PROBE + 1];   // first free-stack index (absolute) or first fresh lane
-    __shared__ int s_seg_end[PSFM_PROBE + 1];     // cumulative birth rank at which the segment ends
-    __shared__ int s_nseg;
-    const int64_t g = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    PsfmStepLoads L;
+    L.t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
+    L.k = psfm_tap_idx(a.H, a.W, L.t);   // flow and occlusion map share the tap geometry
+    L.fnw = a.flow[L.k.nw]; L.fne = a.flow[L.k.ne]; L.fsw = a.flow[L.k.sw]; L.fse = a.flow[L.k.se];
+    L.onw = a.occ[L.k.nw]; L.one = a.occ[L.k.ne]; L.osw = a.occ[L.k.sw]; L.ose = a.occ[L.k.se];
+    return L;
+}
+
+__device__ __forceinline__ PsfmStep psfm_step_finish(const PsfmChainArgs& a, double2 p, const PsfmStepLoads& L)
+{
+    const PsfmTapIdx& k = L.k;
+    const float z = 0.0f;
+    const float fx = psfm_blend(k.inw ? L.fnw.x : z, k.ine ? L.fne.x : z, k.isw ? L.fsw.x : z, k.ise ? L.fse.x : z, L.t);
+    const float fy = psfm_blend(k.inw ? L.fnw.y : z, k.ine ? L.fne.y : z, k.isw ? L.fsw.y : z, k.ise ? L.fse.y : z, L.t);
+    const float oc = psfm_blend((k.inw & (L.onw != 0)) ? 1.0f : z, (k.ine & (L.one != 0)) ? 1.0f : z,
+                                (k.isw & (L.osw != 0)) ? 1.0f : z, (k.ise & (L.ose != 0)) ? 1.0f : z, L.t);
+    const double nx = p.x + (double)fx, ny = p.y + (double)fy;
+    const bool valid = (nx > 0.0) & (nx < (double)(a.W - 1)) & (ny > 0.0) & (ny < (double)(a.H - 1));
+    PsfmStep s;
+    s.next = make_double2(nx, ny);
+    s.alive = valid & !(oc > 0.1f);
+    return s;
+}
+
+// occupied_map[int(y), int(x)] = 1 (trajectory.py:144) folded with the EDT test: mark every stride-r grid
+// point whose disc of radius r contains this pixel.  Candidates are the 3x3 grid cells around the pixel's cell;
+// a cell on the low side can only qualify when the pixel sits exactly on that grid line.  R > 0: compile-time ratio.
+template <int R>
+__device__ __forceinline__ void psfm_block_grid(const PsfmChainArgs& a, int px, int py)
+{
+    const int r = R > 0 ? R : a.ratio, r2 = r * r;
+    int qx, qy;
+    if (R == 1) { qx = px; qy = py; }
+    else if (R == 2) { qx = px >> 1; qy = py >> 1; }
+    else if (R == 4) { qx = px >> 2; qy = py >> 2; }
+    else { qx = (int)psfm_fastdiv((unsigned)px, a.rdiv); qy = (int)psfm_fastdiv((unsigned)py, a.rdiv); }
+    const int ax = px - qx * r, ay = py - qy * r;
+    uint8_t* row = a.blocked_cur + qy * a.GW + qx;
+    const uint8_t st = a.stamp_cur;
+    // dx for column offsets -1, 0, +1 : -(ax + r) [only when ax == 0], -ax, r - ax
+    const int dx0 = ax, dx1 = r - ax, dy0 = ay, dy1 = r - ay;
+    const bool xl = (ax == 0) & (qx > 0), xr = qx + 1 < a.GW;
+    const bool yl = (ay == 0) & (qy > 0), yr = qy + 1 < a.GH;
+    // centre row (dy = -ay)
+    if (dx0 * dx0 + dy0 * dy0 <= r2) row[0] = st;
+    if (xr & (dx1 * dx1 + dy0 * dy0 <= r2)) row[1] = st;
+    if (xl & (r2 + dy0 * dy0 <= r2)) row[-1] = st;
+    // row below (dy = r - ay)
+    if (yr) {
+        uint8_t* rb = row + a.GW;
+        if (dx0 * dx0 + dy1 * dy1 <= r2) rb[0] = st;
+        if (xr & (dx1 * dx1 + dy1 * dy1 <= r2)) rb[1] = st;
+        if (xl & (r2 + dy1 * dy1 <= r2)) rb[-1] = st;
+    }
+    // row above (dy = -r, only when the pixel is on the grid line)
+    if (yl) {
+        uint8_t* ra = row - a.GW;
+        if (dx0 * dx0 + r2 <= r2) ra[0] = st;
+        // the diagonal neighbours are at distance >= r*sqrt(2) > r unless dx == 0, which is the line above
+    }
+}
+
+__device__ __forceinline__ unsigned long long psfm_key(int last_time, int bf, int idx, int shift_b, int shift_d)
+{
+    return ((unsigned long long)last_time << shift_d) | ((unsigned long long)bf << shift_b) | (unsigned long long)idx;
+}
+
+template <int R>
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainArgs a)
+{
+    __shared__ int s_births[PSFM_BLOCK / PSFM_WAVE], s_pend[PSFM_BLOCK / PSFM_WAVE];
+    __shared__ int s_new_g[PSFM_BLOCK];            // grid index of the births, one 64-slot segment per wave
+    __shared__ int s_seg_start[PSFM_PROBE + 1];
+    __shared__ int s_seg_end[PSFM_PROBE + 1];
+    __shared__ int s_nseg, s_alive_any, s_base_fin, s_base_free;
+    const int tid = threadIdx.x, lane = psfm_lane_id(), wave = tid / PSFM_WAVE;
+    const int i = blockIdx.x * PSFM_BLOCK + tid;
+    const int frame = a.frame;
+    const int ratio = R > 0 ? R : a.ratio;
+    // blocks past both the lane high-water mark and the grid have nothing to do (lanes handed out during
+    // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
+    if ((int)(blockIdx.x * PSFM_BLOCK) >= max(a.ctr->n_lanes, a.G)) return;
+    if (tid == 0) s_alive_any = 0;
+
+    // ---- independent early loads: lane state, (speculative) tail position, respawn byte ----
+    int bf = -1;
+    double2 p = make_double2(0.0, 0.0);
+    if (i < a.cap) { bf = a.birth_frame[i]; p = a.log_cur[i]; }
     bool birth = false;
-    int cx = 0, cy = 0;
-    if (g < G) {
-        cx = (int)(g % GW) * ratio;
-        cy = (int)(g / GW) * ratio;
-        const int r2 = ratio * ratio;
-        if (*survivors_f == 0) {
-            birth = ((cy + 1) * (cy + 1) + cx * cx) > r2;
+    if (frame > 0 && i < a.G) {
+        if (*a.surv_prev == 0) {
+            const int gy = (int)psfm_fastdiv((unsigned)i, a.gwdiv), gx = i - gy * a.GW;
+            const int cx = gx * ratio, cy = gy * ratio;
+            birth = ((cy + 1) * (cy + 1) + cx * cx) > ratio * ratio;
         } else {
-            int hit = 0;
-            for (int dy = -ratio; dy <= ratio; ++dy) {
-                const int yy = cy + dy;
-                if (yy < 0 || yy >= H) continue;
-                for (int dx = -ratio; dx <= ratio; ++dx) {
-                    const int xx = cx + dx;
-                    if (dx * dx + dy * dy > r2 || xx < 0 || xx >= W) continue;
-                    hit |= (occupied[(int64_t)yy * W + xx] == stamp);
-                }
-            }
-            birth = !hit;
+            birth = a.blocked_prev[i] != a.stamp_prev;
         }
     }
+    // lanes born AT `frame` (allocated concurrently by other blocks) are not ours; a marker -2-b with b < frame
+    // is a death recorded by the previous launch
+    const bool live = (bf >= 0) & ((bf < frame) | (frame == 0));
+    const int pend_bf = -2 - bf;
+    const bool pend = (bf <= -2) & (pend_bf < frame);
+
+    // ---- block-level counts; the births' grid indices are compacted through LDS ----
     const unsigned long long bm = __ballot(birth);
-    const int lane = psfm_lane_id(), wave = threadIdx.x / PSFM_WAVE;
-    if (lane == 0) s_births[wave] = __popcll(bm);
+    const unsigned long long pm = __ballot(pend);
+    if (lane == 0) { s_births[wave] = __popcll(bm); s_pend[wave] = __popcll(pm); }
+    if (birth) s_new_g[wave * PSFM_WAVE + psfm_rank_in(bm)] = i;
+
+    // ---- gathers of the lane's step (unconditional: idle lanes sample pixel (0,0)) ----
+    const double2 p1 = live ? p : make_double2(0.0, 0.0);
+    const PsfmStepLoads l1 = psfm_step_issue(a, p1);
+
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int need = 0;
-        for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) need += s_births[w];
+    // ---- the newborns' first step, compacted onto the first threads of the block ----
+    int nb = 0, g2 = -1;
+    {
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) {
+            const int c = s_births[w];
+            if (tid >= before && tid < before + c) g2 = s_new_g[w * PSFM_WAVE + (tid - before)];
+            before += c;
+        }
+        nb = before;
+    }
+    const bool newborn = tid < nb;
+    double2 p2 = make_double2(0.0, 0.0);
+    PsfmStepLoads l2;
+    if (newborn) {
+        const int gy = (int)psfm_fastdiv((unsigned)g2, a.gwdiv), gx = g2 - gy * a.GW;
+        p2 = make_double2((double)(gx * ratio), (double)(gy * ratio));
+        l2 = psfm_step_issue(a, p2);
+    }
+    const int shard = blockIdx.x % PSFM_NSHARD;
+    if (tid == 0) {
+        int need = nb, npend = 0;
+        for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) npend += s_pend[w];
+        // three independent atomics, issued back to back: one round trip
+        int old_top = 0, bfin = 0, bfree = 0;
+        const int sh0 = blockIdx.x % PSFM_NSHARD;
+        if (need > 0 || npend > 0) {
+            old_top = atomicSub(&a.sh_pop[sh0].free_top, need);
+            bfin = atomicAdd(&a.sh_fin[shard].fin_cnt, npend);
+            bfree = atomicAdd(&a.sh_push[shard].free_top, npend);
+        }
+        s_base_fin = bfin; s_base_free = bfree;
         int nseg = 0, done = 0;
         for (int k = 0; k < PSFM_PROBE && need > 0; ++k) {
-            const int sh = (blockIdx.x + k * 7) % PSFM_NSHARD;
-            const int old_top = atomicSub(&shards[sh].free_top, need);
+            const int sh = (sh0 + k * 7) % PSFM_NSHARD;
+            if (k > 0) old_top = atomicSub(&a.sh_pop[sh].free_top, need);
             const int take = old_top < 0 ? 0 : (old_top > need ? need : old_top);
-            if (take < need) atomicAdd(&shards[sh].free_top, need - take);   // give back what the stack did not have
+            if (take < need) atomicAdd(&a.sh_pop[sh].free_top, need - take);   // give back what the stack did not have
             if (take > 0) {
-                // entries [old_top - take, old_top) of shard sh; rank q in the segment -> index old_top-1-q
-                s_seg_start[nseg] = sh * free_cap + old_top - 1;
+                s_seg_start[nseg] = sh * a.free_cap + old_top - 1;   // rank q of the segment -> entry start - q
                 done += take;
                 s_seg_end[nseg] = done;
                 ++nseg;
@@ -282,7 +392,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_respawn_kernel(
             }
         }
         if (need > 0) {
-            const int base_new = atomicAdd(&ctr->n_lanes, need);
+            const int base_new = atomicAdd(&a.ctr->n_lanes, need);
             s_seg_start[nseg] = -(base_new + 1);   // negative: fresh lanes base_new, base_new+1, ...
             done += need;
             s_seg_end[nseg] = done;
@@ -291,33 +401,111 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_respawn_kernel(
         s_nseg = nseg;
     }
     __syncthreads();
-    if (birth) {
-        int r = psfm_rank_in(bm);
-        for (int w = 0; w < wave; ++w) r += s_births[w];
-        int k = 0, prev = 0;
-        while (k < s_nseg - 1 && r >= s_seg_end[k]) { prev = s_seg_end[k]; ++k; }
-        const int q = r - prev;
-        const int st = s_seg_start[k];
-        const int L = st >= 0 ? free_stack[st - q] : (-(st + 1) + q);
-        if (L < cap) {
-            birth_frame[L] = next_frame;
-            birth_idx[L] = (int)g;
-            log_next[L] = make_double2((double)cx, (double)cy);
+
+    // ---- (C) deaths of the previous step -> record + free lane ----
+    if (pend) {
+        int r = psfm_rank_in(pm);
+        for (int w = 0; w < wave; ++w) r += s_pend[w];
+        a.birth_frame[i] = -1;
+        const int fpos = s_base_free + r;
+        if (fpos < a.free_cap) a.free_push[(int64_t)shard * a.free_cap + fpos] = i;   // cannot overflow by construction
+        const int rpos = s_base_fin + r;
+        if (rpos < a.shard_cap) {
+            const int64_t o = (int64_t)shard * a.shard_cap + rpos;
+            a.fin_keys[o] = psfm_key(frame - 1, pend_bf, a.birth_idx[i], a.shift_b, a.shift_d);
+            a.fin_lanes[o] = i;
         } else {
-            atomicOr(&ctr->overflow, 1);
+            atomicOr(&a.ctr->overflow, 2);
         }
     }
+    // ---- (B) results of the lane's step ----
+    bool any_alive = false;
+    if (live) {
+        const PsfmStep s1 = psfm_step_finish(a, p1, l1);
+        if (s1.alive) {
+            a.log_next[i] = s1.next;
+            psfm_block_grid<R>(a, (int)s1.next.x, (int)s1.next.y);
+            any_alive = true;
+        } else {
+            a.birth_frame[i] = -2 - bf;
+        }
+    }
+    // ---- (A) the newborn: lane, state, first step ----
+    if (newborn) {
+        const PsfmStep s2 = psfm_step_finish(a, p2, l2);
+        int k = 0, prev = 0;
+        while (k < s_nseg - 1 && tid >= s_seg_end[k]) { prev = s_seg_end[k]; ++k; }
+        const int q = tid - prev;
+        const int st = s_seg_start[k];
+        const int L = st >= 0 ? a.free_pop[st - q] : (-(st + 1) + q);
+        if (L < a.cap) {
+            a.birth_idx[L] = g2;
+            a.log_cur[L] = p2;
+            if (s2.alive) {
+                a.birth_frame[L] = frame;
+                a.log_next[L] = s2.next;
+                psfm_block_grid<R>(a, (int)s2.next.x, (int)s2.next.y);
+                any_alive = true;
+            } else {
+                a.birth_frame[L] = -2 - frame;   // born and lost in the same step: a length-1 trajectory
+            }
+        } else {
+            atomicOr(&a.ctr->overflow, 1);
+        }
+    }
+    // ---- "some track survived this step" (the degenerate respawn rule of the next launch) ----
+    const unsigned long long am = __ballot(any_alive);
+    if (lane == 0 && am != 0ull) s_alive_any = 1;   // benign race: every writer stores 1
+    __syncthreads();
+    if (tid == 0 && s_alive_any) *a.surv_cur = 1;
 }
 
-psfm_status psfm_launch_respawn(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s)
+psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
+                                   int frame, hipStream_t s)
 {
-    const uint8_t stamp = (uint8_t)((frame % 255) + 1);
+    PsfmChainArgs a;
+    a.flow = (const float2*)flow; a.occ = occ;
+    a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch;
+    a.ratio = d.ratio; a.GW = d.GW; a.GH = d.GH; a.G = (int)d.G;
     double2* lg = c->log.as<double2>();
-    hipLaunchKernelGGL(psfm_respawn_kernel, dim3((unsigned)((d.G + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
-                       c->occupied.as<uint8_t>(), stamp, d.H, d.W, d.ratio, d.GW, d.G, c->survivors.as<int>() + frame,
-                       c->birth_frame.as<int>(), c->birth_idx.as<int>(), lg + (int64_t)(frame + 1) * d.cap,
-                       c->counters.as<PsfmCounters>(), c->shards.as<PsfmShard>(), c->free_stack.as<int>(), (int)d.cap,
-                       d.free_cap, frame + 1);
+    a.log_cur = lg + (int64_t)frame * d.cap;
+    a.log_next = lg + (int64_t)(frame + 1) * d.cap;
+    a.birth_frame = c->birth_frame.as<int>(); a.birth_idx = c->birth_idx.as<int>();
+    // blocked maps / free stacks / shard tables are double-buffered by frame parity; stamps wrap every 254 frames
+    uint8_t* maps = c->occupied.as<uint8_t>();
+    const int cur = frame & 1, prev = cur ^ 1;
+    a.blocked_cur = maps + (int64_t)cur * d.G;
+    a.blocked_prev = maps + (int64_t)prev * d.G;
+    a.stamp_cur = (uint8_t)((frame % 254) + 1);
+    a.stamp_prev = (uint8_t)(((frame + 253) % 254) + 1);
+    if (frame > 1 && (frame % 254) <= 1) {
+        // the map about to be written last saw this stamp value 254 frames ago: clear it
+        PSFM_HIP(hipMemsetAsync(a.blocked_cur, 0, (size_t)d.G, s));
+    }
+    a.surv_prev = c->survivors.as<int>() + (frame > 0 ? frame - 1 : 0);
+    a.surv_cur = c->survivors.as<int>() + frame;
+    a.ctr = c->counters.as<PsfmCounters>();
+    PsfmShard* sh = c->shards.as<PsfmShard>();
+    a.sh_pop = sh + (int64_t)cur * PSFM_NSHARD;
+    a.sh_push = sh + (int64_t)prev * PSFM_NSHARD;
+    a.sh_fin = sh;   // trajectory records: one table for the whole sequence
+    int* fs = c->free_stack.as<int>();
+    const int64_t set = (int64_t)d.free_cap * PSFM_NSHARD;
+    a.free_pop = fs + cur * set;
+    a.free_push = fs + prev * set;
+    a.fin_keys = c->fin_keys.as<unsigned long long>(); a.fin_lanes = c->fin_lanes.as<int>();
+    a.cap = (int)d.cap; a.shard_cap = d.shard_cap; a.free_cap = d.free_cap; a.frame = frame;
+    a.shift_b = d.shift_b; a.shift_d = d.shift_d;
+    a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    c->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1);
+    const dim3 grid((unsigned)((d.cap + PSFM_BLOCK - 1) / PSFM_BLOCK)), block(PSFM_BLOCK);
+    switch (d.ratio) {
+        case 1: hipExtLaunchKernelGGL(psfm_chain_step_kernel<1>, grid, block, 0, s, e0, e1, 0, a); break;
+        case 2: hipExtLaunchKernelGGL(psfm_chain_step_kernel<2>, grid, block, 0, s, e0, e1, 0, a); break;
+        case 4: hipExtLaunchKernelGGL(psfm_chain_step_kernel<4>, grid, block, 0, s, e0, e1, 0, a); break;
+        default: hipExtLaunchKernelGGL(psfm_chain_step_kernel<0>, grid, block, 0, s, e0, e1, 0, a); break;
+    }
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
