@@ -95,7 +95,9 @@ def main():
     for _ in range(args.warmup):
         info = step()
     # ---- timed region: exactly K steps, HIP events around every kernel family ----
-    ctx.set_profiling(True)
+    # HIP events around flow_check / finalize and around every 8th chain_step launch (hipExtLaunchKernelGGL
+    # start/stop events = exact kernel begin/end): timing every launch would cost ~0.6 ms of host time per step
+    ctx.set_profiling(0 if os.environ.get("PSFM_BENCH_NOPROF") else 8)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):

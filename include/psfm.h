@@ -133,7 +133,8 @@ psfm_status psfm_result_solve_stats(psfm_ctx* ctx, psfm_solve_stats* stats_host,
 
 /* Per-kernel device time of the last psfm_track / psfm_flow_check when profiling is enabled with
  * psfm_ctx_set_profiling(ctx, 1): HIP events recorded on the launch stream around every launch of
- * the named kernel family.  kind: 0 flow_check, 1 chain_step, 2 respawn, 3 solver, 4 finalize.
+ * the named kernel family (enable = N > 1: only every N-th chain_step launch is timed, which keeps the
+ * event overhead out of a throughput measurement).  kind: 0 flow_check, 1 chain_step, 2 respawn, 3 solver, 4 finalize.
  * Returns the accumulated milliseconds and the number of launches. */
 psfm_status psfm_ctx_set_profiling(psfm_ctx* ctx, int enable);
 psfm_status psfm_profile_get(psfm_ctx* ctx, int kind, double* total_ms, int64_t* launches);

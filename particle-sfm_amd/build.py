@@ -32,6 +32,10 @@ def _newer(target, deps):
 
 
 def build(force=False, verbose=False):
+    extra = os.environ.get("PSFM_EXTRA_FLAGS", "").split()   # e.g. -DPSFM_TIMELINE (debug builds only)
+    if extra:
+        FLAGS.extend(extra)
+        force = True
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]

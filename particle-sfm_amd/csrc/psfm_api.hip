@@ -65,7 +65,7 @@ void PsfmProfiler::begin(int kind, hipStream_t s)
 }
 void PsfmProfiler::kernel_span(int kind, hipEvent_t* a, hipEvent_t* b)
 {
-    if (!enabled) { *a = nullptr; *b = nullptr; return; }
+    if (!enabled || (calls++ % stride) != 0) { *a = nullptr; *b = nullptr; return; }
     Span sp; sp.kind = kind; sp.a = get(); sp.b = get();
     spans.push_back(sp);
     *a = sp.a; *b = sp.b;
@@ -145,6 +145,8 @@ extern "C" psfm_status psfm_ctx_set_profiling(psfm_ctx* c, int enable)
 {
     if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
     c->prof.enabled = enable != 0;
+    c->prof.stride = enable > 1 ? enable : 1;   // enable = N > 1: time every N-th chain_step launch only
+    c->prof.calls = 0;
     c->prof.collect();
     c->prof.reset();
     return PSFM_OK;

@@ -158,8 +158,9 @@ psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
     PSFM_HIP(hipMemcpyAsync(hs, shards, sizeof(PsfmShard) * PSFM_NSHARD, hipMemcpyDeviceToHost, s));
     PSFM_HIP(hipStreamSynchronize(s));
     PsfmShardOffsets so;
-    int64_t n = 0;
+    int64_t n = 0, npts = 0;
     bool over = hc->overflow != 0;
+    for (int k = 0; k < PSFM_NSHARD; ++k) npts += hs[k].points;   // every log write was counted by its block
     for (int k = 0; k < PSFM_NSHARD; ++k) {
         if (hs[k].fin_cnt > d.shard_cap) over = true;
         so.count[k] = hs[k].fin_cnt > d.shard_cap ? d.shard_cap : hs[k].fin_cnt;
@@ -206,10 +207,6 @@ psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
     PSFM_HIP(hipGetLastError());
     PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->res_off.as<int64_t>(),
                                      (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
-    int64_t* hn = (int64_t*)((char*)c->host_pinned + 256);   // (counters at +0, shards at +512)
-    PSFM_HIP(hipMemcpyAsync(hn, c->res_off.as<int64_t>() + n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    PSFM_HIP(hipStreamSynchronize(s));
-    const int64_t npts = *hn;
     c->res_n_points = npts;
     // 4. transpose the frame-major log into the id-ordered CSR
     if ((st = c->res_xy.ensure(sizeof(double2) * (size_t)(npts > 0 ? npts : 1))) != PSFM_OK) return st;

@@ -39,7 +39,8 @@ struct PsfmCounters {
 #define PSFM_NSHARD 64
 struct PsfmShard {
     int fin_cnt;      // trajectory records written into this shard's slice
-    int pad0[31];
+    unsigned points;  // trajectory points written through this shard's blocks (set 0 only)
+    int pad0[30];
     int free_top;     // top of this shard's free-lane stack
     int pad1[31];
 };
@@ -49,6 +50,8 @@ enum { PSFM_PROF_FLOW_CHECK = 0, PSFM_PROF_CHAIN = 1, PSFM_PROF_RESPAWN = 2, PSF
 
 struct PsfmProfiler {
     bool enabled = false;
+    int stride = 1;          // kernel_span() hands out events for every `stride`-th call only
+    int64_t calls = 0;
     struct Span { int kind; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> pool;

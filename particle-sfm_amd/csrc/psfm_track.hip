@@ -17,6 +17,8 @@
 #include "psfm_device.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 
 #include "psfm_internal.h"
 
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
 {
     const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
     if (i == 0) { ctr->n_lanes = (int)G; ctr->overflow = 0; }
-    if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; }
+    if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; shards[i].points = (i == 0) ? (unsigned)G : 0u; }
     if (i >= cap) return;
     if (i < G) {
         birth_frame[i] = 0;
@@ -419,10 +421,11 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
         }
     }
     // ---- (B) results of the lane's step ----
-    bool any_alive = false;
+    bool any_alive = false, live_alive = false, newborn_alive = false, newborn_ok = false;
     if (live) {
         const PsfmStep s1 = psfm_step_finish(a, p1, l1);
         if (s1.alive) {
+            live_alive = true;
             a.log_next[i] = s1.next;
             psfm_block_grid<R>(a, (int)s1.next.x, (int)s1.next.y);
             any_alive = true;
@@ -439,9 +442,11 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
         const int st = s_seg_start[k];
         const int L = st >= 0 ? a.free_pop[st - q] : (-(st + 1) + q);
         if (L < a.cap) {
+            newborn_ok = true;
             a.birth_idx[L] = g2;
             a.log_cur[L] = p2;
             if (s2.alive) {
+                newborn_alive = true;
                 a.birth_frame[L] = frame;
                 a.log_next[L] = s2.next;
                 psfm_block_grid<R>(a, (int)s2.next.x, (int)s2.next.y);
@@ -456,6 +461,12 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
     // ---- "some track survived this step" (the degenerate respawn rule of the next launch) ----
     const unsigned long long am = __ballot(any_alive);
     if (lane == 0 && am != 0ull) s_alive_any = 1;   // benign race: every writer stores 1
+    // trajectory points written by this wave: one per surviving step (log_next) + one per birth (log_cur);
+    // fire-and-forget atomic, summed on the host at finalize to size the result without a second sync
+    {
+        const int npts = __popcll(__ballot(live_alive)) + __popcll(__ballot(newborn_alive)) + __popcll(__ballot(newborn_ok));
+        if (lane == 0 && npts > 0) atomicAdd(&a.sh_fin[shard].points, (unsigned)npts);
+    }
     __syncthreads();
     if (tid == 0 && s_alive_any) *a.surv_cur = 1;
 }

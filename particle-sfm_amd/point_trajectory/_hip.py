@@ -102,7 +102,7 @@ class Context:
         check(lib().psfm_ctx_set_capacity(self._h, float(lane_factor), float(traj_factor)))
 
     def set_profiling(self, enable):
-        check(lib().psfm_ctx_set_profiling(self._h, int(bool(enable))))
+        check(lib().psfm_ctx_set_profiling(self._h, int(enable)))   # 0 off, 1 every launch, N>1 every N-th chain_step
 
     def profile(self):
         out = {}
