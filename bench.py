@@ -108,13 +108,8 @@ def main():
     ctx.set_profiling(False)
 
     points = int(info.n_points)
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    pts = torch.tensor([float(points)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
-    dt_max = float(t_max.item())
-    total_points = float(pts.item())
+    import psfm_dist
+    dt_max, total_points = psfm_dist.reduce_totals(dt, points, device=dev)   # max time, summed units over ranks
 
     if rank == 0:
         # ---- roofline of the flow-chaining kernel (K2): algorithmic bytes per launch / avg duration ----

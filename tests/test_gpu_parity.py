@@ -144,3 +144,18 @@ def test_track_full_size_properties(pt):
     O = orc.track(list(ff), list(oo), r)
     Rk = pt.trajectory.run_track(d["flows_f"][:k], occ[:k], None, None, r)
     assert np.array_equal(Rk.birth, O.birth) and np.array_equal(Rk.length, O.length) and np.array_equal(Rk.xy, O.xy)
+
+
+def test_flow_check_sharded_single_process(pt):
+    """The frame-pair-sharded flow_check (psfm_dist) with world size 1 runs the HIP kernel on the whole stack."""
+    import torch
+    import psfm_dist
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(4, 37, 53, seed=5, sigma=0.4, n_occluders=1, stride2=False)
+    ff = torch.from_numpy(np.stack(d["flows_f"])).cuda()
+    fb = torch.from_numpy(np.stack(d["flows_b"])).cuda()
+    occ = psfm_dist.flow_check_sharded(ff, fb, 1.0, lambda f, b, t: pt.utils.flow_check_device(f, b, t)[1])
+    _, ref = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    assert np.array_equal(occ.cpu().numpy().astype(bool), np.stack(ref))
+    pk = psfm_dist.pack_bits(occ)
+    assert torch.equal(psfm_dist.unpack_bits(pk, 37, 53), occ)
