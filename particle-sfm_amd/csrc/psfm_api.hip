@@ -230,7 +230,7 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
     d.cap = (int64_t)(c->lane_factor * (double)d.G);
     d.cap = ((d.cap + 255) / 256) * 256;
     const int64_t n_blocks = d.cap / 256;
-    d.free_cap = (int)(((n_blocks + PSFM_NSHARD - 1) / PSFM_NSHARD) * 256);
+    d.free_cap = (int)(((n_blocks + PSFM_NSHARD - 1) / PSFM_NSHARD) * 256) + 1024;   // per-shard stack, with slack for other block sizes
     // records are spread over PSFM_NSHARD slices by block index: give every slice head-room
     d.shard_cap = (int)(((int64_t)(c->traj_factor * (double)d.G) + d.cap) / PSFM_NSHARD) + 1024;
     d.traj_cap = (int64_t)d.shard_cap * PSFM_NSHARD;

@@ -298,21 +298,31 @@ __device__ __forceinline__ unsigned long long psfm_key(int last_time, int bf, in
     return ((unsigned long long)last_time << shift_d) | ((unsigned long long)bf << shift_b) | (unsigned long long)idx;
 }
 
+#ifndef PSFM_CHAIN_BLOCK
+#define PSFM_CHAIN_BLOCK 256
+#endif
+#ifndef PSFM_CHAIN_ATTR
+#define PSFM_CHAIN_ATTR
+#endif
+#ifndef PSFM_CHAIN_MINWAVES
+#define PSFM_CHAIN_MINWAVES 1
+#endif
 template <int R>
-__global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainArgs a)
+__global__ __launch_bounds__(PSFM_CHAIN_BLOCK, PSFM_CHAIN_MINWAVES) PSFM_CHAIN_ATTR void psfm_chain_step_kernel(PsfmChainArgs a)
 {
-    __shared__ int s_births[PSFM_BLOCK / PSFM_WAVE], s_pend[PSFM_BLOCK / PSFM_WAVE];
-    __shared__ int s_new_g[PSFM_BLOCK];            // grid index of the births, one 64-slot segment per wave
+    __shared__ int s_births[PSFM_CHAIN_BLOCK / PSFM_WAVE], s_pend[PSFM_CHAIN_BLOCK / PSFM_WAVE];
+    __shared__ int s_new_g[PSFM_CHAIN_BLOCK];            // grid index of the births, one 64-slot segment per wave
+    __shared__ int s_pend_lane[PSFM_CHAIN_BLOCK];        // lanes of the tracks that died in the previous step, same layout
     __shared__ int s_seg_start[PSFM_PROBE + 1];
     __shared__ int s_seg_end[PSFM_PROBE + 1];
     __shared__ int s_nseg, s_alive_any, s_base_fin, s_base_free;
     const int tid = threadIdx.x, lane = psfm_lane_id(), wave = tid / PSFM_WAVE;
-    const int i = blockIdx.x * PSFM_BLOCK + tid;
+    const int i = blockIdx.x * PSFM_CHAIN_BLOCK + tid;
     const int frame = a.frame;
     const int ratio = R > 0 ? R : a.ratio;
     // blocks past both the lane high-water mark and the grid have nothing to do (lanes handed out during
     // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
-    if ((int)(blockIdx.x * PSFM_BLOCK) >= max(a.ctr->n_lanes, a.G)) return;
+    if ((int)(blockIdx.x * PSFM_CHAIN_BLOCK) >= max(a.ctr->n_lanes, a.G)) return;
     if (tid == 0) s_alive_any = 0;
 
     // ---- independent early loads: lane state, (speculative) tail position, respawn byte ----
@@ -334,12 +344,15 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
     const bool live = (bf >= 0) & ((bf < frame) | (frame == 0));
     const int pend_bf = -2 - bf;
     const bool pend = (bf <= -2) & (pend_bf < frame);
+    int pend_idx = 0;
+    if (pend) pend_idx = a.birth_idx[i];   // read NOW: a newborn of this block may inherit (and overwrite) this lane below
 
     // ---- block-level counts; the births' grid indices are compacted through LDS ----
     const unsigned long long bm = __ballot(birth);
     const unsigned long long pm = __ballot(pend);
     if (lane == 0) { s_births[wave] = __popcll(bm); s_pend[wave] = __popcll(pm); }
     if (birth) s_new_g[wave * PSFM_WAVE + psfm_rank_in(bm)] = i;
+    if (pend) s_pend_lane[wave * PSFM_WAVE + psfm_rank_in(pm)] = i;
 
     // ---- gathers of the lane's step (unconditional: idle lanes sample pixel (0,0)) ----
     const double2 p1 = live ? p : make_double2(0.0, 0.0);
@@ -347,17 +360,23 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
 
     __syncthreads();
     // ---- the newborns' first step, compacted onto the first threads of the block ----
-    int nb = 0, g2 = -1;
+    // Newborn #t first inherits the lane of the block's t-th just-died track (no atomics, the lane is recycled
+    // immediately); only the surplus of births pops the free stacks and only the surplus of deaths pushes them.
+    int nb = 0, npd = 0, g2 = -1, L2 = -1;
     {
-        int before = 0;
+        int before = 0, pbefore = 0;
 #pragma unroll
-        for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) {
-            const int c = s_births[w];
+        for (int w = 0; w < PSFM_CHAIN_BLOCK / PSFM_WAVE; ++w) {
+            const int c = s_births[w], pc = s_pend[w];
             if (tid >= before && tid < before + c) g2 = s_new_g[w * PSFM_WAVE + (tid - before)];
+            if (tid >= pbefore && tid < pbefore + pc) L2 = s_pend_lane[w * PSFM_WAVE + (tid - pbefore)];
             before += c;
+            pbefore += pc;
         }
         nb = before;
+        npd = pbefore;
     }
+    const int matched = nb < npd ? nb : npd;
     const bool newborn = tid < nb;
     double2 p2 = make_double2(0.0, 0.0);
     PsfmStepLoads l2;
@@ -368,16 +387,14 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
     }
     const int shard = blockIdx.x % PSFM_NSHARD;
     if (tid == 0) {
-        int need = nb, npend = 0;
-        for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) npend += s_pend[w];
-        // three independent atomics, issued back to back: one round trip
+        int need = nb - matched;            // births that must pop a lane
+        const int n_push = npd - matched;   // deaths whose lane goes back to the free stack
+        // up to three independent atomics, issued back to back: one round trip
         int old_top = 0, bfin = 0, bfree = 0;
         const int sh0 = blockIdx.x % PSFM_NSHARD;
-        if (need > 0 || npend > 0) {
-            old_top = atomicSub(&a.sh_pop[sh0].free_top, need);
-            bfin = atomicAdd(&a.sh_fin[shard].fin_cnt, npend);
-            bfree = atomicAdd(&a.sh_push[shard].free_top, npend);
-        }
+        if (need > 0) old_top = atomicSub(&a.sh_pop[sh0].free_top, need);
+        if (npd > 0) bfin = atomicAdd(&a.sh_fin[shard].fin_cnt, npd);
+        if (n_push > 0) bfree = atomicAdd(&a.sh_push[shard].free_top, n_push);
         s_base_fin = bfin; s_base_free = bfree;
         int nseg = 0, done = 0;
         for (int k = 0; k < PSFM_PROBE && need > 0; ++k) {
@@ -402,19 +419,24 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
         }
         s_nseg = nseg;
     }
+    // the dead track's birth index must be in a register before any newborn may overwrite birth_idx[lane]
+    asm volatile("" : : "v"(pend_idx) : "memory");
     __syncthreads();
 
-    // ---- (C) deaths of the previous step -> record + free lane ----
+    // ---- (C) deaths of the previous step -> record (+ free lane unless a newborn inherits it) ----
     if (pend) {
         int r = psfm_rank_in(pm);
         for (int w = 0; w < wave; ++w) r += s_pend[w];
-        a.birth_frame[i] = -1;
-        const int fpos = s_base_free + r;
-        if (fpos < a.free_cap) a.free_push[(int64_t)shard * a.free_cap + fpos] = i;   // cannot overflow by construction
+        if (r >= matched) {
+            a.birth_frame[i] = -1;
+            const int fpos = s_base_free + (r - matched);
+            if (fpos < a.free_cap) a.free_push[(int64_t)shard * a.free_cap + fpos] = i;
+            else atomicOr(&a.ctr->overflow, 1);
+        }
         const int rpos = s_base_fin + r;
         if (rpos < a.shard_cap) {
             const int64_t o = (int64_t)shard * a.shard_cap + rpos;
-            a.fin_keys[o] = psfm_key(frame - 1, pend_bf, a.birth_idx[i], a.shift_b, a.shift_d);
+            a.fin_keys[o] = psfm_key(frame - 1, pend_bf, pend_idx, a.shift_b, a.shift_d);
             a.fin_lanes[o] = i;
         } else {
             atomicOr(&a.ctr->overflow, 2);
@@ -436,12 +458,16 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_chain_step_kernel(PsfmChainAr
     // ---- (A) the newborn: lane, state, first step ----
     if (newborn) {
         const PsfmStep s2 = psfm_step_finish(a, p2, l2);
-        int k = 0, prev = 0;
-        while (k < s_nseg - 1 && tid >= s_seg_end[k]) { prev = s_seg_end[k]; ++k; }
-        const int q = tid - prev;
-        const int st = s_seg_start[k];
-        const int L = st >= 0 ? a.free_pop[st - q] : (-(st + 1) + q);
-        if (L < a.cap) {
+        int L = L2;                          // inherited from a just-died track of this block (tid < matched) ...
+        if (tid >= matched) {                // ... or popped / fresh
+            const int qq = tid - matched;
+            int k = 0, prev = 0;
+            while (k < s_nseg - 1 && qq >= s_seg_end[k]) { prev = s_seg_end[k]; ++k; }
+            const int q = qq - prev;
+            const int st = s_seg_start[k];
+            L = st >= 0 ? a.free_pop[st - q] : (-(st + 1) + q);
+        }
+        if (L >= 0 && L < a.cap) {
             newborn_ok = true;
             a.birth_idx[L] = g2;
             a.log_cur[L] = p2;
@@ -510,7 +536,7 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
     a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     c->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1);
-    const dim3 grid((unsigned)((d.cap + PSFM_BLOCK - 1) / PSFM_BLOCK)), block(PSFM_BLOCK);
+    const dim3 grid((unsigned)((d.cap + PSFM_CHAIN_BLOCK - 1) / PSFM_CHAIN_BLOCK)), block(PSFM_CHAIN_BLOCK);
     switch (d.ratio) {
         case 1: hipExtLaunchKernelGGL(psfm_chain_step_kernel<1>, grid, block, 0, s, e0, e1, 0, a); break;
         case 2: hipExtLaunchKernelGGL(psfm_chain_step_kernel<2>, grid, block, 0, s, e0, e1, 0, a); break;
