@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=N_FRAMES, help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-pairs", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-pairs", type=int, default=100, help=argparse.SUPPRESS)   # whole workload: ~10 s of CPU
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
