@@ -5,8 +5,8 @@ import os
 
 import numpy as np
 
-from .utils import load_flows, flow_check_device
-from .trajectory import run_track, _as_device_stack
+from .utils import load_flows_device, flow_check_device
+from .trajectory import run_track
 
 
 def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_check_thres=1.0, traj_min_len=3,
@@ -18,16 +18,16 @@ def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_che
         return
 
     # load data (.flo -> HBM once; the error maps of the reference are never consumed, :39-40)
-    flows_f = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_f")), torch.float32, (1, 1, 2))
-    flows_b = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_b")), torch.float32, (1, 1, 2))
+    flows_f = load_flows_device(os.path.join(flow_dir, "flow_f"))
+    flows_b = load_flows_device(os.path.join(flow_dir, "flow_b"))
     n = min(flows_f.shape[0], flows_b.shape[0])
     _, occ_maps = flow_check_device(flows_f[:n], flows_b[:n], flow_check_thres)
     del flows_b
 
     flows_f2 = occ_maps_s2 = None
     if not skip_path_consistency:
-        flows_f2 = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_f2")), torch.float32, (1, 1, 2))
-        flows_b2 = _as_device_stack(load_flows(os.path.join(flow_dir, "flow_b2")), torch.float32, (1, 1, 2))
+        flows_f2 = load_flows_device(os.path.join(flow_dir, "flow_f2"))
+        flows_b2 = load_flows_device(os.path.join(flow_dir, "flow_b2"))
         n2 = min(flows_f2.shape[0], flows_b2.shape[0])
         _, occ_maps_s2 = flow_check_device(flows_f2[:n2], flows_b2[:n2], flow_check_thres)
         del flows_b2

@@ -65,10 +65,13 @@ class TrajectoryList:
 
     def to_trajectory_set(self, traj_min_len=3):
         """main_connect_point_trajectories.py:56-61: ids are list indices, short tracks dropped."""
-        keep = np.nonzero(self.length >= int(traj_min_len))[0]
-        ts = particlesfm.TrajectorySet()
-        ts.trajs = {int(i): self[int(i)] for i in keep}
-        return ts
+        keep_mask = self.length >= int(traj_min_len)
+        keep = np.nonzero(keep_mask)[0]
+        length = self.length[keep]
+        off = np.zeros(len(keep) + 1, np.int64)
+        np.cumsum(length, out=off[1:])
+        xy = self.xy[np.repeat(keep_mask, self.length)]     # array-speed: no per-trajectory Python objects
+        return particlesfm.TrajectorySet._from_csr(keep, self.birth[keep], length, off, xy)
 
 
 def _result_to_host(ctx, info):

@@ -160,3 +160,71 @@ def test_track_npy_roundtrip_and_consumers(tmp_path):
     assert out["locations"][0][0, 3] == 0.0
     out = back.sample_inside_window([0, 1, 2, 3, 4, 5], min_length=1, max_num_tracks=2)
     assert len(out["traj_ids"]) == 2
+
+
+def _reference_sample_inside_window(trajs, frame_ids, min_length):
+    """Plain restatement of trajectory_base.cpp:115-185 (map-of-maps + loops), without the random shrink."""
+    inv = {}
+    for tid, (times, xy) in trajs.items():
+        for i, f in enumerate(times):
+            inv.setdefault(f, {})[tid] = i
+    counter = {}
+    for f in frame_ids:
+        for tid in inv.get(f, {}):
+            counter[tid] = counter.get(tid, 0) + 1
+    ids = [t for t in sorted(counter) if counter[t] >= min_length]
+    K, L = len(ids), len(frame_ids)
+    X, Y, M = np.zeros((K, L)), np.zeros((K, L)), np.zeros((K, L), np.int32)
+    for a, tid in enumerate(ids):
+        for b, f in enumerate(frame_ids):
+            if f in inv and tid in inv[f]:
+                X[a, b], Y[a, b] = trajs[tid][1][inv[f][tid]]
+                M[a, b] = 1
+    return ids, X, Y, M
+
+
+def test_trajectory_set_csr_vs_map_and_reference_semantics(tmp_path, monkeypatch):
+    from point_trajectory.optimize.build import particlesfm
+    from point_trajectory.trajectory import TrajectoryList
+    rng = np.random.default_rng(3)
+    n = 200
+    birth = rng.integers(0, 20, n).astype(np.int32)
+    length = rng.integers(1, 12, n).astype(np.int32)
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum(length)
+    xy = rng.uniform(0, 100, (int(off[-1]), 2))
+    tl = TrajectoryList(birth, length, off, xy)
+    ts = tl.to_trajectory_set(3)                      # CSR-backed
+    kept = [i for i in range(n) if length[i] >= 3]
+    assert len(ts) == len(kept)
+    ref = {i: (list(range(birth[i], birth[i] + length[i])), xy[off[i]:off[i + 1]]) for i in kept}
+    ts.build_invert_indexes()
+    for frames, ml in [([3, 4, 5, 6, 7], 3), (list(range(10, 20)), 3), ([0, 1], 1), ([50, 51, 52], 3), ([5, 5, 6], 3)]:
+        out = ts.sample_inside_window(frames, min_length=ml)
+        ids, X, Y, M = _reference_sample_inside_window(ref, frames, ml)
+        assert out["traj_ids"] == ids
+        assert np.array_equal(out["locations"][0], X) and np.array_equal(out["locations"][1], Y)
+        assert np.array_equal(out["masks"], M)
+    # default pickle state is the compact CSR; the legacy layout is what the pybind module writes/reads
+    fn = str(tmp_path / "track.npy")
+    np.save(fn, ts)
+    back = np.load(fn, allow_pickle=True).item()
+    assert sorted(back.trajs) == kept and np.array_equal(np.array(back.trajs[kept[0]].xys), ref[kept[0]][1])
+    monkeypatch.setenv("PSFM_LEGACY_PICKLE", "1")
+    st = ts.__getstate__()
+    assert sorted(st) == kept and set(st[kept[0]]) == {"frame_ids", "locations", "labels"}
+    assert st[kept[0]]["frame_ids"] == ref[kept[0]][0]
+    fn2 = str(tmp_path / "legacy.npy")
+    np.save(fn2, ts)
+    back2 = np.load(fn2, allow_pickle=True).item()
+    d1, d2 = back.as_dict(), back2.as_dict()
+    assert sorted(d1) == sorted(d2)
+    for k in kept[:20]:
+        assert d1[k]["frame_ids"] == d2[k]["frame_ids"]
+        assert np.array_equal(np.array(d1[k]["locations"]), np.array(d2[k]["locations"]))
+    # map-backed set built the reference way (main_connect_point_trajectories.py:56-61) behaves the same
+    ts_map = particlesfm.TrajectorySet({i: tl[i] for i in kept})
+    ts_map.build_invert_indexes()
+    o1 = ts.sample_inside_window([3, 4, 5, 6, 7])
+    o2 = ts_map.sample_inside_window([3, 4, 5, 6, 7])
+    assert o1["traj_ids"] == o2["traj_ids"] and np.array_equal(o1["locations"][0], o2["locations"][0])

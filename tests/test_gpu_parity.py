@@ -159,3 +159,40 @@ def test_flow_check_sharded_single_process(pt):
     assert np.array_equal(occ.cpu().numpy().astype(bool), np.stack(ref))
     pk = psfm_dist.pack_bits(occ)
     assert torch.equal(psfm_dist.unpack_bits(pk, 37, 53), occ)
+
+
+def test_main_connect_end_to_end(pt, tmp_path):
+    """The stage entry (main_connect_point_trajectories.py:27-62): .flo directories in, track.npy out, consumed
+    through the access patterns of sfm/matches_from_flow.py and motion_seg/load_cut_seq.py; ids/lengths equal the
+    oracle's, positions within tolerance (track_optimize path), and the skip_path_consistency variant bit-exact."""
+    from oracle import oracle as orc
+    from point_trajectory import main_connect_point_trajectories
+    from point_trajectory.utils import write_flo, load_flows_device
+    T, H, W, r = 7, 60, 80, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=77, sigma=0.1, n_occluders=1, stride2=True)
+    fd = tmp_path / "optical_flows"
+    for key, sub in (("flows_f", "flow_f"), ("flows_b", "flow_b"), ("flows_f2", "flow_f2"), ("flows_b2", "flow_b2")):
+        (fd / sub).mkdir(parents=True)
+        for i, f in enumerate(d[key]):
+            write_flo(str(fd / sub / ("%05d.flo" % i)), f)
+    dev = load_flows_device(str(fd / "flow_f"))
+    assert np.array_equal(dev.cpu().numpy(), np.stack(d["flows_f"]))
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    for skip in (True, False):
+        out = tmp_path / ("traj_%d" % skip)
+        main_connect_point_trajectories(str(fd), str(out), sample_ratio=r, skip_path_consistency=skip)
+        ts = np.load(str(out / "track.npy"), allow_pickle=True).item()
+        O = orc.track(d["flows_f"], occ, r) if skip else orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        keep = [i for i in range(O.n_traj) if O.length[i] >= 3]
+        dd = ts.as_dict()
+        assert sorted(dd) == keep
+        for i in keep[::7]:
+            assert dd[i]["frame_ids"] == list(range(O.birth[i], O.birth[i] + O.length[i]))
+            err = np.abs(np.array(dd[i]["locations"]) - O.xy[O.off[i]:O.off[i + 1]]).max()
+            assert err == 0.0 if skip else err <= 1e-4
+        ts.build_invert_indexes()
+        win = ts.sample_inside_window(list(range(T)), max_num_tracks=100000)
+        assert len(win["traj_ids"]) == len(keep)
+        # skip_exists short-circuit (main_connect_point_trajectories.py:31-33)
+        main_connect_point_trajectories(str(fd), str(out), sample_ratio=r, skip_path_consistency=skip, skip_exists=True)
