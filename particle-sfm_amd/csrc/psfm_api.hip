@@ -125,7 +125,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
                        &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
-                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc};
+                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats};
     for (auto b : bufs) b->release();
     c->prof.destroy();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
@@ -258,24 +258,68 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
     c->res_n_traj = c->res_n_points = 0;
     if ((st = psfm_launch_track_init(c, d, s)) != PSFM_OK) return st;
     int64_t total_iters = 0;
-    for (int f = 0; f < n_flows; ++f) {
-        // track.py:31-47 / track_optimize.py:31-50, one loop iteration
-        // one launch: births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
+    // Frame loop.  In track_optimize mode nothing returns to the host inside a window of PSFM_CHECK frames: each
+    // solve is enqueued with `solve_unroll` iterations; a solve that needs more raises a device-side stall flag that
+    // turns every later launch into a no-op, and the checkpoint below resumes it and re-enqueues from there.
+    const int PSFM_CHECK = 8;
+    std::vector<psfm_solve_stats> hstats((size_t)n_flows + 1);
+    int first_unchecked = 1;
+    if (optimize) {
+        if ((st = c->sol_stats.ensure(sizeof(psfm_solve_stats) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
+    }
+    int f = 0;
+    while (f < n_flows) {
+        // track.py:31-47 / track_optimize.py:31-50, one loop iteration:
+        // one launch = births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
         st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * P, f, s);
         if (st != PSFM_OK) return st;
         if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
-            psfm_solve_stats ss;
-            memset(&ss, 0, sizeof(ss));
             c->prof.begin(PSFM_PROF_SOLVER, s);
-            st = psfm_solve_frame(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
-                                  flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f, &ss, s);
+            st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
+                                          flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
+                                          c->solve_unroll, s);
             c->prof.end(s);
             if (st != PSFM_OK) return st;
-            if (ss.termination >= 0) {   // termination == -1: no track had a full buffer, nothing was solved
-                c->solve_stats.push_back(ss);
-                total_iters += ss.iterations;
-            }
         }
+        const bool checkpoint = optimize && f >= 1 && ((f % PSFM_CHECK) == PSFM_CHECK - 1 || f == n_flows - 1);
+        if (checkpoint) {
+            PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
+            PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
+            PSFM_HIP(hipMemcpyAsync(hstats.data() + first_unchecked, c->sol_stats.as<psfm_solve_stats>() + first_unchecked,
+                                    sizeof(psfm_solve_stats) * (size_t)(f - first_unchecked + 1), hipMemcpyDeviceToHost, s));
+            PSFM_HIP(hipStreamSynchronize(s));
+            int last_ok = f;
+            if (hc->stall) {
+                const int fs = hc->stall - 1;
+                psfm_solve_stats ss;
+                memset(&ss, 0, sizeof(ss));
+                st = psfm_solve_frame_resume(c, d, flows + (size_t)(fs - 1) * P * 2, flows + (size_t)fs * P * 2,
+                                             flows_f2 + (size_t)(fs - 1) * P * 2, occ_s2 + (size_t)(fs - 1) * P, fs, &ss, s);
+                if (st != PSFM_OK) return st;
+                hstats[fs] = ss;
+                last_ok = fs;
+            }
+            int max_it = 0;
+            for (int k = first_unchecked; k <= last_ok; ++k) {
+                if (hstats[k].termination == PSFM_TERM_FAILURE) {
+                    psfm_set_error("path-consistency solver: FAILURE at frame %d", k);
+                    return PSFM_ERR_SOLVER;
+                }
+                if (hstats[k].termination >= 0) {   // -1: no track had a full buffer, nothing was solved
+                    c->solve_stats.push_back(hstats[k]);
+                    total_iters += hstats[k].iterations;
+                }
+                if (hstats[k].iterations > max_it) max_it = hstats[k].iterations;
+            }
+            // adapt the unroll to what this sequence needs (+2 head-room), within [4, 64]
+            int want = max_it + 2;
+            want = want < 4 ? 4 : (want > 64 ? 64 : want);
+            c->solve_unroll = want > c->solve_unroll ? want : (c->solve_unroll + want + 1) / 2;
+            first_unchecked = last_ok + 1;
+            f = last_ok + 1;   // after a stall: re-enqueue the (poisoned) frames behind the resumed solve
+            continue;
+        }
+        ++f;
     }
     c->prof.begin(PSFM_PROF_FINALIZE, s);
     st = psfm_finalize(c, d, s);

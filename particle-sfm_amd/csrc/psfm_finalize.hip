@@ -92,8 +92,12 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_decode_kernel(const unsigned 
 }
 
 // Transpose gather: a block owns TILE_J consecutive ids and walks time in chunks of TILE_K steps.
+#ifndef TILE_J
 #define TILE_J 64
+#endif
+#ifndef TILE_K
 #define TILE_K 32
+#endif
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* __restrict__ log, int64_t cap,
                                                                  const int* __restrict__ lanes,
                                                                  const int* __restrict__ birth,

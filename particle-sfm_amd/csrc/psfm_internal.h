@@ -31,7 +31,8 @@ struct PsfmBuf {
 struct PsfmCounters {
     int n_lanes;      // lanes ever handed out (high-water mark); chain_step scans [0, n_lanes)
     int overflow;     // bit0: lane table full, bit1: trajectory table full
-    int pad[14];
+    int stall;        // != 0: solve of frame stall-1 ran out of unrolled iterations; later launches are no-ops
+    int pad[13];
 };
 
 // Death records and free lanes are published through PSFM_NSHARD independent tables so that the
@@ -88,7 +89,8 @@ struct psfm_ctx {
     PsfmBuf res_birth, res_len, res_off, res_xy;
     int64_t res_n_traj = 0, res_n_points = 0;
     // solver workspace
-    PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc;
+    PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats;
+    int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
     std::vector<psfm_solve_stats> solve_stats;
     PsfmProfiler prof;
     void* host_pinned = nullptr;  // small pinned staging block
@@ -118,10 +120,13 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
 psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
 
 // ---- solver (psfm_solver.hip) ---------------------------------------------------------------
-// In-place solve on the trajectory log for frame index f (positions at f-1, f, f+1).
-psfm_status psfm_solve_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
-                             const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
-                             hipStream_t s);
+// In-place solve on the trajectory log for frame index f (positions at f-1, f, f+1): enqueue `unroll`
+// iterations without host synchronisation / resume a solve that raised the stall flag.
+psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                     const float* flow02, const uint8_t* occ02, int frame, int unroll, hipStream_t s);
+psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                    const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
+                                    hipStream_t s);
 // Batch API form (psfm_optimize_location).
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
                              const double* scale, const float* flow12, int64_t n, int w, int h, double* out,

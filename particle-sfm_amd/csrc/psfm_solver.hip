@@ -42,7 +42,7 @@ struct PsfmSolveCtrl {
     double dl_norm;                  // scaled norm of that step when known a priori (cases 1, 2); < 0 -> from the kernel
     int mode, done, termination, iteration;
     int n_invalid, cur, successful, nonGN;
-    int n_tracks, failed, dl_case, pad;
+    int n_tracks, failed, dl_case, launches;
 };
 
 struct PcParams {
@@ -68,6 +68,10 @@ struct PcParams {
     const uint8_t* occ02;
     double* partials;         // [PC_MAX_BLOCKS][PC_NSUM]
     PsfmSolveCtrl* ctrl;
+    int* stall;               // != 0: an earlier solve of this sequence ran out of unrolled iterations -> do nothing
+    unsigned* ticket;         // last-block detection
+    int frame;                // frame index of this solve (stall value / stats slot)
+    psfm_solve_stats* stats_dev;   // per-frame statistics (frame mode) or NULL
 };
 
 // ---- f64 clamp-to-edge bilinear interpolation (linear_interpolation.h:97-123 over ceres::Grid2D) ----
@@ -242,7 +246,9 @@ __device__ __forceinline__ void pc_block_reduce(double acc[PC_NSUM], double* __r
         const int k = threadIdx.x;
         double v = s_red[0][k];
         for (int w = 1; w < PC_BLOCK / PSFM_WAVE; ++w) v = (k == SUM_GMAX) ? fmax(v, s_red[w][k]) : v + s_red[w][k];
-        partials[(int64_t)blockIdx.x * PC_NSUM + k] = v;
+        // write-through (sc0 sc1) store: the last block of the launch reads these with matching loads, so no
+        // agent-scope release (an L2 write-back per block) is needed -- MI355X_MICROARCH.md, valid hand-off forms
+        __hip_atomic_store(&partials[(int64_t)blockIdx.x * PC_NSUM + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -279,11 +285,31 @@ __device__ __forceinline__ void pc_accumulate_point(const double x[4], const dou
     if (!ok) acc[SUM_FAIL] += 1.0;
 }
 
+__device__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
+                                      int is_init);
+
+// Publish this block's partials and find out whether it is the last one to finish: write-through payload ->
+// drain -> ticket (device-scope atomic); the last block reads the payload with cache-bypassing loads.
+__device__ __forceinline__ bool pc_is_last_block(unsigned* ticket)
+{
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u);
+        if (s_last) *ticket = 0u;   // next launch starts from zero (visible after the kernel boundary)
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pc_init: iteration 0.  Frame mode also prepares ref1/ref2/scale (trajectory.py:173-183).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
 {
+    if (*P.stall) return;
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
     double acc[PC_NSUM];
 #pragma unroll
@@ -328,6 +354,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
         pc_accumulate_point(x, r, jac, s, S, mu, acc);
     }
     pc_block_reduce(acc, P.partials);
+    if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,6 +363,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
 {
+    if (*P.stall) return;
     const PsfmSolveCtrl C = *P.ctrl;
     if (C.done) return;
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
@@ -404,6 +432,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
         pc_accumulate_point(xp, rp, jp, s, S, C.mu, acc);
     }
     pc_block_reduce(acc, P.partials);
+    if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,17 +458,18 @@ __device__ void pc_choose_dogleg(PsfmSolveCtrl& C)
     }
 }
 
-__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_ctrl_kernel(PsfmSolveCtrl* __restrict__ ctrl,
-                                                                const double* __restrict__ partials, int n_blocks,
-                                                                int is_init)
+// Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket after an agent-scope
+// release; the reading block acquires before touching the other blocks' partials -- cdna_hip_programming.md G16):
+// fixed-order reduction of the per-block partials, then the scalar control step on thread 0.
+__device__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
+                                      int is_init)
 {
     __shared__ double s_red[PC_BLOCK];
     __shared__ double s_tot[PC_NSUM];
-    if (!is_init && ctrl->done) return;
     for (int k = 0; k < PC_NSUM; ++k) {
         double v = 0.0;
         for (int b = threadIdx.x; b < n_blocks; b += PC_BLOCK) {
-            const double p = partials[(int64_t)b * PC_NSUM + k];
+            const double p = __hip_atomic_load(&partials[(int64_t)b * PC_NSUM + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             v = (k == SUM_GMAX) ? fmax(v, p) : v + p;
         }
         s_red[threadIdx.x] = v;
@@ -530,13 +560,29 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_ctrl_kernel(PsfmSolveCtrl* _
         else if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
     }
     if (!C.done && C.mode == PC_MODE_STEP) pc_choose_dogleg(C);
+    C.launches += 1;
     *ctrl = C;
 }
 
 // final: if the accepted iterate lives in the scratch pair, copy it back (frame mode: into the log)
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P, double* out_rows)
 {
+    if (*P.stall) return;
     const PsfmSolveCtrl C = *P.ctrl;
+    if (!C.done) {
+        // the unrolled iterations did not suffice: poison everything that was enqueued behind this solve; the
+        // host resumes it (psfm_track polls `stall` at its checkpoints) and re-enqueues the later frames
+        if (blockIdx.x == 0 && threadIdx.x == 0) *P.stall = P.frame + 1;
+        return;
+    }
+    if (P.stats_dev && blockIdx.x == 0 && threadIdx.x == 0) {
+        psfm_solve_stats st;
+        st.iterations = C.iteration; st.successful_steps = C.successful;
+        st.termination = C.n_tracks == 0 ? -1 : C.termination; st.dogleg_nonGN = C.nonGN;
+        st.initial_cost = C.initial_cost; st.final_cost = C.x_cost;
+        if (C.failed) st.termination = PSFM_TERM_FAILURE;
+        P.stats_dev[P.frame] = st;
+    }
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
     const double2* xc1 = C.cur ? P.x1b : P.x1a;
     const double2* xc2 = C.cur ? P.x2b : P.x2a;
@@ -565,45 +611,56 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_load_rows_kernel(const doubl
 // ------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------
-static psfm_status pc_run(psfm_ctx* c, PcParams& P, int n_rows_upper, double* out_rows, psfm_solve_stats* st, hipStream_t s)
+static int pc_blocks(int n_rows_upper)
 {
     int n_blocks = (n_rows_upper + PC_BLOCK - 1) / PC_BLOCK;
     if (n_blocks > PC_MAX_BLOCKS) n_blocks = PC_MAX_BLOCKS;
-    if (n_blocks < 1) n_blocks = 1;
+    return n_blocks < 1 ? 1 : n_blocks;
+}
+
+// sol_ctrl layout: [PsfmSolveCtrl][ticket u32][zero word used as the `stall` flag of batch solves]
+static psfm_status pc_setup(psfm_ctx* c, PcParams& P, hipStream_t s)
+{
     psfm_status rc;
     if ((rc = c->sol_partials.ensure(sizeof(double) * PC_MAX_BLOCKS * PC_NSUM)) != PSFM_OK) return rc;
-    if ((rc = c->sol_ctrl.ensure(sizeof(PsfmSolveCtrl))) != PSFM_OK) return rc;
+    const bool fresh = c->sol_ctrl.p == nullptr;
+    if ((rc = c->sol_ctrl.ensure(sizeof(PsfmSolveCtrl) + 64)) != PSFM_OK) return rc;
+    if (fresh) PSFM_HIP(hipMemsetAsync(c->sol_ctrl.p, 0, sizeof(PsfmSolveCtrl) + 64, s));
     P.partials = c->sol_partials.as<double>();
     P.ctrl = c->sol_ctrl.as<PsfmSolveCtrl>();
-    hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    hipLaunchKernelGGL(psfm_pc_ctrl_kernel, dim3(1), dim3(PC_BLOCK), 0, s, P.ctrl, P.partials, n_blocks, 1);
-    PSFM_HIP(hipGetLastError());
+    P.ticket = (unsigned*)((char*)c->sol_ctrl.p + sizeof(PsfmSolveCtrl));
+    if (!P.stall) P.stall = (int*)((char*)c->sol_ctrl.p + sizeof(PsfmSolveCtrl) + 16);
+    return PSFM_OK;
+}
+
+static void pc_fill_stats(const PsfmSolveCtrl* h, psfm_solve_stats* st)
+{
+    st->iterations = h->iteration;
+    st->successful_steps = h->successful;
+    st->termination = h->n_tracks == 0 ? -1 : h->termination;   // -1: nothing to solve (the reference would raise here)
+    st->dogleg_nonGN = h->nonGN;
+    st->initial_cost = h->initial_cost;
+    st->final_cost = h->x_cost;
+}
+
+// Keep launching iterations, polling `done` between chunks, until the solve terminates; then write back.
+static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double* out_rows, psfm_solve_stats* st, hipStream_t s)
+{
     PsfmSolveCtrl* hctrl = (PsfmSolveCtrl*)((char*)c->host_pinned + 512 + sizeof(PsfmShard) * PSFM_NSHARD);
     int launched = 0, chunk = 6;
     for (;;) {
-        for (int k = 0; k < chunk; ++k) {
-            hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-            hipLaunchKernelGGL(psfm_pc_ctrl_kernel, dim3(1), dim3(PC_BLOCK), 0, s, P.ctrl, P.partials, n_blocks, 0);
-        }
-        launched += chunk;
-        PSFM_HIP(hipGetLastError());
         PSFM_HIP(hipMemcpyAsync(hctrl, P.ctrl, sizeof(PsfmSolveCtrl), hipMemcpyDeviceToHost, s));
         PSFM_HIP(hipStreamSynchronize(s));
         if (hctrl->done) break;
         if (launched > 2 * 200 + 64) { psfm_set_error("path-consistency solver did not terminate"); return PSFM_ERR_SOLVER; }
+        for (int k = 0; k < chunk; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+        PSFM_HIP(hipGetLastError());
+        launched += chunk;
         chunk = chunk < 32 ? chunk * 2 : 32;
     }
     hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, out_rows);
     PSFM_HIP(hipGetLastError());
-    if (st) {
-        st->iterations = hctrl->iteration;
-        st->successful_steps = hctrl->successful;
-        st->termination = hctrl->termination;
-        st->dogleg_nonGN = hctrl->nonGN;
-        st->initial_cost = hctrl->initial_cost;
-        st->final_cost = hctrl->x_cost;
-        if (hctrl->n_tracks == 0) st->termination = -1;   // nothing to solve (the reference would raise here)
-    }
+    if (st) pc_fill_stats(hctrl, st);
     if (hctrl->failed) { psfm_set_error("path-consistency solver: FAILURE (invalid steps / Cholesky breakdown)"); return PSFM_ERR_SOLVER; }
     return PSFM_OK;
 }
@@ -617,17 +674,19 @@ static psfm_status pc_workspace(psfm_ctx* c, int64_t rows)
     return PSFM_OK;
 }
 
-psfm_status psfm_solve_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
-                             const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st, hipStream_t s)
+static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                   const float* flow02, const uint8_t* occ02, int frame, PcParams& P, hipStream_t s)
 {
     psfm_status rc;
     if ((rc = pc_workspace(c, d.cap)) != PSFM_OK) return rc;
-    PcParams P;
+    if ((rc = c->sol_stats.ensure(sizeof(psfm_solve_stats) * (size_t)(d.n_flows + 1))) != PSFM_OK) return rc;
     memset(&P, 0, sizeof(P));
     P.H = d.H; P.W = d.W; P.cw = d.cw; P.ch = d.ch;
     P.birth_frame = c->birth_frame.as<int>();
     P.max_birth = frame - 1;    // three buffered positions: times frame-1, frame, frame+1
-    P.n_lanes_ptr = &c->counters.as<PsfmCounters>()->n_lanes;
+    PsfmCounters* ctr = c->counters.as<PsfmCounters>();
+    P.n_lanes_ptr = &ctr->n_lanes;
+    P.stall = &ctr->stall;
     P.n_rows = (int)d.cap;
     double2* lg = c->log.as<double2>();
     P.p0 = lg + (int64_t)(frame - 1) * d.cap;
@@ -641,7 +700,37 @@ psfm_status psfm_solve_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* f
     P.scale = (double*)(P.jscale + d.cap);
     P.flow12 = (const float2*)flow12; P.flow01 = (const float2*)flow01; P.flow02 = (const float2*)flow02;
     P.occ02 = occ02;
-    return pc_run(c, P, (int)d.cap, nullptr, st, s);
+    P.frame = frame;
+    P.stats_dev = c->sol_stats.as<psfm_solve_stats>();
+    return pc_setup(c, P, s);
+}
+
+// Enqueue one frame's solve with `unroll` iterations and NO host synchronisation: if the solve needs more, its
+// write-back kernel raises the device-side stall flag, which turns everything enqueued behind it into no-ops.
+psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                     const float* flow02, const uint8_t* occ02, int frame, int unroll, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    const int n_blocks = pc_blocks((int)d.cap);
+    hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// The stalled solve of `frame`: clear the flag, iterate to termination with host polling, write back.
+psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                    const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
+                                    hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    PSFM_HIP(hipMemsetAsync(P.stall, 0, sizeof(int), s));
+    return pc_finish_sync(c, P, pc_blocks((int)d.cap), nullptr, st, s);
 }
 
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
@@ -667,12 +756,17 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     P.jscale = P.ref2 + n;
     P.scale = (double*)(P.jscale + n);
     P.flow12 = (const float2*)flow12;
+    if ((rc = pc_setup(c, P, s)) != PSFM_OK) return rc;
+    const int n_blocks = pc_blocks((int)n);
     const unsigned nb = (unsigned)((n + PC_BLOCK - 1) / PC_BLOCK);
     hipLaunchKernelGGL(psfm_pc_load_rows_kernel, dim3(nb), dim3(PC_BLOCK), 0, s, uv12, n, P.x1a, P.x2a);
     PSFM_HIP(hipMemcpyAsync(P.ref1, ref1, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
     PSFM_HIP(hipMemcpyAsync(P.ref2, ref2, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
     PSFM_HIP(hipMemcpyAsync(P.scale, scale, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-    rc = pc_run(c, P, (int)n, out, st, s);
+    hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    PSFM_HIP(hipGetLastError());
+    rc = pc_finish_sync(c, P, n_blocks, out, st, s);
     if (rc != PSFM_OK) return rc;
     PSFM_HIP(hipStreamSynchronize(s));
     return PSFM_OK;

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
                                                                      PsfmShard* __restrict__ shards)
 {
     const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
-    if (i == 0) { ctr->n_lanes = (int)G; ctr->overflow = 0; }
+    if (i == 0) { ctr->n_lanes = (int)G; ctr->overflow = 0; ctr->stall = 0; }
     if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; shards[i].points = (i == 0) ? (unsigned)G : 0u; }
     if (i >= cap) return;
     if (i < G) {
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK, PSFM_CHAIN_MINWAVES) PSFM_CHAIN_A
     const int ratio = R > 0 ? R : a.ratio;
     // blocks past both the lane high-water mark and the grid have nothing to do (lanes handed out during
     // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
+    if (a.ctr->stall) return;   // an earlier path-consistency solve is unfinished: this launch will be re-enqueued
     if ((int)(blockIdx.x * PSFM_CHAIN_BLOCK) >= max(a.ctr->n_lanes, a.G)) return;
     if (tid == 0) s_alive_any = 0;
 
@@ -497,6 +498,14 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK, PSFM_CHAIN_MINWAVES) PSFM_CHAIN_A
     if (tid == 0 && s_alive_any) *a.surv_cur = 1;
 }
 
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_clear_map_kernel(const PsfmCounters* __restrict__ ctr,
+                                                                     uint8_t* __restrict__ map, int n)
+{
+    if (ctr->stall) return;
+    const int i = blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    if (i < n) map[i] = 0;
+}
+
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
                                    int frame, hipStream_t s)
 {
@@ -516,8 +525,10 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
     a.stamp_cur = (uint8_t)((frame % 254) + 1);
     a.stamp_prev = (uint8_t)(((frame + 253) % 254) + 1);
     if (frame > 1 && (frame % 254) <= 1) {
-        // the map about to be written last saw this stamp value 254 frames ago: clear it
-        PSFM_HIP(hipMemsetAsync(a.blocked_cur, 0, (size_t)d.G, s));
+        // the map about to be written last saw this stamp value 254 frames ago: clear it (with a kernel that
+        // honours the stall flag -- a memset would also run for launches that are going to be re-enqueued)
+        hipLaunchKernelGGL(psfm_clear_map_kernel, dim3((unsigned)((d.G + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
+                           0, s, c->counters.as<PsfmCounters>(), a.blocked_cur, (int)d.G);
     }
     a.surv_prev = c->survivors.as<int>() + (frame > 0 ? frame - 1 : 0);
     a.surv_cur = c->survivors.as<int>() + frame;
