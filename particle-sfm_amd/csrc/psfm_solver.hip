@@ -10,16 +10,19 @@
 // (TrustRegionMinimizer + DoglegStrategy/TRADITIONAL_DOGLEG + Jacobi scaling + SPARSE_NORMAL_CHOLESKY,
 // max 200 iterations) is reproduced with its scalars reduced over all tracks:
 //
-//   pc_init   per track: refs/scale (fp32 sampler, trajectory.py:173-183), r, J at x0, Jacobi scaling,
-//             partial sums of {cost, |grad|_inf, |x|^2} and of the Gauss-Newton system
-//   pc_iter   per track, ONE launch per trust-region iteration: dogleg step from the block-local
-//             Cholesky + the global dogleg scalars, model decrease, candidate x+ and its cost, and --
-//             speculatively -- r, J and the Gauss-Newton sums AT x+ so that an accepted step needs no
-//             extra pass.  x lives in a ping-pong pair (log slabs <-> scratch).
-//   pc_ctrl   one block: deterministic tree reduction of the per-block partials + the scalar control
-//             logic (accept / reject / radius / mu / termination), written to a device control block
-//             that the next pc_iter reads.  Nothing returns to the host inside the loop; the host only
-//             polls a `done` word between chunks of launches.
+//   pc_init   per track: refs/scale (fp32 sampler, trajectory.py:173-183), Jacobi scaling, and -- in the same launch --
+//             trust-region iteration 1 (below)
+//   pc_iter   ONE launch per trust-region iteration, one pass per track: r, J at x (f64 bilinear gather), the
+//             4x4 block of the normal equations solved by a register-resident Cholesky, the step, the model decrease,
+//             the candidate x+ and its cost.  The dogleg case depends on GLOBAL norms that only exist after the
+//             launch, so the kernel speculates the overwhelmingly common case (pure Gauss-Newton step inside the trust
+//             region); when the reduced norms say otherwise the control step re-issues the iteration with the
+//             interpolation coefficients fixed.  x lives in a ping-pong pair (log slabs <-> scratch).
+//   control   (last block of each launch) deterministic reduction of the per-block partials + Ceres' scalar logic:
+//             accept / reject / radius / mu / the three tolerances.  Consecutive rejections whose shrunken radius
+//             still contains the Gauss-Newton step reproduce the same candidate, so they are replayed in the control
+//             step without relaunching (bit-identical to Ceres, which recomputes the same step each time).
+//             Nothing returns to the host inside the loop.
 //
 // All arithmetic f64 without contraction; reductions have a fixed order (bitwise reproducible for a
 // given lane assignment).
@@ -29,20 +32,20 @@
 #include "psfm_internal.h"
 
 #define PC_BLOCK 256
-#define PC_MAX_BLOCKS 2048
-#define PC_NSUM 12
+#define PC_MAX_BLOCKS 512    // 2 blocks of 256 per CU fill the chip at this kernel's register footprint (2 waves/SIMD)
+#define PC_NSUM 13
 
-enum { PC_MODE_STEP = 0, PC_MODE_SUMS = 1 };
 
 struct PsfmSolveCtrl {
     // trust-region state
     double radius, mu, x_cost, x_norm, gmax, initial_cost;
     double g2, jg2, gn2, dot;        // Gauss-Newton system sums at the current x (for the current mu)
-    double dl_a, dl_b;               // dogleg step = (dl_a * ghat + dl_b * gn) / diag
+    double dl_a, dl_b;               // dogleg step = (dl_a * ghat + dl_b * gn) / diag when dl_fixed
     double dl_norm;                  // scaled norm of that step when known a priori (cases 1, 2); < 0 -> from the kernel
-    int mode, done, termination, iteration;
+    int dl_fixed, done, termination, iteration;   // dl_fixed == 0: the kernel speculates the Gauss-Newton step (0, 1)
     int n_invalid, cur, successful, nonGN;
     int n_tracks, failed, dl_case, launches;
+    int fresh_x, pad0;               // x was accepted by the previous control step: gradient test pending
 };
 
 struct PcParams {
@@ -216,7 +219,7 @@ __device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], 
 
 // sums slots
 enum { SUM_MCC = 0, SUM_COST = 1, SUM_STEP2 = 2, SUM_DL2 = 3, SUM_XN2 = 4, SUM_GMAX = 5, SUM_G2 = 6, SUM_JG2 = 7,
-       SUM_GN2 = 8, SUM_DOT = 9, SUM_FAIL = 10, SUM_CNT = 11 };
+       SUM_GN2 = 8, SUM_DOT = 9, SUM_FAIL = 10, SUM_CNT = 11, SUM_COST0 = 12 };
 
 __device__ __forceinline__ double pc_wave_sum(double v)
 {
@@ -260,10 +263,21 @@ __device__ __forceinline__ bool pc_participates(const PcParams& P, int i, int n)
     return bf >= 0 && bf <= P.max_birth;
 }
 
-// accumulate the state at a point (cost is NOT included; the caller knows whether it is x or x+)
-__device__ __forceinline__ void pc_accumulate_point(const double x[4], const double r[6], const double jac[4], double s,
-                                                    const double S[4], double mu, double acc[PC_NSUM])
+// One trust-region iteration for one track at its current iterate x: everything Ceres evaluates at x (cost terms,
+// gradient max-norm, |x|^2, the Gauss-Newton system and its global sums) plus the step (a * ghat + b * gn) / diag,
+// the model decrease, the candidate and the candidate's cost.  Writes the candidate; returns nothing else.
+__device__ __forceinline__ void pc_track_iteration(const PcParams& P, const double x[4], double2 r1, double2 r2, double s,
+                                                   const double S[4], double mu, double a, double b, double2* xn1,
+                                                   double2* xn2, int i, double acc[PC_NSUM], double* cost_at_x)
 {
+    double r[6], jac[4];
+    pc_eval(P.flow12, P.H, P.W, x, r1, r2, s, r, jac);
+    if (cost_at_x) {
+        double ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ss += r[k] * r[k];
+        *cost_at_x = 0.5 * ss;
+    }
     // |x - Plus(x,-g)|_inf with g = J^T r unscaled (trust_region_minimizer.cc EvaluateGradientAndJacobian)
     const double g[4] = {(r[0] + jac[0] * r[4]) + jac[2] * r[5], (r[1] + jac[1] * r[4]) + jac[3] * r[5],
                          s * r[2] + r[4], s * r[3] + r[5]};
@@ -275,14 +289,45 @@ __device__ __forceinline__ void pc_accumulate_point(const double x[4], const dou
     const PcJac J = pc_scaled_jac(jac, s, S);
     double d[4], gh[4], gn[4], jg2;
     const bool ok = pc_gn_system(J, r, mu, d, gh, gn, &jg2);
+    acc[SUM_JG2] += jg2;
+    if (!ok) acc[SUM_FAIL] += 1.0;
+    // dogleg step in the scaled space, then /diag (ComputeTraditionalDoglegStep)
+    double st[4], xp[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         acc[SUM_G2] += gh[k] * gh[k];
         acc[SUM_GN2] += gn[k] * gn[k];
         acc[SUM_DOT] += gh[k] * gn[k];
+        const double v = a * gh[k] + b * gn[k];
+        acc[SUM_DL2] += v * v;
+        st[k] = v / d[k];
     }
-    acc[SUM_JG2] += jg2;
-    if (!ok) acc[SUM_FAIL] += 1.0;
+    // model_cost_change = -(J step)'(r + J step / 2)
+    {
+        const double m0 = J.a0 * st[0], m1 = J.a1 * st[1], m2 = J.a2 * st[2], m3 = J.a3 * st[3];
+        const double m4 = (J.b0 * st[0] + J.b1 * st[1]) + J.b2 * st[2];
+        const double m5 = (J.c0 * st[0] + J.c1 * st[1]) + J.c3 * st[3];
+        acc[SUM_MCC] += ((((m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0)) + m2 * (r[2] + m2 / 2.0)) +
+                          m3 * (r[3] + m3 / 2.0)) + m4 * (r[4] + m4 / 2.0)) + m5 * (r[5] + m5 / 2.0);
+    }
+    // candidate = x + step .* jacobi_scaling
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xp[k] = x[k] + st[k] * S[k];
+        const double dd = x[k] - xp[k];
+        acc[SUM_STEP2] += dd * dd;
+    }
+    xn1[i] = make_double2(xp[0], xp[1]);
+    xn2[i] = make_double2(xp[2], xp[3]);
+    // cost at the candidate (residuals only)
+    {
+        double f[2], dr[2], dc[2];
+        pc_bilerp(P.flow12, P.H, P.W, xp[1], xp[0], f, dr, dc);
+        const double q0 = xp[0] - r1.x, q1 = xp[1] - r1.y;
+        const double q2 = (xp[2] - r2.x) * s, q3 = (xp[3] - r2.y) * s;
+        const double q4 = (xp[2] - xp[0]) - f[0], q5 = (xp[3] - xp[1]) - f[1];
+        acc[SUM_COST] += 0.5 * (((((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3) + q4 * q4) + q5 * q5);
+    }
 }
 
 __device__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
@@ -322,9 +367,10 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
         if (P.p0) {
             const double2 p0 = P.p0[i];
             const PsfmTaps t = psfm_taps((float)p0.x, (float)p0.y, P.cw, P.ch, P.H, P.W);
-            const float2 f01 = psfm_sample_flow(P.flow01, P.H, P.W, t);
-            const float2 f02 = psfm_sample_flow(P.flow02, P.H, P.W, t);
-            const float o02 = psfm_sample_mask(P.occ02, P.H, P.W, t);
+            const PsfmTapIdx k = psfm_tap_idx(P.H, P.W, t);
+            const float2 f01 = psfm_sample_flow(P.flow01, k, t);
+            const float2 f02 = psfm_sample_flow(P.flow02, k, t);
+            const float o02 = psfm_sample_mask(P.occ02, k, t);
             // (1.0 - occ02) * (|flow02| < 20) in fp32; numpy's norm = sqrt(u*u + v*v) without fma (trajectory.py:179)
             const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
             const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
@@ -337,29 +383,27 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
         }
         const double2 p1 = P.x1a[i], p2 = P.x2a[i];
         const double x[4] = {p1.x, p1.y, p2.x, p2.y};
-        double r[6], jac[4];
-        pc_eval(P.flow12, P.H, P.W, x, r1, r2, s, r, jac);
-        // Jacobi scaling 1/(1+sqrt(colnorm^2)), computed once at iteration 0
-        const double c0 = (1.0 + jac[0] * jac[0]) + jac[2] * jac[2];
-        const double c1 = (1.0 + jac[1] * jac[1]) + jac[3] * jac[3];
+        // Jacobi scaling 1/(1+sqrt(colnorm^2)) from the Jacobian at x0, computed once (trust_region_minimizer.cc)
+        double f[2], dr[2], dc[2];
+        pc_bilerp(P.flow12, P.H, P.W, x[1], x[0], f, dr, dc);
+        const double j0 = -1.0 - dc[0], j1 = 0.0 - dr[0], j2 = 0.0 - dc[1], j3 = -1.0 - dr[1];
+        const double c0 = (1.0 + j0 * j0) + j2 * j2;
+        const double c1 = (1.0 + j1 * j1) + j3 * j3;
         const double c2 = s * s + 1.0;
         const double S2 = 1.0 / (1.0 + sqrt(c2));
         const double S[4] = {1.0 / (1.0 + sqrt(c0)), 1.0 / (1.0 + sqrt(c1)), S2, S2};
         P.jscale[i] = make_double2(S[0], S[1]);
-        double ss = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ss += r[k] * r[k];
-        acc[SUM_COST] += 0.5 * ss;
         acc[SUM_CNT] += 1.0;
-        pc_accumulate_point(x, r, jac, s, S, mu, acc);
+        double c_at_x;
+        pc_track_iteration(P, x, r1, r2, s, S, mu, 0.0, 1.0, P.x1b, P.x2b, i, acc, &c_at_x);   // iteration 1, speculated
+        acc[SUM_COST0] += c_at_x;
     }
     pc_block_reduce(acc, P.partials);
     if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
-// pc_iter: one trust-region iteration (MODE_STEP) or a re-evaluation of the Gauss-Newton sums at the
-// current x after mu changed (MODE_SUMS).
+// pc_iter: one trust-region iteration at the current iterate.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
 {
@@ -371,6 +415,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
     const double2* xc2 = C.cur ? P.x2b : P.x2a;
     double2* xn1 = C.cur ? P.x1a : P.x1b;
     double2* xn2 = C.cur ? P.x2a : P.x2b;
+    const double a = C.dl_fixed ? C.dl_a : 0.0, b = C.dl_fixed ? C.dl_b : 1.0;
     double acc[PC_NSUM];
 #pragma unroll
     for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
@@ -383,53 +428,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
         const double S[4] = {js.x, js.y, S2, S2};
         const double2 p1 = xc1[i], p2 = xc2[i];
         const double x[4] = {p1.x, p1.y, p2.x, p2.y};
-        double r[6], jac[4];
-        pc_eval(P.flow12, P.H, P.W, x, r1, r2, s, r, jac);
-        if (C.mode == PC_MODE_SUMS) {
-            double dummy[PC_NSUM];
-#pragma unroll
-            for (int k = 0; k < PC_NSUM; ++k) dummy[k] = 0.0;
-            pc_accumulate_point(x, r, jac, s, S, C.mu, dummy);
-            acc[SUM_G2] += dummy[SUM_G2]; acc[SUM_JG2] += dummy[SUM_JG2]; acc[SUM_GN2] += dummy[SUM_GN2];
-            acc[SUM_DOT] += dummy[SUM_DOT]; acc[SUM_FAIL] += dummy[SUM_FAIL];
-            continue;
-        }
-        const PcJac J = pc_scaled_jac(jac, s, S);
-        double d[4], gh[4], gn[4], jg2;
-        pc_gn_system(J, r, C.mu, d, gh, gn, &jg2);
-        // dogleg step in the scaled space, then /diag (ComputeTraditionalDoglegStep)
-        double st[4], xp[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double v = C.dl_a * gh[k] + C.dl_b * gn[k];
-            acc[SUM_DL2] += v * v;
-            st[k] = v / d[k];
-        }
-        // model_cost_change = -(J step)'(r + J step / 2)
-        {
-            const double m0 = J.a0 * st[0], m1 = J.a1 * st[1], m2 = J.a2 * st[2], m3 = J.a3 * st[3];
-            const double m4 = (J.b0 * st[0] + J.b1 * st[1]) + J.b2 * st[2];
-            const double m5 = (J.c0 * st[0] + J.c1 * st[1]) + J.c3 * st[3];
-            acc[SUM_MCC] += ((((m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0)) + m2 * (r[2] + m2 / 2.0)) +
-                              m3 * (r[3] + m3 / 2.0)) + m4 * (r[4] + m4 / 2.0)) + m5 * (r[5] + m5 / 2.0);
-        }
-        // candidate = x + step .* jacobi_scaling
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            xp[k] = x[k] + st[k] * S[k];
-            const double dd = x[k] - xp[k];
-            acc[SUM_STEP2] += dd * dd;
-        }
-        xn1[i] = make_double2(xp[0], xp[1]);
-        xn2[i] = make_double2(xp[2], xp[3]);
-        double rp[6], jp[4];
-        pc_eval(P.flow12, P.H, P.W, xp, r1, r2, s, rp, jp);
-        double ss = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ss += rp[k] * rp[k];
-        acc[SUM_COST] += 0.5 * ss;
-        // speculative: everything the NEXT iteration needs if this candidate is accepted
-        pc_accumulate_point(xp, rp, jp, s, S, C.mu, acc);
+        pc_track_iteration(P, x, r1, r2, s, S, C.mu, a, b, xn1, xn2, i, acc, nullptr);
     }
     pc_block_reduce(acc, P.partials);
     if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 0);
@@ -464,23 +463,36 @@ __device__ void pc_choose_dogleg(PsfmSolveCtrl& C)
 __device__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
                                       int is_init)
 {
-    __shared__ double s_red[PC_BLOCK];
+    // Fixed-order reduction of partials[n_blocks][PC_NSUM]: thread t owns slot (t % 16) of the block rows
+    // t/16, t/16 + 16, ...; its loads are independent (issued back to back), summed in increasing row order; the 16
+    // row groups are then combined in order by the first PC_NSUM threads.  (One pass, two barriers: a slot-by-slot tree
+    // with a barrier per level cost ~40 us per launch when the loads bypass the caches.)
+    __shared__ double s_part[16][16];
     __shared__ double s_tot[PC_NSUM];
-    for (int k = 0; k < PC_NSUM; ++k) {
+    {
+        const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
         double v = 0.0;
-        for (int b = threadIdx.x; b < n_blocks; b += PC_BLOCK) {
-            const double p = __hip_atomic_load(&partials[(int64_t)b * PC_NSUM + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            v = (k == SUM_GMAX) ? fmax(v, p) : v + p;
+        if (k < PC_NSUM) {
+            for (int b0 = g; b0 < n_blocks; b0 += 128) {   // 8 rows in flight
+                double p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int bb = b0 + 16 * u;
+                    p[u] = bb < n_blocks ? __hip_atomic_load(&partials[(int64_t)bb * PC_NSUM + k], __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_SYSTEM)
+                                         : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v = (k == SUM_GMAX) ? fmax(v, p[u]) : v + p[u];
+            }
         }
-        s_red[threadIdx.x] = v;
+        s_part[g][k] = v;
         __syncthreads();
-        for (int o = PC_BLOCK / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o)
-                s_red[threadIdx.x] = (k == SUM_GMAX) ? fmax(s_red[threadIdx.x], s_red[threadIdx.x + o])
-                                                    : s_red[threadIdx.x] + s_red[threadIdx.x + o];
-            __syncthreads();
+        if (threadIdx.x < PC_NSUM) {
+            double t = s_part[0][threadIdx.x];
+            for (int gg = 1; gg < 16; ++gg) t = (threadIdx.x == SUM_GMAX) ? fmax(t, s_part[gg][threadIdx.x]) : t + s_part[gg][threadIdx.x];
+            s_tot[threadIdx.x] = t;
         }
-        if (threadIdx.x == 0) s_tot[k] = s_red[0];
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
@@ -489,77 +501,88 @@ __device__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* 
     const double min_relative_decrease = 1e-3, min_radius = 1e-32;
     const double min_mu = 1e-8, mu_increase = 10.0;
     const int max_iter = 200, max_invalid = 5;
-    bool need_checks = false, accepted = false;
     if (is_init) {
         memset(&C, 0, sizeof(C));
         C.radius = 1e4; C.mu = min_mu;
         C.n_tracks = (int)s_tot[SUM_CNT];
-        C.x_cost = s_tot[SUM_COST]; C.initial_cost = C.x_cost;
+        C.x_cost = s_tot[SUM_COST0]; C.initial_cost = C.x_cost;
+        C.termination = PSFM_TERM_MAX_ITER;
+        C.fresh_x = 1;   // iteration 0 counts as a successful step: its gradient test is due now
+        if (C.n_tracks == 0) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
+    }
+    if (!C.done && s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+    if (!C.done) {
+        // quantities of the CURRENT iterate evaluated by this launch
         C.x_norm = sqrt(s_tot[SUM_XN2]);
         C.gmax = s_tot[SUM_GMAX];
         C.g2 = s_tot[SUM_G2]; C.jg2 = s_tot[SUM_JG2]; C.gn2 = s_tot[SUM_GN2]; C.dot = s_tot[SUM_DOT];
-        C.termination = PSFM_TERM_MAX_ITER;
-        C.mode = PC_MODE_STEP;
-        if (C.n_tracks == 0) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
-        if (s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
-        need_checks = true; accepted = true;   // iteration 0 counts as a successful step
-    } else if (C.mode == PC_MODE_SUMS) {
-        C.g2 = s_tot[SUM_G2]; C.jg2 = s_tot[SUM_JG2]; C.gn2 = s_tot[SUM_GN2]; C.dot = s_tot[SUM_DOT];
-        if (s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
-        C.mode = PC_MODE_STEP;
-    } else {
-        C.iteration += 1;
-        if (C.dl_case != 1) C.nonGN += 1;
-        const double mcc = -s_tot[SUM_MCC];
-        const double dogleg_step_norm = C.dl_norm >= 0.0 ? C.dl_norm : sqrt(s_tot[SUM_DL2]);
-        if (!(mcc > 0.0)) {
-            // HandleInvalidStep / StepIsInvalid
-            if (++C.n_invalid >= max_invalid) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
-            C.mu *= mu_increase;
-            C.mode = PC_MODE_SUMS;
-            need_checks = true;
+        if (C.fresh_x) {   // FinalizeIterationAndCheckIfMinimizerCanContinue after a successful step (max_iter and
+            C.fresh_x = 0; // radius were tested when the step was accepted; the gradient is only known now)
+            if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
+        }
+    }
+    if (!C.done) {
+        // Which step did the launch take, and which one does the dogleg prescribe for this radius?
+        const bool used_fixed = C.dl_fixed != 0;
+        const double used_a = C.dl_a, used_b = C.dl_b;
+        pc_choose_dogleg(C);
+        const bool step_ok = (C.dl_case == 1) ? !used_fixed : (used_fixed && used_a == C.dl_a && used_b == C.dl_b);
+        if (!step_ok) {
+            C.dl_fixed = (C.dl_case != 1);   // re-issue this iteration with the prescribed coefficients
         } else {
-            C.n_invalid = 0;
-            const double cand = s_tot[SUM_COST];
-            const double step_norm = sqrt(s_tot[SUM_STEP2]);
-            if (step_norm <= parameter_tolerance * (C.x_norm + parameter_tolerance)) {
-                C.done = 1; C.termination = PSFM_TERM_PARAMETER_TOL;
-            } else if (fabs(C.x_cost - cand) <= function_tolerance * C.x_cost) {
-                C.done = 1; C.termination = PSFM_TERM_FUNCTION_TOL;
+            bool rejected = false;
+            C.iteration += 1;
+            if (C.dl_case != 1) C.nonGN += 1;
+            const double mcc = -s_tot[SUM_MCC];
+            const double dogleg_step_norm = C.dl_norm >= 0.0 ? C.dl_norm : sqrt(s_tot[SUM_DL2]);
+            if (!(mcc > 0.0)) {
+                // HandleInvalidStep / StepIsInvalid: the next launch re-solves with the larger mu
+                if (++C.n_invalid >= max_invalid) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+                C.mu *= mu_increase;
+                C.dl_fixed = 0;
             } else {
-                const double rho = (C.x_cost - cand) / mcc;
-                if (rho > min_relative_decrease) {
-                    // HandleSuccessfulStep + DoglegStrategy::StepAccepted
-                    C.cur ^= 1;
-                    C.x_cost = cand;
-                    C.x_norm = sqrt(s_tot[SUM_XN2]);
-                    C.gmax = s_tot[SUM_GMAX];
-                    C.successful += 1;
-                    if (rho < 0.25) C.radius *= 0.5;
-                    if (rho > 0.75) C.radius = fmax(C.radius, 3.0 * dogleg_step_norm);
-                    const double new_mu = fmax(min_mu, 2.0 * C.mu / mu_increase);
-                    if (new_mu == C.mu) {
-                        C.g2 = s_tot[SUM_G2]; C.jg2 = s_tot[SUM_JG2]; C.gn2 = s_tot[SUM_GN2]; C.dot = s_tot[SUM_DOT];
-                        if (s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
-                    } else {
-                        C.mu = new_mu;
-                        C.mode = PC_MODE_SUMS;   // the speculative sums were formed with the old mu
-                    }
-                    accepted = true;
+                C.n_invalid = 0;
+                const double cand = s_tot[SUM_COST];
+                const double step_norm = sqrt(s_tot[SUM_STEP2]);
+                if (step_norm <= parameter_tolerance * (C.x_norm + parameter_tolerance)) {
+                    C.done = 1; C.termination = PSFM_TERM_PARAMETER_TOL;
+                } else if (fabs(C.x_cost - cand) <= function_tolerance * C.x_cost) {
+                    C.done = 1; C.termination = PSFM_TERM_FUNCTION_TOL;
                 } else {
-                    C.radius *= 0.5;   // StepRejected; the Gauss-Newton sums at x stay valid
+                    const double rho = (C.x_cost - cand) / mcc;
+                    if (rho > min_relative_decrease) {
+                        // HandleSuccessfulStep + DoglegStrategy::StepAccepted
+                        C.cur ^= 1;
+                        C.x_cost = cand;
+                        C.successful += 1;
+                        if (rho < 0.25) C.radius *= 0.5;
+                        if (rho > 0.75) C.radius = fmax(C.radius, 3.0 * dogleg_step_norm);
+                        C.mu = fmax(min_mu, 2.0 * C.mu / mu_increase);
+                        C.fresh_x = 1;
+                        C.dl_fixed = 0;
+                    } else {
+                        rejected = true;
+                    }
                 }
-                need_checks = true;
+            }
+            // FinalizeIterationAndCheckIfMinimizerCanContinue (the gradient test of an accepted step is deferred)
+            if (!C.done) {
+                if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
+                else if (!rejected && C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
+            }
+            // StepRejected: radius /= 2 and the SAME Gauss-Newton system.  While the shrunken region still contains
+            // the Gauss-Newton step the dogleg returns the same step, hence the same candidate and the same
+            // rejection: replay those iterations here instead of relaunching.
+            while (rejected && !C.done) {
+                C.radius *= 0.5;
+                if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; break; }
+                pc_choose_dogleg(C);
+                if (C.dl_case != 1) { C.dl_fixed = 1; break; }
+                C.iteration += 1;   // identical step, identical rho: rejected again
+                if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
             }
         }
     }
-    if (need_checks && !C.done) {
-        // FinalizeIterationAndCheckIfMinimizerCanContinue
-        if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
-        else if (accepted && C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
-        else if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
-    }
-    if (!C.done && C.mode == PC_MODE_STEP) pc_choose_dogleg(C);
     C.launches += 1;
     *ctrl = C;
 }
