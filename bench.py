@@ -44,6 +44,51 @@ def cpu_baseline(flows_f, flows_b, n_pairs):
                       % (n_pairs, N_FRAMES - 1, R.n_points, dt)}, R
 
 
+def secondary_track_optimize(ctx):
+    """track_optimize (chaining + Ceres-compatible path-consistency solve) on a synthetic stand-in of configs[2]
+    (Sintel alley_1 shape: 436x1024, 50 frames, sample_ratio 2): GPU time per sequence and the CPU oracle on the
+    first 6 flows of the same tensors, with the parity of those 6 flows checked on the spot."""
+    import numpy as np
+    import torch
+    import psfm_synth
+    from oracle import oracle as orc
+    from point_trajectory.utils import flow_check_device
+    from point_trajectory.trajectory import run_track, _result_to_host
+    h, w, t, r = 436, 1024, 50, 2
+    d = psfm_synth.synth_sequence_torch(t, h, w, seed=2, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
+    ctx.set_profiling(0)
+
+    def step():
+        _, occ = flow_check_device(d["flows_f"], d["flows_b"], THRES)
+        _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], THRES)
+        return occ, occ2, run_track(d["flows_f"], occ, d["flows_f2"], occ2, r, return_device=True)
+
+    for _ in range(2):
+        occ, occ2, info = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        occ, occ2, info = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    k = 6
+    ff, f2 = list(d["flows_f"][:k].cpu().numpy()), list(d["flows_f2"][:k - 1].cpu().numpy())
+    oo, o2 = list(occ[:k].cpu().numpy()), list(occ2[:k - 1].cpu().numpy())
+    t0 = time.perf_counter()
+    Rc = orc.track_optimize(ff, f2, oo, o2, r)
+    cpu_s = time.perf_counter() - t0
+    Rg = _result_to_host(ctx, run_track(d["flows_f"][:k], occ[:k], d["flows_f2"][:k - 1], occ2[:k - 1], r, return_device=True))
+    same = bool(np.array_equal(Rg.birth, Rc.birth) and np.array_equal(Rg.length, Rc.length))
+    return {"workload": "configs[2] shape: synthetic 436x1024 x 50 frames, sample_ratio=2, flow_check x2 + track_optimize",
+            "ms_per_sequence": ms, "trajectory_points_per_s": info.n_points / (ms * 1e-3), "points": int(info.n_points),
+            "solves": int(info.n_solves), "trust_region_iterations": int(info.solver_iterations),
+            "cpu_port_points_per_s": Rc.n_points / cpu_s, "cpu_port_sample": "first %d flows, 1 core, %.2f s" % (k, cpu_s),
+            "parity_first_flows": {"ids_lengths_equal": same,
+                                   "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None,
+                                   "tolerance_px": 1e-4}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,9 +205,22 @@ def main():
                 "finalize_avg_us": 1e3 * prof["finalize"]["total_ms"] / max(prof["finalize"]["launches"], 1),
             },
         }
+        out["kernels"].pop("respawn_avg_us", None)   # respawn is fused into chain_step
         if world == 1 and not args.no_cpu:
-            cb, Rc = cpu_baseline(flows_f, flows_b, min(args.cpu_pairs, n_flows))
+            n_cpu = min(args.cpu_pairs, n_flows)
+            cb, Rc = cpu_baseline(flows_f, flows_b, n_cpu)
             out["cpu_baseline"] = cb
+            if n_cpu == n_flows:
+                # full-size parity, checked on the spot: ids / lengths bit-exact, positions bit-exact (track mode)
+                from point_trajectory.trajectory import _result_to_host
+                Rg = _result_to_host(ctx, info)
+                same = bool(Rg.birth.shape == Rc.birth.shape and np.array_equal(Rg.birth, Rc.birth)
+                            and np.array_equal(Rg.length, Rc.length))
+                out["parity"] = {"vs": "cpu oracle, whole workload", "ids_lengths_equal": same,
+                                 "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None}
+                del Rg
+            # secondary figure (outside the timed region): the path-consistency path on configs[2]'s shape
+            out["secondary"] = secondary_track_optimize(ctx)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

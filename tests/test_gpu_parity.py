@@ -196,3 +196,62 @@ def test_main_connect_end_to_end(pt, tmp_path):
         assert len(win["traj_ids"]) == len(keep)
         # skip_exists short-circuit (main_connect_point_trajectories.py:31-33)
         main_connect_point_trajectories(str(fd), str(out), sample_ratio=r, skip_path_consistency=skip, skip_exists=True)
+
+
+@pytest.mark.parametrize("H,W,T,r,seed,thres", [
+    (41, 59, 6, 5, 91, 1.0),      # generic-ratio kernel instantiation (R = 0), H*W odd -> scalar flow_check kernel
+    (30, 44, 5, 6, 92, 3.0),      # ratio 6, README's ScanNet threshold
+    (8, 9, 4, 2, 93, 1.0),        # tiny image: every tap near a border
+    (64, 64, 6, 7, 94, 1.0),      # ratio larger than most displacements
+])
+def test_track_odd_ratios_and_sizes(pt, H, W, T, r, seed, thres):
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=0.3, n_occluders=1, stride2=False)
+    e_o, o_o = orc.flow_check(d["flows_f"], d["flows_b"], thres)
+    e_g, o_g = pt.utils.flow_check(d["flows_f"], d["flows_b"], thres)
+    for a, b in zip(e_o, e_g):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(o_o, o_g):
+        assert np.array_equal(a, b)
+    O = orc.track(d["flows_f"], o_o, r)
+    R = pt.track(d["flows_f"], o_g, r)
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+
+
+def test_capacity_overflow_is_reported_and_retried(pt):
+    """Tables that are too small return PSFM_ERR_CAPACITY (never a silently truncated result); the Python mirror
+    grows them and reruns.  Heavy occlusion makes the trajectory table overflow its minimum size."""
+    import ctypes
+    import torch
+    from oracle import oracle as orc
+    hip = pt.hip
+    T, H, W, r = 40, 96, 128, 1
+    d = psfm_synth.synth_sequence(T, H, W, seed=95, sigma=0.6, n_occluders=4, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    O = orc.track(d["flows_f"], occ, r)
+    ctx = hip.context()
+    fl = torch.from_numpy(np.stack(d["flows_f"])).cuda()
+    oc = torch.from_numpy(np.stack(occ).astype(np.uint8)).cuda()
+    ctx.set_capacity(1.0, 1.0)
+    info = hip.TrackInfo()
+    st = hip.lib().psfm_track(ctx.handle, hip.ptr(fl), hip.ptr(oc), None, None, T - 1, H, W, r, ctypes.byref(info),
+                              hip.current_stream_ptr())
+    if O.n_traj > 2 * H * W + 64 * 1024:      # only then is the minimum table guaranteed too small
+        assert st == hip.PSFM_ERR_CAPACITY and b"capacity" in hip.lib().psfm_last_error()
+    R = pt.track(d["flows_f"], occ, r)        # mirror: retries with larger tables
+    assert len(R) == O.n_traj and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+
+
+def test_bad_arguments_are_rejected(pt):
+    import ctypes
+    hip = pt.hip
+    ctx = hip.context()
+    L = hip.lib()
+    assert L.psfm_flow_check(ctx.handle, None, None, 3, 10, 10, 1.0, None, None, None) == hip.PSFM_ERR_ARG
+    assert L.psfm_track(ctx.handle, None, None, None, None, 0, 10, 10, 2, None, None) == hip.PSFM_ERR_ARG
+    assert L.psfm_track(ctx.handle, None, None, None, None, 3, 10, 10, 0, None, None) == hip.PSFM_ERR_ARG
+    assert L.psfm_grid_sample(ctx.handle, None, 3, 10, 10, None, 5, None, None) == hip.PSFM_ERR_ARG
+    assert L.psfm_ctx_set_capacity(ctx.handle, 0.5, 1.0) == hip.PSFM_ERR_ARG
+    assert len(L.psfm_last_error()) > 0
+    with pytest.raises(ValueError):
+        pt.track([], [], 2)
