@@ -301,76 +301,103 @@ __device__ __forceinline__ unsigned long long psfm_key(int last_time, int bf, in
 #ifndef PSFM_CHAIN_BLOCK
 #define PSFM_CHAIN_BLOCK 256
 #endif
-#ifndef PSFM_CHAIN_ATTR
-#define PSFM_CHAIN_ATTR
+#ifndef PSFM_LPT
+#define PSFM_LPT 1          // lanes (and grid points) per thread: lane u of thread t is tile_base + u*BLOCK + t (2 measured no faster)
 #endif
-#ifndef PSFM_CHAIN_MINWAVES
-#define PSFM_CHAIN_MINWAVES 1
-#endif
+#define PSFM_CHAIN_TILE (PSFM_CHAIN_BLOCK * PSFM_LPT)
+#define PSFM_CHAIN_NW (PSFM_CHAIN_BLOCK / PSFM_WAVE)
+#define PSFM_CHAIN_NSEG (PSFM_CHAIN_NW * PSFM_LPT)
+
+// Every thread owns PSFM_LPT lanes, block-strided so that each wave-level load stays fully coalesced.  PSFM_LPT = 2
+// makes the whole 1080p/r=2 grid resident in ONE dispatch round (1017 tiles of 512 at 4 waves per SIMD) with twice the
+// bytes in flight per wave; measured 17.6 us vs 17.1 us for PSFM_LPT = 1 (two rounds at 7 waves per SIMD): the launch
+// is bound by its serialized phases (latency + transfer of two dependent round trips), not by residency.
 template <int R>
-__global__ __launch_bounds__(PSFM_CHAIN_BLOCK, PSFM_CHAIN_MINWAVES) PSFM_CHAIN_ATTR void psfm_chain_step_kernel(PsfmChainArgs a)
+__global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmChainArgs a)
 {
-    __shared__ int s_births[PSFM_CHAIN_BLOCK / PSFM_WAVE], s_pend[PSFM_CHAIN_BLOCK / PSFM_WAVE];
-    __shared__ int s_new_g[PSFM_CHAIN_BLOCK];            // grid index of the births, one 64-slot segment per wave
-    __shared__ int s_pend_lane[PSFM_CHAIN_BLOCK];        // lanes of the tracks that died in the previous step, same layout
+    __shared__ int s_births[PSFM_CHAIN_NSEG], s_pend[PSFM_CHAIN_NSEG];
+    __shared__ int s_new_g[PSFM_CHAIN_TILE];        // grid index of the births, one 64-slot segment per (u, wave)
+    __shared__ int s_pend_lane[PSFM_CHAIN_TILE];    // lanes of the tracks that died in the previous step, same layout
     __shared__ int s_seg_start[PSFM_PROBE + 1];
     __shared__ int s_seg_end[PSFM_PROBE + 1];
     __shared__ int s_nseg, s_alive_any, s_base_fin, s_base_free;
     const int tid = threadIdx.x, lane = psfm_lane_id(), wave = tid / PSFM_WAVE;
-    const int i = blockIdx.x * PSFM_CHAIN_BLOCK + tid;
+    const int tile = blockIdx.x * PSFM_CHAIN_TILE;
     const int frame = a.frame;
     const int ratio = R > 0 ? R : a.ratio;
-    // blocks past both the lane high-water mark and the grid have nothing to do (lanes handed out during
-    // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
     if (a.ctr->stall) return;   // an earlier path-consistency solve is unfinished: this launch will be re-enqueued
-    if ((int)(blockIdx.x * PSFM_CHAIN_BLOCK) >= max(a.ctr->n_lanes, a.G)) return;
+    // tiles past both the lane high-water mark and the grid have nothing to do (lanes handed out during
+    // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
+    if (tile >= max(a.ctr->n_lanes, a.G)) return;
     if (tid == 0) s_alive_any = 0;
 
     // ---- independent early loads: lane state, (speculative) tail position, respawn byte ----
-    int bf = -1;
-    double2 p = make_double2(0.0, 0.0);
-    if (i < a.cap) { bf = a.birth_frame[i]; p = a.log_cur[i]; }
-    bool birth = false;
-    if (frame > 0 && i < a.G) {
-        if (*a.surv_prev == 0) {
-            const int gy = (int)psfm_fastdiv((unsigned)i, a.gwdiv), gx = i - gy * a.GW;
-            const int cx = gx * ratio, cy = gy * ratio;
-            birth = ((cy + 1) * (cy + 1) + cx * cx) > ratio * ratio;
-        } else {
-            birth = a.blocked_prev[i] != a.stamp_prev;
+    int bf[PSFM_LPT];
+    double2 p[PSFM_LPT];
+    bool birth[PSFM_LPT], live[PSFM_LPT], pend[PSFM_LPT];
+    int pend_idx[PSFM_LPT];
+    unsigned long long bm[PSFM_LPT], pm[PSFM_LPT];
+    const int surv_prev = (frame > 0) ? *a.surv_prev : 1;
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u) {
+        const int i = tile + u * PSFM_CHAIN_BLOCK + tid;
+        bf[u] = -1;
+        p[u] = make_double2(0.0, 0.0);
+        if (i < a.cap) { bf[u] = a.birth_frame[i]; p[u] = a.log_cur[i]; }
+        birth[u] = false;
+        if (frame > 0 && i < a.G) {
+            if (surv_prev == 0) {
+                const int gy = (int)psfm_fastdiv((unsigned)i, a.gwdiv), gx = i - gy * a.GW;
+                const int cx = gx * ratio, cy = gy * ratio;
+                birth[u] = ((cy + 1) * (cy + 1) + cx * cx) > ratio * ratio;
+            } else {
+                birth[u] = a.blocked_prev[i] != a.stamp_prev;
+            }
         }
     }
-    // lanes born AT `frame` (allocated concurrently by other blocks) are not ours; a marker -2-b with b < frame
-    // is a death recorded by the previous launch
-    const bool live = (bf >= 0) & ((bf < frame) | (frame == 0));
-    const int pend_bf = -2 - bf;
-    const bool pend = (bf <= -2) & (pend_bf < frame);
-    int pend_idx = 0;
-    if (pend) pend_idx = a.birth_idx[i];   // read NOW: a newborn of this block may inherit (and overwrite) this lane below
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u) {
+        const int i = tile + u * PSFM_CHAIN_BLOCK + tid;
+        // lanes born AT `frame` (allocated concurrently by other blocks) are not ours; a marker -2-b with b < frame
+        // is a death recorded by the previous launch
+        live[u] = (bf[u] >= 0) & ((bf[u] < frame) | (frame == 0));
+        pend[u] = (bf[u] <= -2) & ((-2 - bf[u]) < frame);
+        pend_idx[u] = 0;
+        if (pend[u]) pend_idx[u] = a.birth_idx[i];   // read NOW: a newborn of this block may inherit (and overwrite) this lane
+        // ---- block-level counts; the births' grid indices and the just-died lanes are compacted through LDS ----
+        bm[u] = __ballot(birth[u]);
+        pm[u] = __ballot(pend[u]);
+        const int seg = u * PSFM_CHAIN_NW + wave;
+        if (lane == 0) { s_births[seg] = __popcll(bm[u]); s_pend[seg] = __popcll(pm[u]); }
+        if (birth[u]) s_new_g[seg * PSFM_WAVE + psfm_rank_in(bm[u])] = i;
+        if (pend[u]) s_pend_lane[seg * PSFM_WAVE + psfm_rank_in(pm[u])] = i;
+    }
 
-    // ---- block-level counts; the births' grid indices are compacted through LDS ----
-    const unsigned long long bm = __ballot(birth);
-    const unsigned long long pm = __ballot(pend);
-    if (lane == 0) { s_births[wave] = __popcll(bm); s_pend[wave] = __popcll(pm); }
-    if (birth) s_new_g[wave * PSFM_WAVE + psfm_rank_in(bm)] = i;
-    if (pend) s_pend_lane[wave * PSFM_WAVE + psfm_rank_in(pm)] = i;
-
-    // ---- gathers of the lane's step (unconditional: idle lanes sample pixel (0,0)) ----
-    const double2 p1 = live ? p : make_double2(0.0, 0.0);
-    const PsfmStepLoads l1 = psfm_step_issue(a, p1);
+    // ---- gathers of the lanes' steps (unconditional: idle lanes sample pixel (0,0)) ----
+    double2 p1[PSFM_LPT];
+    PsfmStepLoads l1[PSFM_LPT];
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u) {
+        p1[u] = live[u] ? p[u] : make_double2(0.0, 0.0);
+        l1[u] = psfm_step_issue(a, p1[u]);
+    }
 
     __syncthreads();
     // ---- the newborns' first step, compacted onto the first threads of the block ----
     // Newborn #t first inherits the lane of the block's t-th just-died track (no atomics, the lane is recycled
     // immediately); only the surplus of births pops the free stacks and only the surplus of deaths pushes them.
     int nb = 0, npd = 0, g2 = -1, L2 = -1;
+    int pend_before[PSFM_LPT];   // just-died tracks of this block ranked before this wave's, per u
     {
         int before = 0, pbefore = 0;
 #pragma unroll
-        for (int w = 0; w < PSFM_CHAIN_BLOCK / PSFM_WAVE; ++w) {
-            const int c = s_births[w], pc = s_pend[w];
-            if (tid >= before && tid < before + c) g2 = s_new_g[w * PSFM_WAVE + (tid - before)];
-            if (tid >= pbefore && tid < pbefore + pc) L2 = s_pend_lane[w * PSFM_WAVE + (tid - pbefore)];
+        for (int sg = 0; sg < PSFM_CHAIN_NSEG; ++sg) {
+            const int c = s_births[sg], pc = s_pend[sg];
+            if (tid >= before && tid < before + c) g2 = s_new_g[sg * PSFM_WAVE + (tid - before)];
+            if (tid >= pbefore && tid < pbefore + pc) L2 = s_pend_lane[sg * PSFM_WAVE + (tid - pbefore)];
+#pragma unroll
+            for (int u = 0; u < PSFM_LPT; ++u)
+                if (sg == u * PSFM_CHAIN_NW + wave) pend_before[u] = pbefore;
             before += c;
             pbefore += pc;
         }
@@ -420,48 +447,72 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK, PSFM_CHAIN_MINWAVES) PSFM_CHAIN_A
         }
         s_nseg = nseg;
     }
-    // the dead track's birth index must be in a register before any newborn may overwrite birth_idx[lane]
-    asm volatile("" : : "v"(pend_idx) : "memory");
+    // the dead tracks' birth indices must be in registers before any newborn may overwrite birth_idx[lane]
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u) asm volatile("" : : "v"(pend_idx[u]) : "memory");
     __syncthreads();
 
-    // ---- (C) deaths of the previous step -> record (+ free lane unless a newborn inherits it) ----
-    if (pend) {
-        int r = psfm_rank_in(pm);
-        for (int w = 0; w < wave; ++w) r += s_pend[w];
-        if (r >= matched) {
-            a.birth_frame[i] = -1;
-            const int fpos = s_base_free + (r - matched);
-            if (fpos < a.free_cap) a.free_push[(int64_t)shard * a.free_cap + fpos] = i;
-            else atomicOr(&a.ctr->overflow, 1);
+    bool any_alive = false;
+    int npts = 0;
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u) {
+        const int i = tile + u * PSFM_CHAIN_BLOCK + tid;
+        // ---- (C) deaths of the previous step -> record (+ free lane unless a newborn inherits it) ----
+        if (pend[u]) {
+            const int r = pend_before[u] + psfm_rank_in(pm[u]);
+            if (r >= matched) {
+                a.birth_frame[i] = -1;
+                const int fpos = s_base_free + (r - matched);
+                if (fpos < a.free_cap) a.free_push[(int64_t)shard * a.free_cap + fpos] = i;
+                else atomicOr(&a.ctr->overflow, 1);
+            }
+            const int rpos = s_base_fin + r;
+            if (rpos < a.shard_cap) {
+                const int64_t o = (int64_t)shard * a.shard_cap + rpos;
+                a.fin_keys[o] = psfm_key(frame - 1, -2 - bf[u], pend_idx[u], a.shift_b, a.shift_d);
+                a.fin_lanes[o] = i;
+            } else {
+                atomicOr(&a.ctr->overflow, 2);
+            }
         }
-        const int rpos = s_base_fin + r;
-        if (rpos < a.shard_cap) {
-            const int64_t o = (int64_t)shard * a.shard_cap + rpos;
-            a.fin_keys[o] = psfm_key(frame - 1, pend_bf, pend_idx, a.shift_b, a.shift_d);
-            a.fin_lanes[o] = i;
-        } else {
-            atomicOr(&a.ctr->overflow, 2);
+        // ---- (B) results of the lane's step ----
+        if (live[u]) {
+            const PsfmStep s1 = psfm_step_finish(a, p1[u], l1[u]);
+            if (s1.alive) {
+                a.log_next[i] = s1.next;
+                psfm_block_grid<R>(a, (int)s1.next.x, (int)s1.next.y);
+                any_alive = true;
+                ++npts;
+            } else {
+                a.birth_frame[i] = -2 - bf[u];
+            }
         }
     }
-    // ---- (B) results of the lane's step ----
-    bool any_alive = false, live_alive = false, newborn_alive = false, newborn_ok = false;
-    if (live) {
-        const PsfmStep s1 = psfm_step_finish(a, p1, l1);
-        if (s1.alive) {
-            live_alive = true;
-            a.log_next[i] = s1.next;
-            psfm_block_grid<R>(a, (int)s1.next.x, (int)s1.next.y);
-            any_alive = true;
+    // ---- (A) the newborns: lane, state, first step.  Thread t handles newborn #t; a mass respawn with more births
+    //      than threads (rare) loops with a synchronous sample ----
+    for (int t = tid; t < nb; t += PSFM_CHAIN_BLOCK) {
+        PsfmStep s2;
+        int g = g2, L = L2;
+        double2 pg = p2;
+        if (t == tid) {
+            s2 = psfm_step_finish(a, p2, l2);
         } else {
-            a.birth_frame[i] = -2 - bf;
+            int before = 0, pbefore = 0;
+            g = -1; L = -1;
+            for (int sg = 0; sg < PSFM_CHAIN_NSEG; ++sg) {
+                const int c = s_births[sg], pc = s_pend[sg];
+                if (t >= before && t < before + c) g = s_new_g[sg * PSFM_WAVE + (t - before)];
+                if (t >= pbefore && t < pbefore + pc) L = s_pend_lane[sg * PSFM_WAVE + (t - pbefore)];
+                before += c;
+                pbefore += pc;
+            }
+            const int gy = (int)psfm_fastdiv((unsigned)g, a.gwdiv), gx = g - gy * a.GW;
+            pg = make_double2((double)(gx * ratio), (double)(gy * ratio));
+            const PsfmStepLoads lx = psfm_step_issue(a, pg);
+            s2 = psfm_step_finish(a, pg, lx);
         }
-    }
-    // ---- (A) the newborn: lane, state, first step ----
-    if (newborn) {
-        const PsfmStep s2 = psfm_step_finish(a, p2, l2);
-        int L = L2;                          // inherited from a just-died track of this block (tid < matched) ...
-        if (tid >= matched) {                // ... or popped / fresh
-            const int qq = tid - matched;
+        if (t >= matched) {                  // popped / fresh lane (t < matched: inherited from a just-died track)
+            const int qq = t - matched;
             int k = 0, prev = 0;
             while (k < s_nseg - 1 && qq >= s_seg_end[k]) { prev = s_seg_end[k]; ++k; }
             const int q = qq - prev;
@@ -469,11 +520,11 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK, PSFM_CHAIN_MINWAVES) PSFM_CHAIN_A
             L = st >= 0 ? a.free_pop[st - q] : (-(st + 1) + q);
         }
         if (L >= 0 && L < a.cap) {
-            newborn_ok = true;
-            a.birth_idx[L] = g2;
-            a.log_cur[L] = p2;
+            ++npts;
+            a.birth_idx[L] = g;
+            a.log_cur[L] = pg;
             if (s2.alive) {
-                newborn_alive = true;
+                ++npts;
                 a.birth_frame[L] = frame;
                 a.log_next[L] = s2.next;
                 psfm_block_grid<R>(a, (int)s2.next.x, (int)s2.next.y);
@@ -491,8 +542,10 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK, PSFM_CHAIN_MINWAVES) PSFM_CHAIN_A
     // trajectory points written by this wave: one per surviving step (log_next) + one per birth (log_cur);
     // fire-and-forget atomic, summed on the host at finalize to size the result without a second sync
     {
-        const int npts = __popcll(__ballot(live_alive)) + __popcll(__ballot(newborn_alive)) + __popcll(__ballot(newborn_ok));
-        if (lane == 0 && npts > 0) atomicAdd(&a.sh_fin[shard].points, (unsigned)npts);
+        int w = npts;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
+        if (lane == 0 && w > 0) atomicAdd(&a.sh_fin[shard].points, (unsigned)w);
     }
     __syncthreads();
     if (tid == 0 && s_alive_any) *a.surv_cur = 1;
@@ -547,7 +600,7 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
     a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     c->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1);
-    const dim3 grid((unsigned)((d.cap + PSFM_CHAIN_BLOCK - 1) / PSFM_CHAIN_BLOCK)), block(PSFM_CHAIN_BLOCK);
+    const dim3 grid((unsigned)((d.cap + PSFM_CHAIN_TILE - 1) / PSFM_CHAIN_TILE)), block(PSFM_CHAIN_BLOCK);
     switch (d.ratio) {
         case 1: hipExtLaunchKernelGGL(psfm_chain_step_kernel<1>, grid, block, 0, s, e0, e1, 0, a); break;
         case 2: hipExtLaunchKernelGGL(psfm_chain_step_kernel<2>, grid, block, 0, s, e0, e1, 0, a); break;
