@@ -51,6 +51,19 @@ __device__ __forceinline__ float psfm_blend(float vnw, float vne, float vsw, flo
     return __fmaf_rn(vse, t.se, __fmaf_rn(vsw, t.sw, __fmaf_rn(vne, t.ne, __fmul_rn(vnw, t.nw))));
 }
 
+// ---- base + 32-bit unsigned BYTE offset addressing: lets the compiler use the SGPR-base + VGPR-offset form of
+// global_load / global_store (no 64-bit VALU address arithmetic per access); every map/table here is < 4 GB ----
+template <class T>
+__device__ __forceinline__ T psfm_ld(const T* __restrict__ base, unsigned byte_off)
+{
+    return *(const T*)((const char*)base + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void psfm_st(T* __restrict__ base, unsigned byte_off, T v)
+{
+    *(T*)((char*)base + byte_off) = v;
+}
+
 // Tap addressing: every tap is loaded UNCONDITIONALLY from a clamped (always valid) address and zeroed by a
 // select afterwards (zeros padding).  Branch-free loads let the compiler issue all taps back to back behind a
 // single s_waitcnt; predicated loads compiled to one exec-masked branch + wait per tap (8 serial round trips).
@@ -75,7 +88,8 @@ __device__ __forceinline__ PsfmTapIdx psfm_tap_idx(int H, int W, const PsfmTaps&
 // Two-channel (flow) sample from the .flo-native interleaved (H,W,2) layout: one 8-byte load per tap.
 __device__ __forceinline__ float2 psfm_sample_flow(const float2* __restrict__ map, const PsfmTapIdx& k, const PsfmTaps& t)
 {
-    float2 vnw = map[k.nw], vne = map[k.ne], vsw = map[k.sw], vse = map[k.se];
+    float2 vnw = psfm_ld(map, (unsigned)k.nw * 8u), vne = psfm_ld(map, (unsigned)k.ne * 8u);
+    float2 vsw = psfm_ld(map, (unsigned)k.sw * 8u), vse = psfm_ld(map, (unsigned)k.se * 8u);
     vnw.x = k.inw ? vnw.x : 0.0f; vnw.y = k.inw ? vnw.y : 0.0f;
     vne.x = k.ine ? vne.x : 0.0f; vne.y = k.ine ? vne.y : 0.0f;
     vsw.x = k.isw ? vsw.x : 0.0f; vsw.y = k.isw ? vsw.y : 0.0f;
@@ -90,7 +104,8 @@ __device__ __forceinline__ float2 psfm_sample_flow(const float2* __restrict__ ma
 // One-channel sample of a 0/1 byte map (the occlusion masks), values taken as 0.0f / 1.0f.
 __device__ __forceinline__ float psfm_sample_mask(const uint8_t* __restrict__ map, const PsfmTapIdx& k, const PsfmTaps& t)
 {
-    const uint8_t bnw = map[k.nw], bne = map[k.ne], bsw = map[k.sw], bse = map[k.se];
+    const uint8_t bnw = psfm_ld(map, (unsigned)k.nw), bne = psfm_ld(map, (unsigned)k.ne);
+    const uint8_t bsw = psfm_ld(map, (unsigned)k.sw), bse = psfm_ld(map, (unsigned)k.se);
     const float vnw = (k.inw & (bnw != 0)) ? 1.0f : 0.0f;
     const float vne = (k.ine & (bne != 0)) ? 1.0f : 0.0f;
     const float vsw = (k.isw & (bsw != 0)) ? 1.0f : 0.0f;

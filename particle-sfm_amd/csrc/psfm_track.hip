@@ -75,7 +75,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x4_kernel(
 #pragma unroll
     for (int k = 0; k < PSFM_FC_UNROLL; ++k) {
         const int p = p0 + k * PSFM_BLOCK;
-        f[k] = p < P ? F[p] : make_float2(0.f, 0.f);
+        f[k] = p < P ? psfm_ld(F, (unsigned)p * 8u) : make_float2(0.f, 0.f);
     }
     int y = (int)psfm_fastdiv((unsigned)p0, wdiv), x = p0 - y * W;
 #pragma unroll
@@ -223,30 +223,36 @@ struct PsfmStep { bool alive; double2 next; };
 // psfm_step_issue() computes the tap geometry and performs the eight raw loads (4 flow taps, 4 mask taps);
 // psfm_step_finish() blends them (fp32, bit-exact op order) and applies trajectory.py:50,55-57.
 struct PsfmStepLoads {
-    PsfmTaps t;
-    PsfmTapIdx k;
+    float nw, ne, sw, se;           // bilinear weights
+    int inb;                        // bit 0..3: tap nw/ne/sw/se inside the map
     float2 fnw, fne, fsw, fse;
     uint8_t onw, one, osw, ose;
 };
 
 __device__ __forceinline__ PsfmStepLoads psfm_step_issue(const PsfmChainArgs& a, double2 p)
 {
+    const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
+    const PsfmTapIdx k = psfm_tap_idx(a.H, a.W, t);   // flow and occlusion map share the tap geometry
     PsfmStepLoads L;
-    L.t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
-    L.k = psfm_tap_idx(a.H, a.W, L.t);   // flow and occlusion map share the tap geometry
-    L.fnw = a.flow[L.k.nw]; L.fne = a.flow[L.k.ne]; L.fsw = a.flow[L.k.sw]; L.fse = a.flow[L.k.se];
-    L.onw = a.occ[L.k.nw]; L.one = a.occ[L.k.ne]; L.osw = a.occ[L.k.sw]; L.ose = a.occ[L.k.se];
+    L.nw = t.nw; L.ne = t.ne; L.sw = t.sw; L.se = t.se;
+    L.inb = (k.inw ? 1 : 0) | (k.ine ? 2 : 0) | (k.isw ? 4 : 0) | (k.ise ? 8 : 0);
+    const unsigned onw = (unsigned)k.nw, one = (unsigned)k.ne, osw = (unsigned)k.sw, ose = (unsigned)k.se;
+    L.fnw = psfm_ld(a.flow, onw * 8u); L.fne = psfm_ld(a.flow, one * 8u);
+    L.fsw = psfm_ld(a.flow, osw * 8u); L.fse = psfm_ld(a.flow, ose * 8u);
+    L.onw = psfm_ld(a.occ, onw); L.one = psfm_ld(a.occ, one); L.osw = psfm_ld(a.occ, osw); L.ose = psfm_ld(a.occ, ose);
     return L;
 }
 
 __device__ __forceinline__ PsfmStep psfm_step_finish(const PsfmChainArgs& a, double2 p, const PsfmStepLoads& L)
 {
-    const PsfmTapIdx& k = L.k;
+    PsfmTaps t;
+    t.x0 = 0; t.y0 = 0; t.nw = L.nw; t.ne = L.ne; t.sw = L.sw; t.se = L.se;
+    const bool inw = L.inb & 1, ine = L.inb & 2, isw = L.inb & 4, ise = L.inb & 8;
     const float z = 0.0f;
-    const float fx = psfm_blend(k.inw ? L.fnw.x : z, k.ine ? L.fne.x : z, k.isw ? L.fsw.x : z, k.ise ? L.fse.x : z, L.t);
-    const float fy = psfm_blend(k.inw ? L.fnw.y : z, k.ine ? L.fne.y : z, k.isw ? L.fsw.y : z, k.ise ? L.fse.y : z, L.t);
-    const float oc = psfm_blend((k.inw & (L.onw != 0)) ? 1.0f : z, (k.ine & (L.one != 0)) ? 1.0f : z,
-                                (k.isw & (L.osw != 0)) ? 1.0f : z, (k.ise & (L.ose != 0)) ? 1.0f : z, L.t);
+    const float fx = psfm_blend(inw ? L.fnw.x : z, ine ? L.fne.x : z, isw ? L.fsw.x : z, ise ? L.fse.x : z, t);
+    const float fy = psfm_blend(inw ? L.fnw.y : z, ine ? L.fne.y : z, isw ? L.fsw.y : z, ise ? L.fse.y : z, t);
+    const float oc = psfm_blend((inw & (L.onw != 0)) ? 1.0f : z, (ine & (L.one != 0)) ? 1.0f : z,
+                                (isw & (L.osw != 0)) ? 1.0f : z, (ise & (L.ose != 0)) ? 1.0f : z, t);
     const double nx = p.x + (double)fx, ny = p.y + (double)fy;
     const bool valid = (nx > 0.0) & (nx < (double)(a.W - 1)) & (ny > 0.0) & (ny < (double)(a.H - 1));
     PsfmStep s;
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
         const int i = tile + u * PSFM_CHAIN_BLOCK + tid;
         bf[u] = -1;
         p[u] = make_double2(0.0, 0.0);
-        if (i < a.cap) { bf[u] = a.birth_frame[i]; p[u] = a.log_cur[i]; }
+        if (i < a.cap) { bf[u] = psfm_ld(a.birth_frame, (unsigned)i * 4u); p[u] = psfm_ld(a.log_cur, (unsigned)i * 16u); }
         birth[u] = false;
         if (frame > 0 && i < a.G) {
             if (surv_prev == 0) {
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
                 const int cx = gx * ratio, cy = gy * ratio;
                 birth[u] = ((cy + 1) * (cy + 1) + cx * cx) > ratio * ratio;
             } else {
-                birth[u] = a.blocked_prev[i] != a.stamp_prev;
+                birth[u] = psfm_ld(a.blocked_prev, (unsigned)i) != a.stamp_prev;
             }
         }
     }
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
         if (live[u]) {
             const PsfmStep s1 = psfm_step_finish(a, p1[u], l1[u]);
             if (s1.alive) {
-                a.log_next[i] = s1.next;
+                psfm_st(a.log_next, (unsigned)i * 16u, s1.next);
                 psfm_block_grid<R>(a, (int)s1.next.x, (int)s1.next.y);
                 any_alive = true;
                 ++npts;
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
         PsfmStep s2;
         int g = g2, L = L2;
         double2 pg = p2;
-        if (t == tid) {
+        if (PSFM_LPT == 1 || t == tid) {   // (one lane per thread: at most one newborn per thread)
             s2 = psfm_step_finish(a, p2, l2);
         } else {
             int before = 0, pbefore = 0;
@@ -535,6 +541,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
         } else {
             atomicOr(&a.ctr->overflow, 1);
         }
+        if (PSFM_LPT == 1) break;
     }
     // ---- "some track survived this step" (the degenerate respawn rule of the next launch) ----
     const unsigned long long am = __ballot(any_alive);
