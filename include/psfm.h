@@ -13,6 +13,7 @@
  *                           point_trajectory/track_optimize.py:24-53 track_optimize()
  *                           (+ the IncrementalTrajectorySet / Trajectory bookkeeping they
  *                           drive: trajectory.py:98-194, optimize/src/trajectory_base.cpp:21-93)
+ *   psfm_connect            point_trajectory/main_connect_point_trajectories.py:36-53 (flow_check + track[_optimize])
  *   psfm_result_*           the list of Trajectory objects those functions return and the
  *                           id / min-length rule of main_connect_point_trajectories.py:56-60
  *
@@ -116,6 +117,16 @@ psfm_status psfm_optimize_location(psfm_ctx* ctx, const double* uv12, const doub
 psfm_status psfm_track(psfm_ctx* ctx, const float* flows, const uint8_t* occ, const float* flows_f2,
                        const uint8_t* occ_s2, int n_flows, int h, int w, int sample_ratio,
                        psfm_track_info* info_host, void* stream);
+
+/* The compute part of the stage entry main_connect_point_trajectories.py:36-53 in one call: flow_check of the
+ * stride-1 stacks (and of the stride-2 stacks when flows_f2 != NULL) followed by track / track_optimize, with the
+ * occlusion maps produced on an internal side stream while the frame loop consumes them.
+ *   flows_f, flows_b   (n_flows,H,W,2) f32      flows_f2, flows_b2  (n_flows-1,H,W,2) f32 or NULL
+ *   occ, occ_s2        optional outputs (n_flows,H,W) / (n_flows-1,H,W) u8; NULL = kept in the context
+ * Result access as for psfm_track.  Synchronises `stream`. */
+psfm_status psfm_connect(psfm_ctx* ctx, const float* flows_f, const float* flows_b, const float* flows_f2,
+                         const float* flows_b2, int n_flows, int h, int w, float thres, int sample_ratio,
+                         uint8_t* occ, uint8_t* occ_s2, psfm_track_info* info_host, void* stream);
 
 /* Device-resident result of the last psfm_track: CSR over trajectories in id order.
  *   birth (n_traj) i32 first frame; len (n_traj) i32; off (n_traj+1) i64; xy (n_points,2) f64.

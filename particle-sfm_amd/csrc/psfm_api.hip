@@ -125,9 +125,10 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
                        &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
-                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats};
+                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->occ_own, &c->occ2_own};
     for (auto b : bufs) b->release();
     c->prof.destroy();
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     delete c;
     return PSFM_OK;
@@ -211,9 +212,30 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
     return rc;
 }
 
-extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t* occ, const float* flows_f2,
-                                  const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
-                                  void* stream)
+// Occlusion maps produced on a side stream while the frame loop consumes them (psfm_connect): one event per chunk
+// of frame pairs; the loop waits for the chunk that contains the pair it is about to read.
+struct PsfmOccPipeline {
+    int chunk = 0;                       // frame pairs per chunk (0 = maps already complete)
+    std::vector<hipEvent_t> ready;       // stride-1 maps: chunk c covers pairs [c*chunk, (c+1)*chunk)
+    std::vector<hipEvent_t> ready_s2;    // stride-2 maps
+    int waited = -1, waited_s2 = -1;
+    psfm_status need(int pair, bool s2, hipStream_t s)
+    {
+        if (chunk <= 0) return PSFM_OK;
+        std::vector<hipEvent_t>& ev = s2 ? ready_s2 : ready;
+        int& w = s2 ? waited_s2 : waited;
+        const int cidx = pair / chunk;
+        while (w < cidx && w + 1 < (int)ev.size()) {
+            ++w;
+            PSFM_HIP(hipStreamWaitEvent(s, ev[w], 0));
+        }
+        return PSFM_OK;
+    }
+};
+
+static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_t* occ, const float* flows_f2,
+                                   const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
+                                   void* stream, PsfmOccPipeline* pipe)
 {
     PSFM_CHECK_CTX(c);
     const bool optimize = flows_f2 != nullptr;
@@ -271,9 +293,11 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
     while (f < n_flows) {
         // track.py:31-47 / track_optimize.py:31-50, one loop iteration:
         // one launch = births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
+        if (pipe && (st = pipe->need(f, false, s)) != PSFM_OK) return st;
         st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * P, f, s);
         if (st != PSFM_OK) return st;
         if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
+            if (pipe && (st = pipe->need(f - 1, true, s)) != PSFM_OK) return st;
             c->prof.begin(PSFM_PROF_SOLVER, s);
             st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
                                           flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
@@ -337,6 +361,74 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
         info->n_solves = (int32_t)c->solve_stats.size();
     }
     return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t* occ, const float* flows_f2,
+                                  const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
+                                  void* stream)
+{
+    return psfm_track_impl(c, flows, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, nullptr);
+}
+
+// The compute part of the stage entry (main_connect_point_trajectories.py:36-53): flow_check of the stride-1 (and
+// stride-2) stacks + track / track_optimize.  flow_check is bandwidth-bound, the frame loop is latency-bound: the
+// maps are produced in chunks on a side stream and the loop only waits for the chunk it is about to read, so most
+// of flow_check's time disappears behind the recurrence.
+extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const float* flows_b, const float* flows_f2,
+                                    const float* flows_b2, int n_flows, int h, int w, float thres, int ratio,
+                                    uint8_t* occ, uint8_t* occ_s2, psfm_track_info* info, void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    const bool optimize = flows_f2 != nullptr;
+    if (n_flows < 1 || h < 2 || w < 2 || !flows_f || !flows_b || (optimize && n_flows > 1 && !flows_b2)) {
+        psfm_set_error("psfm_connect: bad argument (n_flows=%d h=%d w=%d)", n_flows, h, w);
+        return PSFM_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t P = (size_t)h * w;
+    psfm_status st;
+    if (!occ) {
+        if ((st = c->occ_own.ensure(P * (size_t)n_flows)) != PSFM_OK) return st;
+        occ = c->occ_own.as<uint8_t>();
+    }
+    const int n2 = optimize ? (n_flows > 1 ? n_flows - 1 : 0) : 0;
+    if (optimize && !occ_s2) {
+        if ((st = c->occ2_own.ensure(P * (size_t)(n2 > 0 ? n2 : 1))) != PSFM_OK) return st;
+        occ_s2 = c->occ2_own.as<uint8_t>();
+    }
+    if (!c->side_stream) PSFM_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    hipStream_t side = c->side_stream;
+    // the side stream starts after whatever the caller enqueued on `stream` (the inputs)
+    hipEvent_t e_in = c->prof.get();
+    PSFM_HIP(hipEventRecord(e_in, s));
+    PSFM_HIP(hipStreamWaitEvent(side, e_in, 0));
+    PsfmOccPipeline pipe;
+    pipe.chunk = 10;
+    c->prof.begin(PSFM_PROF_FLOW_CHECK, side);
+    for (int p0 = 0; p0 < n_flows; p0 += pipe.chunk) {
+        const int np = n_flows - p0 < pipe.chunk ? n_flows - p0 : pipe.chunk;
+        if ((st = psfm_launch_flow_check(flows_f + (size_t)p0 * P * 2, flows_b + (size_t)p0 * P * 2, np, h, w, thres,
+                                         occ + (size_t)p0 * P, nullptr, side)) != PSFM_OK) return st;
+        hipEvent_t e = c->prof.get();
+        PSFM_HIP(hipEventRecord(e, side));
+        pipe.ready.push_back(e);
+        // the stride-2 maps of the same time range follow their stride-1 chunk (needed one frame later)
+        if (p0 < n2) {
+            const int np2 = n2 - p0 < pipe.chunk ? n2 - p0 : pipe.chunk;
+            if ((st = psfm_launch_flow_check(flows_f2 + (size_t)p0 * P * 2, flows_b2 + (size_t)p0 * P * 2, np2, h, w,
+                                             thres, occ_s2 + (size_t)p0 * P, nullptr, side)) != PSFM_OK) return st;
+            hipEvent_t e2 = c->prof.get();
+            PSFM_HIP(hipEventRecord(e2, side));
+            pipe.ready_s2.push_back(e2);
+        }
+    }
+    c->prof.end(side);
+    st = psfm_track_impl(c, flows_f, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, &pipe);
+    // psfm_track_impl synchronised `stream`, which waited on every chunk: the side stream is idle too
+    c->prof.pool.push_back(e_in);
+    for (auto e : pipe.ready) c->prof.pool.push_back(e);
+    for (auto e : pipe.ready_s2) c->prof.pool.push_back(e);
+    return st;
 }
 
 extern "C" psfm_status psfm_result_device(psfm_ctx* c, const int32_t** birth, const int32_t** len, const int64_t** off,

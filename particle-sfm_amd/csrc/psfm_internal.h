@@ -91,6 +91,8 @@ struct psfm_ctx {
     // solver workspace
     PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats;
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
+    PsfmBuf occ_own, occ2_own;           // occlusion maps of psfm_connect when the caller passes none
+    hipStream_t side_stream = nullptr;   // flow_check of psfm_connect runs here, ahead of the frame loop
     std::vector<psfm_solve_stats> solve_stats;
     PsfmProfiler prof;
     void* host_pinned = nullptr;  // small pinned staging block

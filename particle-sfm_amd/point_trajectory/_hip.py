@@ -15,6 +15,7 @@ PROF_KINDS = {"flow_check": 0, "chain_step": 1, "respawn": 2, "solver": 3, "fina
 EXPORTS = [
     "psfm_last_error", "psfm_version", "psfm_device_count", "psfm_ctx_create", "psfm_ctx_destroy",
     "psfm_ctx_set_capacity", "psfm_flow_check", "psfm_grid_sample", "psfm_optimize_location", "psfm_track",
+    "psfm_connect",
     "psfm_result_device", "psfm_result_copy", "psfm_result_solve_stats", "psfm_ctx_set_profiling",
     "psfm_profile_get",
 ]
@@ -69,6 +70,7 @@ def lib():
     L.psfm_grid_sample.argtypes = [vp, vp, i32, i32, i32, vp, i64, vp, vp]
     L.psfm_optimize_location.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, ctypes.POINTER(SolveStats), vp]
     L.psfm_track.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(TrackInfo), vp]
+    L.psfm_connect.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, ctypes.POINTER(TrackInfo), vp]
     L.psfm_result_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.psfm_result_copy.argtypes = [vp, vp, vp, vp, vp, vp]
     L.psfm_result_solve_stats.argtypes = [vp, ctypes.POINTER(SolveStats), i32, ctypes.POINTER(ctypes.c_int32)]

@@ -5,8 +5,8 @@ import os
 
 import numpy as np
 
-from .utils import load_flows_device, flow_check_device
-from .trajectory import run_track
+from .utils import load_flows_device
+from .trajectory import run_connect
 
 
 def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_check_thres=1.0, traj_min_len=3,
@@ -20,20 +20,14 @@ def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_che
     # load data (.flo -> HBM once; the error maps of the reference are never consumed, :39-40)
     flows_f = load_flows_device(os.path.join(flow_dir, "flow_f"))
     flows_b = load_flows_device(os.path.join(flow_dir, "flow_b"))
-    n = min(flows_f.shape[0], flows_b.shape[0])
-    _, occ_maps = flow_check_device(flows_f[:n], flows_b[:n], flow_check_thres)
-    del flows_b
-
-    flows_f2 = occ_maps_s2 = None
+    flows_f2 = flows_b2 = None
     if not skip_path_consistency:
         flows_f2 = load_flows_device(os.path.join(flow_dir, "flow_f2"))
         flows_b2 = load_flows_device(os.path.join(flow_dir, "flow_b2"))
-        n2 = min(flows_f2.shape[0], flows_b2.shape[0])
-        _, occ_maps_s2 = flow_check_device(flows_f2[:n2], flows_b2[:n2], flow_check_thres)
-        del flows_b2
 
-    # connect tracks into point trajectories (track.py / track_optimize.py)
-    trajs = run_track(flows_f, occ_maps, flows_f2, occ_maps_s2, sample_ratio)
+    # fwd/bwd checks (utils.py:94-105) + connecting tracks into point trajectories (track.py / track_optimize.py):
+    # one call, the occlusion maps stream into the frame loop from a side stream
+    trajs = run_connect(flows_f, flows_b, flows_f2, flows_b2, flow_check_thres, sample_ratio)
 
     # save the outputs (:56-62): ids are indices into the full list, short trajectories dropped
     trajectories = trajs.to_trajectory_set(traj_min_len)

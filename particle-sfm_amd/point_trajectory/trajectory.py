@@ -112,6 +112,40 @@ def _as_device_stack(maps, dtype, trailing):
     return t.to(device=dev, dtype=dtype).contiguous()
 
 
+def run_connect(flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, return_device=False):
+    """flow_check + track / track_optimize in ONE psfm_connect call (the compute part of
+    main_connect_point_trajectories.py:36-53): the occlusion maps are produced on a side stream while the frame
+    loop consumes them.  Inputs: (n,H,W,2) float32 device tensors (stride-2 stacks None to skip path consistency)."""
+    import torch
+    ctx = _hip.context()
+    n, H, W = int(flows_f.shape[0]), int(flows_f.shape[1]), int(flows_f.shape[2])
+    if n < 1:
+        raise ValueError("connect: need at least one flow field")
+    n = min(n, int(flows_b.shape[0]))
+    f2 = b2 = None
+    if flows_f2 is not None:
+        f2, b2 = flows_f2, flows_b2
+        if n > 1 and (f2.shape[0] < n - 1 or b2.shape[0] < n - 1):
+            raise ValueError("connect: need %d stride-2 flows" % (n - 1))
+        if f2.numel() == 0:
+            f2 = torch.zeros((1, H, W, 2), dtype=torch.float32, device=flows_f.device)
+            b2 = f2
+    info = _hip.TrackInfo()
+    lane_f, traj_f = 2.0, 8.0
+    for attempt in range(6):
+        ctx.set_capacity(lane_f, traj_f)
+        st = _hip.lib().psfm_connect(ctx.handle, _hip.ptr(flows_f), _hip.ptr(flows_b), _hip.ptr(f2), _hip.ptr(b2), n, H, W,
+                                     float(thres), int(sample_ratio), None, None, ctypes.byref(info),
+                                     _hip.current_stream_ptr())
+        if st != _hip.PSFM_ERR_CAPACITY:
+            break
+        lane_f, traj_f = lane_f * 2.0, traj_f * 4.0
+    _hip.check(st)
+    if return_device:
+        return info
+    return _result_to_host(ctx, info)
+
+
 def run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio, return_device=False):
     """Shared driver of track() / track_optimize(): one psfm_track call (whole frame loop on the device)."""
     import torch
