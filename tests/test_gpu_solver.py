@@ -111,3 +111,33 @@ def test_track_optimize_two_flows_only(pt):
     O1 = orc.track_optimize(d["flows_f"][:1], [], occ[:1], [], 2)
     R1 = pt.track_optimize(d["flows_f"][:1], [], occ[:1], [], 2)
     assert np.array_equal(R1.birth, O1.birth) and np.array_equal(R1.xy, O1.xy)
+
+
+def test_track_optimize_full_size_properties(pt):
+    """configs[3]/[4] shapes with fewer frames: 1080p r=2 and 480x640 r=1 (dense), full path-consistency optimise.
+    Size-independent invariants + the first frames against the oracle."""
+    import torch
+    from oracle import oracle as orc
+    for (H, W, T, r, k) in [(1080, 1920, 10, 2, 4), (480, 640, 40, 1, 4)]:
+        d = psfm_synth.synth_sequence_torch(T, H, W, seed=5, sigma=0.05, n_occluders=2, stride2=True)
+        R = pt.trajectory.run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], 1.0, r)
+        _, occ = pt.utils.flow_check_device(d["flows_f"], d["flows_b"], 1.0)
+        _, occ2 = pt.utils.flow_check_device(d["flows_f2"], d["flows_b2"], 1.0)
+        R_seq = pt.trajectory.run_track(d["flows_f"], occ, d["flows_f2"], occ2, r)
+        # the pipelined stage entry (psfm_connect) and the two-call form give the same bits
+        assert np.array_equal(R.birth, R_seq.birth) and np.array_equal(R.length, R_seq.length) and np.array_equal(R.xy, R_seq.xy)
+        GW, GH = (W + r - 1) // r, (H + r - 1) // r
+        last = R.birth + R.length - 1
+        assert R.off[0] == 0 and np.array_equal(np.diff(R.off), R.length) and R.off[-1] == R.n_points
+        assert int((R.birth == 0).sum()) == GW * GH and last.max() == T - 1 and (np.diff(last) >= 0).all()
+        assert len(R.solve_stats) == T - 2 and all(s["termination"] in (0, 1, 2) for s in R.solve_stats)
+        assert np.isfinite(R.xy).all()
+        ff, f2 = list(d["flows_f"][:k].cpu().numpy()), list(d["flows_f2"][:k - 1].cpu().numpy())
+        oo, o2 = list(occ[:k].cpu().numpy()), list(occ2[:k - 1].cpu().numpy())
+        O = orc.track_optimize(ff, f2, oo, o2, r)
+        Rk = pt.trajectory.run_track(d["flows_f"][:k], occ[:k], d["flows_f2"][:k - 1], occ2[:k - 1], r)
+        assert np.array_equal(Rk.birth, O.birth) and np.array_equal(Rk.length, O.length)
+        assert float(np.abs(Rk.xy - O.xy).max()) <= TOL
+        assert [s["iterations"] for s in Rk.solve_stats] == [s["iterations"] for s in O.solves]
+        del d, R, R_seq
+        torch.cuda.empty_cache()

@@ -56,3 +56,61 @@ def test_reference_traj_to_matches_consumes_our_track_npy(tmp_path, fname):
     ts = np.load(str(traj_dir / "track.npy"), allow_pickle=True).item()
     assert type(ts).__module__ == "point_trajectory.optimize.build.particlesfm"
     assert sorted(ts.as_dict()) == keep
+
+
+@pytest.mark.parametrize("fname,remove_dynamic", [("track_gpu_60x80.npy", True), ("track_gpu_60x80_legacy.npy", False)])
+def test_vectorised_traj_to_matches_equals_reference(tmp_path, fname, remove_dynamic):
+    """particle-sfm_amd/sfm/matches_from_flow.py (NumPy index arithmetic on the CSR) against the
+    reference's loops, element for element -- keypoints, match lists, dict ordering, pair file."""
+    import time
+    from sfm import matches_from_flow as ours      # particle-sfm_amd/sfm (conftest puts it on sys.path)
+    traj_dir = tmp_path / "trajectories"
+    img_dir = tmp_path / "images"
+    traj_dir.mkdir(); img_dir.mkdir()
+    for i in range(7):
+        (img_dir / ("%05d.png" % i)).write_bytes(b"")
+    (traj_dir / "track.npy").write_bytes(open(os.path.join(GOLDEN, fname), "rb").read())
+    ref = _load_reference_consumer()
+    t0 = time.time(); A = ref.traj_to_matches(str(img_dir), str(traj_dir), str(tmp_path / "a.txt"), remove_dynamic=remove_dynamic); ta = time.time() - t0
+    t0 = time.time(); B = ours.traj_to_matches(str(img_dir), str(traj_dir), str(tmp_path / "b.txt"), remove_dynamic=remove_dynamic); tb = time.time() - t0
+    assert list(A) == list(B)
+    for name in A:
+        assert A[name].keypoints == B[name].keypoints
+        assert list(A[name].match_pairs) == list(B[name].match_pairs)
+        for k in A[name].match_pairs:
+            assert A[name].match_pairs[k] == B[name].match_pairs[k], k
+    assert open(str(tmp_path / "a.txt")).read() == open(str(tmp_path / "b.txt")).read()
+    # array form (what sfm/import_feature_matches.py:82,96 turns the lists into anyway)
+    C = ours.traj_to_matches(str(img_dir), str(traj_dir), str(tmp_path / "c.txt"), remove_dynamic=remove_dynamic, as_arrays=True)
+    for name in A:
+        assert np.array_equal(np.array(A[name].keypoints).reshape(-1, 2), C[name].keypoints)
+        for k in A[name].match_pairs:
+            assert np.array_equal(np.array(A[name].match_pairs[k]), C[name].match_pairs[k])
+
+
+def test_vectorised_traj_to_matches_long_tracks_and_dynamic_labels(tmp_path):
+    """Trajectories longer than sample_k = 20 (strided sampling) and dynamic labels (motion-seg output is a plain dict)."""
+    from sfm import matches_from_flow as ours
+    rng = np.random.default_rng(0)
+    n_img = 60
+    trajs = {}
+    for tid in range(40):
+        n = int(rng.integers(1, 58))
+        b = int(rng.integers(0, n_img - n + 1))
+        trajs[tid * 3] = {"frame_ids": list(range(b, b + n)), "locations": [rng.uniform(0, 100, 2) for _ in range(n)],
+                          "labels": (rng.uniform(size=n) < 0.2).tolist()}
+    traj_dir = tmp_path / "t"; img_dir = tmp_path / "i"
+    traj_dir.mkdir(); img_dir.mkdir()
+    for i in range(n_img):
+        (img_dir / ("%05d.png" % i)).write_bytes(b"")
+    np.save(str(traj_dir / "track.npy"), trajs)
+    ref = _load_reference_consumer()
+    for rd in (True, False):
+        A = ref.traj_to_matches(str(img_dir), str(traj_dir), str(tmp_path / "a.txt"), remove_dynamic=rd)
+        B = ours.traj_to_matches(str(img_dir), str(traj_dir), str(tmp_path / "b.txt"), remove_dynamic=rd)
+        for name in A:
+            assert np.allclose(np.array(A[name].keypoints).reshape(-1, 2), np.array(B[name].keypoints).reshape(-1, 2), atol=0)
+            assert list(A[name].match_pairs) == list(B[name].match_pairs)
+            for k in A[name].match_pairs:
+                assert A[name].match_pairs[k] == B[name].match_pairs[k]
+        assert open(str(tmp_path / "a.txt")).read() == open(str(tmp_path / "b.txt")).read()
