@@ -130,6 +130,9 @@ _contexts = {}
 
 
 def context(device=None):
+    """The psfm context of the calling THREAD on `device` (a context is not thread-safe; worker threads that process
+    different sequences concurrently each get their own -- see point_trajectory.batch)."""
+    import threading
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("point_trajectory (MI355X build) needs a HIP device: torch.cuda.is_available() is False "
@@ -137,9 +140,18 @@ def context(device=None):
     if device is None:
         device = torch.cuda.current_device()
     device = int(device)
-    if device not in _contexts:
-        _contexts[device] = Context(device)
-    return _contexts[device]
+    key = (device, threading.get_ident())
+    if key not in _contexts:
+        _contexts[key] = Context(device)
+    return _contexts[key]
+
+
+def release_thread_contexts():
+    """Destroy the calling thread's contexts (worker threads call this before they exit)."""
+    import threading
+    tid = threading.get_ident()
+    for key in [k for k in _contexts if k[1] == tid]:
+        _contexts.pop(key).close()
 
 
 def current_stream_ptr():

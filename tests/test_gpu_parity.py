@@ -255,3 +255,32 @@ def test_bad_arguments_are_rejected(pt):
     assert len(L.psfm_last_error()) > 0
     with pytest.raises(ValueError):
         pt.track([], [], 2)
+
+
+def test_connect_sequences_concurrently(pt, tmp_path):
+    """point_trajectory.batch: several sequences in flight on one GPU (separate streams + contexts) give exactly the
+    files that one-at-a-time processing gives."""
+    from point_trajectory.batch import connect_sequences
+    from point_trajectory import main_connect_point_trajectories
+    from point_trajectory.utils import write_flo
+    flow_dirs, out_a, out_b = [], [], []
+    for sidx in range(4):
+        d = psfm_synth.synth_sequence(6, 50 + 4 * sidx, 70, seed=200 + sidx, sigma=0.1, n_occluders=1, stride2=True)
+        fd = tmp_path / ("seq%d" % sidx) / "optical_flows"
+        for key, sub in (("flows_f", "flow_f"), ("flows_b", "flow_b"), ("flows_f2", "flow_f2"), ("flows_b2", "flow_b2")):
+            (fd / sub).mkdir(parents=True)
+            for i, f in enumerate(d[key]):
+                write_flo(str(fd / sub / ("%05d.flo" % i)), f)
+        flow_dirs.append(str(fd))
+        out_a.append(str(tmp_path / ("seq%d" % sidx) / "traj_seq"))
+        out_b.append(str(tmp_path / ("seq%d" % sidx) / "traj_par"))
+        main_connect_point_trajectories(flow_dirs[-1], out_a[-1], sample_ratio=2)
+    done = connect_sequences(flow_dirs, out_b, sample_ratio=2, concurrency=3)
+    assert done == [0, 1, 2, 3]
+    for a, b in zip(out_a, out_b):
+        ta = np.load(a + "/track.npy", allow_pickle=True).item()
+        tb = np.load(b + "/track.npy", allow_pickle=True).item()
+        assert ta.__getstate__().keys() == tb.__getstate__().keys()
+        sa, sb = ta.__getstate__(), tb.__getstate__()
+        for k in ("ids", "birth", "length", "off", "xy"):
+            assert np.array_equal(sa[k], sb[k]), k
