@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--frames", type=int, default=N_FRAMES, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-pairs", type=int, default=100, help=argparse.SUPPRESS)   # whole workload: ~10 s of CPU
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only warm-up + timed steps (what profiles/*_kernel_stats.csv is collected with): skips the figures "
+                         "measured outside the timed region (overlapped psfm_connect, track_optimize, concurrent sequences)")
     args = ap.parse_args()
 
     import numpy as np
@@ -205,14 +208,16 @@ def main():
     prof = ctx.profile()
     ctx.set_profiling(False)
     # the overlapped variant (psfm_connect), outside the timed region
-    run_connect(flows_f, flows_b, None, None, THRES, RATIO, return_device=True)
-    sync_all()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        info_c = run_connect(flows_f, flows_b, None, None, THRES, RATIO, return_device=True)
-    sync_all()
-    connect_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-    assert int(info_c.n_points) == int(info.n_points)
+    connect_ms = None
+    if not args.no_extras:
+        run_connect(flows_f, flows_b, None, None, THRES, RATIO, return_device=True)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            info_c = run_connect(flows_f, flows_b, None, None, THRES, RATIO, return_device=True)
+        sync_all()
+        connect_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        assert int(info_c.n_points) == int(info.n_points)
 
     points = int(info.n_points)
     import psfm_dist
@@ -283,9 +288,10 @@ def main():
                                  "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None}
                 del Rg
             # secondary figure (outside the timed region): the path-consistency path on configs[2]'s shape
-            out["secondary"] = secondary_track_optimize(ctx)
-            del flows_b
-            out["concurrent"] = concurrent_sequences(3, n_frames)
+            if not args.no_extras:
+                out["secondary"] = secondary_track_optimize(ctx)
+                del flows_b
+                out["concurrent"] = concurrent_sequences(3, n_frames)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
