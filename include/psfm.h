@@ -88,7 +88,7 @@ int psfm_device_count(void);
 psfm_status psfm_ctx_create(int device, psfm_ctx** out);
 psfm_status psfm_ctx_destroy(psfm_ctx* ctx);
 
-/* Lane table = lane_factor * (grid points); finished-trajectory table = traj_factor * (grid points).
+/* Lane table = lane_factor * (grid points); finished-trajectory table = max(traj_factor, n_flows/8) * (grid points).
  * Defaults 2.0 / 8.0.  psfm_track returns PSFM_ERR_CAPACITY when either overflows. */
 psfm_status psfm_ctx_set_capacity(psfm_ctx* ctx, double lane_factor, double traj_factor);
 

@@ -254,7 +254,9 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     const int64_t n_blocks = d.cap / 256;
     d.free_cap = (int)(((n_blocks + PSFM_NSHARD - 1) / PSFM_NSHARD) * 256) + 1024;   // per-shard stack, with slack for other block sizes
     // records are spread over PSFM_NSHARD slices by block index: give every slice head-room
-    d.shard_cap = (int)(((int64_t)(c->traj_factor * (double)d.G) + d.cap) / PSFM_NSHARD) + 1024;
+    // trajectory records: traj_factor x G, but at least G x n_flows / 8 (one death in eight per frame and grid point)
+    const double tf = c->traj_factor > (double)n_flows / 8.0 ? c->traj_factor : (double)n_flows / 8.0;
+    d.shard_cap = (int)(((int64_t)(tf * (double)d.G) + d.cap) / PSFM_NSHARD) + 1024;
     d.traj_cap = (int64_t)d.shard_cap * PSFM_NSHARD;
     if (d.cap > 0x7fffffff / 2 || d.traj_cap > 0x7fffffff / 2) { psfm_set_error("psfm_track: grid too large"); return PSFM_ERR_ARG; }
     d.shift_b = 1; while ((1ll << d.shift_b) < d.G) ++d.shift_b;
