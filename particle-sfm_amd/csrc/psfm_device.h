@@ -18,7 +18,21 @@
 struct PsfmTaps {
     int x0, y0;            // north-west tap
     float nw, ne, sw, se;  // bilinear weights
+    float fw, fn;          // the fractions they are built from (west->east, north->south)
 };
+
+// weights from the two fractions: s*e, s*w, n*e, n*w with e = 1-w, s = 1-n (same op order as psfm_taps)
+__device__ __forceinline__ PsfmTaps psfm_weights(float w, float n)
+{
+    const float e = __fsub_rn(1.0f, w), s = __fsub_rn(1.0f, n);
+    PsfmTaps t;
+    t.x0 = 0; t.y0 = 0; t.fw = w; t.fn = n;
+    t.nw = __fmul_rn(s, e);
+    t.ne = __fmul_rn(s, w);
+    t.sw = __fmul_rn(n, e);
+    t.se = __fmul_rn(n, w);
+    return t;
+}
 
 // cw = (float)((W-1)/2.0), ch = (float)((H-1)/2.0) computed once on the host.
 __device__ __forceinline__ PsfmTaps psfm_taps(float x32, float y32, float cw, float ch, int H, int W)
@@ -31,6 +45,7 @@ __device__ __forceinline__ PsfmTaps psfm_taps(float x32, float y32, float cw, fl
     const float w = __fsub_rn(ix, fx), e = __fsub_rn(1.0f, w);
     const float n = __fsub_rn(iy, fy), s = __fsub_rn(1.0f, n);
     PsfmTaps t;
+    t.fw = w; t.fn = n;
     t.nw = __fmul_rn(s, e);
     t.ne = __fmul_rn(s, w);
     t.sw = __fmul_rn(n, e);

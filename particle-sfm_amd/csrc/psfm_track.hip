@@ -219,23 +219,34 @@ struct PsfmChainArgs {
 
 struct PsfmStep { bool alive; double2 next; };
 
-// One chain step split in two so that the caller can issue the gathers of several steps back to back:
-// psfm_step_issue() computes the tap geometry and performs the eight raw loads (4 flow taps, 4 mask taps);
-// psfm_step_finish() blends them (fp32, bit-exact op order) and applies trajectory.py:50,55-57.
+// One chain step split in two so that the caller can issue the gathers of several steps back to back and keep
+// them in flight across the block's bookkeeping: psfm_step_issue() computes the tap geometry and performs the eight
+// raw loads (4 flow taps, 4 mask taps); psfm_step_finish() REBUILDS the geometry from the position (ALU only: holding
+// weights and flags across the barriers costs the registers that decide 7 vs 8 waves per SIMD), blends the taps
+// (fp32, bit-exact op order) and applies trajectory.py:50,55-57.
 struct PsfmStepLoads {
-    float nw, ne, sw, se;           // bilinear weights
-    int inb;                        // bit 0..3: tap nw/ne/sw/se inside the map
     float2 fnw, fne, fsw, fse;
-    uint8_t onw, one, osw, ose;
+    unsigned onw, one, osw, ose;    // mask bytes, zero-extended
 };
+
+// Pins the raw tap registers at this program point: nothing computed FROM the loads can be scheduled above it, so
+// the s_waitcnt for the gathers cannot drift in front of the bookkeeping that is meant to overlap their latency
+// (the compiler otherwise packed the mask bytes right behind the loads, i.e. before the block's atomics).
+template <bool MASKS>
+__device__ __forceinline__ void psfm_step_pin(PsfmStepLoads& L)
+{
+    asm volatile("" : "+v"(L.fnw.x), "+v"(L.fnw.y), "+v"(L.fne.x), "+v"(L.fne.y), "+v"(L.fsw.x), "+v"(L.fsw.y),
+                      "+v"(L.fse.x), "+v"(L.fse.y));
+    // (the zero-extension of a mask byte must sit in the basic block of its load to fold into global_load_ubyte;
+    // pinning the lanes' bytes, loaded two blocks earlier, would materialise it -- and a wait -- before the barrier)
+    if (MASKS) asm volatile("" : "+v"(L.onw), "+v"(L.one), "+v"(L.osw), "+v"(L.ose));
+}
 
 __device__ __forceinline__ PsfmStepLoads psfm_step_issue(const PsfmChainArgs& a, double2 p)
 {
     const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
     const PsfmTapIdx k = psfm_tap_idx(a.H, a.W, t);   // flow and occlusion map share the tap geometry
     PsfmStepLoads L;
-    L.nw = t.nw; L.ne = t.ne; L.sw = t.sw; L.se = t.se;
-    L.inb = (k.inw ? 1 : 0) | (k.ine ? 2 : 0) | (k.isw ? 4 : 0) | (k.ise ? 8 : 0);
     const unsigned onw = (unsigned)k.nw, one = (unsigned)k.ne, osw = (unsigned)k.sw, ose = (unsigned)k.se;
     L.fnw = psfm_ld(a.flow, onw * 8u); L.fne = psfm_ld(a.flow, one * 8u);
     L.fsw = psfm_ld(a.flow, osw * 8u); L.fse = psfm_ld(a.flow, ose * 8u);
@@ -245,9 +256,11 @@ __device__ __forceinline__ PsfmStepLoads psfm_step_issue(const PsfmChainArgs& a,
 
 __device__ __forceinline__ PsfmStep psfm_step_finish(const PsfmChainArgs& a, double2 p, const PsfmStepLoads& L)
 {
-    PsfmTaps t;
-    t.x0 = 0; t.y0 = 0; t.nw = L.nw; t.ne = L.ne; t.sw = L.sw; t.se = L.se;
-    const bool inw = L.inb & 1, ine = L.inb & 2, isw = L.inb & 4, ise = L.inb & 8;
+    const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
+    const int x0 = t.x0, y0 = t.y0, x1 = t.x0 + 1, y1 = t.y0 + 1;
+    const bool xw = (x0 >= 0) & (x0 < a.W), xe = (x1 >= 0) & (x1 < a.W);
+    const bool yn = (y0 >= 0) & (y0 < a.H), ys = (y1 >= 0) & (y1 < a.H);
+    const bool inw = xw & yn, ine = xe & yn, isw = xw & ys, ise = xe & ys;
     const float z = 0.0f;
     const float fx = psfm_blend(inw ? L.fnw.x : z, ine ? L.fne.x : z, isw ? L.fsw.x : z, ise ? L.fse.x : z, t);
     const float fy = psfm_blend(inw ? L.fnw.y : z, ine ? L.fne.y : z, isw ? L.fsw.y : z, ise ? L.fse.y : z, t);
@@ -310,6 +323,10 @@ __device__ __forceinline__ unsigned long long psfm_key(int last_time, int bf, in
 #ifndef PSFM_LPT
 #define PSFM_LPT 1          // lanes (and grid points) per thread: lane u of thread t is tile_base + u*BLOCK + t (2 measured no faster)
 #endif
+#ifndef PSFM_CHAIN_WPE
+#define PSFM_CHAIN_WPE 8    // waves per SIMD the register allocation targets (64 VGPRs)
+#endif
+#define PSFM_CHAIN_WAVES __attribute__((amdgpu_waves_per_eu(PSFM_CHAIN_WPE, PSFM_CHAIN_WPE)))
 #define PSFM_CHAIN_TILE (PSFM_CHAIN_BLOCK * PSFM_LPT)
 #define PSFM_CHAIN_NW (PSFM_CHAIN_BLOCK / PSFM_WAVE)
 #define PSFM_CHAIN_NSEG (PSFM_CHAIN_NW * PSFM_LPT)
@@ -318,8 +335,27 @@ __device__ __forceinline__ unsigned long long psfm_key(int last_time, int bf, in
 // makes the whole 1080p/r=2 grid resident in ONE dispatch round (1017 tiles of 512 at 4 waves per SIMD) with twice the
 // bytes in flight per wave; measured 17.6 us vs 17.1 us for PSFM_LPT = 1 (two rounds at 7 waves per SIMD): the launch
 // is bound by its serialized phases (latency + transfer of two dependent round trips), not by residency.
+#ifdef PSFM_TIMELINE
+// debug builds only (PSFM_EXTRA_FLAGS=-DPSFM_TIMELINE): per-block phase timestamps of ONE chosen launch
+#define PSFM_TL_SLOTS 8
+__device__ unsigned long long g_psfm_tl[8192 * PSFM_TL_SLOTS];
+__device__ int g_psfm_tl_frame = -1;
+#define PSFM_TL(k) do { if (tl_on && tid == 0) g_psfm_tl[blockIdx.x * PSFM_TL_SLOTS + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int psfm_debug_timeline(int frame, unsigned long long* out_host, int n_blocks)
+{
+    if (out_host) {
+        if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_psfm_tl), (size_t)n_blocks * PSFM_TL_SLOTS * 8) != hipSuccess) return 1;
+    } else {
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_psfm_tl_frame), &frame, sizeof(int)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#else
+#define PSFM_TL(k) do {} while (0)
+#endif
+
 template <int R>
-__global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmChainArgs a)
+__global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_step_kernel(PsfmChainArgs a)
 {
     __shared__ int s_births[PSFM_CHAIN_NSEG], s_pend[PSFM_CHAIN_NSEG];
     __shared__ int s_new_g[PSFM_CHAIN_TILE];        // grid index of the births, one 64-slot segment per (u, wave)
@@ -331,6 +367,16 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
     const int tile = blockIdx.x * PSFM_CHAIN_TILE;
     const int frame = a.frame;
     const int ratio = R > 0 ? R : a.ratio;
+#ifdef PSFM_TIMELINE
+    const bool tl_on = (a.frame == g_psfm_tl_frame) && blockIdx.x < 8192;
+    if (tl_on && threadIdx.x == 0) {
+        g_psfm_tl[blockIdx.x * PSFM_TL_SLOTS + 0] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_psfm_tl[blockIdx.x * PSFM_TL_SLOTS + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     if (a.ctr->stall) return;   // an earlier path-consistency solve is unfinished: this launch will be re-enqueued
     // tiles past both the lane high-water mark and the grid have nothing to do (lanes handed out during
     // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
@@ -369,7 +415,6 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
         live[u] = (bf[u] >= 0) & ((bf[u] < frame) | (frame == 0));
         pend[u] = (bf[u] <= -2) & ((-2 - bf[u]) < frame);
         pend_idx[u] = 0;
-        if (pend[u]) pend_idx[u] = a.birth_idx[i];   // read NOW: a newborn of this block may inherit (and overwrite) this lane
         // ---- block-level counts; the births' grid indices and the just-died lanes are compacted through LDS ----
         bm[u] = __ballot(birth[u]);
         pm[u] = __ballot(pend[u]);
@@ -387,8 +432,16 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
         p1[u] = live[u] ? p[u] : make_double2(0.0, 0.0);
         l1[u] = psfm_step_issue(a, p1[u]);
     }
+    // birth index of the tracks that died in the previous step: needed for their records; read BEHIND the gathers (an
+    // earlier load would be waited for together with the tail position, i.e. one more round trip in front of the
+    // gathers) and before the second barrier, after which a newborn of this block may inherit and overwrite the lane
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u)
+        if (pend[u]) pend_idx[u] = psfm_ld(a.birth_idx, (unsigned)(tile + u * PSFM_CHAIN_BLOCK + tid) * 4u);
 
+    PSFM_TL(1);
     __syncthreads();
+    PSFM_TL(2);
     // ---- the newborns' first step, compacted onto the first threads of the block ----
     // Newborn #t first inherits the lane of the block's t-th just-died track (no atomics, the lane is recycled
     // immediately); only the surplus of births pops the free stacks and only the surplus of deaths pushes them.
@@ -412,12 +465,10 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
     }
     const int matched = nb < npd ? nb : npd;
     const bool newborn = tid < nb;
-    double2 p2 = make_double2(0.0, 0.0);
-    PsfmStepLoads l2;
+    PsfmStepLoads l2 = {};
     if (newborn) {
         const int gy = (int)psfm_fastdiv((unsigned)g2, a.gwdiv), gx = g2 - gy * a.GW;
-        p2 = make_double2((double)(gx * ratio), (double)(gy * ratio));
-        l2 = psfm_step_issue(a, p2);
+        l2 = psfm_step_issue(a, make_double2((double)(gx * ratio), (double)(gy * ratio)));
     }
     const int shard = blockIdx.x % PSFM_NSHARD;
     if (tid == 0) {
@@ -456,7 +507,22 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
     // the dead tracks' birth indices must be in registers before any newborn may overwrite birth_idx[lane]
 #pragma unroll
     for (int u = 0; u < PSFM_LPT; ++u) asm volatile("" : : "v"(pend_idx[u]) : "memory");
+    PSFM_TL(3);
     __syncthreads();
+    PSFM_TL(4);
+    // positions / grid index made opaque: the tap geometry is recomputed from them below instead of being carried
+    // across the barriers in registers
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u) asm volatile("" : "+v"(p1[u].x), "+v"(p1[u].y));
+    asm volatile("" : "+v"(g2));
+    double2 p2 = make_double2(0.0, 0.0);
+    if (newborn) {
+        const int gy = (int)psfm_fastdiv((unsigned)g2, a.gwdiv), gx = g2 - gy * a.GW;
+        p2 = make_double2((double)(gx * ratio), (double)(gy * ratio));
+    }
+#pragma unroll
+    for (int u = 0; u < PSFM_LPT; ++u) psfm_step_pin<false>(l1[u]);
+    psfm_step_pin<true>(l2);
 
     bool any_alive = false;
     int npts = 0;
@@ -554,8 +620,10 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) void psfm_chain_step_kernel(PsfmC
         for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
         if (lane == 0 && w > 0) atomicAdd(&a.sh_fin[shard].points, (unsigned)w);
     }
+    PSFM_TL(5);
     __syncthreads();
     if (tid == 0 && s_alive_any) *a.surv_cur = 1;
+    PSFM_TL(6);
 }
 
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_clear_map_kernel(const PsfmCounters* __restrict__ ctr,
