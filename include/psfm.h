@@ -76,7 +76,7 @@ typedef struct psfm_track_info {
     int64_t lane_capacity;
     int64_t solver_iterations; /* total trust-region iterations over all frames (track_optimize) */
     int32_t n_solves;
-    int32_t reserved;
+    int32_t chain_mode;        /* how the frame recurrence ran: 1 one launch per frame, 2 one persistent launch */
 } psfm_track_info;
 
 const char* psfm_last_error(void);
@@ -91,6 +91,14 @@ psfm_status psfm_ctx_destroy(psfm_ctx* ctx);
 /* Lane table = lane_factor * (grid points); finished-trajectory table = max(traj_factor, n_flows/8) * (grid points).
  * Defaults 2.0 / 8.0.  psfm_track returns PSFM_ERR_CAPACITY when either overflows. */
 psfm_status psfm_ctx_set_capacity(psfm_ctx* ctx, double lane_factor, double traj_factor);
+
+/* How psfm_track runs the frame recurrence in track mode (flows_f2 == NULL):
+ *   0 (default) one persistent launch for the whole sequence when every lane of the stride-r grid can be resident on
+ *     the device at once (grid points <= 256 x resident blocks: 1080p at sample_ratio 2 fits an MI355X), else one
+ *     launch per frame; the persistent loop hands over to per-frame launches by itself if it runs out of lanes;
+ *   1 one launch per frame always;  2 persistent launch or PSFM_ERR_ARG / PSFM_ERR_CAPACITY.
+ * Results are identical in every mode.  track_optimize always uses one launch per frame (the solves sit in between). */
+psfm_status psfm_ctx_set_chain_mode(psfm_ctx* ctx, int mode);
 
 /* utils.py:94-105.  flows_f, flows_b: (n_pairs,H,W,2) f32 stacks in the .flo-native interleaved
  * layout.  occ_out: (n_pairs,H,W) u8 0/1.  err_out: (n_pairs,H,W) f32 or NULL (the reference
@@ -144,8 +152,9 @@ psfm_status psfm_result_solve_stats(psfm_ctx* ctx, psfm_solve_stats* stats_host,
 
 /* Per-kernel device time of the last psfm_track / psfm_flow_check when profiling is enabled with
  * psfm_ctx_set_profiling(ctx, 1): HIP events recorded on the launch stream around every launch of
- * the named kernel family (enable = N > 1: only every N-th chain_step launch is timed, which keeps the
- * event overhead out of a throughput measurement).  kind: 0 flow_check, 1 chain_step, 2 respawn, 3 solver, 4 finalize.
+ * the named kernel family (enable = N > 1: only every N-th per-frame chain_step launch is timed, which keeps the
+ * event overhead out of a throughput measurement; a persistent launch is always timed and counts as ONE launch).
+ * kind: 0 flow_check, 1 chain_step, 2 respawn, 3 solver, 4 finalize.
  * Returns the accumulated milliseconds and the number of launches. */
 psfm_status psfm_ctx_set_profiling(psfm_ctx* ctx, int enable);
 psfm_status psfm_profile_get(psfm_ctx* ctx, int kind, double* total_ms, int64_t* launches);

@@ -2,10 +2,12 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 
 #include "psfm_internal.h"
 
 static thread_local char g_err[512] = "";
+static std::mutex g_persist_mutex[16];   // per device: one persistent frame loop at a time (all its blocks must be resident)
 
 void psfm_set_error(const char* fmt, ...)
 {
@@ -63,9 +65,9 @@ void PsfmProfiler::begin(int kind, hipStream_t s)
     (void)hipEventRecord(sp.a, s);
     spans.push_back(sp);
 }
-void PsfmProfiler::kernel_span(int kind, hipEvent_t* a, hipEvent_t* b)
+void PsfmProfiler::kernel_span(int kind, hipEvent_t* a, hipEvent_t* b, bool always)
 {
-    if (!enabled || (calls++ % stride) != 0) { *a = nullptr; *b = nullptr; return; }
+    if (!enabled || (!always && (calls++ % stride) != 0)) { *a = nullptr; *b = nullptr; return; }
     Span sp; sp.kind = kind; sp.a = get(); sp.b = get();
     spans.push_back(sp);
     *a = sp.a; *b = sp.b;
@@ -125,11 +127,13 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
                        &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
-                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->occ_own, &c->occ2_own};
+                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->occ_own, &c->occ2_own,
+                       &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar};
     for (auto b : bufs) b->release();
     c->prof.destroy();
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    if (c->host_seg) (void)hipHostFree(c->host_seg);
     delete c;
     return PSFM_OK;
 }
@@ -139,6 +143,13 @@ extern "C" psfm_status psfm_ctx_set_capacity(psfm_ctx* c, double lane_factor, do
     if (!c || !(lane_factor >= 1.0) || !(traj_factor >= 1.0)) { psfm_set_error("psfm_ctx_set_capacity: factors must be >= 1"); return PSFM_ERR_ARG; }
     c->lane_factor = lane_factor;
     c->traj_factor = traj_factor;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_ctx_set_chain_mode(psfm_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 2) { psfm_set_error("psfm_ctx_set_chain_mode: mode must be 0 (auto), 1 (per-frame launches) or 2 (persistent loop)"); return PSFM_ERR_ARG; }
+    c->chain_mode = mode;
     return PSFM_OK;
 }
 
@@ -274,12 +285,71 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     if ((st = c->shards.ensure(sizeof(PsfmShard) * PSFM_NSHARD * 2)) != PSFM_OK) return st;
     if ((st = c->fin_keys.ensure(sizeof(unsigned long long) * d.traj_cap)) != PSFM_OK) return st;
     if ((st = c->fin_lanes.ensure(sizeof(int) * d.traj_cap)) != PSFM_OK) return st;
-    if ((st = c->occupied.ensure((size_t)d.G * 2)) != PSFM_OK) return st;
+    if ((st = c->occupied.ensure((size_t)d.G * 3)) != PSFM_OK) return st;   // (the persistent loop rotates three maps)
     if ((st = c->counters.ensure(sizeof(PsfmCounters))) != PSFM_OK) return st;
     if ((st = c->survivors.ensure(sizeof(int) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
 
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;
+
+    // ---- track mode: the whole recurrence as ONE persistent launch when every lane can be resident at once ----
+    if (!optimize && c->chain_mode != 1) {
+        const int maxb = psfm_persist_max_blocks(c);
+        const int64_t need_blocks = (d.G + 255) / 256;
+        if (maxb > 0 && need_blocks <= maxb) {
+            PsfmTrackDims dp = d;
+            int64_t nb = need_blocks + need_blocks / 8 + 2;   // spare lanes for tracks born faster than lanes come back
+            dp.nblk = (int)(nb < maxb ? nb : maxb);
+            dp.cap = (int64_t)dp.nblk * (256 + psfm_persist_guests());   // log columns: thread lanes, then guest lanes
+            dp.free_cap = (int)(((dp.nblk + PSFM_NSHARD - 1) / PSFM_NSHARD) * 256) + 1024;
+            dp.seg_cap = (int)(d.traj_cap / dp.nblk) + 64;
+            dp.spill_cap = (int)(d.traj_cap / 8) + 4096;
+            const int64_t fin_total = (int64_t)dp.nblk * dp.seg_cap + dp.spill_cap;
+            if ((st = c->log.ensure(sizeof(double2) * (size_t)(n_flows + 1) * dp.cap)) != PSFM_OK) return st;
+            if ((st = c->free_stack.ensure(sizeof(int) * (size_t)dp.free_cap * PSFM_NSHARD * 2)) != PSFM_OK) return st;
+            if ((st = c->fin_keys.ensure(sizeof(unsigned long long) * fin_total)) != PSFM_OK) return st;
+            if ((st = c->fin_lanes.ensure(sizeof(int) * fin_total)) != PSFM_OK) return st;
+            if ((st = c->handoff.ensure((size_t)dp.nblk * 256 * 24)) != PSFM_OK) return st;
+            if ((st = c->seg_info.ensure(sizeof(int) * 2 * (size_t)dp.nblk)) != PSFM_OK) return st;
+            if ((st = c->persist_bar.ensure((size_t)(4 * PSFM_NSHARD + 1) * 128)) != PSFM_OK) return st;
+            if (pipe && (st = pipe->need(n_flows - 1, false, s)) != PSFM_OK) return st;   // every occlusion map
+            bool fallback = false;
+            {
+                // all blocks of the loop must be resident together: one such kernel per device at a time
+                std::lock_guard<std::mutex> lock(g_persist_mutex[c->device & 15]);
+                if ((st = psfm_launch_chain_persist(c, dp, flows, occ, s)) != PSFM_OK) return st;
+                c->prof.begin(PSFM_PROF_FINALIZE, s);
+                st = psfm_finalize_persist(c, dp, &fallback, s);
+                c->prof.end(s);
+            }
+            if (st != PSFM_OK) return st;
+            if (!fallback) {
+                PSFM_HIP(hipStreamSynchronize(s));
+                c->prof.collect();
+                if (info) {
+                    memset(info, 0, sizeof(*info));
+                    info->n_traj = c->res_n_traj;
+                    info->n_points = c->res_n_points;
+                    info->n_lanes_peak = ((PsfmCounters*)c->host_pinned)->n_lanes;
+                    info->lane_capacity = dp.cap;
+                    info->chain_mode = 2;
+                }
+                return PSFM_OK;
+            }
+            if (c->chain_mode == 2) {
+                psfm_set_error("psfm_track: the persistent loop gave up (overflow bits %d) and chain mode 2 forbids the per-frame path",
+                               ((PsfmCounters*)c->host_pinned)->overflow);
+                return PSFM_ERR_CAPACITY;
+            }
+            c->prof.collect();
+        } else if (c->chain_mode == 2) {
+            psfm_set_error("psfm_track: persistent loop unavailable (%lld blocks needed, %d resident)", (long long)need_blocks, maxb);
+            return PSFM_ERR_ARG;
+        }
+    } else if (optimize && c->chain_mode == 2) {
+        psfm_set_error("psfm_track: chain mode 2 (persistent loop) applies to track mode only");
+        return PSFM_ERR_ARG;
+    }
     if ((st = psfm_launch_track_init(c, d, s)) != PSFM_OK) return st;
     int64_t total_iters = 0;
     // Frame loop.  In track_optimize mode nothing returns to the host inside a window of PSFM_CHECK frames: each
@@ -361,6 +431,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         info->lane_capacity = d.cap;
         info->solver_iterations = total_iters;
         info->n_solves = (int32_t)c->solve_stats.size();
+        info->chain_mode = 1;
     }
     return PSFM_OK;
 }

@@ -10,6 +10,7 @@
 // frame-major log is transposed into a track-major (n_points,2) f64 array through LDS tiles so that
 // both the slab reads (consecutive lanes) and the result writes (consecutive times) are coalesced.
 #include <cstring>
+#include <stdio.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -146,6 +147,44 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* 
     }
 }
 
+// common tail: (key, lane) records already compacted into the SECOND halves of sort_keys / sort_lanes
+static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int64_t n, int64_t npts, hipStream_t s)
+{
+    psfm_status st;
+    unsigned long long* k_in = c->sort_keys.as<unsigned long long>() + n;
+    unsigned long long* k_out = c->sort_keys.as<unsigned long long>();
+    int* l_in = c->sort_lanes.as<int>() + n;
+    int* l_out = c->sort_lanes.as<int>();
+    int tbits = 1;
+    while ((1ll << tbits) < (long long)d.n_flows + 2) ++tbits;
+    const unsigned end_bit = (unsigned)(d.shift_d + tbits);
+    size_t tmp_bytes = 0, scan_bytes = 0;
+    PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+    PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
+                                     (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+    if ((st = c->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
+    PSFM_HIP(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+    // decode + offsets
+    if ((st = c->res_birth.ensure(sizeof(int) * n)) != PSFM_OK) return st;
+    if ((st = c->res_len.ensure(sizeof(int) * n)) != PSFM_OK) return st;
+    if ((st = c->res_off.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
+    if ((st = c->scan_tmp.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
+    hipLaunchKernelGGL(psfm_decode_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
+                       c->sort_keys.as<unsigned long long>(), n, d.shift_b, d.shift_d, c->res_birth.as<int>(),
+                       c->res_len.as<int>(), c->scan_tmp.as<int64_t>());
+    PSFM_HIP(hipGetLastError());
+    PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->res_off.as<int64_t>(),
+                                     (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+    c->res_n_points = npts;
+    // transpose the frame-major log into the id-ordered CSR
+    if ((st = c->res_xy.ensure(sizeof(double2) * (size_t)(npts > 0 ? npts : 1))) != PSFM_OK) return st;
+    hipLaunchKernelGGL(psfm_gather_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
+                       c->log.as<double2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
+                       c->res_len.as<int>(), c->res_off.as<int64_t>(), n, c->res_xy.as<double2>());
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
 psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
 {
     PsfmCounters* ctr = c->counters.as<PsfmCounters>();
@@ -184,39 +223,73 @@ psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
     psfm_status st;
     if ((st = c->sort_keys.ensure(sizeof(unsigned long long) * n * 2)) != PSFM_OK) return st;
     if ((st = c->sort_lanes.ensure(sizeof(int) * n * 2)) != PSFM_OK) return st;
-    unsigned long long* k_in = c->sort_keys.as<unsigned long long>() + n;
-    unsigned long long* k_out = c->sort_keys.as<unsigned long long>();
-    int* l_in = c->sort_lanes.as<int>() + n;
-    int* l_out = c->sort_lanes.as<int>();
     hipLaunchKernelGGL(psfm_compact_shards_kernel, dim3(64, PSFM_NSHARD), dim3(PSFM_BLOCK), 0, s,
-                       c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), d.shard_cap, so, k_in, l_in);
+                       c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), d.shard_cap, so,
+                       c->sort_keys.as<unsigned long long>() + n, c->sort_lanes.as<int>() + n);
     PSFM_HIP(hipGetLastError());
-    int tbits = 1;
-    while ((1ll << tbits) < (long long)d.n_flows + 2) ++tbits;
-    const unsigned end_bit = (unsigned)(d.shift_d + tbits);
-    size_t tmp_bytes = 0, scan_bytes = 0;
-    PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
-    PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
-                                     (size_t)(n + 1), rocprim::plus<int64_t>(), s));
-    if ((st = c->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
-    PSFM_HIP(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
-    // 3. decode + offsets
-    if ((st = c->res_birth.ensure(sizeof(int) * n)) != PSFM_OK) return st;
-    if ((st = c->res_len.ensure(sizeof(int) * n)) != PSFM_OK) return st;
-    if ((st = c->res_off.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
-    if ((st = c->scan_tmp.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
-    hipLaunchKernelGGL(psfm_decode_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
-                       c->sort_keys.as<unsigned long long>(), n, d.shift_b, d.shift_d, c->res_birth.as<int>(),
-                       c->res_len.as<int>(), c->scan_tmp.as<int64_t>());
+    return psfm_finalize_sorted(c, d, n, npts, s);
+}
+
+// ---- persistent frame loop: records sit in one private segment per block (+ a shared tail) ----
+struct PsfmSegRow { long long src; long long dst; int count; int pad; };
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_compact_segments_kernel(
+    const unsigned long long* __restrict__ fin_keys, const int* __restrict__ fin_lanes,
+    const PsfmSegRow* __restrict__ rows, unsigned long long* __restrict__ keys, int* __restrict__ lanes)
+{
+    const PsfmSegRow r = rows[blockIdx.x];
+    for (int i = threadIdx.x; i < r.count; i += PSFM_BLOCK) {
+        keys[r.dst + i] = fin_keys[r.src + i];
+        lanes[r.dst + i] = fin_lanes[r.src + i];
+    }
+}
+
+psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fallback, hipStream_t s)
+{
+    *fallback = false;
+    const int nseg = d.nblk + 1;
+    const size_t need = sizeof(int2) * (size_t)d.nblk + sizeof(PsfmSegRow) * (size_t)nseg;
+    if (c->host_seg_bytes < need) {
+        if (c->host_seg) (void)hipHostFree(c->host_seg);
+        c->host_seg = nullptr; c->host_seg_bytes = 0;
+        PSFM_HIP(hipHostMalloc(&c->host_seg, need, hipHostMallocDefault));
+        c->host_seg_bytes = need;
+    }
+    int2* hinfo = (int2*)c->host_seg;
+    PsfmSegRow* hrows = (PsfmSegRow*)((char*)c->host_seg + sizeof(int2) * (size_t)d.nblk);
+    PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
+    PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipMemcpyAsync(hinfo, c->seg_info.p, sizeof(int2) * (size_t)d.nblk, hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    if (hc->pad[0]) fprintf(stderr, "psfm persist check: site %d index %d\n", hc->pad[0], hc->pad[1]);
+    if (hc->overflow & (4 | 8)) {   // more tracks than resident lanes / a barrier gave up: per-frame launches take over
+        *fallback = true;
+        return PSFM_OK;
+    }
+    int64_t n = 0, npts = 0;
+    for (int b = 0; b < d.nblk; ++b) {
+        hrows[b].src = (long long)b * d.seg_cap; hrows[b].dst = n; hrows[b].count = hinfo[b].x; hrows[b].pad = 0;
+        n += hinfo[b].x;
+        npts += hinfo[b].y;
+    }
+    const int spilled = hc->spill_cnt < d.spill_cap ? hc->spill_cnt : d.spill_cap;
+    hrows[d.nblk].src = (long long)d.nblk * d.seg_cap; hrows[d.nblk].dst = n; hrows[d.nblk].count = spilled; hrows[d.nblk].pad = 0;
+    n += spilled;
+    if (hc->overflow != 0) {
+        psfm_set_error("capacity exceeded (persistent loop): overflow bits %d, trajectory records %lld (%d spilled of %d); "
+                       "raise psfm_ctx_set_capacity", hc->overflow, (long long)n, hc->spill_cnt, d.spill_cap);
+        return PSFM_ERR_CAPACITY;
+    }
+    c->res_n_traj = n;
+    c->res_n_points = 0;
+    if (n == 0) return PSFM_OK;
+    psfm_status st;
+    if ((st = c->sort_keys.ensure(sizeof(unsigned long long) * n * 2)) != PSFM_OK) return st;
+    if ((st = c->sort_lanes.ensure(sizeof(int) * n * 2)) != PSFM_OK) return st;
+    if ((st = c->seg_table.ensure(sizeof(PsfmSegRow) * (size_t)nseg)) != PSFM_OK) return st;
+    PSFM_HIP(hipMemcpyAsync(c->seg_table.p, hrows, sizeof(PsfmSegRow) * (size_t)nseg, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(psfm_compact_segments_kernel, dim3((unsigned)nseg), dim3(PSFM_BLOCK), 0, s,
+                       c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), c->seg_table.as<PsfmSegRow>(),
+                       c->sort_keys.as<unsigned long long>() + n, c->sort_lanes.as<int>() + n);
     PSFM_HIP(hipGetLastError());
-    PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->res_off.as<int64_t>(),
-                                     (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
-    c->res_n_points = npts;
-    // 4. transpose the frame-major log into the id-ordered CSR
-    if ((st = c->res_xy.ensure(sizeof(double2) * (size_t)(npts > 0 ? npts : 1))) != PSFM_OK) return st;
-    hipLaunchKernelGGL(psfm_gather_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
-                       c->log.as<double2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
-                       c->res_len.as<int>(), c->res_off.as<int64_t>(), n, c->res_xy.as<double2>());
-    PSFM_HIP(hipGetLastError());
-    return PSFM_OK;
+    return psfm_finalize_sorted(c, d, n, npts, s);
 }

@@ -30,9 +30,12 @@ struct PsfmBuf {
 // Device-side counters of the frame recurrence (one cache line, zeroed at init).
 struct PsfmCounters {
     int n_lanes;      // lanes ever handed out (high-water mark); chain_step scans [0, n_lanes)
-    int overflow;     // bit0: lane table full, bit1: trajectory table full
+    int overflow;     // bit0: lane table / free stack full, bit1: trajectory table full, bit2: more tracks than resident
+                      // lanes (persistent loop), bit3: barrier spin limit hit (persistent loop)
     int stall;        // != 0: solve of frame stall-1 ran out of unrolled iterations; later launches are no-ops
-    int pad[13];
+    int abort;        // persistent frame loop: a block gave up (spin limit); every block leaves at its next barrier
+    int spill_cnt;    // persistent frame loop: records written to the shared tail behind the private segments
+    int pad[11];
 };
 
 // Death records and free lanes are published through PSFM_NSHARD independent tables so that the
@@ -60,7 +63,7 @@ struct PsfmProfiler {
     int64_t launches[PSFM_PROF_KINDS] = {0};
     hipEvent_t get();
     void begin(int kind, hipStream_t s);
-    void kernel_span(int kind, hipEvent_t* a, hipEvent_t* b);  // events for hipExtLaunchKernelGGL (exact kernel begin/end)
+    void kernel_span(int kind, hipEvent_t* a, hipEvent_t* b, bool always = false);  // events for hipExtLaunchKernelGGL (exact kernel begin/end)
     void end(hipStream_t s);
     void collect();  // after a stream sync: fold spans into totals
     void reset();
@@ -84,6 +87,15 @@ struct psfm_ctx {
     PsfmBuf counters;     // PsfmCounters
     PsfmBuf shards;       // 2 x PSFM_NSHARD x PsfmShard
     PsfmBuf survivors;    // (n_flows+1) i32
+    // persistent frame loop (psfm_persist.hip)
+    PsfmBuf handoff;      // cap x 3 u64: newborn handed to the owner of a popped lane
+    PsfmBuf seg_info;     // per block: records in its private segment, trajectory points it wrote
+    PsfmBuf seg_table;    // finalize: (src start, count, dst start) per record segment
+    PsfmBuf persist_bar;  // barrier: 64 arrival counters, 1 top counter, 64 release flags (128 B apart)
+    int persist_max_blocks = -1;   // resident 256-thread blocks on this device (-1: not queried yet)
+    int chain_mode = 0;            // 0 auto, 1 per-frame launches only, 2 persistent loop required
+    void* host_seg = nullptr;      // pinned staging for seg_info / seg_table
+    size_t host_seg_bytes = 0;
     // finalize workspace + result
     PsfmBuf sort_keys, sort_lanes, sort_tmp, scan_tmp;
     PsfmBuf res_birth, res_len, res_off, res_xy;
@@ -112,14 +124,23 @@ struct PsfmTrackDims {
     int free_cap;           // free-lane stack entries per shard
     int shift_b, shift_d;   // key = death<<shift_d | birth<<shift_b | grid index
     float cw, ch;
+    int nblk = 0, seg_cap = 0, spill_cap = 0;   // persistent loop: blocks, records per private segment, shared tail
 };
 
 psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
                                    int frame, hipStream_t s);
 
+// ---- persistent frame loop (psfm_persist.hip) ---------------------------------------------------
+int psfm_persist_max_blocks(psfm_ctx* c);
+int psfm_persist_guests(void);   // LDS-resident extra lanes per block
+psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ,
+                                      hipStream_t s);
+
 // ---- finalize (psfm_finalize.hip) -----------------------------------------------------------
 psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
+// after psfm_launch_chain_persist; *fallback = true (and PSFM_OK): the loop gave up, rerun with per-frame launches
+psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fallback, hipStream_t s);
 
 // ---- solver (psfm_solver.hip) ---------------------------------------------------------------
 // In-place solve on the trajectory log for frame index f (positions at f-1, f, f+1): enqueue `unroll`

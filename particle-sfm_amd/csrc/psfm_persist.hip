@@ -1,0 +1,653 @@
+// psfm_persist.hip -- K2+K3 as ONE persistent launch per sequence (track mode, track.py:24-50).
+//
+// Why: a per-frame chain_step launch moves 35 MB and lasts ~16 us on MI355X, of which ~2 us are launch/drain, ~4 us the
+// round trip that re-reads the state the previous launch had just written (birth frame, tail position), and the
+// rest two more dependent round trips -- latency, not bandwidth (per-block timeline).  Here
+// every block stays resident for the whole sequence (all blocks co-resident: 8 blocks of 256 per CU), a thread IS a
+// lane and keeps its track (birth frame, birth grid index, f64 position) in registers, and frames are separated by
+// a device-wide barrier (two-level arrival counters + 64 replicated release flags: ~2.5 us) instead of a launch.
+//
+// What crosses blocks inside the kernel goes through write-through stores / L2-bypassing loads (the eight XCDs
+// have private L2s): the grid-resolution `blocked` maps, the "some track survived" flag, the free-lane stacks and
+// the hand-off slots below.  Everything else (the trajectory log, the death records) is only read after the kernel.
+//
+// Per frame t and thread (lane L = blockIdx*256 + tid, grid point g = L):
+//   A  a live track issues its eight gathers at once (position from registers) -- before the barrier wait
+//   B  wait for barrier t-1 (all marks of step t-1 are visible)
+//   C  read-and-clear blocked[g] -> birth?; a POOLED lane polls its hand-off slot (a lane popped by another
+//      block at t-1 finds its newborn there); lanes that died at t-1 (PEND) offer themselves as hosts
+//   D  the first threads of the block take the "phase-2 steps": the block's newborns (from their grid points) and
+//      the tracks adopted in C; newborn #k is hosted by the block's k-th PEND lane (state through LDS), surplus
+//      births pop lanes from the global stacks (hand-off slot written for the owner), surplus PEND lanes are pushed
+//   E  finish: blends, advance, bounds; log[t+1], marks of the survivors, death records into the block's PRIVATE
+//      record segment (no atomics; spill to a shared tail when a segment is full)
+//   F  all stores acknowledged -> arrive at barrier t
+// A block also owns PP_GUESTS "guest" lanes whose state sits in LDS: births that find no local PEND lane go there
+// before anything is popped from the global stacks, and live guests are stepped as phase-2 entries.  They are the
+// head-room above the 256 x (resident blocks) thread lanes (1080p at sample_ratio 2 peaks at 525.5k lanes against
+// 524288 threads on an MI355X).
+// The results (ids, lengths, positions) do not depend on which lane hosts which track: ids derive from the key
+// (last valid time, birth frame, birth grid index) at finalize.
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+#include "psfm_internal.h"
+#include "psfm_chain.h"
+
+#define PP_BLOCK 256
+#define PP_NW (PP_BLOCK / PSFM_WAVE)
+#define PP_PROBE 8
+#ifndef PP_PRE_WAVES
+#define PP_PRE_WAVES 4   // waves of a block that run E ahead of the barrier wait (measured: 4 -> 13.9, 3 -> 14.3, 2 -> 14.8, 0 -> 19 us per frame)
+#endif
+#ifndef PP_KEEP
+#define PP_KEEP 0      // free thread lanes a block keeps for its own future births; only the excess goes to the global stacks
+#endif
+#define PP_GUESTS 32   // extra lanes per block whose state lives in LDS (stepped as phase-2 entries)
+#define PP_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))
+
+// lane states kept in the `bf` register: >= 0 birth frame of the live track; PP_POOLED: free, reachable through the
+// global stacks (or never used) -> polls its hand-off slot; PP_PEND: free, kept by the block for its own births
+// (its track died in an earlier step)
+#ifdef PSFM_PERSIST_CHECK
+// debug builds: bounds-check every lane-indexed store, remember the first offending site in ctr->pad
+#define PP_CHK(idx, lim, code) (((idx) >= 0 && (idx) < (lim)) ? true : (atomicCAS(&a.ctr->pad[0], 0, (code)), atomicMax(&a.ctr->pad[1], (int)(idx)), false))
+#else
+#define PP_CHK(idx, lim, code) true
+#endif
+#ifndef PP_COH_MARKS
+#define PP_COH_MARKS true
+#endif
+#define PP_POOLED (-1)
+#define PP_PEND (-2)
+
+struct PsfmPersistArgs {
+    const float2* flows; const uint8_t* occ;   // (n_flows,H,W,2) f32 / (n_flows,H,W) u8
+    int H, W; float cw, ch;
+    int ratio, GW, GH, G;
+    double2* log; int cap;                     // (n_flows+1, cap): cap = gridDim.x * (256 + PP_GUESTS) columns
+    int cap_main;                              // gridDim.x * 256 thread lanes (columns [cap_main, cap) are the guests)
+    uint8_t* maps;                             // 3 x G, 0/1, zeroed: marks of step t go to map t % 3
+    unsigned* survsh;                          // 2 x 64 words (128 B apart): frame+1 of the last step a block of the shard had a survivor in
+    PsfmCounters* ctr;
+    PsfmShard* shards;                         // 2 x PSFM_NSHARD (free_top per parity set)
+    int* free_stack; int free_cap;
+    unsigned long long* handoff;               // cap x 3: x bits, y bits, gi | (2*birth_frame + alive) << 32
+    unsigned long long* fin_keys; int* fin_lanes;
+    int seg_cap; int spill_base; int spill_cap;
+    int2* seg_info;                            // per block: records, points
+    unsigned* bar;                             // [0, 64) shard counters, [64] top counter, [65, 129) release flags; 32 words apart
+    int n_flows, shift_b, shift_d;
+    PsfmFastDiv gwdiv, rdiv;
+    int spin_limit;
+};
+
+// what psfm_step_issue / psfm_step_finish / psfm_block_grid need for one frame
+struct PsfmFrameView {
+    const float2* flow; const uint8_t* occ;
+    int H, W; float cw, ch;
+    int ratio, GW, GH;
+    uint8_t* blocked_cur; uint8_t stamp_cur;
+    PsfmFastDiv rdiv;
+};
+
+__device__ __forceinline__ void psfm_put_record(const PsfmPersistArgs& a, int slot, unsigned long long key, int lane)
+{
+    int64_t o;
+    if (slot < a.seg_cap) {
+        o = (int64_t)blockIdx.x * a.seg_cap + slot;
+    } else {   // private segment full: shared tail
+        const int q = atomicAdd(&a.ctr->spill_cnt, 1);
+        if (q >= a.spill_cap) { atomicOr(&a.ctr->overflow, 2); return; }
+        o = (int64_t)a.spill_base + q;
+    }
+    if (!PP_CHK(lane, a.cap, 6)) return;
+    a.fin_keys[o] = key;
+    a.fin_lanes[o] = lane;
+}
+
+// slots for `n_dead` records of this wave in the block's private segment (LDS counter, no global atomic)
+__device__ __forceinline__ int psfm_record_slot(int* s_rec_cnt, bool dead)
+{
+    const unsigned long long dm = __ballot(dead);
+    if (dm == 0ull) return 0;
+    int base = 0;
+    if (psfm_lane_id() == (int)__builtin_ctzll(dm)) base = atomicAdd(s_rec_cnt, __popcll(dm));
+    base = __shfl(base, (int)__builtin_ctzll(dm));
+    return base + psfm_rank_in(dm);
+}
+
+#ifdef PSFM_TIMELINE
+__device__ unsigned long long g_pp_tl[4096 * 8];
+__device__ int g_pp_st[4096 * 8];
+__device__ int g_pp_tl_frame = -1;
+#define PP_TL(k) do { if (t == g_pp_tl_frame && tid == 0) g_pp_tl[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int psfm_debug_persist_timeline(int frame, unsigned long long* out_host, int n_blocks)
+{
+    if (out_host && n_blocks < 0) return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pp_st), (size_t)(-n_blocks) * 32) != hipSuccess;
+    if (out_host) return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pp_tl), (size_t)n_blocks * 64) != hipSuccess;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_tl_frame), &frame, sizeof(int)) != hipSuccess;
+}
+#else
+#define PP_TL(k) do {} while (0)
+#endif
+
+// entry k of the phase-2 list: kind 1 newborn (ex = grid index, host = local PEND thread or -1), kind 2 adopted
+// track (ex = owner thread), kind 3 live guest (ex = guest slot), kind 0 none
+struct PsfmEntry { int kind, ex, host; };
+
+template <int R>
+__global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(PsfmPersistArgs a)
+{
+    __shared__ int s_births[PP_NW], s_adopt[PP_NW], s_pend[PP_NW];
+    __shared__ int s_new_g[PP_BLOCK];       // grid index of the births, one 64-slot segment per wave
+    __shared__ int s_ad_tid[PP_BLOCK];      // threads that adopted a handed-off track in this frame, same layout
+    __shared__ int s_pend_tid[PP_BLOCK];    // threads whose track died in the previous step, same layout
+    __shared__ double2 s_xp[PP_BLOCK];      // exchange slots indexed by the OWNER thread: position in / out
+    __shared__ int s_xg[PP_BLOCK];          // ... birth grid index
+    __shared__ int s_xf[PP_BLOCK];          // ... 0 nothing, 1 track alive (take it), 2 track died in its step
+    __shared__ int s_gi[PP_BLOCK];          // birth grid index of the thread's live track (only needed when it dies)
+    __shared__ int s_npts[PP_BLOCK];        // trajectory points written by the thread
+    __shared__ int s_seg_start[PP_PROBE + 1], s_seg_end[PP_PROBE + 1];
+    __shared__ int s_nseg, s_base_free, s_ok, s_alive_any, s_rec_cnt;
+    __shared__ double2 s_gp[PP_GUESTS];     // guest lanes: position at time t,
+    __shared__ int s_gbf[PP_GUESTS];        // birth frame (-1 free),
+    __shared__ int s_ggi[PP_GUESTS];        // birth grid index;
+    __shared__ int s_glive[PP_GUESTS], s_gfree[PP_GUESTS], s_nglive, s_ngfree;   // this frame's live / free slots
+
+    int tid = threadIdx.x;
+    int L = blockIdx.x * PP_BLOCK + tid;
+    const int ratio = R > 0 ? R : a.ratio;
+    const int shard = blockIdx.x % PSFM_NSHARD;
+    const size_t P = (size_t)a.H * a.W;
+
+    // (the per-thread indices are re-derived from `tid` at the top of every frame: values hoisted out of the frame loop
+    // cost registers for its whole body, and this kernel must fit 64 VGPRs for 8 blocks per CU)
+    // ---- frame-0 births on the full grid (trajectory.py:108,110-120) ----
+    // registers across frames: bf (state / birth frame) and p (position at time t; zero unless live)
+    int bf = PP_POOLED;
+    double2 p = make_double2(0.0, 0.0);
+    s_gi[tid] = L;
+    s_npts[tid] = 0;
+    if (L < a.G) {
+        const int gy = (int)psfm_fastdiv((unsigned)L, a.gwdiv), gx = L - gy * a.GW;
+        p = make_double2((double)(gx * ratio), (double)(gy * ratio));
+        bf = 0;
+        a.log[L] = p;
+        s_npts[tid] = 1;
+    }
+    s_xf[tid] = 0;
+    if (tid < PP_GUESTS) s_gbf[tid] = -1;
+    if (tid == 0) { s_rec_cnt = 0; s_alive_any = 0; }
+    __syncthreads();
+
+    for (int t = 0; t < a.n_flows; ++t) {
+        asm volatile("" : "+v"(tid));
+        L = blockIdx.x * PP_BLOCK + tid;
+        const int lane = tid & (PSFM_WAVE - 1), wave = tid / PSFM_WAVE;
+        PsfmFrameView v;
+        v.flow = a.flows + (size_t)t * P; v.occ = a.occ + (size_t)t * P;
+        v.H = a.H; v.W = a.W; v.cw = a.cw; v.ch = a.ch; v.ratio = a.ratio; v.GW = a.GW; v.GH = a.GH; v.rdiv = a.rdiv;
+        v.blocked_cur = a.maps + (size_t)(t % 3) * a.G; v.stamp_cur = 1;
+        double2* log_cur = a.log + (size_t)t * a.cap;
+        double2* log_next = a.log + (size_t)(t + 1) * a.cap;
+        const int cur = t & 1, prev = cur ^ 1;
+
+        PP_TL(0);
+        // ---- A: gathers of the live tracks (unconditional: idle lanes sample pixel (0,0)) ----
+        const bool live = bf >= 0;
+        PsfmStepLoads l1 = psfm_step_issue(v, p);
+
+        // ---- E: the live tracks' own step.  It needs nothing from other blocks, and its marks go to a map nobody reads
+        // before barrier t (three maps), so the first PP_PRE_WAVES waves run it BEFORE waiting for barrier t-1 (their
+        // ALU hides under the barrier latency) and the others behind the loads of C (under that round trip) ----
+        bool any_alive = false;
+        int npts = 0;
+        auto do_E = [&]() {
+            PsfmStep s1;
+            s1.alive = true;
+            if (live) s1 = psfm_step_finish(v, p, l1);
+            const int slot1 = psfm_record_slot(&s_rec_cnt, !s1.alive);
+            if (live) {
+                if (s1.alive) {
+                    if (PP_CHK(L, a.cap, 1)) log_next[L] = s1.next;
+                    psfm_block_grid<R, PP_COH_MARKS>(v, (int)s1.next.x, (int)s1.next.y);
+                    p = s1.next;
+                    any_alive = true;
+                    ++npts;
+                } else {
+                    psfm_put_record(a, slot1, psfm_key(t, bf, s_gi[tid], a.shift_b, a.shift_d), L);
+                    bf = PP_PEND;       // free from t+1 on (`live` keeps it out of this frame's PEND list)
+                    p = make_double2(0.0, 0.0);
+                }
+            }
+        };
+        if (wave < PP_PRE_WAVES) do_E();
+
+        // ---- B: barrier t-1 ----
+        if (t > 0) {
+            if (tid == 0) {
+                const unsigned* flag = a.bar + (65 + shard) * 32;
+                int ok = 1, n = 0;
+                while (psfm_coh_ld(flag) < (unsigned)t) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++n > a.spin_limit) { atomicOr(&a.ctr->overflow, 8); psfm_coh_st(&a.ctr->abort, 1); ok = 0; break; }
+                    if ((n & 127) == 0 && psfm_coh_ld(&a.ctr->abort)) { ok = 0; break; }
+                }
+                s_ok = ok;
+            }
+            __syncthreads();
+            if (!s_ok) return;
+        }
+
+#ifndef PP_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(3);   // behind the barrier a block is on the frame's critical path ...
+#endif
+        PP_TL(1);
+        // ---- C (issue): respawn byte, survivor flag, hand-off slot -- consumed after E, which runs under their latency ----
+        const bool poll = t > 0 && bf == PP_POOLED;
+        const bool gridpt = t > 0 && L < a.G;
+        uint8_t* map_prev = a.maps + (size_t)((t + 2) % 3) * a.G;   // marks of step t-1; cleared here, written again at t+2
+        unsigned sv = 0, byte = 0;
+        unsigned long long h0 = 0, h1 = 0, h2 = ~0ull;
+        // "did any track survive step t-1?" only matters to grid point 0 (see below): one wave reads the 64 shard words.
+        // (One flag word read by every thread would queue half a million L2-bypassing loads on one memory channel.)
+        if (t > 0 && blockIdx.x == 0 && tid < PSFM_NSHARD) sv = psfm_coh_ld(a.survsh + (prev * PSFM_NSHARD + tid) * 32);
+        if (gridpt) byte = psfm_coh_ld(map_prev + L);
+        if (poll) {
+            const unsigned long long* h = a.handoff + (size_t)L * 3;
+            h0 = psfm_coh_ld(h); h1 = psfm_coh_ld(h + 1); h2 = psfm_coh_ld(h + 2);
+        }
+
+        if (wave >= PP_PRE_WAVES) do_E();
+
+        // ---- C (consume): respawn test, adoption ----
+        bool birth = false;
+        if (gridpt) {
+            if (byte != 0) psfm_coh_st(map_prev + L, (uint8_t)0);
+            birth = byte == 0;
+            // No survivor at all: nothing is marked, every grid point respawns -- except that SciPy's EDT then measures
+            // to a phantom feature at (y=-1, x=0): (cy+1)^2 + cx^2 > r^2 fails at grid point 0 only (1 > r^2 is false).
+            if (L == 0 && __ballot(sv == (unsigned)t) == 0ull) birth = ((0 + 1) * (0 + 1) + 0 * 0) > ratio * ratio;
+        }
+        bool adopted = false;
+        if (poll) {
+            const int tag = (int)(h2 >> 32);
+            if ((tag >> 1) == t - 1) {          // a block popped this lane for a track born at t-1
+                if (tag & 1) {
+                    adopted = true;             // stepped below as a phase-2 entry; picked up after it
+                    s_xp[tid] = make_double2(__longlong_as_double((long long)h0), __longlong_as_double((long long)h1));
+                    s_xg[tid] = (int)(unsigned)h2;
+                } else {
+                    bf = PP_PEND;               // born and lost in its first step: the lane is free again
+                }
+            }
+        }
+        const bool pend = (bf == PP_PEND) & !live;
+        const unsigned long long bm = __ballot(birth), am = __ballot(adopted), pm = __ballot(pend);
+        if (lane == 0) { s_births[wave] = __popcll(bm); s_adopt[wave] = __popcll(am); s_pend[wave] = __popcll(pm); }
+        if (birth) s_new_g[wave * PSFM_WAVE + psfm_rank_in(bm)] = L;
+        if (adopted) s_ad_tid[wave * PSFM_WAVE + psfm_rank_in(am)] = tid;
+        if (pend) s_pend_tid[wave * PSFM_WAVE + psfm_rank_in(pm)] = tid;
+        if (wave == 0) {   // guest slots: live ones are stepped below, free ones take births
+            const int gb = tid < PP_GUESTS ? s_gbf[tid] : -1;
+            const bool gl = gb >= 0, gf = (tid < PP_GUESTS) & (gb < 0);
+            const unsigned long long glm = __ballot(gl), gfm = __ballot(gf);
+            if (lane == 0) { s_nglive = __popcll(glm); s_ngfree = __popcll(gfm); }
+            if (gl) s_glive[psfm_rank_in(glm)] = tid;
+            if (gf) s_gfree[psfm_rank_in(gfm)] = tid;
+        }
+        __syncthreads();
+
+        PP_TL(2);
+        int nb = 0, nad = 0, npd = 0, my_pend_before = 0;
+#pragma unroll
+        for (int w = 0; w < PP_NW; ++w) {
+            if (w == wave) my_pend_before = npd;
+            nb += s_births[w]; nad += s_adopt[w]; npd += s_pend[w];
+        }
+        const int matched = nb < npd ? nb : npd;                  // newborns hosted by the block's PEND lanes
+        const int ngl = s_nglive;
+        const int gmatched = (nb - matched) < s_ngfree ? (nb - matched) : s_ngfree;   // ... by its free guest lanes
+        const int n2 = nb + nad + ngl;
+
+        // ---- D/E: phase-2 steps in passes of one entry per thread (a second pass only after a mass respawn) ----
+        for (int base = 0; base == 0 || base < n2; base += PP_BLOCK) {
+            const int k = base + tid;
+            PsfmEntry e;
+            e.kind = 0; e.ex = -1; e.host = -1;
+            if (k < nb) {
+                int before = 0, pb = 0;
+#pragma unroll
+                for (int w = 0; w < PP_NW; ++w) {
+                    const int c = s_births[w], pc = s_pend[w];
+                    if (k >= before && k < before + c) e.ex = s_new_g[w * PSFM_WAVE + (k - before)];
+                    if (k >= pb && k < pb + pc) e.host = s_pend_tid[w * PSFM_WAVE + (k - pb)];   // k < matched only
+                    before += c; pb += pc;
+                }
+                e.kind = 1;
+            } else if (k < nb + nad) {
+                const int kk = k - nb;
+                int before = 0;
+#pragma unroll
+                for (int w = 0; w < PP_NW; ++w) {
+                    const int c = s_adopt[w];
+                    if (kk >= before && kk < before + c) e.ex = s_ad_tid[w * PSFM_WAVE + (kk - before)];
+                    before += c;
+                }
+                e.kind = 2;
+            } else if (k < n2) {
+                e.ex = s_glive[k - nb - nad];
+                e.kind = 3;
+            }
+            PsfmStepLoads l2 = {};
+            if (e.kind != 0) {
+                double2 q;
+                if (e.kind == 1) {
+                    const int gy = (int)psfm_fastdiv((unsigned)e.ex, a.gwdiv), gx = e.ex - gy * a.GW;
+                    q = make_double2((double)(gx * ratio), (double)(gy * ratio));
+                } else if (e.kind == 2) {
+                    q = s_xp[e.ex];
+                } else {
+                    q = s_gp[e.ex];
+                }
+                l2 = psfm_step_issue(v, q);
+            }
+#ifdef PSFM_TIMELINE
+            if (base == 0 && tid == 0 && t == g_pp_tl_frame) {
+                int* st = g_pp_st + blockIdx.x * 8;
+                st[0] = nb; st[1] = nad; st[2] = npd; st[3] = ngl; st[4] = s_ngfree; st[5] = nb - matched - gmatched; st[6] = npd - matched - PP_KEEP;
+            }
+#endif
+            if (base == 0 && tid == 0) {
+                PsfmShard* sh_pop = a.shards + cur * PSFM_NSHARD;
+                PsfmShard* sh_push = a.shards + prev * PSFM_NSHARD;
+                int need = nb - matched - gmatched; // births that must pop a lane
+                const int n_push = npd - matched - PP_KEEP;   // free lanes beyond the block's own reserve go to the global stacks
+                int bfree = 0;
+                if (n_push > 0) bfree = atomicAdd(&sh_push[shard].free_top, n_push);
+                int nseg = 0, done = 0;
+                // pops: rounds of four independent atomics (own shard first), one round trip per round.  The request is
+                // SPLIT over the four stacks: a stack is only ever asked for what will be taken from it if it has it, so
+                // a count is given back only by a popper that found the stack exhausted (top < 0 meanwhile: nobody else
+                // can pop below entries that are about to be handed back)
+                for (int rd = 0; rd < PP_PROBE / 4 && need > 0; ++rd) {
+                    const int q4 = need >> 2, r4 = need & 3;
+                    int sh[4], ask[4], old[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sh[j] = (shard + (rd * 4 + j) * 7) % PSFM_NSHARD;
+                        ask[j] = q4 + (j < r4 ? 1 : 0);
+                        old[j] = ask[j] > 0 ? atomicSub(&sh_pop[sh[j]].free_top, ask[j]) : 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int take = old[j] < 0 ? 0 : (old[j] > ask[j] ? ask[j] : old[j]);
+                        if (take < ask[j]) atomicAdd(&sh_pop[sh[j]].free_top, ask[j] - take);
+                        if (take > 0) {
+                            s_seg_start[nseg] = sh[j] * a.free_cap + old[j] - 1;   // rank q of the segment -> entry start - q
+                            done += take;
+                            s_seg_end[nseg] = done;
+                            ++nseg;
+                            need -= take;
+                        }
+                    }
+                }
+                s_base_free = bfree;
+                if (need > 0) {
+                    const int base_new = atomicAdd(&a.ctr->n_lanes, need);
+                    s_seg_start[nseg] = -(base_new + 1);   // negative: fresh lanes base_new, base_new+1, ...
+                    done += need;
+                    s_seg_end[nseg] = done;
+                    ++nseg;
+                }
+                s_nseg = nseg;
+            }
+            PP_TL(3);
+            __syncthreads();
+            PP_TL(4);
+
+            if (base == 0) {
+                // ---- free lanes beyond the newborns they host and the block's reserve go to the global stacks (poppable
+                //      from the next frame on); the others stay PEND = free, local ----
+                if (pend) {
+                    const int r = my_pend_before + psfm_rank_in(pm);
+                    if (r >= matched + PP_KEEP) {
+                        int* free_push = a.free_stack + (size_t)prev * a.free_cap * PSFM_NSHARD;
+                        const int fpos = s_base_free + (r - matched - PP_KEEP);
+                        if (fpos < a.free_cap && PP_CHK(fpos, a.free_cap, 7)) psfm_coh_st(free_push + (size_t)shard * a.free_cap + fpos, L);
+                        else atomicOr(&a.ctr->overflow, 1);
+                        bf = PP_POOLED;
+                    }
+                }
+            }
+            // ---- phase-2 results ----
+            psfm_step_pin<true>(l2);
+            asm volatile("" : "+v"(e.ex));   // the entry's position is rebuilt, not carried across the barrier
+            if (e.kind == 1) {
+                const int gy = (int)psfm_fastdiv((unsigned)e.ex, a.gwdiv), gx = e.ex - gy * a.GW;
+                const double2 q = make_double2((double)(gx * ratio), (double)(gy * ratio));
+                const PsfmStep s2 = psfm_step_finish(v, q, l2);
+                // lane of the newborn: the block's k-th PEND lane, else a popped / fresh lane
+                int Lt;
+                int gs = -1;
+                if (k < matched) {
+                    Lt = blockIdx.x * PP_BLOCK + e.host;
+                } else if (k < matched + gmatched) {
+                    gs = s_gfree[k - matched];
+                    Lt = a.cap_main + blockIdx.x * PP_GUESTS + gs;
+                } else {
+                    const int* free_pop = a.free_stack + (size_t)cur * a.free_cap * PSFM_NSHARD;
+                    const int qq = k - matched - gmatched;
+                    int j = 0, pv = 0;
+                    while (j < s_nseg - 1 && qq >= s_seg_end[j]) { pv = s_seg_end[j]; ++j; }
+                    const int st = s_seg_start[j];
+                    if (st >= 0) (void)PP_CHK(st - (qq - pv), 2 * a.free_cap * PSFM_NSHARD, 9);
+                    Lt = st >= 0 ? psfm_coh_ld(free_pop + (st - (qq - pv))) : (-(st + 1) + (qq - pv));
+                    if (Lt >= a.cap_main) Lt = -1;
+                }
+                if (Lt >= 0) {
+                    if (PP_CHK(Lt, a.cap, 2)) log_cur[Lt] = q;
+                    ++npts;
+                    if (s2.alive) {
+                        if (PP_CHK(Lt, a.cap, 3)) log_next[Lt] = s2.next;
+                        psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
+                        any_alive = true;
+                        ++npts;
+                    } else {   // born and lost in the same step: a length-1 trajectory
+                        const int slot = atomicAdd(&s_rec_cnt, 1);
+                        psfm_put_record(a, slot, psfm_key(t, t, e.ex, a.shift_b, a.shift_d), Lt);
+                    }
+                    if (k >= matched + gmatched && s2.alive && t == a.n_flows - 1) {
+                        // born in the last frame on a popped lane: its owner never gets to adopt it, so the
+                        // "still active at the end" record (last valid time n_flows) is written here
+                        const int slot = atomicAdd(&s_rec_cnt, 1);
+                        psfm_put_record(a, slot, psfm_key(a.n_flows, t, e.ex, a.shift_b, a.shift_d), Lt);
+                    }
+                    if (k < matched) {
+                        s_xp[e.host] = s2.next; s_xg[e.host] = e.ex; s_xf[e.host] = s2.alive ? 1 : 2;
+                    } else if (gs >= 0) {
+                        if (s2.alive) { s_gp[gs] = s2.next; s_ggi[gs] = e.ex; s_gbf[gs] = t; }
+                    } else {
+                        if (!PP_CHK(Lt, a.cap_main, 8)) continue;
+                        unsigned long long* h = a.handoff + (size_t)Lt * 3;
+                        psfm_coh_st(h, (unsigned long long)__double_as_longlong(s2.next.x));
+                        psfm_coh_st(h + 1, (unsigned long long)__double_as_longlong(s2.next.y));
+                        psfm_coh_st(h + 2, (unsigned long long)(unsigned)e.ex |
+                                               ((unsigned long long)(unsigned)(2 * t + (s2.alive ? 1 : 0)) << 32));
+                    }
+                } else {
+                    atomicOr(&a.ctr->overflow, 4);   // more tracks than resident lanes: the per-frame path takes over
+                }
+            } else if (e.kind == 2) {
+                const double2 q = s_xp[e.ex];
+                const PsfmStep s2 = psfm_step_finish(v, q, l2);
+                const int Lo = blockIdx.x * PP_BLOCK + e.ex;
+                if (s2.alive) {
+                    if (PP_CHK(Lo, a.cap, 4)) log_next[Lo] = s2.next;
+                    psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
+                    any_alive = true;
+                    ++npts;
+                    s_xp[e.ex] = s2.next; s_xf[e.ex] = 1;
+                } else {
+                    const int slot = atomicAdd(&s_rec_cnt, 1);
+                    psfm_put_record(a, slot, psfm_key(t, t - 1, s_xg[e.ex], a.shift_b, a.shift_d), Lo);
+                    s_xf[e.ex] = 2;
+                }
+            } else if (e.kind == 3) {
+                const double2 q = s_gp[e.ex];
+                const PsfmStep s2 = psfm_step_finish(v, q, l2);
+                const int Lg = a.cap_main + blockIdx.x * PP_GUESTS + e.ex;
+                if (s2.alive) {
+                    if (PP_CHK(Lg, a.cap, 5)) log_next[Lg] = s2.next;
+                    psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
+                    any_alive = true;
+                    ++npts;
+                    s_gp[e.ex] = s2.next;
+                } else {
+                    const int slot = atomicAdd(&s_rec_cnt, 1);
+                    psfm_put_record(a, slot, psfm_key(t, s_gbf[e.ex], s_ggi[e.ex], a.shift_b, a.shift_d), Lg);
+                    s_gbf[e.ex] = -1;   // free from the next frame on (this frame's free list is already fixed)
+                }
+            }
+        }
+        PP_TL(5);
+        if (npts) s_npts[tid] += npts;
+        const unsigned long long alm = __ballot(any_alive);
+        if (lane == 0 && alm != 0ull) s_alive_any = 1;   // benign race: every writer stores 1
+        __syncthreads();
+        // ---- owners pick up what the phase-2 threads computed for them ----
+        {
+            const int f = s_xf[tid];
+            if (f != 0) {
+                s_xf[tid] = 0;
+                if (f == 1) {
+                    bf = adopted ? t - 1 : t;   // adopted: born at t-1 in the block that popped this lane; else hosted newborn
+                    s_gi[tid] = s_xg[tid];
+                    p = s_xp[tid];
+                } else {
+                    bf = PP_PEND;               // the track died in this step (its record is written): free from t+1
+                }
+            }
+        }
+        if (tid == 0 && s_alive_any) { psfm_coh_st(a.survsh + (cur * PSFM_NSHARD + shard) * 32, (unsigned)(t + 1)); s_alive_any = 0; }
+        // ---- F: everything this block wrote is acknowledged -> arrive ----
+        __builtin_amdgcn_s_waitcnt(0);
+        PP_TL(6);
+        __syncthreads();
+        PP_TL(7);
+        if (tid < PSFM_WAVE) {
+            int last = 0;
+            if (tid == 0) {
+                const int nblk = (int)gridDim.x;
+                const unsigned members = (unsigned)((nblk - shard + PSFM_NSHARD - 1) / PSFM_NSHARD);
+                const unsigned old = __hip_atomic_fetch_add(a.bar + shard * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + 1 == members * (unsigned)(t + 1)) {
+                    const unsigned nsh = (unsigned)(nblk < PSFM_NSHARD ? nblk : PSFM_NSHARD);
+                    const unsigned o2 = __hip_atomic_fetch_add(a.bar + 64 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (o2 + 1 == nsh * (unsigned)(t + 1)) last = 1;
+                }
+            }
+            last = __builtin_amdgcn_readfirstlane(last);
+            if (last) psfm_coh_st(a.bar + (65 + tid) * 32, (unsigned)(t + 1));
+        }
+#ifndef PP_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(0);   // ... its next step ahead of the barrier is not
+#endif
+    }
+
+    // ---- the tracks still active at the end (clear_active, trajectory.py:154-158): last valid time = n_flows ----
+    const int lane = tid & (PSFM_WAVE - 1), wave = tid / PSFM_WAVE;
+    {
+        const bool alive = bf >= 0;
+        const int slot = psfm_record_slot(&s_rec_cnt, alive);
+        if (alive) psfm_put_record(a, slot, psfm_key(a.n_flows, bf, s_gi[tid], a.shift_b, a.shift_d), L);
+        if (tid < PP_GUESTS && s_gbf[tid] >= 0) {
+            const int gslot = atomicAdd(&s_rec_cnt, 1);
+            psfm_put_record(a, gslot, psfm_key(a.n_flows, s_gbf[tid], s_ggi[tid], a.shift_b, a.shift_d),
+                            a.cap_main + blockIdx.x * PP_GUESTS + tid);
+        }
+    }
+    // trajectory points written by this block (sizes the result without a second host sync)
+    {
+        __shared__ int s_pts[PP_NW];
+        int w = s_npts[tid];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += __shfl_down(w, o);
+        if (lane == 0) s_pts[wave] = w;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int j = 0; j < PP_NW; ++j) tot += s_pts[j];
+            const int c = s_rec_cnt;
+            a.seg_info[blockIdx.x] = make_int2(c < a.seg_cap ? c : a.seg_cap, tot);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void psfm_persist_init_kernel(PsfmCounters* ctr, PsfmShard* shards, int G)
+{
+    const int i = threadIdx.x;
+    if (i == 0) { ctr->n_lanes = G; ctr->overflow = 0; ctr->stall = 0; ctr->abort = 0; ctr->spill_cnt = 0; ctr->pad[0] = 0; ctr->pad[1] = 0; }
+    if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; shards[i].points = 0u; }
+}
+
+// Largest grid of 256-thread blocks that is resident at once on this device (0: unknown / not available).
+int psfm_persist_guests(void) { return PP_GUESTS; }
+
+int psfm_persist_max_blocks(psfm_ctx* c)
+{
+    if (c->persist_max_blocks >= 0) return c->persist_max_blocks;
+    int per_cu = 0, cus = 0;
+    c->persist_max_blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, psfm_chain_persist_kernel<2>, PP_BLOCK, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    c->persist_max_blocks = per_cu * cus;
+    return c->persist_max_blocks;
+}
+
+psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, hipStream_t s)
+{
+    const size_t bar_bytes = (size_t)(4 * PSFM_NSHARD + 1) * 128;   // barrier lines + 2 x 64 survivor words
+    PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.G * 3, s));
+    PSFM_HIP(hipMemsetAsync(c->persist_bar.p, 0, bar_bytes, s));
+    PSFM_HIP(hipMemsetAsync(c->handoff.p, 0xff, (size_t)d.nblk * PP_BLOCK * 24, s));   // tag -1: no hand-off
+    hipLaunchKernelGGL(psfm_persist_init_kernel, dim3(1), dim3(256), 0, s, c->counters.as<PsfmCounters>(),
+                       c->shards.as<PsfmShard>(), (int)d.G);
+    PsfmPersistArgs a;
+    a.flows = (const float2*)flows; a.occ = occ;
+    a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch;
+    a.ratio = d.ratio; a.GW = d.GW; a.GH = d.GH; a.G = (int)d.G;
+    a.log = c->log.as<double2>(); a.cap = (int)d.cap; a.cap_main = d.nblk * PP_BLOCK;
+    a.maps = c->occupied.as<uint8_t>();
+    a.ctr = c->counters.as<PsfmCounters>();
+    a.shards = c->shards.as<PsfmShard>();
+    a.free_stack = c->free_stack.as<int>(); a.free_cap = d.free_cap;
+    a.handoff = c->handoff.as<unsigned long long>();
+    a.fin_keys = c->fin_keys.as<unsigned long long>(); a.fin_lanes = c->fin_lanes.as<int>();
+    a.seg_cap = d.seg_cap; a.spill_base = d.nblk * d.seg_cap; a.spill_cap = d.spill_cap;
+    a.seg_info = c->seg_info.as<int2>();
+    a.bar = c->persist_bar.as<unsigned>();
+    a.survsh = a.bar + (2 * PSFM_NSHARD + 1) * 32;
+    a.n_flows = d.n_flows; a.shift_b = d.shift_b; a.shift_d = d.shift_d;
+    a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
+    a.spin_limit = 1 << 20;   // ~1 s of polling before a block gives up (the per-frame path then reruns the sequence)
+    if (const char* e = getenv("PSFM_PERSIST_SPIN_LIMIT")) a.spin_limit = atoi(e);   // tests: 0 forces the hand-over
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    c->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1, true);
+    const dim3 grid((unsigned)d.nblk), block(PP_BLOCK);
+    switch (d.ratio) {
+        case 1: hipExtLaunchKernelGGL(psfm_chain_persist_kernel<1>, grid, block, 0, s, e0, e1, 0, a); break;
+        case 2: hipExtLaunchKernelGGL(psfm_chain_persist_kernel<2>, grid, block, 0, s, e0, e1, 0, a); break;
+        case 4: hipExtLaunchKernelGGL(psfm_chain_persist_kernel<4>, grid, block, 0, s, e0, e1, 0, a); break;
+        default: hipExtLaunchKernelGGL(psfm_chain_persist_kernel<0>, grid, block, 0, s, e0, e1, 0, a); break;
+    }
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}

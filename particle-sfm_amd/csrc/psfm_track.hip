@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "psfm_internal.h"
+#include "psfm_chain.h"
 
 #define PSFM_BLOCK 256
 
@@ -216,106 +217,6 @@ struct PsfmChainArgs {
     int cap, shard_cap, free_cap, frame, shift_b, shift_d;
     PsfmFastDiv gwdiv, rdiv;   // division by GW (grid index -> row/col) and by the sample ratio
 };
-
-struct PsfmStep { bool alive; double2 next; };
-
-// One chain step split in two so that the caller can issue the gathers of several steps back to back and keep
-// them in flight across the block's bookkeeping: psfm_step_issue() computes the tap geometry and performs the eight
-// raw loads (4 flow taps, 4 mask taps); psfm_step_finish() REBUILDS the geometry from the position (ALU only: holding
-// weights and flags across the barriers costs the registers that decide 7 vs 8 waves per SIMD), blends the taps
-// (fp32, bit-exact op order) and applies trajectory.py:50,55-57.
-struct PsfmStepLoads {
-    float2 fnw, fne, fsw, fse;
-    unsigned onw, one, osw, ose;    // mask bytes, zero-extended
-};
-
-// Pins the raw tap registers at this program point: nothing computed FROM the loads can be scheduled above it, so
-// the s_waitcnt for the gathers cannot drift in front of the bookkeeping that is meant to overlap their latency
-// (the compiler otherwise packed the mask bytes right behind the loads, i.e. before the block's atomics).
-template <bool MASKS>
-__device__ __forceinline__ void psfm_step_pin(PsfmStepLoads& L)
-{
-    asm volatile("" : "+v"(L.fnw.x), "+v"(L.fnw.y), "+v"(L.fne.x), "+v"(L.fne.y), "+v"(L.fsw.x), "+v"(L.fsw.y),
-                      "+v"(L.fse.x), "+v"(L.fse.y));
-    // (the zero-extension of a mask byte must sit in the basic block of its load to fold into global_load_ubyte;
-    // pinning the lanes' bytes, loaded two blocks earlier, would materialise it -- and a wait -- before the barrier)
-    if (MASKS) asm volatile("" : "+v"(L.onw), "+v"(L.one), "+v"(L.osw), "+v"(L.ose));
-}
-
-__device__ __forceinline__ PsfmStepLoads psfm_step_issue(const PsfmChainArgs& a, double2 p)
-{
-    const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
-    const PsfmTapIdx k = psfm_tap_idx(a.H, a.W, t);   // flow and occlusion map share the tap geometry
-    PsfmStepLoads L;
-    const unsigned onw = (unsigned)k.nw, one = (unsigned)k.ne, osw = (unsigned)k.sw, ose = (unsigned)k.se;
-    L.fnw = psfm_ld(a.flow, onw * 8u); L.fne = psfm_ld(a.flow, one * 8u);
-    L.fsw = psfm_ld(a.flow, osw * 8u); L.fse = psfm_ld(a.flow, ose * 8u);
-    L.onw = psfm_ld(a.occ, onw); L.one = psfm_ld(a.occ, one); L.osw = psfm_ld(a.occ, osw); L.ose = psfm_ld(a.occ, ose);
-    return L;
-}
-
-__device__ __forceinline__ PsfmStep psfm_step_finish(const PsfmChainArgs& a, double2 p, const PsfmStepLoads& L)
-{
-    const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
-    const int x0 = t.x0, y0 = t.y0, x1 = t.x0 + 1, y1 = t.y0 + 1;
-    const bool xw = (x0 >= 0) & (x0 < a.W), xe = (x1 >= 0) & (x1 < a.W);
-    const bool yn = (y0 >= 0) & (y0 < a.H), ys = (y1 >= 0) & (y1 < a.H);
-    const bool inw = xw & yn, ine = xe & yn, isw = xw & ys, ise = xe & ys;
-    const float z = 0.0f;
-    const float fx = psfm_blend(inw ? L.fnw.x : z, ine ? L.fne.x : z, isw ? L.fsw.x : z, ise ? L.fse.x : z, t);
-    const float fy = psfm_blend(inw ? L.fnw.y : z, ine ? L.fne.y : z, isw ? L.fsw.y : z, ise ? L.fse.y : z, t);
-    const float oc = psfm_blend((inw & (L.onw != 0)) ? 1.0f : z, (ine & (L.one != 0)) ? 1.0f : z,
-                                (isw & (L.osw != 0)) ? 1.0f : z, (ise & (L.ose != 0)) ? 1.0f : z, t);
-    const double nx = p.x + (double)fx, ny = p.y + (double)fy;
-    const bool valid = (nx > 0.0) & (nx < (double)(a.W - 1)) & (ny > 0.0) & (ny < (double)(a.H - 1));
-    PsfmStep s;
-    s.next = make_double2(nx, ny);
-    s.alive = valid & !(oc > 0.1f);
-    return s;
-}
-
-// occupied_map[int(y), int(x)] = 1 (trajectory.py:144) folded with the EDT test: mark every stride-r grid
-// point whose disc of radius r contains this pixel.  Candidates are the 3x3 grid cells around the pixel's cell;
-// a cell on the low side can only qualify when the pixel sits exactly on that grid line.  R > 0: compile-time ratio.
-template <int R>
-__device__ __forceinline__ void psfm_block_grid(const PsfmChainArgs& a, int px, int py)
-{
-    const int r = R > 0 ? R : a.ratio, r2 = r * r;
-    int qx, qy;
-    if (R == 1) { qx = px; qy = py; }
-    else if (R == 2) { qx = px >> 1; qy = py >> 1; }
-    else if (R == 4) { qx = px >> 2; qy = py >> 2; }
-    else { qx = (int)psfm_fastdiv((unsigned)px, a.rdiv); qy = (int)psfm_fastdiv((unsigned)py, a.rdiv); }
-    const int ax = px - qx * r, ay = py - qy * r;
-    uint8_t* row = a.blocked_cur + qy * a.GW + qx;
-    const uint8_t st = a.stamp_cur;
-    // dx for column offsets -1, 0, +1 : -(ax + r) [only when ax == 0], -ax, r - ax
-    const int dx0 = ax, dx1 = r - ax, dy0 = ay, dy1 = r - ay;
-    const bool xl = (ax == 0) & (qx > 0), xr = qx + 1 < a.GW;
-    const bool yl = (ay == 0) & (qy > 0), yr = qy + 1 < a.GH;
-    // centre row (dy = -ay)
-    if (dx0 * dx0 + dy0 * dy0 <= r2) row[0] = st;
-    if (xr & (dx1 * dx1 + dy0 * dy0 <= r2)) row[1] = st;
-    if (xl & (r2 + dy0 * dy0 <= r2)) row[-1] = st;
-    // row below (dy = r - ay)
-    if (yr) {
-        uint8_t* rb = row + a.GW;
-        if (dx0 * dx0 + dy1 * dy1 <= r2) rb[0] = st;
-        if (xr & (dx1 * dx1 + dy1 * dy1 <= r2)) rb[1] = st;
-        if (xl & (r2 + dy1 * dy1 <= r2)) rb[-1] = st;
-    }
-    // row above (dy = -r, only when the pixel is on the grid line)
-    if (yl) {
-        uint8_t* ra = row - a.GW;
-        if (dx0 * dx0 + r2 <= r2) ra[0] = st;
-        // the diagonal neighbours are at distance >= r*sqrt(2) > r unless dx == 0, which is the line above
-    }
-}
-
-__device__ __forceinline__ unsigned long long psfm_key(int last_time, int bf, int idx, int shift_b, int shift_d)
-{
-    return ((unsigned long long)last_time << shift_d) | ((unsigned long long)bf << shift_b) | (unsigned long long)idx;
-}
 
 #ifndef PSFM_CHAIN_BLOCK
 #define PSFM_CHAIN_BLOCK 256

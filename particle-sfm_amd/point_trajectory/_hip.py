@@ -17,7 +17,7 @@ EXPORTS = [
     "psfm_ctx_set_capacity", "psfm_flow_check", "psfm_grid_sample", "psfm_optimize_location", "psfm_track",
     "psfm_connect",
     "psfm_result_device", "psfm_result_copy", "psfm_result_solve_stats", "psfm_ctx_set_profiling",
-    "psfm_profile_get",
+    "psfm_profile_get", "psfm_ctx_set_chain_mode",
 ]
 
 
@@ -33,10 +33,10 @@ class SolveStats(ctypes.Structure):
 class TrackInfo(ctypes.Structure):
     _fields_ = [("n_traj", ctypes.c_int64), ("n_points", ctypes.c_int64), ("n_lanes_peak", ctypes.c_int64),
                 ("lane_capacity", ctypes.c_int64), ("solver_iterations", ctypes.c_int64),
-                ("n_solves", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("n_solves", ctypes.c_int32), ("chain_mode", ctypes.c_int32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class PsfmError(RuntimeError):
@@ -75,6 +75,7 @@ def lib():
     L.psfm_result_copy.argtypes = [vp, vp, vp, vp, vp, vp]
     L.psfm_result_solve_stats.argtypes = [vp, ctypes.POINTER(SolveStats), i32, ctypes.POINTER(ctypes.c_int32)]
     L.psfm_ctx_set_profiling.argtypes = [vp, i32]
+    L.psfm_ctx_set_chain_mode.argtypes = [vp, i32]
     L.psfm_profile_get.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(i64)]
     for name in EXPORTS:
         if name != "psfm_last_error":
@@ -102,6 +103,10 @@ class Context:
 
     def set_capacity(self, lane_factor, traj_factor):
         check(lib().psfm_ctx_set_capacity(self._h, float(lane_factor), float(traj_factor)))
+
+    def set_chain_mode(self, mode):
+        """0 auto (persistent frame loop when the grid fits the device), 1 per-frame launches, 2 persistent loop only."""
+        check(lib().psfm_ctx_set_chain_mode(self._h, int(mode)))
 
     def set_profiling(self, enable):
         check(lib().psfm_ctx_set_profiling(self._h, int(enable)))   # 0 off, 1 every launch, N>1 every N-th chain_step

@@ -6,6 +6,8 @@ This module keeps the reference's *callable surface*: `grid_sample` (:25-37) and
 `track()` / `track_optimize()` return -- a list-like of Trajectory in full_trajs order.
 """
 import ctypes
+import os
+import sys
 
 import numpy as np
 
@@ -176,6 +178,8 @@ def run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio, return_devic
                                    int(sample_ratio), ctypes.byref(info), _hip.current_stream_ptr())
         if st != _hip.PSFM_ERR_CAPACITY:
             break
+        if os.environ.get("PSFM_VERBOSE"):
+            print("psfm_track: %s -> retry with larger tables" % _hip.lib().psfm_last_error().decode(), file=sys.stderr)
         lane_f, traj_f = lane_f * 2.0, traj_f * 4.0   # tables too small for this sequence: grow and rerun
     _hip.check(st)
     if return_device:

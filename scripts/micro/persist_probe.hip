@@ -76,8 +76,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         if (a.mode >= 1 && live) {
             const int px = min(max((int)p.x, 0), a.W - 1) >> 1, py = min(max((int)p.y, 0), a.H - 1) >> 1;
-            __hip_atomic_store(map_cur + (size_t)py * a.GW + px, (uint8_t)(t + 1 + (b & 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            uint8_t* m = map_cur + (size_t)py * a.GW + px;
+            const uint8_t val = (uint8_t)(t + 1 + (b & 0));
+            if (a.mode <= 3) {
+                __hip_atomic_store(m, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (a.mode == 4) {        // 4 write-through byte stores per track
+                __hip_atomic_store(m, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (px + 1 < a.GW) __hip_atomic_store(m + 1, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (py + 1 < a.H / 2) {
+                    __hip_atomic_store(m + a.GW, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (px + 1 < a.GW) __hip_atomic_store(m + a.GW + 1, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            } else if (a.mode == 5) {        // one device-scope atomicOr per track on a bit map (no aggregation)
+                const int cell = py * a.GW + px;
+                __hip_atomic_fetch_or((unsigned*)map_cur + (cell >> 5), 1u << (cell & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (a.mode == 6) {        // 4 plain byte stores per track, made visible by a release fence before the arrival
+                m[0] = val;
+                if (px + 1 < a.GW) m[1] = val;
+                if (py + 1 < a.H / 2) { m[a.GW] = val; if (px + 1 < a.GW) m[a.GW + 1] = val; }
+            } else if (a.mode == 7) {        // 4 device-scope atomicOr per track on a bit map
+                const int cell = py * a.GW + px;
+                unsigned* w = (unsigned*)map_cur;
+                __hip_atomic_fetch_or(w + (cell >> 5), 1u << (cell & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_or(w + ((cell + 1) >> 5), 1u << ((cell + 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (py + 1 < a.H / 2) {
+                    __hip_atomic_fetch_or(w + ((cell + a.GW) >> 5), 1u << ((cell + a.GW) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(w + ((cell + a.GW + 1) >> 5), 1u << ((cell + a.GW + 1) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
+        if (a.mode == 6) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_s_waitcnt(0);   // all of this wave's memory operations acknowledged
         __syncthreads();
         if (tid < 64) {
@@ -125,9 +153,9 @@ int main(int argc, char** argv)
     if (nblk > nb_per_cu * prop.multiProcessorCount) { printf("grid %d does not fit\n", nblk); return 1; }
     a.nblk = nblk;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
         a.mode = mode;
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int rep = 0; rep < 2; ++rep) {
             CK(hipMemset(arrive, 0, 4 * frames)); CK(hipMemset(bar, 0, 128 * (2 * NSH + 1))); CK(hipMemset(abortf, 0, 4)); CK(hipMemset(map, 0, 2 * G));
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));

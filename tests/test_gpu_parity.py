@@ -22,6 +22,16 @@ def pt():
     return ns
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["per-frame-launches", "auto-persistent"])
+def chain_mode(request, pt):
+    """Every test of this module runs twice: with one chain_step launch per frame, and with the default policy
+    (track mode: ONE persistent launch per sequence whenever the grid fits the device).  Results must not differ."""
+    ctx = pt.hip.context()
+    ctx.set_chain_mode(request.param)
+    yield request.param
+    ctx.set_chain_mode(0)
+
+
 def test_sampler_golden(pt):
     import torch
     g = golden("sampler")
@@ -284,3 +294,52 @@ def test_connect_sequences_concurrently(pt, tmp_path):
         sa, sb = ta.__getstate__(), tb.__getstate__()
         for k in ("ids", "birth", "length", "off", "xy"):
             assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_chain_modes_report_what_ran(pt, chain_mode):
+    """psfm_track_info.chain_mode: 2 = persistent frame loop, 1 = per-frame launches; track_optimize is always 1."""
+    d = psfm_synth.synth_sequence(8, 60, 80, seed=5, sigma=0.2, n_occluders=1, stride2=True)
+    _, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    R = pt.track(d["flows_f"], occ, 2)
+    assert R.info["chain_mode"] == (1 if chain_mode == 1 else 2)
+    _, occ2 = pt.utils.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    R2 = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+    assert R2.info["chain_mode"] == 1
+
+
+def test_persistent_loop_hands_over_to_per_frame_launches(pt, chain_mode, monkeypatch):
+    """A persistent loop that gives up (here: barrier spin limit forced to 0) must not produce a result of its own:
+    psfm_track reruns the sequence with per-frame launches and returns exactly the same trajectories."""
+    if chain_mode == 1:
+        pytest.skip("per-frame mode never starts the persistent loop")
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(10, 120, 160, seed=77, sigma=0.3, n_occluders=2, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    O = orc.track(d["flows_f"], occ, 1)
+    monkeypatch.setenv("PSFM_PERSIST_SPIN_LIMIT", "0")
+    R = pt.track(d["flows_f"], occ, 1)
+    assert R.info["chain_mode"] == 1
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+    monkeypatch.delenv("PSFM_PERSIST_SPIN_LIMIT")
+    R = pt.track(d["flows_f"], occ, 1)
+    assert R.info["chain_mode"] == 2
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+
+
+def test_persistent_mode_required_but_unavailable(pt):
+    """chain mode 2 on a grid with more points than resident lanes (1080p at sample_ratio 1) is an argument error."""
+    import ctypes
+    import torch
+    hip = pt.hip
+    ctx = hip.context()
+    H, W = 1080, 1920
+    fl = torch.zeros((1, H, W, 2), dtype=torch.float32, device="cuda")
+    oc = torch.zeros((1, H, W), dtype=torch.uint8, device="cuda")
+    ctx.set_chain_mode(2)
+    st = hip.lib().psfm_track(ctx.handle, hip.ptr(fl), hip.ptr(oc), None, None, 1, H, W, 1, None, hip.current_stream_ptr())
+    assert st == hip.PSFM_ERR_ARG and b"persistent" in hip.lib().psfm_last_error()
+    ctx.set_chain_mode(0)
+    info = hip.TrackInfo()
+    hip.check(hip.lib().psfm_track(ctx.handle, hip.ptr(fl), hip.ptr(oc), None, None, 1, H, W, 1, ctypes.byref(info),
+                                   hip.current_stream_ptr()))
+    assert info.chain_mode == 1 and info.n_traj == H * W      # zero flow: nothing moves, nothing dies
