@@ -218,6 +218,23 @@ def main():
         sync_all()
         connect_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         assert int(info_c.n_points) == int(info.n_points)
+    # the other way of running the recurrence (one chain_step launch per frame), outside the timed region
+    per_frame = None
+    if not args.no_extras and int(info.chain_mode) == 2:
+        ctx.set_chain_mode(1)
+        step()
+        ctx.set_profiling(8)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            info_p = step()
+        sync_all()
+        pf_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        pp = ctx.profile()["chain_step"]
+        ctx.set_profiling(False)
+        ctx.set_chain_mode(0)
+        assert int(info_p.n_points) == int(info.n_points) and int(info_p.n_traj) == int(info.n_traj)
+        per_frame = {"ms_per_step": pf_ms, "chain_step_avg_launch_us": 1e3 * pp["total_ms"] / max(pp["launches"], 1)}
 
     points = int(info.n_points)
     import psfm_dist
@@ -239,9 +256,15 @@ def main():
         chain_bytes = min(8 * P, 32 * A) + min(P, 4 * A) + 16 * A + 16 * A + A
         ch = prof["chain_step"]
         chain_us = 1e3 * ch["total_ms"] / max(ch["launches"], 1)
+        persistent = int(info.chain_mode) == 2
+        frame_bytes = chain_bytes
+        if persistent:
+            # ONE launch runs all n_flows steps (psfm_chain_persist_kernel): algorithmic bytes per launch = the per-step
+            # figure x n_flows -- the positions it keeps in registers between steps are still counted as read
+            chain_bytes = chain_bytes * n_flows
         achieved = chain_bytes / (chain_us * 1e-6) / 1e9 if chain_us > 0 else 0.0
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_chain_step.json")
+        tfile = os.path.join(ROOT, "profiles", "traffic_chain_persist.json" if persistent else "traffic_chain_step.json")
         if os.path.exists(tfile):
             try:
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
@@ -260,10 +283,13 @@ def main():
                        "frames": n_frames, "height": H, "width": W, "sample_ratio": RATIO,
                        "flow_check_thres": THRES, "points_per_sequence": points, "trajectories": int(info.n_traj),
                        "parallelism": "sequence-per-gpu x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "psfm_chain_step_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "psfm_chain_persist_kernel" if persistent else "psfm_chain_step_kernel",
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": chain_bytes, "avg_launch_us": chain_us,
-                         "avg_alive_tracks": A},
+                         "steps_per_launch": n_flows if persistent else 1,
+                         "us_per_step": chain_us / (n_flows if persistent else 1),
+                         "bytes_per_step": frame_bytes, "avg_alive_tracks": A},
             "kernels": {
                 "flow_check": {"avg_launch_us": fc_us, "bytes_per_launch": fc_bytes,
                                "achieved_GBs": fc_bytes / (fc_us * 1e-6) / 1e9 if fc_us > 0 else 0.0,
@@ -271,6 +297,7 @@ def main():
                 "respawn_avg_us": 1e3 * prof["respawn"]["total_ms"] / max(prof["respawn"]["launches"], 1),
                 "finalize_avg_us": 1e3 * prof["finalize"]["total_ms"] / max(prof["finalize"]["launches"], 1),
                 "connect_overlap_ms_per_step": connect_ms,
+                "per_frame_launch_path": per_frame,
             },
         }
         out["kernels"].pop("respawn_avg_us", None)   # respawn is fused into chain_step

@@ -3,11 +3,41 @@
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
+#include <shared_mutex>
+#include <chrono>
+#include <stdlib.h>
 
 #include "psfm_internal.h"
 
 static thread_local char g_err[512] = "";
-static std::mutex g_persist_mutex[16];   // per device: one persistent frame loop at a time (all its blocks must be resident)
+// Per device: every entry point that launches kernels holds this gate SHARED; the persistent frame loop needs it
+// EXCLUSIVE.  All blocks of that kernel must be resident at once, and with another queue feeding the device they may
+// never be (measured: a second host thread running psfm_connect alongside stalls the loop until its spin limit) -- so it
+// only runs when no other psfm call of this process is in flight on the device, and calls that arrive meanwhile wait for
+// it (<= a few ms).  A call that finds the device busy uses per-frame launches, which overlap well with other sequences.
+static std::shared_mutex g_dev_gate[16];
+struct PsfmGate {
+    std::shared_mutex& m;
+    bool exclusive = false;
+    PsfmGate(int device, int want_exclusive /* 0 no, 1 if free, 2 wait for it */) : m(g_dev_gate[device & 15])
+    {
+        if (want_exclusive == 2) { m.lock(); exclusive = true; }
+        else if (want_exclusive == 1 && m.try_lock()) exclusive = true;
+        else m.lock_shared();
+    }
+    ~PsfmGate() { if (exclusive) m.unlock(); else m.unlock_shared(); }
+    PsfmGate(const PsfmGate&) = delete;
+    PsfmGate& operator=(const PsfmGate&) = delete;
+};
+// would psfm_track try the persistent loop for this call? (0 no, 1 yes if the device is free, 2 required)
+static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int ratio)
+{
+    if (optimize || c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;
+    const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
+    const int maxb = psfm_persist_max_blocks(c);
+    if (maxb <= 0 || (G + 255) / 256 > maxb) return 0;
+    return c->chain_mode == 2 ? 2 : 1;
+}
 
 void psfm_set_error(const char* fmt, ...)
 {
@@ -182,6 +212,7 @@ extern "C" psfm_status psfm_flow_check(psfm_ctx* c, const float* flows_f, const 
                                        float thres, uint8_t* occ_out, float* err_out, void* stream)
 {
     PSFM_CHECK_CTX(c);
+    PsfmGate gate(c->device, 0);
     if (n_pairs < 0 || h < 2 || w < 2 || (n_pairs > 0 && (!flows_f || !flows_b || !occ_out))) {
         psfm_set_error("psfm_flow_check: bad argument (n_pairs=%d h=%d w=%d)", n_pairs, h, w);
         return PSFM_ERR_ARG;
@@ -197,6 +228,7 @@ extern "C" psfm_status psfm_grid_sample(psfm_ctx* c, const float* map_hwc, int c
                                         int64_t n, float* out, void* stream)
 {
     PSFM_CHECK_CTX(c);
+    PsfmGate gate(c->device, 0);
     if ((ch != 1 && ch != 2) || h < 2 || w < 2 || n < 0 || (n > 0 && (!map_hwc || !xy || !out))) {
         psfm_set_error("psfm_grid_sample: bad argument (c=%d h=%d w=%d n=%lld)", ch, h, w, (long long)n);
         return PSFM_ERR_ARG;
@@ -209,6 +241,7 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
                                               double* out, psfm_solve_stats* stats_host, void* stream)
 {
     PSFM_CHECK_CTX(c);
+    PsfmGate gate(c->device, 0);
     if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
         psfm_set_error("psfm_optimize_location: bad argument (n=%lld h=%d w=%d)", (long long)n, h, w);
         return PSFM_ERR_ARG;
@@ -246,7 +279,7 @@ struct PsfmOccPipeline {
 
 static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_t* occ, const float* flows_f2,
                                    const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
-                                   void* stream, PsfmOccPipeline* pipe)
+                                   void* stream, PsfmOccPipeline* pipe, bool device_is_ours)
 {
     PSFM_CHECK_CTX(c);
     const bool optimize = flows_f2 != nullptr;
@@ -296,7 +329,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     if (!optimize && c->chain_mode != 1) {
         const int maxb = psfm_persist_max_blocks(c);
         const int64_t need_blocks = (d.G + 255) / 256;
-        if (maxb > 0 && need_blocks <= maxb) {
+        if (maxb > 0 && need_blocks <= maxb && device_is_ours) {   // (not ours: another psfm call is in flight on this device)
             PsfmTrackDims dp = d;
             int64_t nb = need_blocks + need_blocks / 8 + 2;   // spare lanes for tracks born faster than lanes come back
             dp.nblk = (int)(nb < maxb ? nb : maxb);
@@ -315,12 +348,18 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
             if (pipe && (st = pipe->need(n_flows - 1, false, s)) != PSFM_OK) return st;   // every occlusion map
             bool fallback = false;
             {
-                // all blocks of the loop must be resident together: one such kernel per device at a time
-                std::lock_guard<std::mutex> lock(g_persist_mutex[c->device & 15]);
+                const bool trace = getenv("PSFM_TRACE") != nullptr;
+                const auto t1 = std::chrono::steady_clock::now();
                 if ((st = psfm_launch_chain_persist(c, dp, flows, occ, s)) != PSFM_OK) return st;
                 c->prof.begin(PSFM_PROF_FINALIZE, s);
                 st = psfm_finalize_persist(c, dp, &fallback, s);
                 c->prof.end(s);
+                if (trace) {
+                    const auto t2 = std::chrono::steady_clock::now();
+                    fprintf(stderr, "[psfm %p] persistent loop: launch+finalize %.2f ms, fallback %d, overflow %d\n", (void*)c,
+                            std::chrono::duration<double, std::milli>(t2 - t1).count(), (int)fallback,
+                            ((PsfmCounters*)c->host_pinned)->overflow);
+                }
             }
             if (st != PSFM_OK) return st;
             if (!fallback) {
@@ -440,7 +479,9 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
                                   const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
                                   void* stream)
 {
-    return psfm_track_impl(c, flows, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, nullptr);
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    PsfmGate gate(c->device, psfm_wants_persist(c, flows_f2 != nullptr, h, w, ratio));
+    return psfm_track_impl(c, flows, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, nullptr, gate.exclusive);
 }
 
 // The compute part of the stage entry (main_connect_point_trajectories.py:36-53): flow_check of the stride-1 (and
@@ -453,6 +494,7 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
 {
     PSFM_CHECK_CTX(c);
     const bool optimize = flows_f2 != nullptr;
+    PsfmGate gate(c->device, psfm_wants_persist(c, optimize, h, w, ratio));
     if (n_flows < 1 || h < 2 || w < 2 || !flows_f || !flows_b || (optimize && n_flows > 1 && !flows_b2)) {
         psfm_set_error("psfm_connect: bad argument (n_flows=%d h=%d w=%d)", n_flows, h, w);
         return PSFM_ERR_ARG;
@@ -496,7 +538,7 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
         }
     }
     c->prof.end(side);
-    st = psfm_track_impl(c, flows_f, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, &pipe);
+    st = psfm_track_impl(c, flows_f, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, &pipe, gate.exclusive);
     // psfm_track_impl synchronised `stream`, which waited on every chunk: the side stream is idle too
     c->prof.pool.push_back(e_in);
     for (auto e : pipe.ready) c->prof.pool.push_back(e);

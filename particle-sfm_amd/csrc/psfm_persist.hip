@@ -637,7 +637,7 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
     a.survsh = a.bar + (2 * PSFM_NSHARD + 1) * 32;
     a.n_flows = d.n_flows; a.shift_b = d.shift_b; a.shift_d = d.shift_d;
     a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
-    a.spin_limit = 1 << 20;   // ~1 s of polling before a block gives up (the per-frame path then reruns the sequence)
+    a.spin_limit = 1 << 18;   // ~35 ms of polling before a block gives up (the per-frame path then reruns the sequence)
     if (const char* e = getenv("PSFM_PERSIST_SPIN_LIMIT")) a.spin_limit = atoi(e);   // tests: 0 forces the hand-over
     hipEvent_t e0 = nullptr, e1 = nullptr;
     c->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1, true);
