@@ -6,6 +6,7 @@
 A *step* is one pass of the hot path over one synthetic sequence: BASELINE.json configs[1] =
 100 x (1920x1080) forward/backward flow pairs, sample_ratio=2, chaining + occlusion only, i.e.
     flow_check(100 pairs) -> track(100 flows) -> finalize (ids, lengths, id-ordered CSR result),
+= ONE psfm_connect call (the compute part of the stage entry main_connect_point_trajectories.py:36-53),
 with the flow stacks already resident in HBM when the timed region starts and the result left in HBM.
 metric  = trajectory points per second (sum over all trajectories of their length / wall time).
 N > 1   = N independent sequences, one per rank/GPU (sequences are the unit the reference's driver
@@ -181,9 +182,12 @@ def main():
     ctx = _hip.context(local_rank)
 
     def step():
-        # flow_check, then the frame recurrence + finalize, back to back on one stream: every kernel runs alone, so
-        # the per-kernel durations (roofline) are the kernels' own.  psfm_connect (the stage entry's path) overlaps
-        # the two and is ~5 % faster end to end; it is reported separately below as "connect_overlap_ms_per_step".
+        # psfm_connect: with the device to itself it is ONE persistent launch that checks flow consistency and runs the
+        # recurrence (+ finalize).  The two-call form (flow_check, then psfm_track on the maps) and the per-frame-launch
+        # path are measured below, outside the timed region, on the same data.
+        return run_connect(flows_f, flows_b, None, None, THRES, RATIO, return_device=True)
+
+    def step_two_calls():
         _, occ = flow_check_device(flows_f, flows_b, THRES)
         return run_track(flows_f, occ, None, None, RATIO, return_device=True)
 
@@ -207,34 +211,35 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile()
     ctx.set_profiling(False)
-    # the overlapped variant (psfm_connect), outside the timed region
-    connect_ms = None
-    if not args.no_extras:
-        run_connect(flows_f, flows_b, None, None, THRES, RATIO, return_device=True)
+    # ---- the other ways of running the same step, outside the timed region ----
+    def timed(fn, mode, prof_stride):
+        ctx.set_chain_mode(mode)
+        fn()
+        ctx.set_profiling(prof_stride)
         sync_all()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            info_c = run_connect(flows_f, flows_b, None, None, THRES, RATIO, return_device=True)
+            inf = fn()
         sync_all()
-        connect_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-        assert int(info_c.n_points) == int(info.n_points)
-    # the other way of running the recurrence (one chain_step launch per frame), outside the timed region
-    per_frame = None
-    if not args.no_extras and int(info.chain_mode) == 2:
-        ctx.set_chain_mode(1)
-        step()
-        ctx.set_profiling(8)
-        sync_all()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            info_p = step()
-        sync_all()
-        pf_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-        pp = ctx.profile()["chain_step"]
+        ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        pr = ctx.profile()
         ctx.set_profiling(False)
         ctx.set_chain_mode(0)
-        assert int(info_p.n_points) == int(info.n_points) and int(info_p.n_traj) == int(info.n_traj)
-        per_frame = {"ms_per_step": pf_ms, "chain_step_avg_launch_us": 1e3 * pp["total_ms"] / max(pp["launches"], 1)}
+        assert int(inf.n_points) == int(info.n_points) and int(inf.n_traj) == int(info.n_traj)
+        return ms, pr, inf
+    variants = None
+    if not args.no_extras:
+        us = lambda pr, k: 1e3 * pr[k]["total_ms"] / max(pr[k]["launches"], 1)
+        ms2, pr2, inf2 = timed(step_two_calls, 0, 1)       # flow_check kernel, then the persistent loop on its maps
+        ms1, pr1, inf1 = timed(step, 1, 8)                 # psfm_connect with one chain_step launch per frame
+        variants = {
+            "two_calls_flow_check_then_track": {"ms_per_step": ms2, "chain_mode": int(inf2.chain_mode),
+                                                "flow_check_launch_us": us(pr2, "flow_check"),
+                                                "chain_launch_us": us(pr2, "chain_step"),
+                                                "chain_us_per_step": us(pr2, "chain_step") / (n_flows if int(inf2.chain_mode) == 2 else 1)},
+            "per_frame_launches_overlapped": {"ms_per_step": ms1, "chain_mode": int(inf1.chain_mode),
+                                              "chain_step_avg_launch_us": us(pr1, "chain_step")},
+        }
 
     points = int(info.n_points)
     import psfm_dist
@@ -257,14 +262,19 @@ def main():
         ch = prof["chain_step"]
         chain_us = 1e3 * ch["total_ms"] / max(ch["launches"], 1)
         persistent = int(info.chain_mode) == 2
+        fused = persistent and prof["flow_check"]["launches"] == 0    # no stand-alone flow_check ran: it is in the loop
         frame_bytes = chain_bytes
+        fc_step_bytes = 17.0 * P
         if persistent:
             # ONE launch runs all n_flows steps (psfm_chain_persist_kernel): algorithmic bytes per launch = the per-step
-            # figure x n_flows -- the positions it keeps in registers between steps are still counted as read
-            chain_bytes = chain_bytes * n_flows
+            # figure x n_flows -- the positions it keeps in registers between steps are still counted as read.  When
+            # psfm_connect fuses flow_check into the loop, that kernel also moves flow_check's 17P bytes per step.
+            frame_bytes = chain_bytes + (fc_step_bytes if fused else 0.0)
+            chain_bytes = frame_bytes * n_flows
         achieved = chain_bytes / (chain_us * 1e-6) / 1e9 if chain_us > 0 else 0.0
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_chain_persist.json" if persistent else "traffic_chain_step.json")
+        tfile = os.path.join(ROOT, "profiles", ("traffic_chain_fused.json" if fused else "traffic_chain_persist.json")
+                             if persistent else "traffic_chain_step.json")
         if os.path.exists(tfile):
             try:
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
@@ -273,6 +283,8 @@ def main():
         fc = prof["flow_check"]
         fc_us = 1e3 * fc["total_ms"] / max(fc["launches"], 1)
         fc_bytes = 17.0 * P * n_flows
+        if fused and variants:    # the stand-alone kernel, from the two-call variant
+            fc_us = variants["two_calls_flow_check_then_track"]["flow_check_launch_us"]
         out = {
             "metric": "trajectory-points/s", "value": total_points * args.steps / dt_max,
             "unit": "trajectory-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,21 +295,27 @@ def main():
                        "frames": n_frames, "height": H, "width": W, "sample_ratio": RATIO,
                        "flow_check_thres": THRES, "points_per_sequence": points, "trajectories": int(info.n_traj),
                        "parallelism": "sequence-per-gpu x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "psfm_chain_persist_kernel" if persistent else "psfm_chain_step_kernel",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("psfm_chain_persist_kernel (flow_check fused in)" if fused else "psfm_chain_persist_kernel")
+                         if persistent else "psfm_chain_step_kernel",
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": chain_bytes, "avg_launch_us": chain_us,
                          "steps_per_launch": n_flows if persistent else 1,
                          "us_per_step": chain_us / (n_flows if persistent else 1),
-                         "bytes_per_step": frame_bytes, "avg_alive_tracks": A},
+                         "bytes_per_step": frame_bytes,
+                         "bytes_per_step_breakdown": {"chain_step": frame_bytes - (fc_step_bytes if fused else 0.0),
+                                                      "flow_check": fc_step_bytes if fused else 0.0},
+                         "avg_alive_tracks": A},
             "kernels": {
-                "flow_check": {"avg_launch_us": fc_us, "bytes_per_launch": fc_bytes,
+                "flow_check": {"note": "stand-alone kernel (two-call variant); in the timed step it is fused into the loop"
+                                       if fused else "stand-alone kernel",
+                               "avg_launch_us": fc_us, "bytes_per_launch": fc_bytes,
                                "achieved_GBs": fc_bytes / (fc_us * 1e-6) / 1e9 if fc_us > 0 else 0.0,
                                "frac": fc_bytes / (fc_us * 1e-6) / 1e9 / HBM_PEAK_GBS if fc_us > 0 else 0.0},
                 "respawn_avg_us": 1e3 * prof["respawn"]["total_ms"] / max(prof["respawn"]["launches"], 1),
                 "finalize_avg_us": 1e3 * prof["finalize"]["total_ms"] / max(prof["finalize"]["launches"], 1),
-                "connect_overlap_ms_per_step": connect_ms,
-                "per_frame_launch_path": per_frame,
+                "variants": variants,
             },
         }
         out["kernels"].pop("respawn_avg_us", None)   # respawn is fused into chain_step

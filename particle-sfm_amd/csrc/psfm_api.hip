@@ -279,8 +279,12 @@ struct PsfmOccPipeline {
 
 static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_t* occ, const float* flows_f2,
                                    const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
-                                   void* stream, PsfmOccPipeline* pipe, bool device_is_ours)
+                                   void* stream, PsfmOccPipeline* pipe, bool device_is_ours,
+                                   const float* fuse_flows_b = nullptr, float fuse_thres = 0.f, int64_t occ_pitch = 0)
 {
+    // fuse_flows_b != NULL (psfm_connect): `occ` is still EMPTY -- the persistent loop computes the maps itself (fused
+    // flow_check); any other way of running the recurrence first fills them with the stand-alone kernel.
+    if (occ_pitch == 0) occ_pitch = (int64_t)h * w;
     PSFM_CHECK_CTX(c);
     const bool optimize = flows_f2 != nullptr;
     if (n_flows < 1 || h < 2 || w < 2 || ratio < 1 || !flows || !occ || (optimize && !occ_s2 && n_flows > 1)) {
@@ -350,7 +354,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
             {
                 const bool trace = getenv("PSFM_TRACE") != nullptr;
                 const auto t1 = std::chrono::steady_clock::now();
-                if ((st = psfm_launch_chain_persist(c, dp, flows, occ, s)) != PSFM_OK) return st;
+                if ((st = psfm_launch_chain_persist(c, dp, flows, occ, occ_pitch, fuse_flows_b, fuse_thres, s)) != PSFM_OK) return st;
                 c->prof.begin(PSFM_PROF_FINALIZE, s);
                 st = psfm_finalize_persist(c, dp, &fallback, s);
                 c->prof.end(s);
@@ -389,6 +393,13 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         psfm_set_error("psfm_track: chain mode 2 (persistent loop) applies to track mode only");
         return PSFM_ERR_ARG;
     }
+    if (fuse_flows_b) {   // the persistent loop did not run (or gave up): the maps it would have produced, stand-alone
+        c->prof.begin(PSFM_PROF_FLOW_CHECK, s);
+        for (int f = 0; f < n_flows; ++f)
+            if ((st = psfm_launch_flow_check(flows + (size_t)f * P * 2, fuse_flows_b + (size_t)f * P * 2, 1, h, w, fuse_thres,
+                                             const_cast<uint8_t*>(occ) + (size_t)f * occ_pitch, nullptr, s)) != PSFM_OK) return st;
+        c->prof.end(s);
+    }
     if ((st = psfm_launch_track_init(c, d, s)) != PSFM_OK) return st;
     int64_t total_iters = 0;
     // Frame loop.  In track_optimize mode nothing returns to the host inside a window of PSFM_CHECK frames: each
@@ -405,7 +416,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         // track.py:31-47 / track_optimize.py:31-50, one loop iteration:
         // one launch = births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
         if (pipe && (st = pipe->need(f, false, s)) != PSFM_OK) return st;
-        st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * P, f, s);
+        st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * occ_pitch, f, s);
         if (st != PSFM_OK) return st;
         if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
             if (pipe && (st = pipe->need(f - 1, true, s)) != PSFM_OK) return st;
@@ -502,6 +513,20 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
     hipStream_t s = (hipStream_t)stream;
     const size_t P = (size_t)h * w;
     psfm_status st;
+    // Track mode with the device to ourselves: ONE persistent launch computes the occlusion maps AND runs the recurrence
+    // (the blocks check flow consistency in the time they would otherwise wait at the frame barriers).  The maps are
+    // written through to HBM by their producers and first read by other XCDs a few barriers later; a cache line must
+    // not straddle two maps, hence the 128-byte pitch (caller-provided buffers qualify when H*W is a multiple of 128).
+    if (gate.exclusive && !optimize && (!occ || P % 128 == 0)) {
+        int64_t pitch = (int64_t)P;
+        if (!occ) {
+            pitch = (int64_t)((P + 127) / 128 * 128);
+            if ((st = c->occ_own.ensure((size_t)pitch * (size_t)n_flows)) != PSFM_OK) return st;
+            occ = c->occ_own.as<uint8_t>();
+        }
+        return psfm_track_impl(c, flows_f, occ, nullptr, nullptr, n_flows, h, w, ratio, info, stream, nullptr, true, flows_b,
+                               thres, pitch);
+    }
     if (!occ) {
         if ((st = c->occ_own.ensure(P * (size_t)n_flows)) != PSFM_OK) return st;
         occ = c->occ_own.as<uint8_t>();

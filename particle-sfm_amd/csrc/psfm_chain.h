@@ -20,6 +20,23 @@ template <bool COH> __device__ __forceinline__ void psfm_mark(uint8_t* p, uint8_
     if (COH) psfm_coh_st(p, v); else *p = v;
 }
 
+// ---- one pixel of flow_check (utils.py:58-105): forward flow f at pixel (x,y), backward field B ----
+__device__ __forceinline__ uint8_t psfm_flow_check_px(const float2* __restrict__ B, int x, int y, float2 f, int H, int W,
+                                                      float cw, float ch, float thres, float* err)
+{
+    // utils.py:73-78: pixel coordinate + flow in fp32
+    const float X = __fadd_rn((float)x, f.x), Y = __fadd_rn((float)y, f.y);
+    const PsfmTaps t = psfm_taps(X, Y, cw, ch, H, W);           // utils.py:79-82
+    const float2 b = psfm_sample_flow(B, H, W, t);
+    // utils.py:87: torch.norm(warp + flow, dim=1) == sqrtf(fma(ev,ev, eu*eu)); sqrtf is correctly rounded
+    const float eu = __fadd_rn(b.x, f.x), ev = __fadd_rn(b.y, f.y);
+    const float e = sqrtf(__fmaf_rn(ev, ev, __fmul_rn(eu, eu)));
+    // utils.py:58-68 (oob) and :88-91 (union)
+    const bool oob = (X < 0.0f) | (X > (float)(W - 1)) | (Y < 0.0f) | (Y > (float)(H - 1));
+    *err = e;
+    return (uint8_t)((e > thres) | oob);
+}
+
 struct PsfmStep { bool alive; double2 next; };
 
 // One chain step split in two so that the caller can issue the gathers of several steps back to back and keep

@@ -134,8 +134,9 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
 // ---- persistent frame loop (psfm_persist.hip) ---------------------------------------------------
 int psfm_persist_max_blocks(psfm_ctx* c);
 int psfm_persist_guests(void);   // LDS-resident extra lanes per block
+// flows_b != NULL: the occlusion maps are computed inside the loop (fused flow_check) and written to `occ`
 psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ,
-                                      hipStream_t s);
+                                      int64_t occ_pitch, const float* flows_b, float thres, hipStream_t s);
 
 // ---- finalize (psfm_finalize.hip) -----------------------------------------------------------
 psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);

@@ -43,6 +43,11 @@
 #ifndef PP_KEEP
 #define PP_KEEP 0      // free thread lanes a block keeps for its own future births; only the excess goes to the global stacks
 #endif
+#ifndef PP_FC_AHEAD
+#define PP_FC_AHEAD 4    // fused flow_check: how far ahead of the current step a waiting wave may work (3 is mandatory).
+                         // 1080p sequence end to end: window 4 -> 2.80 ms, 3 -> 2.84, 8 -> 2.96, unbounded -> 3.19 (front-loads the
+                         // memory system), slices also behind the barrier -> 3.12, always one slice per frame -> 2.86
+#endif
 #define PP_GUESTS 32   // extra lanes per block whose state lives in LDS (stepped as phase-2 entries)
 #define PP_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))
 
@@ -62,7 +67,11 @@
 #define PP_PEND (-2)
 
 struct PsfmPersistArgs {
-    const float2* flows; const uint8_t* occ;   // (n_flows,H,W,2) f32 / (n_flows,H,W) u8
+    const float2* flows; const uint8_t* occ;   // (n_flows,H,W,2) f32 / n_flows maps of H*W u8, `occ_pitch` bytes apart
+    // fused flow_check (psfm_connect): the blocks compute the occlusion maps themselves, in the time they would spend
+    // waiting at the frame barriers, always at least three frames ahead of the step that samples them
+    const float2* flows_b; uint8_t* occ_w; float thres; int fc;
+    int64_t occ_pitch; PsfmFastDiv wdiv;
     int H, W; float cw, ch;
     int ratio, GW, GH, G;
     double2* log; int cap;                     // (n_flows+1, cap): cap = gridDim.x * (256 + PP_GUESTS) columns
@@ -118,19 +127,81 @@ __device__ __forceinline__ int psfm_record_slot(int* s_rec_cnt, bool dead)
 }
 
 #ifdef PSFM_TIMELINE
-__device__ unsigned long long g_pp_tl[4096 * 8];
+__device__ unsigned long long g_pp_tl[2 * 4096 * 8];   // two consecutive frames
 __device__ int g_pp_st[4096 * 8];
 __device__ int g_pp_tl_frame = -1;
-#define PP_TL(k) do { if (t == g_pp_tl_frame && tid == 0) g_pp_tl[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PP_TL(k) do { if ((unsigned)(t - g_pp_tl_frame) < 2u && tid == 0) g_pp_tl[((t - g_pp_tl_frame) * 4096 + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int psfm_debug_persist_timeline(int frame, unsigned long long* out_host, int n_blocks)
 {
     if (out_host && n_blocks < 0) return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pp_st), (size_t)(-n_blocks) * 32) != hipSuccess;
-    if (out_host) return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pp_tl), (size_t)n_blocks * 64) != hipSuccess;
+    if (out_host) return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pp_tl), (size_t)2 * 4096 * 64) != hipSuccess;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_tl_frame), &frame, sizeof(int)) != hipSuccess;
 }
 #else
 #define PP_TL(k) do {} while (0)
 #endif
+
+// ---- device-wide barrier #k (k = 0: prologue, k = t + 1: end of frame t).  Arrival: 64 shard counters -> the last
+// arriver of a shard bumps the top counter -> the last of those publishes k + 1 in 64 replicated release flags ----
+__device__ __forceinline__ void psfm_bar_arrive(const PsfmPersistArgs& a, int shard, int k, int lane)
+{
+    int last = 0;
+    if (lane == 0) {
+        const int nblk = (int)gridDim.x;
+        const unsigned members = (unsigned)((nblk - shard + PSFM_NSHARD - 1) / PSFM_NSHARD);
+        const unsigned old = __hip_atomic_fetch_add(a.bar + shard * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == members * (unsigned)(k + 1)) {
+            const unsigned nsh = (unsigned)(nblk < PSFM_NSHARD ? nblk : PSFM_NSHARD);
+            const unsigned o2 = __hip_atomic_fetch_add(a.bar + 64 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (o2 + 1 == nsh * (unsigned)(k + 1)) last = 1;
+        }
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (last) psfm_coh_st(a.bar + (65 + lane) * 32, (unsigned)(k + 1));
+}
+// thread 0 only: spin until barrier #k is released; false = gave up / somebody else did
+__device__ __forceinline__ bool psfm_bar_wait(const PsfmPersistArgs& a, int shard, int k)
+{
+    const unsigned* flag = a.bar + (65 + shard) * 32;
+    int n = 0;
+    while (psfm_coh_ld(flag) < (unsigned)(k + 1)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++n > a.spin_limit) { atomicOr(&a.ctr->overflow, 8); psfm_coh_st(&a.ctr->abort, 1); return false; }
+        if ((n & 127) == 0 && psfm_coh_ld(&a.ctr->abort)) return false;
+    }
+    return true;
+}
+
+// ---- fused flow_check (utils.py:94-105): this thread's pixels of frame pair f.  Chunks of 1024 pixels, one per block
+// and round (block-strided over the map); a thread owns 4 pixels 256 apart, so every load / store instruction of a
+// wave is one contiguous run.  The mask bytes are written through: other XCDs sample them a few frames later ----
+__device__ __forceinline__ void psfm_fc_slice(const PsfmPersistArgs& a, int f, int tid)
+{
+    const int P = a.H * a.W;
+    const float2* __restrict__ F = a.flows + (size_t)f * P;
+    const float2* __restrict__ B = a.flows_b + (size_t)f * P;
+    uint8_t* O = a.occ_w + (size_t)f * a.occ_pitch;
+    for (int c0 = blockIdx.x * 1024; c0 < P; c0 += gridDim.x * 1024) {
+        const int p0 = c0 + tid;
+        float2 fv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = p0 + k * 256;
+            fv[k] = p < P ? psfm_ld(F, (unsigned)p * 8u) : make_float2(0.f, 0.f);
+        }
+        int y = (int)psfm_fastdiv((unsigned)p0, a.wdiv), x = p0 - y * a.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = p0 + k * 256;
+            if (p >= P) break;
+            float e;
+            const uint8_t o = psfm_flow_check_px(B, x, y, fv[k], a.H, a.W, a.cw, a.ch, a.thres, &e);
+            psfm_coh_st(O + p, o);
+            x += 256;
+            while (x >= a.W) { x -= a.W; ++y; }
+        }
+    }
+}
 
 // entry k of the phase-2 list: kind 1 newborn (ex = grid index, host = local PEND thread or -1), kind 2 adopted
 // track (ex = owner thread), kind 3 live guest (ex = guest slot), kind 0 none
@@ -179,14 +250,21 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
     s_xf[tid] = 0;
     if (tid < PP_GUESTS) s_gbf[tid] = -1;
     if (tid == 0) { s_rec_cnt = 0; s_alive_any = 0; }
+    // ---- prologue: the occlusion maps of the first two frame pairs, then barrier #0 ----
+    int fc_next = 0;     // (per wave) frame pairs whose occlusion map this wave has finished its share of
+    if (a.fc) {
+        for (; fc_next < 2 && fc_next < a.n_flows; ++fc_next) psfm_fc_slice(a, fc_next, tid);
+        __builtin_amdgcn_s_waitcnt(0);
+    }
     __syncthreads();
+    if (tid / PSFM_WAVE == PP_NW - 1) psfm_bar_arrive(a, shard, 0, tid & (PSFM_WAVE - 1));
 
     for (int t = 0; t < a.n_flows; ++t) {
         asm volatile("" : "+v"(tid));
         L = blockIdx.x * PP_BLOCK + tid;
         const int lane = tid & (PSFM_WAVE - 1), wave = tid / PSFM_WAVE;
         PsfmFrameView v;
-        v.flow = a.flows + (size_t)t * P; v.occ = a.occ + (size_t)t * P;
+        v.flow = a.flows + (size_t)t * P; v.occ = a.occ + (size_t)t * a.occ_pitch;
         v.H = a.H; v.W = a.W; v.cw = a.cw; v.ch = a.ch; v.ratio = a.ratio; v.GW = a.GW; v.GH = a.GH; v.rdiv = a.rdiv;
         v.blocked_cur = a.maps + (size_t)(t % 3) * a.G; v.stamp_cur = 1;
         double2* log_cur = a.log + (size_t)t * a.cap;
@@ -222,23 +300,24 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                 }
             }
         };
-        if (wave < PP_PRE_WAVES) do_E();
+        // (letting a block that finds barrier t-1 already released skip ahead and run E behind C made no difference)
+        const bool e_first = wave < PP_PRE_WAVES;
+        if (e_first) do_E();
 
-        // ---- B: barrier t-1 ----
-        if (t > 0) {
-            if (tid == 0) {
-                const unsigned* flag = a.bar + (65 + shard) * 32;
-                int ok = 1, n = 0;
-                while (psfm_coh_ld(flag) < (unsigned)t) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++n > a.spin_limit) { atomicOr(&a.ctr->overflow, 8); psfm_coh_st(&a.ctr->abort, 1); ok = 0; break; }
-                    if ((n & 127) == 0 && psfm_coh_ld(&a.ctr->abort)) { ok = 0; break; }
-                }
-                s_ok = ok;
+        // ---- B: barrier #t (end of frame t-1; #0 = prologue).  While it is not released the waves work ahead on the
+        //      occlusion maps (each wave for itself: a slice has no LDS and no block barrier in it) ----
+        if (a.fc) {
+            const unsigned* flag = a.bar + (65 + shard) * 32;
+            const int fc_lim = t + PP_FC_AHEAD < a.n_flows ? t + PP_FC_AHEAD : a.n_flows;
+            while (fc_next < fc_lim) {
+                if (__builtin_amdgcn_readfirstlane((int)psfm_coh_ld(flag)) >= t + 1) break;
+                psfm_fc_slice(a, fc_next, tid);
+                ++fc_next;
             }
-            __syncthreads();
-            if (!s_ok) return;
         }
+        if (tid == 0) s_ok = psfm_bar_wait(a, shard, t) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) return;
 
 #ifndef PP_NO_SETPRIO
         __builtin_amdgcn_s_setprio(3);   // behind the barrier a block is on the frame's critical path ...
@@ -259,7 +338,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
             h0 = psfm_coh_ld(h); h1 = psfm_coh_ld(h + 1); h2 = psfm_coh_ld(h + 2);
         }
 
-        if (wave >= PP_PRE_WAVES) do_E();
+        if (!e_first) do_E();
 
         // ---- C (consume): respawn test, adoption ----
         bool birth = false;
@@ -532,25 +611,19 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         }
         if (tid == 0 && s_alive_any) { psfm_coh_st(a.survsh + (cur * PSFM_NSHARD + shard) * 32, (unsigned)(t + 1)); s_alive_any = 0; }
         // ---- F: everything this block wrote is acknowledged -> arrive ----
+        // (a step samples the occlusion map of its frame as early as right after the previous arrival, when only the
+        // barrier before that one is known to be complete: maps up to t+2 must be finished before arriving at #t+1)
+        if (a.fc) {
+            const int need = t + 3 < a.n_flows ? t + 3 : a.n_flows;
+            for (; fc_next < need; ++fc_next) psfm_fc_slice(a, fc_next, tid);
+        }
         __builtin_amdgcn_s_waitcnt(0);
         PP_TL(6);
         __syncthreads();
         PP_TL(7);
-        if (tid < PSFM_WAVE) {
-            int last = 0;
-            if (tid == 0) {
-                const int nblk = (int)gridDim.x;
-                const unsigned members = (unsigned)((nblk - shard + PSFM_NSHARD - 1) / PSFM_NSHARD);
-                const unsigned old = __hip_atomic_fetch_add(a.bar + shard * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old + 1 == members * (unsigned)(t + 1)) {
-                    const unsigned nsh = (unsigned)(nblk < PSFM_NSHARD ? nblk : PSFM_NSHARD);
-                    const unsigned o2 = __hip_atomic_fetch_add(a.bar + 64 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (o2 + 1 == nsh * (unsigned)(t + 1)) last = 1;
-                }
-            }
-            last = __builtin_amdgcn_readfirstlane(last);
-            if (last) psfm_coh_st(a.bar + (65 + tid) * 32, (unsigned)(t + 1));
-        }
+        // (the LAST wave arrives: wave 0 carries the phase-2 work and the barrier poll of the next frame and should not sit
+        // out the round trip of the arrival atomic)
+        if (wave == PP_NW - 1) psfm_bar_arrive(a, shard, t + 1, lane);
 #ifndef PP_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);   // ... its next step ahead of the barrier is not
 #endif
@@ -612,7 +685,8 @@ int psfm_persist_max_blocks(psfm_ctx* c)
     return c->persist_max_blocks;
 }
 
-psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, hipStream_t s)
+psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ,
+                                      int64_t occ_pitch, const float* flows_b, float thres, hipStream_t s)
 {
     const size_t bar_bytes = (size_t)(4 * PSFM_NSHARD + 1) * 128;   // barrier lines + 2 x 64 survivor words
     PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.G * 3, s));
@@ -622,6 +696,9 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
                        c->shards.as<PsfmShard>(), (int)d.G);
     PsfmPersistArgs a;
     a.flows = (const float2*)flows; a.occ = occ;
+    a.occ_pitch = occ_pitch;
+    a.flows_b = (const float2*)flows_b; a.occ_w = const_cast<uint8_t*>(occ); a.thres = thres; a.fc = flows_b != nullptr;
+    a.wdiv = psfm_fastdiv_make((unsigned)d.W);
     a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch;
     a.ratio = d.ratio; a.GW = d.GW; a.GH = d.GH; a.G = (int)d.G;
     a.log = c->log.as<double2>(); a.cap = (int)d.cap; a.cap_main = d.nblk * PP_BLOCK;

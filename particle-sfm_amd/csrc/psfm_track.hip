@@ -30,22 +30,6 @@
 // near p+F) + P (occ) = 17P.  Vector form: a thread owns 4 consecutive pixels -> F arrives as two
 // 16-byte loads, the mask leaves as one 4-byte store; blockIdx.y = frame pair (one launch for all pairs).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint8_t psfm_flow_check_px(const float2* __restrict__ B, int x, int y, float2 f, int H, int W,
-                                                      float cw, float ch, float thres, float* err)
-{
-    // utils.py:73-78: pixel coordinate + flow in fp32
-    const float X = __fadd_rn((float)x, f.x), Y = __fadd_rn((float)y, f.y);
-    const PsfmTaps t = psfm_taps(X, Y, cw, ch, H, W);           // utils.py:79-82
-    const float2 b = psfm_sample_flow(B, H, W, t);
-    // utils.py:87: torch.norm(warp + flow, dim=1) == sqrtf(fma(ev,ev, eu*eu)); sqrtf is correctly rounded
-    const float eu = __fadd_rn(b.x, f.x), ev = __fadd_rn(b.y, f.y);
-    const float e = sqrtf(__fmaf_rn(ev, ev, __fmul_rn(eu, eu)));
-    // utils.py:58-68 (oob) and :88-91 (union)
-    const bool oob = (X < 0.0f) | (X > (float)(W - 1)) | (Y < 0.0f) | (Y > (float)(H - 1));
-    *err = e;
-    return (uint8_t)((e > thres) | oob);
-}
-
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_kernel(
     const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, int H, int W, float cw, float ch,
     float thres, uint8_t* __restrict__ occ_out, float* __restrict__ err_out)

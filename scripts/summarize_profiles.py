@@ -3,7 +3,7 @@
   <tag>_pmc_summary.json   per-kernel averages of the PMC passes (per launch)
   <tag>_bench.json         the default bench line
   traffic_chain_{step,persist}.json  HBM bytes per launch of the chain kernels (FETCH_SIZE calibrated on flow_check)
-Usage: python scripts/summarize_profiles.py r01_d
+Usage: python scripts/summarize_profiles.py r01_d [--fused]   (--fused: the bench step ran psfm_connect with flow_check inside the loop)
 """
 import csv, json, os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,7 +48,7 @@ H, W, NF = 1080, 1920, 100
 fc = summary.get("psfm_flow_check_x4_kernel")
 if fc and "FETCH_SIZE" in fc:
     cal = (16.0 * H * W * NF / 1024.0) / fc["FETCH_SIZE"]      # known read volume / counter (KB)
-    for kern, out in (("psfm_chain_step_kernel<2>", "traffic_chain_step.json"), ("psfm_chain_persist_kernel<2>", "traffic_chain_persist.json")):
+    for kern, out in (("psfm_chain_step_kernel<2>", "traffic_chain_step.json"), ("psfm_chain_persist_kernel<2>", "traffic_chain_fused.json" if "--fused" in sys.argv else "traffic_chain_persist.json")):
         k = summary.get(kern)
         if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
             continue

@@ -22,9 +22,11 @@ for it in range(3):
     info = run_track(d["flows_f"], occ, None, None, r, return_device=True)
     torch.cuda.synchronize()
 NB = 2048
-buf = np.zeros((NB, 8), np.uint64)
-assert fn(0, buf.ctypes.data, NB) == 0
+buf2 = np.zeros((2, 4096, 8), np.uint64)
+assert fn(0, buf2.ctypes.data, NB) == 0
+buf = buf2[0, :NB]
 t = buf.astype(np.int64)
+t_next = buf2[1, :NB].astype(np.int64)
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0
 names = ["frame start", "barrier passed", "C done (sync1)", "issue+atomics", "sync2", "results done", "stores acked", "sync F"]
@@ -61,3 +63,11 @@ for b in order[-16:]:
     print("  %4d %6.1f %s  nb=%d nad=%d npd=%d ngl=%d need=%d push=%d" % (b, dur[b], np.round(ph[b], 1), st[b, 0], st[b, 1], st[b, 2], st[b, 3], st[b, 5], st[b, 6]))
 big = st[:, 0] >= 64
 print("blocks with >= 64 births: %d, post-barrier median %.1f max %.1f; others median %.1f max %.1f" % (big.sum(), np.median(dur[big]) if big.any() else 0, dur[big].max() if big.any() else 0, np.median(dur[~big]), dur[~big].max()))
+
+usn = (t_next - t0) / 100.0
+print("frame t: last sync F %.2f | frame t+1: first barrier pass %.2f, median %.2f, last %.2f  => release latency after the last arrival %.2f us" % (
+    us[:, 7].max(), usn[:, 1].min(), np.median(usn[:, 1]), usn[:, 1].max(), usn[:, 1].min() - us[:, 7].max()))
+print("period (median barrier pass t+1 - t): %.2f us" % (np.median(usn[:, 1]) - np.median(us[:, 1])))
+late = usn[:, 0] - us[:, 7]
+print("arrive -> next frame start: median %.2f ; next frame start -> barrier pass: median %.2f min %.2f (blocks that were last: %s)" % (
+    np.median(late), np.median(usn[:, 1] - usn[:, 0]), (usn[:, 1] - usn[:, 0]).min(), np.round(np.sort(usn[:, 1] - usn[:, 0])[:5], 2)))
