@@ -127,8 +127,12 @@ psfm_status psfm_track(psfm_ctx* ctx, const float* flows, const uint8_t* occ, co
                        psfm_track_info* info_host, void* stream);
 
 /* The compute part of the stage entry main_connect_point_trajectories.py:36-53 in one call: flow_check of the
- * stride-1 stacks (and of the stride-2 stacks when flows_f2 != NULL) followed by track / track_optimize, with the
- * occlusion maps produced on an internal side stream while the frame loop consumes them.
+ * stride-1 stacks (and of the stride-2 stacks when flows_f2 != NULL) followed by track / track_optimize.
+ *   - track mode with the device to itself (see psfm_ctx_set_chain_mode): ONE persistent launch that computes the
+ *     occlusion maps and runs the recurrence -- the blocks check flow consistency in the time they would otherwise wait
+ *     at the frame barriers (a caller-provided `occ` takes part when H*W is a multiple of 128, else the stand-alone
+ *     kernel fills it first);
+ *   - otherwise the maps are produced on an internal side stream while the frame loop consumes them.
  *   flows_f, flows_b   (n_flows,H,W,2) f32      flows_f2, flows_b2  (n_flows-1,H,W,2) f32 or NULL
  *   occ, occ_s2        optional outputs (n_flows,H,W) / (n_flows-1,H,W) u8; NULL = kept in the context
  * Result access as for psfm_track.  Synchronises `stream`. */

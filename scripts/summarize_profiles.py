@@ -46,8 +46,16 @@ json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), inde
 # ---- traffic of the chain kernels ----
 H, W, NF = 1080, 1920, 100
 fc = summary.get("psfm_flow_check_x4_kernel")
+cal, cal_src = None, ""
 if fc and "FETCH_SIZE" in fc:
     cal = (16.0 * H * W * NF / 1024.0) / fc["FETCH_SIZE"]      # known read volume / counter (KB)
+    cal_src = "calibrated in the same run on psfm_flow_check_x4_kernel"
+else:   # the stand-alone flow_check kernel did not run (fused step): the calibration of the previous collection
+    prev = os.path.join(dst, "traffic_chain_persist.json")
+    if os.path.exists(prev):
+        cal = json.load(open(prev))["fetch_calibration"]
+        cal_src = "calibration factor taken from profiles/traffic_chain_persist.json (same device type, flow_check kernel of that run)"
+if cal:
     for kern, out in (("psfm_chain_step_kernel<2>", "traffic_chain_step.json"), ("psfm_chain_persist_kernel<2>", "traffic_chain_fused.json" if "--fused" in sys.argv else "traffic_chain_persist.json")):
         k = summary.get(kern)
         if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
@@ -57,7 +65,7 @@ if fc and "FETCH_SIZE" in fc:
                    "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1 --no-cpu --no-extras)" % tag,
                    "FETCH_SIZE_KB_per_launch": k["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": k["WRITE_SIZE"],
                    "fetch_calibration": cal,
-                   "calibration_note": "MI355X_MICROARCH.md: FETCH_SIZE is uncalibrated on gfx950 for accesses other than 16 B/lane -> calibrated in the same run on psfm_flow_check_x4_kernel, whose read volume is known exactly (16*H*W*100 bytes per launch, 8-byte/lane loads like the chain kernels' taps). WRITE_SIZE is used as is.",
+                   "calibration_note": "MI355X_MICROARCH.md: FETCH_SIZE is uncalibrated on gfx950 for accesses other than 16 B/lane -> " + cal_src + ", whose read volume is known exactly (16*H*W*100 bytes per launch, 8-byte/lane loads like the chain kernels' taps). WRITE_SIZE is used as is.",
                    "hbm_bytes_per_launch": hbm}, open(os.path.join(dst, out), "w"), indent=1)
         print(kern, "HBM bytes per launch %.4g (fetch cal %.3f)" % (hbm, cal))
 bj = os.path.join(src, "bench.json")

@@ -343,3 +343,29 @@ def test_persistent_mode_required_but_unavailable(pt):
     hip.check(hip.lib().psfm_track(ctx.handle, hip.ptr(fl), hip.ptr(oc), None, None, 1, H, W, 1, ctypes.byref(info),
                                    hip.current_stream_ptr()))
     assert info.chain_mode == 1 and info.n_traj == H * W      # zero flow: nothing moves, nothing dies
+
+
+@pytest.mark.parametrize("H,W,T,r", [(64, 128, 9, 2), (45, 70, 8, 1), (120, 160, 6, 3)])
+def test_connect_fused_flow_check(pt, chain_mode, H, W, T, r):
+    """psfm_connect = flow_check + track.  With the device to itself (default mode) the persistent loop computes the
+    occlusion maps itself; the maps it hands back and the trajectories equal the two-call form and the oracle."""
+    import ctypes
+    import torch
+    from oracle import oracle as orc
+    hip = pt.hip
+    d = psfm_synth.synth_sequence(T, H, W, seed=123 + H, sigma=0.3, n_occluders=2, stride2=False)
+    _, occ_o = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    O = orc.track(d["flows_f"], occ_o, r)
+    ff = torch.from_numpy(np.stack(d["flows_f"])).cuda()
+    fb = torch.from_numpy(np.stack(d["flows_b"])).cuda()
+    ctx = hip.context()
+    for give_occ in (False, True):
+        occ_out = torch.full((T - 1, H, W), 9, dtype=torch.uint8, device="cuda") if give_occ else None
+        info = hip.TrackInfo()
+        hip.check(hip.lib().psfm_connect(ctx.handle, hip.ptr(ff), hip.ptr(fb), None, None, T - 1, H, W, 1.0, r,
+                                         hip.ptr(occ_out), None, ctypes.byref(info), hip.current_stream_ptr()))
+        R = pt.trajectory._result_to_host(ctx, info)
+        assert info.chain_mode == (1 if chain_mode == 1 else 2)
+        assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+        if give_occ:
+            assert np.array_equal(occ_out.cpu().numpy().astype(bool), np.stack(occ_o).astype(bool))
