@@ -258,6 +258,11 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
     }
     __syncthreads();
     if (tid / PSFM_WAVE == PP_NW - 1) psfm_bar_arrive(a, shard, 0, tid & (PSFM_WAVE - 1));
+    if (a.fc) {   // step 0 samples map 0 ahead of its barrier wait: every block's share of it must be in HBM first
+        if (tid == 0) s_ok = psfm_bar_wait(a, shard, 0) ? 1 : 0;
+        __syncthreads();
+        if (!s_ok) return;
+    }
 
     for (int t = 0; t < a.n_flows; ++t) {
         asm volatile("" : "+v"(tid));

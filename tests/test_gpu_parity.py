@@ -320,10 +320,20 @@ def test_persistent_loop_hands_over_to_per_frame_launches(pt, chain_mode, monkey
     R = pt.track(d["flows_f"], occ, 1)
     assert R.info["chain_mode"] == 1
     assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+    # the same through psfm_connect, where the loop would also have produced the occlusion maps
+    import torch
+    ff = torch.from_numpy(np.stack(d["flows_f"])).cuda()
+    fb = torch.from_numpy(np.stack(d["flows_b"])).cuda()
+    Rc = pt.trajectory.run_connect(ff, fb, None, None, 1.0, 1)
+    assert Rc.info["chain_mode"] == 1
+    assert np.array_equal(Rc.birth, O.birth) and np.array_equal(Rc.length, O.length) and np.array_equal(Rc.xy, O.xy)
     monkeypatch.delenv("PSFM_PERSIST_SPIN_LIMIT")
     R = pt.track(d["flows_f"], occ, 1)
     assert R.info["chain_mode"] == 2
     assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+    Rc = pt.trajectory.run_connect(ff, fb, None, None, 1.0, 1)
+    assert Rc.info["chain_mode"] == 2
+    assert np.array_equal(Rc.birth, O.birth) and np.array_equal(Rc.length, O.length) and np.array_equal(Rc.xy, O.xy)
 
 
 def test_persistent_mode_required_but_unavailable(pt):
