@@ -379,3 +379,29 @@ def test_connect_fused_flow_check(pt, chain_mode, H, W, T, r):
         assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
         if give_occ:
             assert np.array_equal(occ_out.cpu().numpy().astype(bool), np.stack(occ_o).astype(bool))
+
+
+def test_random_sequences_all_paths_agree(pt):
+    """Randomised shapes / noise / occluders: psfm_connect with per-frame launches, psfm_connect with the fused
+    persistent loop and flow_check + psfm_track (persistent loop on ready maps) return identical trajectories."""
+    import torch
+    rng = np.random.default_rng(2024)
+    ctx = pt.hip.context()
+    try:
+        for i in range(24):
+            H, W = int(rng.integers(20, 300)), int(rng.integers(20, 400))
+            T, r = int(rng.integers(2, 30)), int(rng.choice([1, 2, 2, 3, 4]))
+            d = psfm_synth.synth_sequence_torch(T, H, W, seed=int(rng.integers(0, 1 << 30)), sigma=float(rng.choice([0.05, 0.3, 0.8])),
+                                                n_occluders=int(rng.integers(0, 4)), stride2=False)
+            res = []
+            for mode in (1, 0):
+                ctx.set_chain_mode(mode)
+                res.append(pt.trajectory.run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, r))
+            _, occ = pt.utils.flow_check_device(d["flows_f"], d["flows_b"], 1.0)
+            res.append(pt.trajectory.run_track(d["flows_f"], occ, None, None, r))
+            assert res[0].info["chain_mode"] == 1 and res[1].info["chain_mode"] == 2 and res[2].info["chain_mode"] == 2
+            for B in res[1:]:
+                assert np.array_equal(res[0].birth, B.birth) and np.array_equal(res[0].length, B.length)
+                assert np.array_equal(res[0].xy, B.xy), (i, H, W, T, r)
+    finally:
+        ctx.set_chain_mode(0)
