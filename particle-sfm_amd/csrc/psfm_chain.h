@@ -1,6 +1,6 @@
 // psfm_chain.h -- device building blocks of one chain step, shared by the per-frame kernel (psfm_track.hip) and the
 // persistent frame loop (psfm_persist.hip).  `A` is any struct with the fields the function names use
-// (flow, occ, H, W, cw, ch / ratio, rdiv, GW, GH, blocked_cur, stamp_cur).
+// (flow, occ, H, W, cw, ch, rcw, rch / ratio, rdiv, GW, GH, blocked_cur, stamp_cur).
 #pragma once
 #include "psfm_device.h"
 
@@ -21,20 +21,41 @@ template <bool COH> __device__ __forceinline__ void psfm_mark(uint8_t* p, uint8_
 }
 
 // ---- one pixel of flow_check (utils.py:58-105): forward flow f at pixel (x,y), backward field B ----
-__device__ __forceinline__ uint8_t psfm_flow_check_px(const float2* __restrict__ B, int x, int y, float2 f, int H, int W,
-                                                      float cw, float ch, float thres, float* err)
+// NEED_ERR: the caller wants the error map (reference API flow_check()): true division and the square root.
+// Otherwise only the mask: fast exact division (psfm_div_r) and the threshold moved under the root --
+// sqrtf is correctly rounded and monotonic, so sqrtf(s) > thres  <=>  s > t2 with t2 = max{s : sqrtf(s) <= thres}
+// (psfm_sq_threshold() on the host).
+struct PsfmFcParams { int H, W; float cw, ch, rcw, rch, thres, t2; };
+static inline float psfm_sq_threshold(float thres)
+{
+    if (thres != thres) return INFINITY;              // e > NaN is never true
+    if (thres < 0.0f) return -1.0f;                   // e >= 0 > thres for every non-NaN e
+    if (thres == INFINITY) return INFINITY;
+    float t2 = thres * thres;
+    if (t2 == INFINITY) t2 = 3.4028234663852886e38f;
+    while (sqrtf(t2) > thres) t2 = nextafterf(t2, -INFINITY);
+    while (t2 < 3.4028234663852886e38f && sqrtf(nextafterf(t2, INFINITY)) <= thres) t2 = nextafterf(t2, INFINITY);
+    return t2;
+}
+template <bool NEED_ERR>
+__device__ __forceinline__ uint8_t psfm_flow_check_px(const float2* __restrict__ B, int x, int y, float2 f, const PsfmFcParams& q,
+                                                      float* err)
 {
     // utils.py:73-78: pixel coordinate + flow in fp32
     const float X = __fadd_rn((float)x, f.x), Y = __fadd_rn((float)y, f.y);
-    const PsfmTaps t = psfm_taps(X, Y, cw, ch, H, W);           // utils.py:79-82
-    const float2 b = psfm_sample_flow(B, H, W, t);
+    const PsfmTaps t = psfm_taps_t<!NEED_ERR>(X, Y, q.cw, q.ch, q.rcw, q.rch, q.H, q.W);           // utils.py:79-82
+    const float2 b = psfm_sample_flow(B, q.H, q.W, t);
     // utils.py:87: torch.norm(warp + flow, dim=1) == sqrtf(fma(ev,ev, eu*eu)); sqrtf is correctly rounded
     const float eu = __fadd_rn(b.x, f.x), ev = __fadd_rn(b.y, f.y);
-    const float e = sqrtf(__fmaf_rn(ev, ev, __fmul_rn(eu, eu)));
+    const float s2 = __fmaf_rn(ev, ev, __fmul_rn(eu, eu));
     // utils.py:58-68 (oob) and :88-91 (union)
-    const bool oob = (X < 0.0f) | (X > (float)(W - 1)) | (Y < 0.0f) | (Y > (float)(H - 1));
-    *err = e;
-    return (uint8_t)((e > thres) | oob);
+    const bool oob = (X < 0.0f) | (X > (float)(q.W - 1)) | (Y < 0.0f) | (Y > (float)(q.H - 1));
+    if (NEED_ERR) {
+        const float e = sqrtf(s2);
+        *err = e;
+        return (uint8_t)((e > q.thres) | oob);
+    }
+    return (uint8_t)((s2 > q.t2) | oob);
 }
 
 struct PsfmStep { bool alive; double2 next; };
@@ -65,7 +86,7 @@ __device__ __forceinline__ void psfm_step_pin(PsfmStepLoads& L)
 template <class A>
 __device__ __forceinline__ PsfmStepLoads psfm_step_issue(const A& a, double2 p)
 {
-    const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
+    const PsfmTaps t = psfm_taps_fast((float)p.x, (float)p.y, a.cw, a.ch, a.rcw, a.rch, a.H, a.W);
     const PsfmTapIdx k = psfm_tap_idx(a.H, a.W, t);   // flow and occlusion map share the tap geometry
     PsfmStepLoads L;
     const unsigned onw = (unsigned)k.nw, one = (unsigned)k.ne, osw = (unsigned)k.sw, ose = (unsigned)k.se;
@@ -78,7 +99,7 @@ __device__ __forceinline__ PsfmStepLoads psfm_step_issue(const A& a, double2 p)
 template <class A>
 __device__ __forceinline__ PsfmStep psfm_step_finish(const A& a, double2 p, const PsfmStepLoads& L)
 {
-    const PsfmTaps t = psfm_taps((float)p.x, (float)p.y, a.cw, a.ch, a.H, a.W);
+    const PsfmTaps t = psfm_taps_fast((float)p.x, (float)p.y, a.cw, a.ch, a.rcw, a.rch, a.H, a.W);
     const int x0 = t.x0, y0 = t.y0, x1 = t.x0 + 1, y1 = t.y0 + 1;
     const bool xw = (x0 >= 0) & (x0 < a.W), xe = (x1 >= 0) & (x1 < a.W);
     const bool yn = (y0 >= 0) & (y0 < a.H), ys = (y1 >= 0) & (y1 < a.H);

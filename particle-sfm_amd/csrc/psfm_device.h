@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 #define PSFM_WAVE 64
 #pragma clang fp contract(off)
@@ -34,11 +35,35 @@ __device__ __forceinline__ PsfmTaps psfm_weights(float w, float n)
     return t;
 }
 
-// cw = (float)((W-1)/2.0), ch = (float)((H-1)/2.0) computed once on the host.
-__device__ __forceinline__ PsfmTaps psfm_taps(float x32, float y32, float cw, float ch, int H, int W)
+// ---- x / c for the launch-invariant divisor c = (size-1)/2, correctly rounded like the true division ----
+// r = the refined reciprocal of c (psfm_rcp_host() below, a kernel argument).  q = x*r; two residual corrections
+// e = fma(-c,q,x), q = fma(e,r,q): the core of the compiler's own IEEE expansion of `/` (v_div_scale / v_div_fmas /
+// v_div_fixup only add the scaling of extreme exponents and the inf/NaN/zero fix-ups), 5 VALU ops instead of 11.
+// Bit-identical to x / c for 1e-30 < |x| < 1e30 and x = +0 (1.2e9 random and adversarial operands over every
+// c = (W-1)/2, W <= 8192, with r perturbed by +-1 ulp: oracle/test_fastdiv.c).  Outside that range (no pixel coordinate
+// is) the quotient may differ (overflow -> NaN, -0 -> +0); both still sample "all taps out of bounds".  Callers that
+// must reproduce the reference's ERROR MAP for absurd flows use psfm_taps() with the true division.
+__device__ __forceinline__ float psfm_div_r(float x, float c, float r)
 {
-    float gx = __fsub_rn(__fdiv_rn(x32, cw), 1.0f);
-    float gy = __fsub_rn(__fdiv_rn(y32, ch), 1.0f);
+    float q = __fmul_rn(x, r);
+    float e = __fmaf_rn(-c, q, x);
+    q = __fmaf_rn(e, r, q);
+    e = __fmaf_rn(-c, q, x);
+    return __fmaf_rn(e, r, q);
+}
+static inline float psfm_rcp_host(float c)   // host: refined reciprocal for psfm_div_r
+{
+    const float r0 = (float)(1.0 / (double)c);
+    const float e = fmaf(-c, r0, 1.0f);
+    return fmaf(e, r0, r0);
+}
+
+// cw = (float)((W-1)/2.0), ch = (float)((H-1)/2.0) computed once on the host.
+template <bool FAST>
+__device__ __forceinline__ PsfmTaps psfm_taps_t(float x32, float y32, float cw, float ch, float rcw, float rch, int H, int W)
+{
+    float gx = __fsub_rn(FAST ? psfm_div_r(x32, cw, rcw) : __fdiv_rn(x32, cw), 1.0f);
+    float gy = __fsub_rn(FAST ? psfm_div_r(y32, ch, rch) : __fdiv_rn(y32, ch), 1.0f);
     const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), cw);
     const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), ch);
     const float fx = floorf(ix), fy = floorf(iy);
@@ -59,6 +84,14 @@ __device__ __forceinline__ PsfmTaps psfm_taps(float x32, float y32, float cw, fl
     t.x0 = (int)cx;
     t.y0 = (int)cy;
     return t;
+}
+__device__ __forceinline__ PsfmTaps psfm_taps(float x32, float y32, float cw, float ch, int H, int W)
+{
+    return psfm_taps_t<false>(x32, y32, cw, ch, 0.f, 0.f, H, W);
+}
+__device__ __forceinline__ PsfmTaps psfm_taps_fast(float x32, float y32, float cw, float ch, float rcw, float rch, int H, int W)
+{
+    return psfm_taps_t<true>(x32, y32, cw, ch, rcw, rch, H, W);
 }
 
 __device__ __forceinline__ float psfm_blend(float vnw, float vne, float vsw, float vse, const PsfmTaps& t)

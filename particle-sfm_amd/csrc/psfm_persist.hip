@@ -70,9 +70,9 @@ struct PsfmPersistArgs {
     const float2* flows; const uint8_t* occ;   // (n_flows,H,W,2) f32 / n_flows maps of H*W u8, `occ_pitch` bytes apart
     // fused flow_check (psfm_connect): the blocks compute the occlusion maps themselves, in the time they would spend
     // waiting at the frame barriers, always at least three frames ahead of the step that samples them
-    const float2* flows_b; uint8_t* occ_w; float thres; int fc;
+    const float2* flows_b; uint8_t* occ_w; float thres, t2; int fc;
     int64_t occ_pitch; PsfmFastDiv wdiv;
-    int H, W; float cw, ch;
+    int H, W; float cw, ch, rcw, rch;
     int ratio, GW, GH, G;
     double2* log; int cap;                     // (n_flows+1, cap): cap = gridDim.x * (256 + PP_GUESTS) columns
     int cap_main;                              // gridDim.x * 256 thread lanes (columns [cap_main, cap) are the guests)
@@ -94,7 +94,7 @@ struct PsfmPersistArgs {
 // what psfm_step_issue / psfm_step_finish / psfm_block_grid need for one frame
 struct PsfmFrameView {
     const float2* flow; const uint8_t* occ;
-    int H, W; float cw, ch;
+    int H, W; float cw, ch, rcw, rch;
     int ratio, GW, GH;
     uint8_t* blocked_cur; uint8_t stamp_cur;
     PsfmFastDiv rdiv;
@@ -178,6 +178,8 @@ __device__ __forceinline__ bool psfm_bar_wait(const PsfmPersistArgs& a, int shar
 __device__ __forceinline__ void psfm_fc_slice(const PsfmPersistArgs& a, int f, int tid)
 {
     const int P = a.H * a.W;
+    PsfmFcParams q;
+    q.H = a.H; q.W = a.W; q.cw = a.cw; q.ch = a.ch; q.rcw = a.rcw; q.rch = a.rch; q.thres = a.thres; q.t2 = a.t2;
     const float2* __restrict__ F = a.flows + (size_t)f * P;
     const float2* __restrict__ B = a.flows_b + (size_t)f * P;
     uint8_t* O = a.occ_w + (size_t)f * a.occ_pitch;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void psfm_fc_slice(const PsfmPersistArgs& a, int f, i
             const int p = p0 + k * 256;
             if (p >= P) break;
             float e;
-            const uint8_t o = psfm_flow_check_px(B, x, y, fv[k], a.H, a.W, a.cw, a.ch, a.thres, &e);
+            const uint8_t o = psfm_flow_check_px<false>(B, x, y, fv[k], q, &e);
             psfm_coh_st(O + p, o);
             x += 256;
             while (x >= a.W) { x -= a.W; ++y; }
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         const int lane = tid & (PSFM_WAVE - 1), wave = tid / PSFM_WAVE;
         PsfmFrameView v;
         v.flow = a.flows + (size_t)t * P; v.occ = a.occ + (size_t)t * a.occ_pitch;
-        v.H = a.H; v.W = a.W; v.cw = a.cw; v.ch = a.ch; v.ratio = a.ratio; v.GW = a.GW; v.GH = a.GH; v.rdiv = a.rdiv;
+        v.H = a.H; v.W = a.W; v.cw = a.cw; v.ch = a.ch; v.rcw = a.rcw; v.rch = a.rch; v.ratio = a.ratio; v.GW = a.GW; v.GH = a.GH; v.rdiv = a.rdiv;
         v.blocked_cur = a.maps + (size_t)(t % 3) * a.G; v.stamp_cur = 1;
         double2* log_cur = a.log + (size_t)t * a.cap;
         double2* log_next = a.log + (size_t)(t + 1) * a.cap;
@@ -702,9 +704,9 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
     PsfmPersistArgs a;
     a.flows = (const float2*)flows; a.occ = occ;
     a.occ_pitch = occ_pitch;
-    a.flows_b = (const float2*)flows_b; a.occ_w = const_cast<uint8_t*>(occ); a.thres = thres; a.fc = flows_b != nullptr;
+    a.flows_b = (const float2*)flows_b; a.occ_w = const_cast<uint8_t*>(occ); a.thres = thres; a.t2 = psfm_sq_threshold(thres); a.fc = flows_b != nullptr;
     a.wdiv = psfm_fastdiv_make((unsigned)d.W);
-    a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch;
+    a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch; a.rcw = psfm_rcp_host(d.cw); a.rch = psfm_rcp_host(d.ch);
     a.ratio = d.ratio; a.GW = d.GW; a.GH = d.GH; a.G = (int)d.G;
     a.log = c->log.as<double2>(); a.cap = (int)d.cap; a.cap_main = d.nblk * PP_BLOCK;
     a.maps = c->occupied.as<uint8_t>();

@@ -30,28 +30,30 @@
 // near p+F) + P (occ) = 17P.  Vector form: a thread owns 4 consecutive pixels -> F arrives as two
 // 16-byte loads, the mask leaves as one 4-byte store; blockIdx.y = frame pair (one launch for all pairs).
 // ------------------------------------------------------------------------------------------------
+template <bool NEED_ERR>
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_kernel(
-    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, int H, int W, float cw, float ch,
-    float thres, uint8_t* __restrict__ occ_out, float* __restrict__ err_out)
+    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q,
+    uint8_t* __restrict__ occ_out, float* __restrict__ err_out)
 {
-    const int64_t P = (int64_t)H * W;
+    const int64_t P = (int64_t)q.H * q.W;
     const int64_t p = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
     if (p >= P) return;
     const int64_t base = (int64_t)blockIdx.y * P;
-    const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
-    float e;
-    occ_out[base + p] = psfm_flow_check_px(flows_b + base, x, y, flows_f[base + p], H, W, cw, ch, thres, &e);
-    if (err_out) err_out[base + p] = e;
+    const int y = (int)(p / q.W), x = (int)(p - (int64_t)y * q.W);
+    float e = 0.f;
+    occ_out[base + p] = psfm_flow_check_px<NEED_ERR>(flows_b + base, x, y, flows_f[base + p], q, &e);
+    if (NEED_ERR) err_out[base + p] = e;
 }
 
 // 4 pixels per thread, strided by the block size: every load/store instruction stays fully coalesced
 // (64 lanes x 8 B contiguous) while each wave keeps 4x more bytes in flight.
 #define PSFM_FC_UNROLL 4
+template <bool NEED_ERR>
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x4_kernel(
-    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, int H, int W, float cw, float ch,
-    float thres, uint8_t* __restrict__ occ_out, float* __restrict__ err_out, PsfmFastDiv wdiv)
+    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q,
+    uint8_t* __restrict__ occ_out, float* __restrict__ err_out, PsfmFastDiv wdiv)
 {
-    const int P = H * W;
+    const int P = q.H * q.W;
     const int p0 = blockIdx.x * (PSFM_BLOCK * PSFM_FC_UNROLL) + threadIdx.x;
     const int64_t base = (int64_t)blockIdx.y * P;
     const float2* __restrict__ F = flows_f + base;
@@ -62,17 +64,27 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x4_kernel(
         const int p = p0 + k * PSFM_BLOCK;
         f[k] = p < P ? psfm_ld(F, (unsigned)p * 8u) : make_float2(0.f, 0.f);
     }
-    int y = (int)psfm_fastdiv((unsigned)p0, wdiv), x = p0 - y * W;
+    int y = (int)psfm_fastdiv((unsigned)p0, wdiv), x = p0 - y * q.W;
 #pragma unroll
     for (int k = 0; k < PSFM_FC_UNROLL; ++k) {
         const int p = p0 + k * PSFM_BLOCK;
         if (p >= P) break;
-        float e;
-        occ_out[base + p] = psfm_flow_check_px(B, x, y, f[k], H, W, cw, ch, thres, &e);
-        if (err_out) err_out[base + p] = e;
+        float e = 0.f;
+        occ_out[base + p] = psfm_flow_check_px<NEED_ERR>(B, x, y, f[k], q, &e);
+        if (NEED_ERR) err_out[base + p] = e;
         x += PSFM_BLOCK;
-        while (x >= W) { x -= W; ++y; }
+        while (x >= q.W) { x -= q.W; ++y; }
     }
+}
+
+PsfmFcParams psfm_fc_params(int h, int w, float thres)
+{
+    PsfmFcParams q;
+    q.H = h; q.W = w;
+    q.cw = (float)((double)(w - 1) / 2.0); q.ch = (float)((double)(h - 1) / 2.0);
+    q.rcw = psfm_rcp_host(q.cw); q.rch = psfm_rcp_host(q.ch);
+    q.thres = thres; q.t2 = psfm_sq_threshold(thres);
+    return q;
 }
 
 psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs, int h, int w, float thres,
@@ -80,15 +92,23 @@ psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs
 {
     if (n_pairs <= 0) return PSFM_OK;
     const int64_t P = (int64_t)h * w;
-    const float cw = (float)((double)(w - 1) / 2.0), ch = (float)((double)(h - 1) / 2.0);
+    const PsfmFcParams q = psfm_fc_params(h, w, thres);
     if (P >= PSFM_BLOCK * PSFM_FC_UNROLL) {
         dim3 grid((unsigned)((P + PSFM_BLOCK * PSFM_FC_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_UNROLL)), (unsigned)n_pairs);
-        hipLaunchKernelGGL(psfm_flow_check_x4_kernel, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
-                           h, w, cw, ch, thres, occ, err, psfm_fastdiv_make((unsigned)w));
+        if (err)
+            hipLaunchKernelGGL(psfm_flow_check_x4_kernel<true>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
+                               q, occ, err, psfm_fastdiv_make((unsigned)w));
+        else
+            hipLaunchKernelGGL(psfm_flow_check_x4_kernel<false>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
+                               q, occ, err, psfm_fastdiv_make((unsigned)w));
     } else {
         dim3 grid((unsigned)((P + PSFM_BLOCK - 1) / PSFM_BLOCK), (unsigned)n_pairs);
-        hipLaunchKernelGGL(psfm_flow_check_kernel, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
-                           h, w, cw, ch, thres, occ, err);
+        if (err)
+            hipLaunchKernelGGL(psfm_flow_check_kernel<true>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
+                               q, occ, err);
+        else
+            hipLaunchKernelGGL(psfm_flow_check_kernel<false>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
+                               q, occ, err);
     }
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
@@ -188,7 +208,7 @@ psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStrea
 
 struct PsfmChainArgs {
     const float2* flow; const uint8_t* occ;
-    int H, W; float cw, ch;
+    int H, W; float cw, ch, rcw, rch;
     int ratio, GW, GH; int G;
     double2* log_cur; double2* log_next;
     int* birth_frame; int* birth_idx;
@@ -524,7 +544,7 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
 {
     PsfmChainArgs a;
     a.flow = (const float2*)flow; a.occ = occ;
-    a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch;
+    a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch; a.rcw = psfm_rcp_host(d.cw); a.rch = psfm_rcp_host(d.ch);
     a.ratio = d.ratio; a.GW = d.GW; a.GH = d.GH; a.G = (int)d.G;
     double2* lg = c->log.as<double2>();
     a.log_cur = lg + (int64_t)frame * d.cap;

@@ -228,3 +228,15 @@ def test_trajectory_set_csr_vs_map_and_reference_semantics(tmp_path, monkeypatch
     o1 = ts.sample_inside_window([3, 4, 5, 6, 7])
     o2 = ts_map.sample_inside_window([3, 4, 5, 6, 7])
     assert o1["traj_ids"] == o2["traj_ids"] and np.array_equal(o1["locations"][0], o2["locations"][0])
+
+
+def test_fast_division_and_threshold_shortcuts_are_exact():
+    """The HIP sampler divides by (size-1)/2 through a refined reciprocal + two fma corrections, and flow_check compares
+    the squared error against a pre-squared threshold: oracle/test_fastdiv.c enumerates ~5e7 operands (every
+    W <= 8192, reciprocal off by up to 1 ulp) and the floats around thres^2 against the true division / sqrtf."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["make", "-s", "-C", odir, "build/test_fastdiv"], check=True)
+    r = subprocess.run([os.path.join(odir, "build", "test_fastdiv"), "2000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 counter-examples" in r.stdout
