@@ -348,13 +348,14 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         if (!e_first) do_E();
 
         // ---- C (consume): respawn test, adoption ----
+        const unsigned long long svm = __ballot(sv == (unsigned)t);   // (all 64 lanes of block 0 / wave 0 vote: shards with a survivor)
         bool birth = false;
         if (gridpt) {
             if (byte != 0) psfm_coh_st(map_prev + L, (uint8_t)0);
             birth = byte == 0;
             // No survivor at all: nothing is marked, every grid point respawns -- except that SciPy's EDT then measures
             // to a phantom feature at (y=-1, x=0): (cy+1)^2 + cx^2 > r^2 fails at grid point 0 only (1 > r^2 is false).
-            if (L == 0 && __ballot(sv == (unsigned)t) == 0ull) birth = ((0 + 1) * (0 + 1) + 0 * 0) > ratio * ratio;
+            if (L == 0 && svm == 0ull) birth = ((0 + 1) * (0 + 1) + 0 * 0) > ratio * ratio;
         }
         bool adopted = false;
         if (poll) {

@@ -405,3 +405,18 @@ def test_random_sequences_all_paths_agree(pt):
                 assert np.array_equal(res[0].xy, B.xy), (i, H, W, T, r)
     finally:
         ctx.set_chain_mode(0)
+
+
+def test_region_without_survivors_still_respawns_its_corner(pt):
+    """Every track in the top rows dies in one step while the rest of the image survives: grid point (0,0) must respawn
+    like its neighbours (the SciPy 'no survivor at all' corner rule applies only when NOTHING survived anywhere)."""
+    from oracle import oracle as orc
+    H, W, T, r = 48, 64, 5, 1
+    flows = [np.zeros((H, W, 2), np.float32) for _ in range(T - 1)]
+    occ = [np.zeros((H, W), bool) for _ in range(T - 1)]
+    occ[1][:8, :] = True
+    O = orc.track(flows, occ, r)
+    R = pt.track(flows, occ, r)
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+    first = O.xy[np.concatenate([[0], np.cumsum(O.length)[:-1]])]
+    assert ((O.birth == 2) & (first[:, 0] == 0) & (first[:, 1] == 0)).any()      # the corner itself respawned at frame 2
