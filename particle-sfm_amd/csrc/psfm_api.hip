@@ -490,7 +490,7 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
                                   const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
                                   void* stream)
 {
-    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    PSFM_CHECK_CTX(c);   // (selects the context's device: the residency query below is per device)
     PsfmGate gate(c->device, psfm_wants_persist(c, flows_f2 != nullptr, h, w, ratio));
     return psfm_track_impl(c, flows, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, nullptr, gate.exclusive);
 }
