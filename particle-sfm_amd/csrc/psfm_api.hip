@@ -322,7 +322,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     if ((st = c->shards.ensure(sizeof(PsfmShard) * PSFM_NSHARD * 2)) != PSFM_OK) return st;
     if ((st = c->fin_keys.ensure(sizeof(unsigned long long) * d.traj_cap)) != PSFM_OK) return st;
     if ((st = c->fin_lanes.ensure(sizeof(int) * d.traj_cap)) != PSFM_OK) return st;
-    if ((st = c->occupied.ensure((size_t)d.G * 3)) != PSFM_OK) return st;   // (the persistent loop rotates three maps)
+    if ((st = c->occupied.ensure((size_t)d.G * 3 + 8)) != PSFM_OK) return st;   // (the persistent loop rotates three maps)
     if ((st = c->counters.ensure(sizeof(PsfmCounters))) != PSFM_OK) return st;
     if ((st = c->survivors.ensure(sizeof(int) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
 

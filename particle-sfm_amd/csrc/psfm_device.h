@@ -40,7 +40,7 @@ __device__ __forceinline__ PsfmTaps psfm_weights(float w, float n)
 // e = fma(-c,q,x), q = fma(e,r,q): the core of the compiler's own IEEE expansion of `/` (v_div_scale / v_div_fmas /
 // v_div_fixup only add the scaling of extreme exponents and the inf/NaN/zero fix-ups), 5 VALU ops instead of 11.
 // Bit-identical to x / c for 1e-30 < |x| < 1e30 and x = +0 (1.2e9 random and adversarial operands over every
-// c = (W-1)/2, W <= 8192, with r perturbed by +-1 ulp: oracle/test_fastdiv.c).  Outside that range (no pixel coordinate
+// c = (W-1)/2, W <= 8192, with r perturbed by +-1 ulp: the enumeration test run by tests/test_abi_and_host.py).  Outside that range (no pixel coordinate
 // is) the quotient may differ (overflow -> NaN, -0 -> +0); both still sample "all taps out of bounds".  Callers that
 // must reproduce the reference's ERROR MAP for absurd flows use psfm_taps() with the true division.
 __device__ __forceinline__ float psfm_div_r(float x, float c, float r)

@@ -62,16 +62,34 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_kernel(
     }
 }
 
+// The sort key (last << shift_d | birth << shift_b | idx) has birth <= last: the pair (last, birth) is re-coded as the
+// triangular index last*(last+1)/2 + birth, which orders like the pair and needs ~1 bit less.  When that makes the key
+// fit 32 bits (100 frames at 1080p/r=2: 13 + 19) the radix sort runs on 4-byte keys in 4 passes instead of 8-byte
+// keys in 5.
+struct PsfmKeyFmt { int shift_b, shift_d; int use32; };
+__device__ __forceinline__ unsigned psfm_key32(unsigned long long k, const PsfmKeyFmt& f)
+{
+    const unsigned last = (unsigned)(k >> f.shift_d);
+    const unsigned birth = (unsigned)((k >> f.shift_b) & ((1ull << (f.shift_d - f.shift_b)) - 1ull));
+    const unsigned idx = (unsigned)(k & ((1ull << f.shift_b) - 1ull));
+    return ((last * (last + 1u) / 2u + birth) << f.shift_b) | idx;
+}
+__device__ __forceinline__ void psfm_put_key(unsigned long long* keys, int64_t pos, unsigned long long k, const PsfmKeyFmt& f)
+{
+    if (f.use32) ((unsigned*)keys)[pos] = psfm_key32(k, f);
+    else keys[pos] = k;
+}
+
 // gather the per-shard record slices into one contiguous (key, lane) array for the sort
 struct PsfmShardOffsets { int count[PSFM_NSHARD]; int64_t start[PSFM_NSHARD]; };
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_compact_shards_kernel(
     const unsigned long long* __restrict__ fin_keys, const int* __restrict__ fin_lanes, int shard_cap,
-    PsfmShardOffsets so, unsigned long long* __restrict__ keys, int* __restrict__ lanes)
+    PsfmShardOffsets so, unsigned long long* __restrict__ keys, int* __restrict__ lanes, PsfmKeyFmt fmt)
 {
     const int shard = blockIdx.y;
     const int n = so.count[shard];
     for (int i = blockIdx.x * PSFM_BLOCK + threadIdx.x; i < n; i += gridDim.x * PSFM_BLOCK) {
-        keys[so.start[shard] + i] = fin_keys[(int64_t)shard * shard_cap + i];
+        psfm_put_key(keys, so.start[shard] + i, fin_keys[(int64_t)shard * shard_cap + i], fmt);
         lanes[so.start[shard] + i] = fin_lanes[(int64_t)shard * shard_cap + i];
     }
 }
@@ -90,6 +108,24 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_decode_kernel(const unsigned 
     birth[i] = b;
     len[i] = last - b + 1;
     len64[i] = (int64_t)(last - b + 1);
+}
+
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_decode32_kernel(const unsigned* __restrict__ keys, int64_t n, int shift_b,
+                                                                   int* __restrict__ birth, int* __restrict__ len,
+                                                                   int64_t* __restrict__ len64)
+{
+    const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { len64[i] = 0; return; }
+    const unsigned tri = keys[i] >> shift_b;
+    // last = the largest l with l*(l+1)/2 <= tri
+    int l = (int)((sqrtf(8.0f * (float)tri + 1.0f) - 1.0f) * 0.5f);
+    while (l > 0 && (unsigned)l * (unsigned)(l + 1) / 2u > tri) --l;
+    while ((unsigned)(l + 1) * (unsigned)(l + 2) / 2u <= tri) ++l;
+    const int b = (int)(tri - (unsigned)l * (unsigned)(l + 1) / 2u);
+    birth[i] = b;
+    len[i] = l - b + 1;
+    len64[i] = (int64_t)(l - b + 1);
 }
 
 // Transpose gather: a block owns TILE_J consecutive ids and walks time in chunks of TILE_K steps.
@@ -147,31 +183,60 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* 
     }
 }
 
-// common tail: (key, lane) records already compacted into the SECOND halves of sort_keys / sort_lanes
+// key format of a sequence: 32-bit triangular keys when they fit
+static PsfmKeyFmt psfm_key_fmt(const PsfmTrackDims& d, unsigned* end_bit)
+{
+    PsfmKeyFmt f;
+    f.shift_b = d.shift_b; f.shift_d = d.shift_d;
+    const long long lmax = (long long)d.n_flows + 1;            // last valid time <= n_flows
+    const long long tri_max = lmax * (lmax + 1) / 2 + lmax;
+    int tri_bits = 1;
+    while ((1ll << tri_bits) <= tri_max) ++tri_bits;
+    f.use32 = (tri_bits + d.shift_b <= 32) ? 1 : 0;
+    int tbits = 1;
+    while ((1ll << tbits) < (long long)d.n_flows + 2) ++tbits;
+    *end_bit = f.use32 ? (unsigned)(tri_bits + d.shift_b) : (unsigned)(d.shift_d + tbits);
+    return f;
+}
+
+// common tail: (key, lane) records already compacted into the SECOND halves of sort_keys / sort_lanes (keys in the
+// format psfm_key_fmt() chose: n 8-byte or n 4-byte entries behind the first n entries of the same width)
 static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int64_t n, int64_t npts, hipStream_t s)
 {
     psfm_status st;
-    unsigned long long* k_in = c->sort_keys.as<unsigned long long>() + n;
-    unsigned long long* k_out = c->sort_keys.as<unsigned long long>();
+    unsigned end_bit = 0;
+    const PsfmKeyFmt fmt = psfm_key_fmt(d, &end_bit);
     int* l_in = c->sort_lanes.as<int>() + n;
     int* l_out = c->sort_lanes.as<int>();
-    int tbits = 1;
-    while ((1ll << tbits) < (long long)d.n_flows + 2) ++tbits;
-    const unsigned end_bit = (unsigned)(d.shift_d + tbits);
     size_t tmp_bytes = 0, scan_bytes = 0;
-    PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
     PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
                                      (size_t)(n + 1), rocprim::plus<int64_t>(), s));
-    if ((st = c->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
-    PSFM_HIP(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+    if (fmt.use32) {
+        unsigned* k_in = c->sort_keys.as<unsigned>() + n;
+        unsigned* k_out = c->sort_keys.as<unsigned>();
+        PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+        if ((st = c->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
+        PSFM_HIP(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+    } else {
+        unsigned long long* k_in = c->sort_keys.as<unsigned long long>() + n;
+        unsigned long long* k_out = c->sort_keys.as<unsigned long long>();
+        PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+        if ((st = c->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
+        PSFM_HIP(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
+    }
     // decode + offsets
     if ((st = c->res_birth.ensure(sizeof(int) * n)) != PSFM_OK) return st;
     if ((st = c->res_len.ensure(sizeof(int) * n)) != PSFM_OK) return st;
     if ((st = c->res_off.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
     if ((st = c->scan_tmp.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
-    hipLaunchKernelGGL(psfm_decode_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
-                       c->sort_keys.as<unsigned long long>(), n, d.shift_b, d.shift_d, c->res_birth.as<int>(),
-                       c->res_len.as<int>(), c->scan_tmp.as<int64_t>());
+    if (fmt.use32)
+        hipLaunchKernelGGL(psfm_decode32_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
+                           c->sort_keys.as<unsigned>(), n, d.shift_b, c->res_birth.as<int>(), c->res_len.as<int>(),
+                           c->scan_tmp.as<int64_t>());
+    else
+        hipLaunchKernelGGL(psfm_decode_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
+                           c->sort_keys.as<unsigned long long>(), n, d.shift_b, d.shift_d, c->res_birth.as<int>(),
+                           c->res_len.as<int>(), c->scan_tmp.as<int64_t>());
     PSFM_HIP(hipGetLastError());
     PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->res_off.as<int64_t>(),
                                      (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
@@ -223,9 +288,12 @@ psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
     psfm_status st;
     if ((st = c->sort_keys.ensure(sizeof(unsigned long long) * n * 2)) != PSFM_OK) return st;
     if ((st = c->sort_lanes.ensure(sizeof(int) * n * 2)) != PSFM_OK) return st;
+    unsigned end_bit_unused = 0;
+    const PsfmKeyFmt fmt = psfm_key_fmt(d, &end_bit_unused);
+    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(c->sort_keys.as<unsigned>() + n) : c->sort_keys.as<unsigned long long>() + n;
     hipLaunchKernelGGL(psfm_compact_shards_kernel, dim3(64, PSFM_NSHARD), dim3(PSFM_BLOCK), 0, s,
                        c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), d.shard_cap, so,
-                       c->sort_keys.as<unsigned long long>() + n, c->sort_lanes.as<int>() + n);
+                       kdst, c->sort_lanes.as<int>() + n, fmt);
     PSFM_HIP(hipGetLastError());
     return psfm_finalize_sorted(c, d, n, npts, s);
 }
@@ -234,11 +302,11 @@ psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
 struct PsfmSegRow { long long src; long long dst; int count; int pad; };
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_compact_segments_kernel(
     const unsigned long long* __restrict__ fin_keys, const int* __restrict__ fin_lanes,
-    const PsfmSegRow* __restrict__ rows, unsigned long long* __restrict__ keys, int* __restrict__ lanes)
+    const PsfmSegRow* __restrict__ rows, unsigned long long* __restrict__ keys, int* __restrict__ lanes, PsfmKeyFmt fmt)
 {
     const PsfmSegRow r = rows[blockIdx.x];
     for (int i = threadIdx.x; i < r.count; i += PSFM_BLOCK) {
-        keys[r.dst + i] = fin_keys[r.src + i];
+        psfm_put_key(keys, r.dst + i, fin_keys[r.src + i], fmt);
         lanes[r.dst + i] = fin_lanes[r.src + i];
     }
 }
@@ -287,9 +355,12 @@ psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fal
     if ((st = c->sort_lanes.ensure(sizeof(int) * n * 2)) != PSFM_OK) return st;
     if ((st = c->seg_table.ensure(sizeof(PsfmSegRow) * (size_t)nseg)) != PSFM_OK) return st;
     PSFM_HIP(hipMemcpyAsync(c->seg_table.p, hrows, sizeof(PsfmSegRow) * (size_t)nseg, hipMemcpyHostToDevice, s));
+    unsigned end_bit_unused = 0;
+    const PsfmKeyFmt fmt = psfm_key_fmt(d, &end_bit_unused);
+    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(c->sort_keys.as<unsigned>() + n) : c->sort_keys.as<unsigned long long>() + n;
     hipLaunchKernelGGL(psfm_compact_segments_kernel, dim3((unsigned)nseg), dim3(PSFM_BLOCK), 0, s,
                        c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), c->seg_table.as<PsfmSegRow>(),
-                       c->sort_keys.as<unsigned long long>() + n, c->sort_lanes.as<int>() + n);
+                       kdst, c->sort_lanes.as<int>() + n, fmt);
     PSFM_HIP(hipGetLastError());
     return psfm_finalize_sorted(c, d, n, npts, s);
 }

@@ -666,11 +666,18 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
     }
 }
 
-__global__ __launch_bounds__(256) void psfm_persist_init_kernel(PsfmCounters* ctr, PsfmShard* shards, int G)
+// one launch instead of three memsets + a counter kernel in front of every sequence
+__global__ __launch_bounds__(256) void psfm_persist_init_kernel(PsfmCounters* ctr, PsfmShard* shards, int G,
+                                                                unsigned long long* maps64, size_t n_maps64,
+                                                                unsigned long long* bar64, size_t n_bar64,
+                                                                unsigned long long* handoff, size_t n_handoff)
 {
-    const int i = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
     if (i == 0) { ctr->n_lanes = G; ctr->overflow = 0; ctr->stall = 0; ctr->abort = 0; ctr->spill_cnt = 0; ctr->pad[0] = 0; ctr->pad[1] = 0; }
     if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; shards[i].points = 0u; }
+    for (size_t k = i; k < n_maps64; k += stride) maps64[k] = 0ull;
+    for (size_t k = i; k < n_bar64; k += stride) bar64[k] = 0ull;
+    for (size_t k = i; k < n_handoff; k += stride) handoff[k] = ~0ull;   // tag -1: no hand-off
 }
 
 // Largest grid of 256-thread blocks that is resident at once on this device (0: unknown / not available).
@@ -697,11 +704,12 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
                                       int64_t occ_pitch, const float* flows_b, float thres, hipStream_t s)
 {
     const size_t bar_bytes = (size_t)(4 * PSFM_NSHARD + 1) * 128;   // barrier lines + 2 x 64 survivor words
-    PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.G * 3, s));
-    PSFM_HIP(hipMemsetAsync(c->persist_bar.p, 0, bar_bytes, s));
-    PSFM_HIP(hipMemsetAsync(c->handoff.p, 0xff, (size_t)d.nblk * PP_BLOCK * 24, s));   // tag -1: no hand-off
-    hipLaunchKernelGGL(psfm_persist_init_kernel, dim3(1), dim3(256), 0, s, c->counters.as<PsfmCounters>(),
-                       c->shards.as<PsfmShard>(), (int)d.G);
+    {
+        const size_t n_maps64 = ((size_t)d.G * 3 + 7) / 8, n_bar64 = bar_bytes / 8, n_handoff = (size_t)d.nblk * PP_BLOCK * 3;
+        hipLaunchKernelGGL(psfm_persist_init_kernel, dim3(1024), dim3(256), 0, s, c->counters.as<PsfmCounters>(),
+                           c->shards.as<PsfmShard>(), (int)d.G, c->occupied.as<unsigned long long>(), n_maps64,
+                           c->persist_bar.as<unsigned long long>(), n_bar64, c->handoff.as<unsigned long long>(), n_handoff);
+    }
     PsfmPersistArgs a;
     a.flows = (const float2*)flows; a.occ = occ;
     a.occ_pitch = occ_pitch;

@@ -114,6 +114,13 @@ def _as_device_stack(maps, dtype, trailing):
     return t.to(device=dev, dtype=dtype).contiguous()
 
 
+def _capacity_of(ctx, key):
+    """Table factors that worked for this shape on this context (default 2 x lanes, 8 x trajectory records)."""
+    if not isinstance(getattr(ctx, "_capacity", None), dict):
+        ctx._capacity = {}
+    return ctx._capacity.get(key, (2.0, 8.0))
+
+
 def run_connect(flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, return_device=False):
     """flow_check + track / track_optimize in ONE psfm_connect call (the compute part of
     main_connect_point_trajectories.py:36-53): the occlusion maps are produced on a side stream while the frame
@@ -133,10 +140,11 @@ def run_connect(flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, retur
             f2 = torch.zeros((1, H, W, 2), dtype=torch.float32, device=flows_f.device)
             b2 = f2
     info = _hip.TrackInfo()
-    lane_f, traj_f = getattr(ctx, "_capacity", (2.0, 8.0))
+    cap_key = ("connect", n, H, W, int(sample_ratio), f2 is not None)
+    lane_f, traj_f = _capacity_of(ctx, cap_key)
     for attempt in range(6):
         ctx.set_capacity(lane_f, traj_f)
-        ctx._capacity = (lane_f, traj_f)      # remembered: a sequence that needed larger tables keeps them
+        ctx._capacity[cap_key] = (lane_f, traj_f)      # remembered per shape: a sequence that needed larger tables keeps them
         st = _hip.lib().psfm_connect(ctx.handle, _hip.ptr(flows_f), _hip.ptr(flows_b), _hip.ptr(f2), _hip.ptr(b2), n, H, W,
                                      float(thres), int(sample_ratio), None, None, ctypes.byref(info),
                                      _hip.current_stream_ptr())
@@ -170,10 +178,11 @@ def run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio, return_devic
             f2 = torch.zeros((1, H, W, 2), dtype=torch.float32, device=fl.device)
             o2 = torch.zeros((1, H, W), dtype=torch.uint8, device=fl.device)
     info = _hip.TrackInfo()
-    lane_f, traj_f = getattr(ctx, "_capacity", (2.0, 8.0))
+    cap_key = ("track", n, H, W, int(sample_ratio), f2 is not None)
+    lane_f, traj_f = _capacity_of(ctx, cap_key)
     for attempt in range(6):
         ctx.set_capacity(lane_f, traj_f)
-        ctx._capacity = (lane_f, traj_f)
+        ctx._capacity[cap_key] = (lane_f, traj_f)
         st = _hip.lib().psfm_track(ctx.handle, _hip.ptr(fl), _hip.ptr(oc), _hip.ptr(f2), _hip.ptr(o2), n, H, W,
                                    int(sample_ratio), ctypes.byref(info), _hip.current_stream_ptr())
         if st != _hip.PSFM_ERR_CAPACITY:

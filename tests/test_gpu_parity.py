@@ -98,6 +98,7 @@ def test_track_all_tracks_die(pt):
     (135, 241, 10, 3, 42, 0.35, 2),
     (96, 130, 30, 1, 43, 0.1, 2),
     (200, 300, 300, 4, 44, 0.05, 1),     # > 255 frames: exercises the occupied-stamp wrap
+    (64, 90, 1100, 1, 45, 0.1, 1),       # long + dense: (last, birth, idx) no longer fits 32 bits -> 64-bit sort keys
 ])
 def test_track_vs_oracle(pt, H, W, T, r, seed, sigma, nocc):
     from oracle import oracle as orc
