@@ -154,6 +154,21 @@ psfm_status psfm_result_copy(psfm_ctx* ctx, int32_t* birth_host, int32_t* len_ho
 psfm_status psfm_result_solve_stats(psfm_ctx* ctx, psfm_solve_stats* stats_host, int32_t max_n,
                                     int32_t* n_out);
 
+/* The motion-segmentation window tensors (motion_seg/load_cut_seq.py:60-89) from the device-resident result of the last
+ * psfm_track / psfm_connect -- TrajectorySet::sample_inside_window (optimize/src/trajectory_base.cpp:127-185) for the
+ * contiguous window [frame0, frame0 + n_frames) plus the resize / normalise of motion_seg/core/dataset/data_utils.py:74-89:
+ *   trajectories of length >= traj_min_len (the saved set, main_connect_point_trajectories.py:56-61) with >= min_length
+ *   observations inside the window, ascending id; more than max_num_tracks -> a random subset in shuffled order
+ *   (seeded; the reference shuffles unseeded).
+ * Outputs, all DEVICE pointers, any may be NULL (all NULL = count only); `capacity` = rows the buffers can hold:
+ *   ids_out (K) i32   xy_raw (K,n_frames,2) f64 zero-padded   mask_absent (K,n_frames) f64, 1.0 where the trajectory
+ *   has no point (load_cut_seq's `1 - masks`)   xy_norm (K,n_frames,2) f64 = clip(xy / (raw/in) / in, 0, 1)
+ * *k_host = K.  Synchronises `stream`. */
+psfm_status psfm_window_sample(psfm_ctx* ctx, int frame0, int n_frames, int traj_min_len, int min_length,
+                               int64_t max_num_tracks, uint64_t seed, int raw_h, int raw_w, int in_h, int in_w,
+                               int64_t capacity, int32_t* ids_out, double* xy_raw, double* xy_norm, double* mask_absent,
+                               int64_t* k_host, void* stream);
+
 /* Per-kernel device time of the last psfm_track / psfm_flow_check when profiling is enabled with
  * psfm_ctx_set_profiling(ctx, 1): HIP events recorded on the launch stream around every launch of
  * the named kernel family (enable = N > 1: only every N-th per-frame chain_step launch is timed, which keeps the

@@ -104,6 +104,7 @@ struct psfm_ctx {
     PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats;
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
     PsfmBuf occ_own, occ2_own;           // occlusion maps of psfm_connect when the caller passes none
+    PsfmBuf win_ws;                      // psfm_window_sample workspace
     hipStream_t side_stream = nullptr;   // flow_check of psfm_connect runs here, ahead of the frame loop
     std::vector<psfm_solve_stats> solve_stats;
     PsfmProfiler prof;

@@ -421,3 +421,45 @@ def test_region_without_survivors_still_respawns_its_corner(pt):
     assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
     first = O.xy[np.concatenate([[0], np.cumsum(O.length)[:-1]])]
     assert ((O.birth == 2) & (first[:, 0] == 0) & (first[:, 1] == 0)).any()      # the corner itself respawned at frame 2
+
+
+def test_motion_seg_window_tensors(pt):
+    """SURVEY f-4: psfm_window_sample (device) against the host path the reference takes --
+    TrajectorySet.sample_inside_window per window (trajectory_base.cpp:127-185) + resize_point_traj / normalize_point_traj
+    (motion_seg/core/dataset/data_utils.py:74-89), restated in NumPy below."""
+    from motion_seg.load_cut_seq import cut_trajectory_windows, window_ranges, sample_window_device
+    T, H, W, r = 23, 96, 128, 2
+    d = psfm_synth.synth_sequence_torch(T, H, W, seed=31, sigma=0.3, n_occluders=2, stride2=False)
+    R = pt.trajectory.run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, r)      # result stays in the context
+    ts = R.to_trajectory_set(3)
+    ts.build_invert_indexes()
+    raw_hw, input_size, window = (H, W), (60, 100), 10
+    got = cut_trajectory_windows(T, window, raw_hw, input_size, traj_max_num=10 ** 9, as_numpy=True)
+    assert window_ranges(T, window) == [(0, 10), (10, 10), (13, 10)]
+    for w, (f0, n) in enumerate(window_ranges(T, window)):
+        out = ts.sample_inside_window(list(range(f0, f0 + n)), min_length=3, max_num_tracks=10 ** 9)
+        raw = np.concatenate([out["locations"][0][:, :, None], out["locations"][1][:, :, None]], 2)   # load_cut_seq.py:76
+        nor = raw.copy()
+        nor[:, :, 0] /= float(raw_hw[1]) / float(input_size[1]); nor[:, :, 1] /= float(raw_hw[0]) / float(input_size[0])
+        nor[:, :, 0] /= input_size[1]; nor[:, :, 1] /= input_size[0]
+        nor = np.clip(nor, 0.0, 1.0)
+        mask = (1 - out["masks"]).astype(float)[:, :, None]
+        assert np.array_equal(got[4][w], np.asarray(out["traj_ids"], np.int32)) and len(out["traj_ids"]) > 50
+        assert np.array_equal(got[0][w], raw) and np.array_equal(got[1][w], nor) and np.array_equal(got[2][w], mask)
+        assert np.array_equal(got[3][w], np.arange(f0, f0 + n))
+    # window >= sequence: one window over everything (load_cut_seq.py:50-58)
+    one = cut_trajectory_windows(T, 64, raw_hw, input_size, traj_max_num=10 ** 9, as_numpy=True)
+    full = ts.sample_inside_window(list(range(T)), max_num_tracks=10 ** 9)
+    assert len(one[0]) == 1 and np.array_equal(one[4][0], np.asarray(full["traj_ids"], np.int32))
+    # more trajectories than max_num_tracks: a seeded random subset (the reference shuffles unseeded)
+    ctx = pt.hip.context()
+    all_ids = set(full["traj_ids"])
+    a = sample_window_device(ctx, 0, T, raw_hw, input_size, traj_max_num=40, seed=5)
+    b = sample_window_device(ctx, 0, T, raw_hw, input_size, traj_max_num=40, seed=5)
+    c2 = sample_window_device(ctx, 0, T, raw_hw, input_size, traj_max_num=40, seed=6)
+    ia, ib, ic = (x[0].cpu().numpy() for x in (a, b, c2))
+    assert len(ia) == 40 and len(set(ia.tolist())) == 40 and set(ia.tolist()) <= all_ids
+    assert np.array_equal(ia, ib) and not np.array_equal(ia, ic)
+    row = {i: k for k, i in enumerate(full["traj_ids"])}
+    sel = np.array([row[i] for i in ia.tolist()])
+    assert np.array_equal(a[1].cpu().numpy()[:, :, 0], full["locations"][0][sel]) and np.array_equal(a[3].cpu().numpy()[:, :, 0], 1.0 - full["masks"][sel])
