@@ -457,8 +457,10 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                 }
                 if (hstats[k].iterations > max_it) max_it = hstats[k].iterations;
             }
-            // adapt the unroll to what this sequence needs (+2 head-room), within [4, 64]
-            int want = max_it + 2;
+            // adapt the unroll to what this sequence needs, within [4, 64]: a solve of k iterations needs k-1 pc_iter
+            // launches (pc_init does the first), so max+1 leaves two spare launches for the slowest solve seen in the
+            // window (a spare launch is a ~5 us no-op; a solve that still runs out raises the stall flag)
+            int want = max_it + 1;
             want = want < 4 ? 4 : (want > 64 ? 64 : want);
             c->solve_unroll = want > c->solve_unroll ? want : (c->solve_unroll + want + 1) / 2;
             first_unchecked = last_ok + 1;
