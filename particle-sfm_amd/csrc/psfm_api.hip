@@ -300,7 +300,11 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     d.cap = (int64_t)(c->lane_factor * (double)d.G);
     d.cap = ((d.cap + 255) / 256) * 256;
     const int64_t n_blocks = d.cap / 256;
-    d.free_cap = (int)(((n_blocks + PSFM_NSHARD - 1) / PSFM_NSHARD) * 256) + 1024;   // per-shard stack, with slack for other block sizes
+    {   // free-lane stacks: one per block of the grid up to PSFM_NSHARD (a small grid must not probe stacks nobody fills)
+        const int64_t gb = (d.G + 255) / 256;
+        d.nsh = (int)(gb < PSFM_NSHARD ? (gb > 0 ? gb : 1) : PSFM_NSHARD);
+    }
+    d.free_cap = (int)(((n_blocks + d.nsh - 1) / d.nsh) * 256) + 1024;   // per-stack entries: every lane of the blocks that push there
     // records are spread over PSFM_NSHARD slices by block index: give every slice head-room
     // trajectory records: traj_factor x G, but at least G x n_flows / 8 (one death in eight per frame and grid point)
     const double tf = c->traj_factor > (double)n_flows / 8.0 ? c->traj_factor : (double)n_flows / 8.0;
@@ -335,10 +339,13 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         const int64_t need_blocks = (d.G + 255) / 256;
         if (maxb > 0 && need_blocks <= maxb && device_is_ours) {   // (not ours: another psfm call is in flight on this device)
             PsfmTrackDims dp = d;
-            int64_t nb = need_blocks + need_blocks / 8 + 2;   // spare lanes for tracks born faster than lanes come back
+            // spare lanes for tracks born faster than lanes come back (alive tracks can exceed the grid where flows
+            // converge): twice the grid while that is cheap, a quarter more otherwise, never more than fits the device
+            int64_t nb = need_blocks <= 256 ? 2 * need_blocks + 4 : need_blocks + need_blocks / 4;
             dp.nblk = (int)(nb < maxb ? nb : maxb);
             dp.cap = (int64_t)dp.nblk * (256 + psfm_persist_guests());   // log columns: thread lanes, then guest lanes
-            dp.free_cap = (int)(((dp.nblk + PSFM_NSHARD - 1) / PSFM_NSHARD) * 256) + 1024;
+            dp.nsh = dp.nblk < PSFM_NSHARD ? dp.nblk : PSFM_NSHARD;
+            dp.free_cap = (int)(((dp.nblk + dp.nsh - 1) / dp.nsh) * 256) + 1024;
             dp.seg_cap = (int)(d.traj_cap / dp.nblk) + 64;
             dp.spill_cap = (int)(d.traj_cap / 8) + 4096;
             const int64_t fin_total = (int64_t)dp.nblk * dp.seg_cap + dp.spill_cap;

@@ -123,6 +123,7 @@ struct PsfmTrackDims {
     int64_t G, cap, traj_cap;
     int shard_cap;          // trajectory records per shard (traj_cap = PSFM_NSHARD * shard_cap)
     int free_cap;           // free-lane stack entries per shard
+    int nsh = PSFM_NSHARD;  // free-lane stacks in use (fewer on small grids)
     int shift_b, shift_d;   // key = death<<shift_d | birth<<shift_b | grid index
     float cw, ch;
     int nblk = 0, seg_cap = 0, spill_cap = 0;   // persistent loop: blocks, records per private segment, shared tail

@@ -80,7 +80,7 @@ struct PsfmPersistArgs {
     unsigned* survsh;                          // 2 x 64 words (128 B apart): frame+1 of the last step a block of the shard had a survivor in
     PsfmCounters* ctr;
     PsfmShard* shards;                         // 2 x PSFM_NSHARD (free_top per parity set)
-    int* free_stack; int free_cap;
+    int* free_stack; int free_cap; int nsh;   // nsh: free-lane stacks in use = min(PSFM_NSHARD, blocks)
     unsigned long long* handoff;               // cap x 3: x bits, y bits, gi | (2*birth_frame + alive) << 32
     unsigned long long* fin_keys; int* fin_lanes;
     int seg_cap; int spill_base; int spill_cap;
@@ -452,7 +452,8 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                 int need = nb - matched - gmatched; // births that must pop a lane
                 const int n_push = npd - matched - PP_KEEP;   // free lanes beyond the block's own reserve go to the global stacks
                 int bfree = 0;
-                if (n_push > 0) bfree = atomicAdd(&sh_push[shard].free_top, n_push);
+                const int fsh = blockIdx.x % a.nsh;   // (the barrier keeps its own 64 shards)
+                if (n_push > 0) bfree = atomicAdd(&sh_push[fsh].free_top, n_push);
                 int nseg = 0, done = 0;
                 // pops: rounds of four independent atomics (own shard first), one round trip per round.  The request is
                 // SPLIT over the four stacks: a stack is only ever asked for what will be taken from it if it has it, so
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                     int sh[4], ask[4], old[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        sh[j] = (shard + (rd * 4 + j) * 7) % PSFM_NSHARD;
+                        sh[j] = (fsh + (rd * 4 + j) * 7) % a.nsh;
                         ask[j] = q4 + (j < r4 ? 1 : 0);
                         old[j] = ask[j] > 0 ? atomicSub(&sh_pop[sh[j]].free_top, ask[j]) : 0;
                     }
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                     if (r >= matched + PP_KEEP) {
                         int* free_push = a.free_stack + (size_t)prev * a.free_cap * PSFM_NSHARD;
                         const int fpos = s_base_free + (r - matched - PP_KEEP);
-                        if (fpos < a.free_cap && PP_CHK(fpos, a.free_cap, 7)) psfm_coh_st(free_push + (size_t)shard * a.free_cap + fpos, L);
+                        if (fpos < a.free_cap && PP_CHK(fpos, a.free_cap, 7)) psfm_coh_st(free_push + (size_t)(blockIdx.x % a.nsh) * a.free_cap + fpos, L);
                         else atomicOr(&a.ctr->overflow, 1);
                         bf = PP_POOLED;
                     }
@@ -721,7 +722,7 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
     a.maps = c->occupied.as<uint8_t>();
     a.ctr = c->counters.as<PsfmCounters>();
     a.shards = c->shards.as<PsfmShard>();
-    a.free_stack = c->free_stack.as<int>(); a.free_cap = d.free_cap;
+    a.free_stack = c->free_stack.as<int>(); a.free_cap = d.free_cap; a.nsh = d.nsh;
     a.handoff = c->handoff.as<unsigned long long>();
     a.fin_keys = c->fin_keys.as<unsigned long long>(); a.fin_lanes = c->fin_lanes.as<int>();
     a.seg_cap = d.seg_cap; a.spill_base = d.nblk * d.seg_cap; a.spill_cap = d.spill_cap;

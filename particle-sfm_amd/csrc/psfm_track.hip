@@ -219,6 +219,7 @@ struct PsfmChainArgs {
     const int* free_pop; int* free_push;
     unsigned long long* fin_keys; int* fin_lanes;
     int cap, shard_cap, free_cap, frame, shift_b, shift_d;
+    int nsh;                   // free-lane stacks in use: min(PSFM_NSHARD, blocks of the grid) -- a small grid must not probe stacks nobody fills
     PsfmFastDiv gwdiv, rdiv;   // division by GW (grid index -> row/col) and by the sample ratio
 };
 
@@ -381,14 +382,14 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
         const int n_push = npd - matched;   // deaths whose lane goes back to the free stack
         // up to three independent atomics, issued back to back: one round trip
         int old_top = 0, bfin = 0, bfree = 0;
-        const int sh0 = blockIdx.x % PSFM_NSHARD;
+        const int sh0 = blockIdx.x % a.nsh;
         if (need > 0) old_top = atomicSub(&a.sh_pop[sh0].free_top, need);
         if (npd > 0) bfin = atomicAdd(&a.sh_fin[shard].fin_cnt, npd);
-        if (n_push > 0) bfree = atomicAdd(&a.sh_push[shard].free_top, n_push);
+        if (n_push > 0) bfree = atomicAdd(&a.sh_push[sh0].free_top, n_push);
         s_base_fin = bfin; s_base_free = bfree;
         int nseg = 0, done = 0;
         for (int k = 0; k < PSFM_PROBE && need > 0; ++k) {
-            const int sh = (sh0 + k * 7) % PSFM_NSHARD;
+            const int sh = (sh0 + k * 7) % a.nsh;
             if (k > 0) old_top = atomicSub(&a.sh_pop[sh].free_top, need);
             const int take = old_top < 0 ? 0 : (old_top > need ? need : old_top);
             if (take < need) atomicAdd(&a.sh_pop[sh].free_top, need - take);   // give back what the stack did not have
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
             if (r >= matched) {
                 a.birth_frame[i] = -1;
                 const int fpos = s_base_free + (r - matched);
-                if (fpos < a.free_cap) a.free_push[(int64_t)shard * a.free_cap + fpos] = i;
+                if (fpos < a.free_cap) a.free_push[(int64_t)(blockIdx.x % a.nsh) * a.free_cap + fpos] = i;
                 else atomicOr(&a.ctr->overflow, 1);
             }
             const int rpos = s_base_fin + r;
@@ -575,7 +576,7 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
     a.free_pop = fs + cur * set;
     a.free_push = fs + prev * set;
     a.fin_keys = c->fin_keys.as<unsigned long long>(); a.fin_lanes = c->fin_lanes.as<int>();
-    a.cap = (int)d.cap; a.shard_cap = d.shard_cap; a.free_cap = d.free_cap; a.frame = frame;
+    a.cap = (int)d.cap; a.shard_cap = d.shard_cap; a.free_cap = d.free_cap; a.frame = frame; a.nsh = d.nsh;
     a.shift_b = d.shift_b; a.shift_d = d.shift_d;
     a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -30,6 +30,10 @@ for i in range(n_cases):
     ctx.set_chain_mode(0)
     info = run_track(d["flows_f"], occ, None, None, r, return_device=True)
     out[("t", 0)] = (_result_to_host(ctx, info), info.chain_mode)
+    for key in (("c", 0), ("t", 0)):
+        if out[key][1] != 2:
+            print("fell back: case %d %s T=%d %dx%d r=%d sigma=%.2f nocc=%d seed=%d  n_traj %d lanes_peak %s cap %s" % (
+                i, key, T, H, W, r, sigma, nocc, seed, len(out[key][0]), out[key][0].info.get("n_lanes_peak"), out[key][0].info.get("lane_capacity")))
     A = out[("c", 1)][0]
     for key in (("c", 0), ("t", 0)):
         B = out[key][0]
