@@ -1,40 +1,34 @@
-"""Experiment: two independent sequences processed concurrently on ONE GPU (two contexts, two streams, two host
-threads) vs back to back -- how much idle time inside the phase-serialised chain_step launches can be filled?"""
-import os, sys, time, threading
+"""Debug: several sequences in flight on one GPU with the persistent loop -- per-call times and which path ran."""
+import ctypes, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "particle-sfm_amd"))
-import ctypes, torch
+import torch
 import psfm_synth
 from point_trajectory import _hip
-
-H, W, T, r = 1080, 1920, 101, 2
-nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-data = [psfm_synth.synth_sequence_torch(T, H, W, seed=k, sigma=0.05, n_occluders=2, stride2=False) for k in range(nseq)]
-ctxs = [_hip.Context(0) for _ in range(nseq)]
-streams = [torch.cuda.Stream() for _ in range(nseq)]
+H, W, T, R = 1080, 1920, 101, 2
+n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 L = _hip.lib()
-
-def run(k, reps):
-    d, ctx, st = data[k], ctxs[k], streams[k]
-    occ = torch.empty((T - 1, H, W), dtype=torch.uint8, device="cuda")
+data = [psfm_synth.synth_sequence_torch(T, H, W, seed=100 + k, sigma=0.05, n_occluders=2, stride2=False) for k in range(n_seq)]
+ctxs = [_hip.Context(0) for _ in range(n_seq)]
+for c in ctxs: c.set_chain_mode(mode)
+streams = [torch.cuda.Stream() for _ in range(n_seq)]
+log = [[] for _ in range(n_seq)]
+def worker(k, n):
+    torch.cuda.set_device(0)
+    sp = ctypes.c_void_p(streams[k].cuda_stream)
     info = _hip.TrackInfo()
-    sp = ctypes.c_void_p(st.cuda_stream)
-    for _ in range(reps):
-        _hip.check(L.psfm_flow_check(ctx.handle, _hip.ptr(d["flows_f"]), _hip.ptr(d["flows_b"]), T - 1, H, W, 1.0, _hip.ptr(occ), None, sp))
-        _hip.check(L.psfm_track(ctx.handle, _hip.ptr(d["flows_f"]), _hip.ptr(occ), None, None, T - 1, H, W, r, ctypes.byref(info), sp))
-    return info.n_points
-
-for k in range(nseq): run(k, 2)
-torch.cuda.synchronize()
-reps = 5
-t0 = time.perf_counter()
-pts = sum(run(k, reps) for k in range(nseq))
-torch.cuda.synchronize()
-t_seq = time.perf_counter() - t0
-ths = [threading.Thread(target=run, args=(k, reps)) for k in range(nseq)]
-t0 = time.perf_counter()
-for t in ths: t.start()
-for t in ths: t.join()
-torch.cuda.synchronize()
-t_con = time.perf_counter() - t0
-print("sequences %d  back-to-back %.2f ms/seq   concurrent %.2f ms/seq  (%.2fx)" % (nseq, 1e3 * t_seq / (reps * nseq), 1e3 * t_con / (reps * nseq), t_seq / t_con))
+    d = data[k]
+    for _ in range(n):
+        t0 = time.perf_counter()
+        _hip.check(L.psfm_connect(ctxs[k].handle, _hip.ptr(d["flows_f"]), _hip.ptr(d["flows_b"]), None, None, T - 1, H, W, 1.0, R, None, None, ctypes.byref(info), sp))
+        log[k].append((round(1e3 * (time.perf_counter() - t0), 2), info.chain_mode))
+for reps in (2, 4):
+    for l in log: l.clear()
+    ths = [threading.Thread(target=worker, args=(k, reps)) for k in range(n_seq)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("reps %d: %.2f ms per sequence" % (reps, 1e3 * dt / (reps * n_seq)))
+    for k in range(n_seq): print("   thread", k, log[k])
