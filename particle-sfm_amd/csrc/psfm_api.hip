@@ -525,8 +525,9 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
     // Track mode with the device to ourselves: ONE persistent launch computes the occlusion maps AND runs the recurrence
     // (the blocks check flow consistency in the time they would otherwise wait at the frame barriers).  The maps are
     // written through to HBM by their producers and first read by other XCDs a few barriers later; a cache line must
-    // not straddle two maps, hence the 128-byte pitch (caller-provided buffers qualify when H*W is a multiple of 128).
-    if (gate.exclusive && !optimize && (!occ || P % 128 == 0)) {
+    // not straddle two maps, hence the 128-byte pitch (caller-provided buffers qualify when H*W is a multiple of 128
+    // and the buffer is 128-byte aligned).
+    if (gate.exclusive && !optimize && (!occ || (P % 128 == 0 && ((uintptr_t)occ & 127) == 0))) {
         int64_t pitch = (int64_t)P;
         if (!occ) {
             pitch = (int64_t)((P + 127) / 128 * 128);
