@@ -154,6 +154,16 @@ psfm_status psfm_result_copy(psfm_ctx* ctx, int32_t* birth_host, int32_t* len_ho
 psfm_status psfm_result_solve_stats(psfm_ctx* ctx, psfm_solve_stats* stats_host, int32_t max_n,
                                     int32_t* n_out);
 
+/* The saved trajectory set of main_connect_point_trajectories.py:56-61 -- trajectories of length >= traj_min_len, ids =
+ * their indices in the full list -- compacted in HBM from the result of the last psfm_track / psfm_connect, so that only
+ * what is kept crosses PCIe (the host-side filter is a boolean gather over every point).
+ *   psfm_result_filter        builds the filtered CSR in the context, returns its sizes; synchronises `stream`
+ *   psfm_result_filtered_copy copies it to HOST buffers: ids (k) i32, birth (k) i32, len (k) i32, off (k+1) i64,
+ *                             xy (n_points,2) f64; any may be NULL */
+psfm_status psfm_result_filter(psfm_ctx* ctx, int traj_min_len, int64_t* n_traj_host, int64_t* n_points_host, void* stream);
+psfm_status psfm_result_filtered_copy(psfm_ctx* ctx, int32_t* ids_host, int32_t* birth_host, int32_t* len_host,
+                                      int64_t* off_host, double* xy_host, void* stream);
+
 /* The motion-segmentation window tensors (motion_seg/load_cut_seq.py:60-89) from the device-resident result of the last
  * psfm_track / psfm_connect -- TrajectorySet::sample_inside_window (optimize/src/trajectory_base.cpp:127-185) for the
  * contiguous window [frame0, frame0 + n_frames) plus the resize / normalise of motion_seg/core/dataset/data_utils.py:74-89:

@@ -104,7 +104,9 @@ struct psfm_ctx {
     PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats;
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
     PsfmBuf occ_own, occ2_own;           // occlusion maps of psfm_connect when the caller passes none
-    PsfmBuf win_ws;                      // psfm_window_sample workspace
+    PsfmBuf win_ws;                      // psfm_window_sample / psfm_result_filter workspace
+    PsfmBuf flt_ids, flt_birth, flt_len, flt_off, flt_xy;   // psfm_result_filter: the saved set (length >= traj_min_len), CSR
+    int64_t flt_n_traj = 0, flt_n_points = 0;
     hipStream_t side_stream = nullptr;   // flow_check of psfm_connect runs here, ahead of the frame loop
     std::vector<psfm_solve_stats> solve_stats;
     PsfmProfiler prof;

@@ -11,6 +11,7 @@
 // trip, no per-trajectory Python objects.
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
 
 #include "psfm_device.h"
@@ -151,6 +152,124 @@ extern "C" psfm_status psfm_window_sample(psfm_ctx* c, int frame0, int n_frames,
     const int64_t total_e = K * (int64_t)n_frames;
     hipLaunchKernelGGL(psfm_window_gather_kernel, dim3((unsigned)((total_e + PW_BLOCK - 1) / PW_BLOCK)), dim3(PW_BLOCK), 0, s, a);
     PSFM_HIP(hipGetLastError());
+    PSFM_HIP(hipStreamSynchronize(s));
+    return PSFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The saved trajectory set (main_connect_point_trajectories.py:56-61): trajectories of length >= traj_min_len, ids =
+// indices into the full list.  Filtering on the host means a boolean gather over ~5e7 points; here the CSR is
+// compacted in HBM (flag -> select -> scan -> one wave per kept trajectory copies its run) and only what is kept
+// crosses PCIe.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_BLOCK) void psfm_filter_flag_kernel(const int* __restrict__ len, int64_t n, int min_len,
+                                                                  uint8_t* __restrict__ flag, int* __restrict__ iota)
+{
+    const int64_t i = (int64_t)blockIdx.x * PW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (uint8_t)(len[i] >= min_len);
+    iota[i] = (int)i;
+}
+__global__ __launch_bounds__(PW_BLOCK) void psfm_filter_meta_kernel(const int* __restrict__ ids, int64_t k, const int* __restrict__ birth,
+                                                                  const int* __restrict__ len, int* __restrict__ birth_out,
+                                                                  int* __restrict__ len_out, int64_t* __restrict__ len64)
+{
+    const int64_t i = (int64_t)blockIdx.x * PW_BLOCK + threadIdx.x;
+    if (i > k) return;
+    if (i == k) { len64[i] = 0; return; }
+    const int id = ids[i];
+    birth_out[i] = birth[id];
+    len_out[i] = len[id];
+    len64[i] = (int64_t)len[id];
+}
+__global__ __launch_bounds__(PW_BLOCK) void psfm_filter_copy_kernel(const int* __restrict__ ids, int64_t k, const int* __restrict__ len,
+                                                                  const int64_t* __restrict__ off, const int64_t* __restrict__ off_out,
+                                                                  const double2* __restrict__ xy, double2* __restrict__ xy_out)
+{
+    const int lane = threadIdx.x & (PSFM_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * PW_BLOCK + threadIdx.x) / PSFM_WAVE, nw = (int64_t)gridDim.x * (PW_BLOCK / PSFM_WAVE);
+    for (int64_t t = wave; t < k; t += nw) {
+        const int id = ids[t];
+        const int n = len[id];
+        const int64_t src = off[id], dst = off_out[t];
+        for (int j = lane; j < n; j += PSFM_WAVE) xy_out[dst + j] = xy[src + j];
+    }
+}
+
+extern "C" psfm_status psfm_result_filter(psfm_ctx* c, int traj_min_len, int64_t* n_traj_host, int64_t* n_points_host, void* stream)
+{
+    if (!c || !n_traj_host || !n_points_host) { psfm_set_error("psfm_result_filter: NULL argument"); return PSFM_ERR_ARG; }
+    PSFM_HIP(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = c->res_n_traj;
+    *n_traj_host = 0; *n_points_host = 0;
+    c->flt_n_traj = c->flt_n_points = 0;
+    if (n == 0) return PSFM_OK;
+    psfm_status st;
+    const size_t o_iota = ((size_t)n + 255) / 256 * 256, o_cnt = o_iota + 4 * (size_t)n, total = o_cnt + 256;
+    if ((st = c->win_ws.ensure(total)) != PSFM_OK) return st;
+    if ((st = c->flt_ids.ensure(4 * (size_t)n)) != PSFM_OK) return st;
+    char* ws = (char*)c->win_ws.p;
+    uint8_t* flag = (uint8_t*)ws;
+    int* iota = (int*)(ws + o_iota);
+    size_t* d_cnt = (size_t*)(ws + o_cnt);
+    hipLaunchKernelGGL(psfm_filter_flag_kernel, dim3((unsigned)((n + PW_BLOCK - 1) / PW_BLOCK)), dim3(PW_BLOCK), 0, s,
+                       c->res_len.as<int>(), n, traj_min_len, flag, iota);
+    PSFM_HIP(hipGetLastError());
+    size_t tmp = 0;
+    PSFM_HIP(rocprim::select(nullptr, tmp, iota, flag, c->flt_ids.as<int>(), d_cnt, (size_t)n, s));
+    if ((st = c->sort_tmp.ensure(tmp)) != PSFM_OK) return st;
+    PSFM_HIP(rocprim::select(c->sort_tmp.p, tmp, iota, flag, c->flt_ids.as<int>(), d_cnt, (size_t)n, s));
+    size_t* h_cnt = (size_t*)((char*)c->host_pinned + 256);
+    PSFM_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(size_t), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    const int64_t k = (int64_t)*h_cnt;
+    c->flt_n_traj = k;
+    *n_traj_host = k;
+    if (k == 0) return PSFM_OK;
+    if ((st = c->flt_birth.ensure(4 * (size_t)k)) != PSFM_OK) return st;
+    if ((st = c->flt_len.ensure(4 * (size_t)k)) != PSFM_OK) return st;
+    if ((st = c->flt_off.ensure(8 * (size_t)(k + 1))) != PSFM_OK) return st;
+    if ((st = c->scan_tmp.ensure(8 * (size_t)(k + 1))) != PSFM_OK) return st;
+    hipLaunchKernelGGL(psfm_filter_meta_kernel, dim3((unsigned)((k + 1 + PW_BLOCK - 1) / PW_BLOCK)), dim3(PW_BLOCK), 0, s,
+                       c->flt_ids.as<int>(), k, c->res_birth.as<int>(), c->res_len.as<int>(), c->flt_birth.as<int>(),
+                       c->flt_len.as<int>(), c->scan_tmp.as<int64_t>());
+    PSFM_HIP(hipGetLastError());
+    size_t scan_bytes = 0;
+    PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(k + 1),
+                                     rocprim::plus<int64_t>(), s));
+    if ((st = c->sort_tmp.ensure(scan_bytes)) != PSFM_OK) return st;
+    PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->flt_off.as<int64_t>(), (int64_t)0,
+                                     (size_t)(k + 1), rocprim::plus<int64_t>(), s));
+    int64_t* h_np = (int64_t*)((char*)c->host_pinned + 264);
+    PSFM_HIP(hipMemcpyAsync(h_np, c->flt_off.as<int64_t>() + k, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    const int64_t np_keep = *h_np;
+    c->flt_n_points = np_keep;
+    *n_points_host = np_keep;
+    if ((st = c->flt_xy.ensure(16 * (size_t)(np_keep > 0 ? np_keep : 1))) != PSFM_OK) return st;
+    hipLaunchKernelGGL(psfm_filter_copy_kernel, dim3(4096), dim3(PW_BLOCK), 0, s, c->flt_ids.as<int>(), k, c->res_len.as<int>(),
+                       c->res_off.as<int64_t>(), c->flt_off.as<int64_t>(), c->res_xy.as<double2>(), c->flt_xy.as<double2>());
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_result_filtered_copy(psfm_ctx* c, int32_t* ids_host, int32_t* birth_host, int32_t* len_host,
+                                                 int64_t* off_host, double* xy_host, void* stream)
+{
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    PSFM_HIP(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t k = c->flt_n_traj, np_keep = c->flt_n_points;
+    if (k > 0) {
+        if (ids_host) PSFM_HIP(hipMemcpyAsync(ids_host, c->flt_ids.p, 4 * (size_t)k, hipMemcpyDeviceToHost, s));
+        if (birth_host) PSFM_HIP(hipMemcpyAsync(birth_host, c->flt_birth.p, 4 * (size_t)k, hipMemcpyDeviceToHost, s));
+        if (len_host) PSFM_HIP(hipMemcpyAsync(len_host, c->flt_len.p, 4 * (size_t)k, hipMemcpyDeviceToHost, s));
+        if (off_host) PSFM_HIP(hipMemcpyAsync(off_host, c->flt_off.p, 8 * (size_t)(k + 1), hipMemcpyDeviceToHost, s));
+        if (xy_host && np_keep > 0) PSFM_HIP(hipMemcpyAsync(xy_host, c->flt_xy.p, 16 * (size_t)np_keep, hipMemcpyDeviceToHost, s));
+    } else if (off_host) {
+        off_host[0] = 0;
+    }
     PSFM_HIP(hipStreamSynchronize(s));
     return PSFM_OK;
 }

@@ -17,7 +17,7 @@ EXPORTS = [
     "psfm_ctx_set_capacity", "psfm_flow_check", "psfm_grid_sample", "psfm_optimize_location", "psfm_track",
     "psfm_connect",
     "psfm_result_device", "psfm_result_copy", "psfm_result_solve_stats", "psfm_ctx_set_profiling",
-    "psfm_profile_get", "psfm_ctx_set_chain_mode", "psfm_window_sample",
+    "psfm_profile_get", "psfm_ctx_set_chain_mode", "psfm_window_sample", "psfm_result_filter", "psfm_result_filtered_copy",
 ]
 
 
@@ -76,6 +76,8 @@ def lib():
     L.psfm_result_solve_stats.argtypes = [vp, ctypes.POINTER(SolveStats), i32, ctypes.POINTER(ctypes.c_int32)]
     L.psfm_ctx_set_profiling.argtypes = [vp, i32]
     L.psfm_ctx_set_chain_mode.argtypes = [vp, i32]
+    L.psfm_result_filter.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), vp]
+    L.psfm_result_filtered_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.psfm_window_sample.argtypes = [vp, i32, i32, i32, i32, i64, ctypes.c_uint64, i32, i32, i32, i32, i64, vp, vp, vp, vp,
                                      ctypes.POINTER(i64), vp]
     L.psfm_profile_get.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(i64)]

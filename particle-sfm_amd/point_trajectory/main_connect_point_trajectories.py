@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 from .utils import load_flows_device
-from .trajectory import run_connect
+from . import _hip
+from .trajectory import run_connect, result_to_trajectory_set, save_track_npy
 
 
 def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_check_thres=1.0, traj_min_len=3,
@@ -27,11 +28,12 @@ def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_che
 
     # fwd/bwd checks (utils.py:94-105) + connecting tracks into point trajectories (track.py / track_optimize.py):
     # one call, the occlusion maps stream into the frame loop from a side stream
-    trajs = run_connect(flows_f, flows_b, flows_f2, flows_b2, flow_check_thres, sample_ratio)
+    info = run_connect(flows_f, flows_b, flows_f2, flows_b2, flow_check_thres, sample_ratio, return_device=True)
 
-    # save the outputs (:56-62): ids are indices into the full list, short trajectories dropped
-    trajectories = trajs.to_trajectory_set(traj_min_len)
-    np.save(output_npy_fname, trajectories)
+    # save the outputs (:56-62): ids are indices into the full list, short trajectories dropped -- filtered on the
+    # device, staged through pinned memory, written as the same .npy/pickle container np.save produces
+    trajectories = result_to_trajectory_set(_hip.context(), info, traj_min_len, reuse_pinned=True)
+    save_track_npy(output_npy_fname, trajectories)
 
 
 def main(args):

@@ -94,6 +94,48 @@ def _result_to_host(ctx, info):
     return TrajectoryList(birth, length, off, xy, info.as_dict(), stats)
 
 
+def result_to_trajectory_set(ctx, info, traj_min_len=3, reuse_pinned=False):
+    """The saved set of main_connect_point_trajectories.py:56-61 from the device-resident result: the min-length filter
+    runs on the GPU (psfm_result_filter) and only the kept trajectories cross PCIe.  reuse_pinned=True stages them in
+    a pinned buffer owned by the context -- twice the copy rate, but the arrays of the returned TrajectorySet are views
+    of that buffer and are overwritten by the next call (for callers that save the set straight away)."""
+    import torch
+    L = _hip.lib()
+    k, npt = ctypes.c_int64(0), ctypes.c_int64(0)
+    _hip.check(L.psfm_result_filter(ctx.handle, int(traj_min_len), ctypes.byref(k), ctypes.byref(npt), _hip.current_stream_ptr()))
+    k, npt = int(k.value), int(npt.value)
+    sizes = [4 * k, 4 * k, 4 * k, 8 * (k + 1), 16 * npt]
+    offs = np.concatenate([[0], np.cumsum([(x + 63) // 64 * 64 for x in sizes])])
+    if reuse_pinned:
+        buf = getattr(ctx, "_pinned_result", None)
+        if buf is None or buf.numel() < int(offs[-1]):
+            buf = torch.empty(int(offs[-1]) + (64 << 20), dtype=torch.uint8, pin_memory=True)
+            ctx._pinned_result = buf
+        raw = buf.numpy()
+    else:
+        raw = np.empty(int(offs[-1]), np.uint8)
+    ids = raw[offs[0]:offs[0] + sizes[0]].view(np.int32)
+    birth = raw[offs[1]:offs[1] + sizes[1]].view(np.int32)
+    length = raw[offs[2]:offs[2] + sizes[2]].view(np.int32)
+    off = raw[offs[3]:offs[3] + sizes[3]].view(np.int64)
+    xy = raw[offs[4]:offs[4] + sizes[4]].view(np.float64).reshape(-1, 2)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _hip.check(L.psfm_result_filtered_copy(ctx.handle, vp(ids), vp(birth), vp(length), vp(off), vp(xy), _hip.current_stream_ptr()))
+    return particlesfm.TrajectorySet._from_csr(ids.astype(np.int64), birth, length, off, xy)
+
+
+def save_track_npy(path, trajectories):
+    """np.save(path, trajectories) for consumers that np.load(path, allow_pickle=True).item(): the same .npy container
+    (object array header + pickle), written with pickle protocol 5 so that the CSR arrays stream to the file without an
+    intermediate bytes copy."""
+    import pickle
+    arr = np.empty((), dtype=object)
+    arr[()] = trajectories
+    with open(path if str(path).endswith(".npy") else str(path) + ".npy", "wb") as fp:
+        np.lib.format.write_array_header_1_0(fp, np.lib.format.header_data_from_array_1_0(arr))
+        pickle.dump(arr, fp, protocol=5)
+
+
 def _as_device_stack(maps, dtype, trailing):
     """list of (H,W[,2]) arrays | (n,H,W[,2]) array/tensor -> contiguous device tensor."""
     import torch

@@ -36,48 +36,75 @@ def load_flows(dir):
     return [read_flo(name) for name in sorted(glob.glob(dir + "/*.flo"))]
 
 
-def load_flows_device(dir, device=None, n_staging=3):
-    """`load_flows` (utils.py:26-32) straight into HBM: every .flo is read into a pinned host buffer and copied
-    to its slot of one (n,H,W,2) device tensor with an asynchronous H2D copy on a side stream, so the disk read of
-    file i+1 overlaps the PCIe transfer of file i (at cfg 4 the stacks are 26.5 GB, ingest bounds the
-    end-to-end time once the kernels are fast).  Returns a float32 device tensor (empty (0,0,0,2) if no files)."""
+def load_flows_device(dir, device=None, n_staging=8, n_readers=4):
+    """`load_flows` (utils.py:26-32) straight into HBM: the .flo files are read by a few reader threads into pinned
+    host buffers (owned by the context, reused across calls) and copied to their slot of one (n,H,W,2) device tensor with
+    asynchronous H2D copies on a side stream, so disk / page-cache reads and PCIe transfers overlap (at
+    cfg 4 the stacks are 26.5 GB, ingest bounds the end-to-end time once the kernels are fast).
+    Returns a float32 device tensor (empty (0,0,0,2) if no files)."""
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     names = sorted(glob.glob(dir + "/*.flo"))
     ctx = _hip.context(device)
     dev = torch.device("cuda", ctx.device)
     if not names:
         return torch.zeros((0, 0, 0, 2), dtype=torch.float32, device=dev)
 
-    def header(name):
-        with open(name, 'rb') as f:
-            tag = np.fromfile(f, np.float32, count=1)[0]
-            assert tag == TAG_FLOAT, 'Flow number %r incorrect. Invalid .flo file' % tag
-            w = int(np.fromfile(f, np.int32, count=1)[0])
-            h = int(np.fromfile(f, np.int32, count=1)[0])
+    def header(f, name):
+        tag = np.fromfile(f, np.float32, count=1)[0]
+        assert tag == TAG_FLOAT, 'Flow number %r incorrect. Invalid .flo file %r' % (tag, name)
+        w = int(np.fromfile(f, np.int32, count=1)[0])
+        h = int(np.fromfile(f, np.int32, count=1)[0])
         return h, w
 
-    h, w = header(names[0])
+    with open(names[0], 'rb') as f:
+        h, w = header(f, names[0])
     out = torch.empty((len(names), h, w, 2), dtype=torch.float32, device=dev)
-    staging = [torch.empty((h, w, 2), dtype=torch.float32).pin_memory() for _ in range(max(2, int(n_staging)))]
-    done = [None] * len(staging)
-    copy_stream = torch.cuda.Stream(device=dev)
-    for i, name in enumerate(names):
-        k = i % len(staging)
-        if done[k] is not None:
-            done[k].synchronize()            # the previous copy out of this staging buffer has finished
-        hh, ww = header(name)
-        assert (hh, ww) == (h, w), "flow size mismatch in %r" % name
+    n_staging = max(2, min(int(n_staging), len(names)))
+    key = (h, w, n_staging)
+    cache = getattr(ctx, "_flo_staging", None)
+    if cache is None or cache[0] != key:
+        cache = (key, [torch.empty((h, w, 2), dtype=torch.float32).pin_memory() for _ in range(n_staging)])
+        ctx._flo_staging = cache
+    staging = cache[1]
+
+    def read(i, k):
+        name = names[i]
         with open(name, 'rb') as f:
-            f.seek(12)
+            assert header(f, name) == (h, w), "flow size mismatch in %r" % name
             buf = staging[k].numpy().reshape(-1)
             got = f.readinto(memoryview(buf).cast('B'))
             assert got == buf.nbytes, "truncated .flo file %r" % name
-        with torch.cuda.stream(copy_stream):
-            out[i].copy_(staging[k], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(copy_stream)
-            done[k] = ev
+        return i
+
+    done = [None] * n_staging          # H2D copy out of staging buffer k
+    copy_stream = torch.cuda.Stream(device=dev)
+    with ThreadPoolExecutor(max_workers=max(1, int(n_readers))) as pool:
+        pending = {}
+        nxt = 0
+
+        def submit_upto(limit):
+            nonlocal nxt
+            while nxt < len(names) and nxt < limit:
+                k = nxt % n_staging
+                if done[k] is not None:
+                    done[k].synchronize()        # the previous copy out of this staging buffer has finished
+                    done[k] = None
+                pending[nxt] = pool.submit(read, nxt, k)
+                nxt += 1
+
+        submit_upto(n_staging)
+        for i in range(len(names)):
+            pending.pop(i).result()
+            k = i % n_staging
+            with torch.cuda.stream(copy_stream):
+                out[i].copy_(staging[k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+                done[k] = ev
+            submit_upto(i + 1 + n_staging)
     torch.cuda.current_stream(dev).wait_stream(copy_stream)
+    copy_stream.synchronize()            # the staging buffers belong to the context: nothing may still read them
     return out
 
 

@@ -1,0 +1,54 @@
+"""the stage entry end to end -- .flo files on disk -> track.npy on disk -- with its phases timed:
+ingest (.flo -> pinned host -> HBM), compute (psfm_connect), result to host, TrajectorySet + np.save, np.load back.
+    python scripts/end_to_end.py [frames=101] [workdir=/tmp/psfm_e2e]
+Writes synthetic 1080p flows (sample_ratio 2, track mode, like BASELINE configs[1]) as .flo files first (not timed)."""
+import os, shutil, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "particle-sfm_amd"))
+import numpy as np
+import torch
+import psfm_synth
+from point_trajectory import _hip
+from point_trajectory.utils import write_flo, load_flows_device
+from point_trajectory.trajectory import run_connect
+from point_trajectory.main_connect_point_trajectories import main_connect_point_trajectories
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 101
+work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/psfm_e2e"
+H, W, r = 1080, 1920, 2
+shutil.rmtree(work, ignore_errors=True)
+d = psfm_synth.synth_sequence_torch(T, H, W, seed=0, sigma=0.05, n_occluders=2, stride2=False)
+for name, key in (("flow_f", "flows_f"), ("flow_b", "flows_b")):
+    os.makedirs(os.path.join(work, "flows", name))
+    arr = d[key].cpu().numpy()
+    for i in range(T - 1):
+        write_flo(os.path.join(work, "flows", name, "%05d.flo" % i), arr[i])
+del d
+torch.cuda.synchronize()
+gb = 2 * (T - 1) * H * W * 8 / 1e9
+ctx = _hip.context()
+sync = torch.cuda.synchronize
+for rep in range(2):     # second pass = warm page cache / warm workspaces
+    t0 = time.perf_counter()
+    ff = load_flows_device(os.path.join(work, "flows", "flow_f")); fb = load_flows_device(os.path.join(work, "flows", "flow_b")); sync()
+    t1 = time.perf_counter()
+    info = run_connect(ff, fb, None, None, 1.0, r, return_device=True); sync()
+    t2 = time.perf_counter()
+    from point_trajectory.trajectory import result_to_trajectory_set, save_track_npy
+    ts = result_to_trajectory_set(ctx, info, 3, reuse_pinned=True)      # min-length filter on the device, pinned staging
+    t3 = time.perf_counter()
+    save_track_npy(os.path.join(work, "track.npy"), ts)
+    t4 = time.perf_counter()
+    back = np.load(os.path.join(work, "track.npy"), allow_pickle=True).item()
+    t5 = time.perf_counter()
+    nk = len(ts._csr[0])
+    print("pass %d: ingest %.0f ms (%.2f GB of .flo, %.1f GB/s) | compute %.2f ms | filter + D2H %.0f ms (%d of %d trajectories kept) | "
+          "save track.npy %.0f ms | np.load %.0f ms | points %d" % (
+              rep, (t1 - t0) * 1e3, gb, gb / (t1 - t0), (t2 - t1) * 1e3, (t3 - t2) * 1e3, nk, info.n_traj, (t4 - t3) * 1e3,
+              (t5 - t4) * 1e3, info.n_points))
+    del ff, fb, ts, back
+t0 = time.perf_counter()
+main_connect_point_trajectories(os.path.join(work, "flows"), os.path.join(work, "traj"), sample_ratio=r, skip_path_consistency=True)
+print("main_connect_point_trajectories (the stage entry, warm): %.2f s" % (time.perf_counter() - t0))
+print("track.npy: %.2f GB" % (os.path.getsize(os.path.join(work, "traj", "track.npy")) / 1e9))
+shutil.rmtree(work, ignore_errors=True)

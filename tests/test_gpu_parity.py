@@ -463,3 +463,29 @@ def test_motion_seg_window_tensors(pt):
     row = {i: k for k, i in enumerate(full["traj_ids"])}
     sel = np.array([row[i] for i in ia.tolist()])
     assert np.array_equal(a[1].cpu().numpy()[:, :, 0], full["locations"][0][sel]) and np.array_equal(a[3].cpu().numpy()[:, :, 0], 1.0 - full["masks"][sel])
+
+
+def test_saved_set_filtered_on_the_device(pt, tmp_path):
+    """psfm_result_filter (min-length filter in HBM, main_connect_point_trajectories.py:56-61) + the protocol-5 .npy
+    writer give exactly what the host path gives: TrajectoryList.to_trajectory_set + np.save."""
+    from point_trajectory.trajectory import result_to_trajectory_set, save_track_npy
+    d = psfm_synth.synth_sequence_torch(14, 90, 120, seed=77, sigma=0.4, n_occluders=2, stride2=False)
+    info = pt.trajectory.run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, 2, return_device=True)
+    ctx = pt.hip.context()
+    host = pt.trajectory._result_to_host(ctx, info).to_trajectory_set(3)
+    for pinned in (False, True):
+        dev = result_to_trajectory_set(ctx, info, 3, reuse_pinned=pinned)
+        for a, b in zip(host._csr[:5], dev._csr[:5]):
+            assert np.array_equal(a, b)
+        assert len(dev._csr[0]) < info.n_traj        # something was filtered out
+    save_track_npy(str(tmp_path / "track.npy"), dev)
+    np.save(str(tmp_path / "track_ref.npy"), host)
+    a = np.load(str(tmp_path / "track.npy"), allow_pickle=True).item()
+    b = np.load(str(tmp_path / "track_ref.npy"), allow_pickle=True).item()
+    for x, y in zip(a._csr[:5], b._csr[:5]):
+        assert np.array_equal(x, y)
+    a.build_invert_indexes()
+    assert sorted(a.as_dict()) == sorted(b.as_dict())
+    # empty result of the filter (every trajectory shorter than the minimum)
+    none = result_to_trajectory_set(ctx, info, 10 ** 6)
+    assert len(none._csr[0]) == 0 and none._csr[4].shape == (0, 2)
