@@ -76,12 +76,31 @@ class TrajectoryList:
         return particlesfm.TrajectorySet._from_csr(keep, self.birth[keep], length, off, xy)
 
 
+def _host_arrays(sizes_bytes, pinned_limit=2 << 30):
+    """One host allocation cut into 64-byte aligned uint8 views.  Page-locked (torch's caching host allocator: no
+    hipHostMalloc per call once warm, D2H at the full PCIe rate) up to `pinned_limit` bytes, pageable beyond."""
+    offs = np.concatenate([[0], np.cumsum([(int(x) + 63) // 64 * 64 for x in sizes_bytes])])
+    total = int(offs[-1])
+    raw = None
+    if 0 < total <= pinned_limit:
+        try:
+            import torch
+            raw = torch.empty(total, dtype=torch.uint8, pin_memory=True).numpy()   # the views keep the tensor alive
+        except Exception:
+            raw = None
+    if raw is None:
+        raw = np.empty(total, np.uint8)
+    return [raw[offs[i]:offs[i] + int(sizes_bytes[i])] for i in range(len(sizes_bytes))]
+
+
 def _result_to_host(ctx, info):
     n, npnt = int(info.n_traj), int(info.n_points)
-    birth = np.empty(n, np.int32)
-    length = np.empty(n, np.int32)
-    off = np.zeros(n + 1, np.int64)
-    xy = np.empty((npnt, 2), np.float64)
+    b_birth, b_len, b_off, b_xy = _host_arrays([4 * n, 4 * n, 8 * (n + 1), 16 * npnt])
+    birth = b_birth.view(np.int32)
+    length = b_len.view(np.int32)
+    off = b_off.view(np.int64)
+    off[:] = 0
+    xy = b_xy.view(np.float64).reshape(-1, 2)
     _hip.check(_hip.lib().psfm_result_copy(ctx.handle, birth.ctypes.data_as(ctypes.c_void_p),
                                            length.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p),
                                            xy.ctypes.data_as(ctypes.c_void_p), _hip.current_stream_ptr()))
