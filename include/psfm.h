@@ -92,11 +92,14 @@ psfm_status psfm_ctx_destroy(psfm_ctx* ctx);
  * Defaults 2.0 / 8.0.  psfm_track returns PSFM_ERR_CAPACITY when either overflows. */
 psfm_status psfm_ctx_set_capacity(psfm_ctx* ctx, double lane_factor, double traj_factor);
 
-/* How psfm_track runs the frame recurrence in track mode (flows_f2 == NULL):
- *   0 (default) one persistent launch for the whole sequence when every lane of the stride-r grid can be resident on
- *     the device at once (grid points <= 256 x resident blocks: 1080p at sample_ratio 2 fits an MI355X), else one
- *     launch per frame; the persistent loop hands over to per-frame launches by itself if it runs out of lanes;
- *   1 one launch per frame always;  2 persistent launch or PSFM_ERR_ARG / PSFM_ERR_CAPACITY.
+/* How psfm_track / psfm_connect run the frame recurrence in track mode (flows_f2 == NULL):
+ *   0 (default) by shape: ONE persistent launch for the whole sequence where that is the faster way on an MI355X
+ *     (sample_ratio >= 2 and >= 100 k grid points; psfm_connect, which then also checks flow consistency inside that
+ *     launch, additionally wants >= 400 k grid points and <= 6 pixels per grid point, e.g. 1080p at sample_ratio 2),
+ *     one launch per frame elsewhere.  The persistent loop needs every lane of the stride-r grid resident at once
+ *     (grid points <= 256 x resident blocks) and the device to itself; it hands over to per-frame launches by itself
+ *     when it runs out of lanes or of patience at a barrier;
+ *   1 one launch per frame always;  2 the persistent loop wherever it can run (waits for the device), per-frame elsewhere.
  * Results are identical in every mode.  track_optimize always uses one launch per frame (the solves sit in between). */
 psfm_status psfm_ctx_set_chain_mode(psfm_ctx* ctx, int mode);
 

@@ -29,14 +29,26 @@ struct PsfmGate {
     PsfmGate(const PsfmGate&) = delete;
     PsfmGate& operator=(const PsfmGate&) = delete;
 };
-// would psfm_track try the persistent loop for this call? (0 no, 1 yes if the device is free, 2 required)
-static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int ratio)
+// Would this call run the persistent loop?  0 no, 1 yes if the device is free, 2 yes, wait for the device.
+// Mode 0 decides by shape, from measurements on MI355X (scripts/probe_shapes.py; 100 frames, flow_check + recurrence +
+// finalize, persistent / per-frame): the loop costs ~14 us per frame whatever the frame size (a barrier and five
+// dependent memory operations), a per-frame launch 7-16 us.
+//   psfm_track on ready maps: 1080p r=2 0.93, 1080p r=4 0.93, 720p r=2 0.94, 436x1024 r=2 0.98, 4K r=4 0.92 -- but
+//     480x854 r=4 (25 k grid points) 1.03 and every r=1 shape 1.13-1.14  ->  sample_ratio >= 2 and >= 100 k grid points;
+//   psfm_connect with flow_check fused in: 1080p r=2 0.94 -- 720p r=2 1.01, 1080p r=4 1.42, 4K r=4 1.09 (flow_check
+//     inside the loop only runs where waves wait; beside a short or flow_check-heavy step the side stream is better)
+//     ->  additionally >= 400 k grid points and at most 6 pixels per grid point.
+static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int ratio, bool fused)
 {
     if (optimize || c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;
     const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
+    const int64_t P = (int64_t)h * w;
     const int maxb = psfm_persist_max_blocks(c);
     if (maxb <= 0 || (G + 255) / 256 > maxb) return 0;
-    return c->chain_mode == 2 ? 2 : 1;
+    if (c->chain_mode == 2) return 2;
+    if (ratio < 2 || G < 100000) return 0;
+    if (fused && (G < 400000 || P > 6 * G)) return 0;
+    return 1;
 }
 
 void psfm_set_error(const char* fmt, ...)
@@ -343,6 +355,13 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
             // converge): twice the grid while that is cheap, a quarter more otherwise, never more than fits the device
             int64_t nb = need_blocks <= 256 ? 2 * need_blocks + 4 : need_blocks + need_blocks / 4;
             dp.nblk = (int)(nb < maxb ? nb : maxb);
+            // fused flow_check: the occlusion maps are computed by whatever blocks exist -- enough of them to cover the
+            // image in one round of 1024-pixel chunks (blocks without grid points only check flows and lend lanes)
+            if (fuse_flows_b) {
+                const int64_t fc_blocks = (P + 1023) / 1024;
+                const int64_t want = fc_blocks < maxb ? fc_blocks : maxb;
+                if (want > dp.nblk) dp.nblk = (int)want;
+            }
             dp.cap = (int64_t)dp.nblk * (256 + psfm_persist_guests());   // log columns: thread lanes, then guest lanes
             dp.nsh = dp.nblk < PSFM_NSHARD ? dp.nblk : PSFM_NSHARD;
             dp.free_cap = (int)(((dp.nblk + dp.nsh - 1) / dp.nsh) * 256) + 1024;
@@ -386,19 +405,8 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                 }
                 return PSFM_OK;
             }
-            if (c->chain_mode == 2) {
-                psfm_set_error("psfm_track: the persistent loop gave up (overflow bits %d) and chain mode 2 forbids the per-frame path",
-                               ((PsfmCounters*)c->host_pinned)->overflow);
-                return PSFM_ERR_CAPACITY;
-            }
             c->prof.collect();
-        } else if (c->chain_mode == 2) {
-            psfm_set_error("psfm_track: persistent loop unavailable (%lld blocks needed, %d resident)", (long long)need_blocks, maxb);
-            return PSFM_ERR_ARG;
         }
-    } else if (optimize && c->chain_mode == 2) {
-        psfm_set_error("psfm_track: chain mode 2 (persistent loop) applies to track mode only");
-        return PSFM_ERR_ARG;
     }
     if (fuse_flows_b) {   // the persistent loop did not run (or gave up): the maps it would have produced, stand-alone
         c->prof.begin(PSFM_PROF_FLOW_CHECK, s);
@@ -500,7 +508,7 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
                                   void* stream)
 {
     PSFM_CHECK_CTX(c);   // (selects the context's device: the residency query below is per device)
-    PsfmGate gate(c->device, psfm_wants_persist(c, flows_f2 != nullptr, h, w, ratio));
+    PsfmGate gate(c->device, psfm_wants_persist(c, flows_f2 != nullptr, h, w, ratio, false));
     return psfm_track_impl(c, flows, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, nullptr, gate.exclusive);
 }
 
@@ -514,7 +522,7 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
 {
     PSFM_CHECK_CTX(c);
     const bool optimize = flows_f2 != nullptr;
-    PsfmGate gate(c->device, psfm_wants_persist(c, optimize, h, w, ratio));
+    PsfmGate gate(c->device, psfm_wants_persist(c, optimize, h, w, ratio, true));
     if (n_flows < 1 || h < 2 || w < 2 || !flows_f || !flows_b || (optimize && n_flows > 1 && !flows_b2)) {
         psfm_set_error("psfm_connect: bad argument (n_flows=%d h=%d w=%d)", n_flows, h, w);
         return PSFM_ERR_ARG;

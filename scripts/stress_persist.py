@@ -22,20 +22,20 @@ for i in range(n_cases):
     sigma = float(rng.choice([0.05, 0.2, 0.4, 0.8])); nocc = int(rng.integers(0, 4)); seed = int(rng.integers(0, 1 << 30))
     d = psfm_synth.synth_sequence_torch(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=False)
     out = {}
-    for mode in (1, 0):
+    for mode in (1, 2):
         ctx.set_chain_mode(mode)
         info = run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, r, return_device=True)
         out[("c", mode)] = (_result_to_host(ctx, info), info.chain_mode)
     _, occ = flow_check_device(d["flows_f"], d["flows_b"], 1.0)
-    ctx.set_chain_mode(0)
+    ctx.set_chain_mode(2)
     info = run_track(d["flows_f"], occ, None, None, r, return_device=True)
-    out[("t", 0)] = (_result_to_host(ctx, info), info.chain_mode)
-    for key in (("c", 0), ("t", 0)):
+    out[("t", 2)] = (_result_to_host(ctx, info), info.chain_mode)
+    for key in (("c", 2), ("t", 2)):
         if out[key][1] != 2:
             print("fell back: case %d %s T=%d %dx%d r=%d sigma=%.2f nocc=%d seed=%d  n_traj %d lanes_peak %s cap %s" % (
                 i, key, T, H, W, r, sigma, nocc, seed, len(out[key][0]), out[key][0].info.get("n_lanes_peak"), out[key][0].info.get("lane_capacity")))
     A = out[("c", 1)][0]
-    for key in (("c", 0), ("t", 0)):
+    for key in (("c", 2), ("t", 2)):
         B = out[key][0]
         same = len(A) == len(B) and np.array_equal(A.birth, B.birth) and np.array_equal(A.length, B.length) and np.array_equal(A.xy, B.xy)
         if not same:

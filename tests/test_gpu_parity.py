@@ -22,10 +22,11 @@ def pt():
     return ns
 
 
-@pytest.fixture(autouse=True, params=[1, 0], ids=["per-frame-launches", "auto-persistent"])
+@pytest.fixture(autouse=True, params=[1, 2], ids=["per-frame-launches", "persistent-loop"])
 def chain_mode(request, pt):
-    """Every test of this module runs twice: with one chain_step launch per frame, and with the default policy
-    (track mode: ONE persistent launch per sequence whenever the grid fits the device).  Results must not differ."""
+    """Every test of this module runs twice: with one chain_step launch per frame, and with the persistent frame loop
+    wherever it can run (track mode: ONE resident launch per sequence; mode 0 would pick it by shape).  Results must
+    not differ."""
     ctx = pt.hip.context()
     ctx.set_chain_mode(request.param)
     yield request.param
@@ -337,23 +338,39 @@ def test_persistent_loop_hands_over_to_per_frame_launches(pt, chain_mode, monkey
     assert np.array_equal(Rc.birth, O.birth) and np.array_equal(Rc.length, O.length) and np.array_equal(Rc.xy, O.xy)
 
 
-def test_persistent_mode_required_but_unavailable(pt):
-    """chain mode 2 on a grid with more points than resident lanes (1080p at sample_ratio 1) is an argument error."""
+def test_chain_mode_policy(pt):
+    """Mode 2 runs the persistent loop wherever it can and per-frame launches elsewhere (grid larger than the resident
+    lanes, track_optimize); mode 0 decides by shape: sample_ratio >= 2 with >= 100 k grid points for psfm_track,
+    additionally >= 400 k grid points and <= 6 pixels per grid point for the fused psfm_connect."""
     import ctypes
     import torch
     hip = pt.hip
     ctx = hip.context()
-    H, W = 1080, 1920
-    fl = torch.zeros((1, H, W, 2), dtype=torch.float32, device="cuda")
-    oc = torch.zeros((1, H, W), dtype=torch.uint8, device="cuda")
-    ctx.set_chain_mode(2)
-    st = hip.lib().psfm_track(ctx.handle, hip.ptr(fl), hip.ptr(oc), None, None, 1, H, W, 1, None, hip.current_stream_ptr())
-    assert st == hip.PSFM_ERR_ARG and b"persistent" in hip.lib().psfm_last_error()
-    ctx.set_chain_mode(0)
-    info = hip.TrackInfo()
-    hip.check(hip.lib().psfm_track(ctx.handle, hip.ptr(fl), hip.ptr(oc), None, None, 1, H, W, 1, ctypes.byref(info),
-                                   hip.current_stream_ptr()))
-    assert info.chain_mode == 1 and info.n_traj == H * W      # zero flow: nothing moves, nothing dies
+
+    def track(H, W, r, connect=False):
+        fl = torch.zeros((2, H, W, 2), dtype=torch.float32, device="cuda")
+        oc = torch.zeros((2, H, W), dtype=torch.uint8, device="cuda")
+        info = hip.TrackInfo()
+        if connect:
+            hip.check(hip.lib().psfm_connect(ctx.handle, hip.ptr(fl), hip.ptr(fl), None, None, 2, H, W, 1.0, r, None, None,
+                                             ctypes.byref(info), hip.current_stream_ptr()))
+        else:
+            hip.check(hip.lib().psfm_track(ctx.handle, hip.ptr(fl), hip.ptr(oc), None, None, 2, H, W, r, ctypes.byref(info),
+                                           hip.current_stream_ptr()))
+        assert info.n_traj >= ((H + r - 1) // r) * ((W + r - 1) // r)
+        return info.chain_mode
+    try:
+        ctx.set_chain_mode(2)
+        assert track(1080, 1920, 1) == 1            # 2.07 M grid points: more than the device holds resident
+        assert track(96, 128, 1) == 2               # anything that fits
+        ctx.set_chain_mode(0)
+        assert track(1080, 1920, 2) == 2 and track(1080, 1920, 2, connect=True) == 2
+        assert track(720, 1280, 2) == 2 and track(720, 1280, 2, connect=True) == 1
+        assert track(540, 960, 1) == 1 and track(96, 128, 2) == 1
+        ctx.set_chain_mode(1)
+        assert track(1080, 1920, 2) == 1
+    finally:
+        ctx.set_chain_mode(0)
 
 
 @pytest.mark.parametrize("H,W,T,r", [(64, 128, 9, 2), (45, 70, 8, 1), (120, 160, 6, 3)])
@@ -395,7 +412,7 @@ def test_random_sequences_all_paths_agree(pt):
             d = psfm_synth.synth_sequence_torch(T, H, W, seed=int(rng.integers(0, 1 << 30)), sigma=float(rng.choice([0.05, 0.3, 0.8])),
                                                 n_occluders=int(rng.integers(0, 4)), stride2=False)
             res = []
-            for mode in (1, 0):
+            for mode in (1, 2):
                 ctx.set_chain_mode(mode)
                 res.append(pt.trajectory.run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, r))
             _, occ = pt.utils.flow_check_device(d["flows_f"], d["flows_b"], 1.0)
