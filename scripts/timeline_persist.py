@@ -10,7 +10,7 @@ from point_trajectory.utils import flow_check_device
 from point_trajectory.trajectory import run_track
 
 frame = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-T, H, W, r = 101, 1080, 1920, 2
+T, H, W, r = 101, int(sys.argv[2]) if len(sys.argv) > 4 else 1080, int(sys.argv[3]) if len(sys.argv) > 4 else 1920, int(sys.argv[4]) if len(sys.argv) > 4 else 2
 d = psfm_synth.synth_sequence_torch(T, H, W, seed=0, sigma=0.05, n_occluders=2, stride2=False)
 _, occ = flow_check_device(d["flows_f"], d["flows_b"], 1.0)
 lib = _hip.lib()
@@ -21,7 +21,7 @@ for it in range(3):
     assert fn(frame if it == 2 else -1, None, 0) == 0
     info = run_track(d["flows_f"], occ, None, None, r, return_device=True)
     torch.cuda.synchronize()
-NB = 2048
+NB = int(info.lane_capacity) // (256 + 32)
 buf2 = np.zeros((2, 4096, 8), np.uint64)
 assert fn(0, buf2.ctypes.data, NB) == 0
 buf = buf2[0, :NB]
