@@ -32,7 +32,10 @@
 #include "psfm_internal.h"
 
 #define PC_BLOCK 256
-#define PC_MAX_BLOCKS 512    // 2 blocks of 256 per CU fill the chip at this kernel's register footprint (2 waves/SIMD)
+#ifndef PC_MAX_BLOCKS
+#define PC_MAX_BLOCKS 512    // 152 VGPRs = 3 waves/SIMD; 512 blocks measured best on the 401-frame 1080p run (66 ms; 768: 67.6,
+                             // 384: 70.9; capped to 128 VGPRs / 4 waves with 14 spills: 78 ms)
+#endif
 #define PC_NSUM 13
 
 
@@ -330,8 +333,10 @@ __device__ __forceinline__ void pc_track_iteration(const PcParams& P, const doub
     }
 }
 
-__device__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
-                                      int is_init);
+// (force-inlined: as a called function it dragged the call ABI's register budget into the kernels -- 248 VGPRs,
+// 2 waves/SIMD -- although the per-track code needs 152)
+__device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
+                                                      int is_init);
 
 // Publish this block's partials and find out whether it is the last one to finish: write-through payload ->
 // drain -> ticket (device-scope atomic); the last block reads the payload with cache-bypassing loads.
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
 // ------------------------------------------------------------------------------------------------
 // pc_ctrl: reduce the partials in a fixed order and run Ceres' scalar control logic.
 // ------------------------------------------------------------------------------------------------
-__device__ void pc_choose_dogleg(PsfmSolveCtrl& C)
+__device__ __forceinline__ void pc_choose_dogleg(PsfmSolveCtrl& C)
 {
     // ComputeTraditionalDoglegStep, with alpha = |ghat|^2 / |Js ghat/diag|^2 (ComputeCauchyPoint)
     const double gnorm = sqrt(C.g2), gnn = sqrt(C.gn2);
@@ -460,8 +465,8 @@ __device__ void pc_choose_dogleg(PsfmSolveCtrl& C)
 // Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket after an agent-scope
 // release; the reading block acquires before touching the other blocks' partials -- cdna_hip_programming.md G16):
 // fixed-order reduction of the per-block partials, then the scalar control step on thread 0.
-__device__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
-                                      int is_init)
+__device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
+                                                      int is_init)
 {
     // Fixed-order reduction of partials[n_blocks][PC_NSUM]: thread t owns slot (t % 16) of the block rows
     // t/16, t/16 + 16, ...; its loads are independent (issued back to back), summed in increasing row order; the 16
