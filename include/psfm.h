@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PSFM_VERSION 100
+#define PSFM_VERSION 110
 
 typedef enum psfm_status {
     PSFM_OK = 0,
