@@ -32,6 +32,9 @@
 #include "psfm_internal.h"
 
 #define PC_BLOCK 256
+#ifndef PC_RED_ROWS
+#define PC_RED_ROWS 32        // partial rows a thread of the last block keeps in flight
+#endif
 #ifndef PC_MAX_BLOCKS
 #define PC_MAX_BLOCKS 512    // 152 VGPRs = 3 waves/SIMD; 512 blocks measured best on the 401-frame 1080p run (66 ms; 768: 67.6,
                              // 384: 70.9; capped to 128 VGPRs / 4 waves with 14 spills: 78 ms)
@@ -478,17 +481,19 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
         const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
         double v = 0.0;
         if (k < PC_NSUM) {
-            for (int b0 = g; b0 < n_blocks; b0 += 128) {   // 8 rows in flight
-                double p[8];
+            // all rows of this thread in flight at once (32 for 512 blocks): the loads bypass the caches, so every
+            // batch is a full round trip on the tail of the launch -- one batch instead of four (summed in the same order)
+            for (int b0 = g; b0 < n_blocks; b0 += 16 * PC_RED_ROWS) {
+                double p[PC_RED_ROWS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < PC_RED_ROWS; ++u) {
                     const int bb = b0 + 16 * u;
                     p[u] = bb < n_blocks ? __hip_atomic_load(&partials[(int64_t)bb * PC_NSUM + k], __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_SYSTEM)
                                          : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v = (k == SUM_GMAX) ? fmax(v, p[u]) : v + p[u];
+                for (int u = 0; u < PC_RED_ROWS; ++u) v = (k == SUM_GMAX) ? fmax(v, p[u]) : v + p[u];
             }
         }
         s_part[g][k] = v;
