@@ -240,3 +240,30 @@ def test_fast_division_and_threshold_shortcuts_are_exact():
     r = subprocess.run([os.path.join(odir, "build", "test_fastdiv"), "2000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 counter-examples" in r.stdout
+
+
+def test_window_ranges_and_track_npy_writer(tmp_path):
+    """Host logic that needs no GPU: the window cut of load_cut_seq.py:50-73 and the protocol-5 track.npy writer (same
+    container as np.save: consumers np.load(..., allow_pickle=True).item())."""
+    from motion_seg.load_cut_seq import window_ranges
+    from point_trajectory.trajectory import save_track_npy
+    from point_trajectory.optimize.build.particlesfm import TrajectorySet
+    assert window_ranges(23, 10) == [(0, 10), (10, 10), (13, 10)]
+    assert window_ranges(20, 10) == [(0, 10), (10, 10)]
+    assert window_ranges(7, 10) == [(0, 7)] and window_ranges(10, 10) == [(0, 10)]
+    ids = np.array([0, 3, 4], np.int64)
+    birth = np.array([0, 1, 2], np.int32)
+    length = np.array([3, 4, 3], np.int32)
+    off = np.array([0, 3, 7, 10], np.int64)
+    xy = np.arange(20, dtype=np.float64).reshape(10, 2)
+    ts = TrajectorySet._from_csr(ids, birth, length, off, xy)
+    save_track_npy(str(tmp_path / "track.npy"), ts)
+    np.save(str(tmp_path / "ref.npy"), ts)
+    a = np.load(str(tmp_path / "track.npy"), allow_pickle=True).item()
+    b = np.load(str(tmp_path / "ref.npy"), allow_pickle=True).item()
+    assert a.as_dict().keys() == b.as_dict().keys() == {0, 3, 4}
+    assert list(a.as_dict()[3]["frame_ids"]) == [1, 2, 3, 4]
+    assert np.array_equal(np.asarray(a.as_dict()[3]["locations"]), np.asarray(b.as_dict()[3]["locations"]))
+    a.build_invert_indexes()
+    out = a.sample_inside_window([2, 3, 4], min_length=3)
+    assert out["traj_ids"] == [3, 4]
