@@ -37,7 +37,8 @@
 #endif
 #ifndef PC_MAX_BLOCKS
 #define PC_MAX_BLOCKS 512    // 152 VGPRs = 3 waves/SIMD; 512 blocks measured best on the 401-frame 1080p run (66 ms; 768: 67.6,
-                             // 384: 70.9; capped to 128 VGPRs / 4 waves with 14 spills: 78 ms)
+                             // 384: 70.9, 430: 69.2, 537: 71 -- an equal number of blocks on every CU matters more than an equal number of
+                             // tracks per thread; capped to 128 VGPRs / 4 waves with 14 spills: 78 ms)
 #endif
 #define PC_NSUM 13
 
@@ -413,11 +414,29 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
 // ------------------------------------------------------------------------------------------------
 // pc_iter: one trust-region iteration at the current iterate.
 // ------------------------------------------------------------------------------------------------
+#ifdef PSFM_TIMELINE
+// debug builds only: phase timestamps of the pc_iter launches (first 64 real launches), per block
+__device__ unsigned long long g_pc_tl[64 * 1024 * 4];
+__device__ int g_pc_tl_n = 0;
+extern "C" int psfm_debug_solver_timeline(unsigned long long* out_host, int* n_host)
+{
+    if (hipMemcpyFromSymbol(n_host, HIP_SYMBOL(g_pc_tl_n), sizeof(int)) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pc_tl), sizeof(unsigned long long) * 64 * 1024 * 4) != hipSuccess;
+}
+#define PC_TL(k) do { if (tl_slot >= 0 && threadIdx.x == 0) g_pc_tl[((size_t)tl_slot * 1024 + blockIdx.x) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PC_TL(k) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
 {
     if (*P.stall) return;
     const PsfmSolveCtrl C = *P.ctrl;
     if (C.done) return;
+#ifdef PSFM_TIMELINE
+    const int tl_slot = C.iteration == 1 && g_pc_tl_n < 64 ? g_pc_tl_n : -1;   // the first pc_iter launch of a solve
+    PC_TL(0);
+#endif
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
     const double2* xc1 = C.cur ? P.x1b : P.x1a;
     const double2* xc2 = C.cur ? P.x2b : P.x2a;
@@ -438,8 +457,17 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
         const double x[4] = {p1.x, p1.y, p2.x, p2.y};
         pc_track_iteration(P, x, r1, r2, s, S, C.mu, a, b, xn1, xn2, i, acc, nullptr);
     }
+    PC_TL(1);
     pc_block_reduce(acc, P.partials);
-    if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 0);
+    const bool last_block = pc_is_last_block(P.ticket);
+    PC_TL(2);
+    if (last_block) {
+        pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 0);
+        PC_TL(3);
+#ifdef PSFM_TIMELINE
+        if (threadIdx.x == 0 && tl_slot >= 0) { g_pc_tl[((size_t)tl_slot * 1024 + 1023) * 4 + 0] = blockIdx.x; g_pc_tl_n = tl_slot + 1; }
+#endif
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
