@@ -241,26 +241,37 @@ __device__ __forceinline__ double pc_wave_max(double v)
     return v;
 }
 
-// block reduction of acc[PC_NSUM] (slot SUM_GMAX by max, others by sum) -> partials[blockIdx]
+// block reduction of acc[PC_NSUM] (slot SUM_GMAX by max, others by sum) -> partials[blockIdx], in a fixed order:
+// through LDS (every thread parks its 13 accumulators; 13 x 16 threads add 16 values each in thread order; 13 threads
+// add the 16 group sums).  The wave-shuffle form (13 sums x 6 steps x 2 ds_bpermute per wave) took ~4 us of every
+// launch's tail.
 __device__ __forceinline__ void pc_block_reduce(double acc[PC_NSUM], double* __restrict__ partials)
 {
-    __shared__ double s_red[PC_BLOCK / PSFM_WAVE][PC_NSUM];
-    const int lane = psfm_lane_id(), wave = threadIdx.x / PSFM_WAVE;
+    __shared__ double s_acc[PC_NSUM][PC_BLOCK + 1];
+    __shared__ double s_grp[PC_NSUM][16];
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < PC_NSUM; ++k) {
-        const double v = (k == SUM_GMAX) ? pc_wave_max(acc[k]) : pc_wave_sum(acc[k]);
-        if (lane == 0) s_red[wave][k] = v;
+    for (int k = 0; k < PC_NSUM; ++k) s_acc[k][tid] = acc[k];
+    __syncthreads();
+    if (tid < PC_NSUM * 16) {
+        const int k = tid >> 4, g = tid & 15;
+        double v = s_acc[k][g * 16];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) v = (k == SUM_GMAX) ? fmax(v, s_acc[k][g * 16 + j]) : v + s_acc[k][g * 16 + j];
+        s_grp[k][g] = v;
     }
     __syncthreads();
-    if (threadIdx.x < PC_NSUM) {
-        const int k = threadIdx.x;
-        double v = s_red[0][k];
-        for (int w = 1; w < PC_BLOCK / PSFM_WAVE; ++w) v = (k == SUM_GMAX) ? fmax(v, s_red[w][k]) : v + s_red[w][k];
+    if (tid < PC_NSUM) {
+        const int k = tid;
+        double v = s_grp[k][0];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) v = (k == SUM_GMAX) ? fmax(v, s_grp[k][g]) : v + s_grp[k][g];
         // write-through (sc0 sc1) store: the last block of the launch reads these with matching loads, so no
         // agent-scope release (an L2 write-back per block) is needed -- MI355X_MICROARCH.md, valid hand-off forms
         __hip_atomic_store(&partials[(int64_t)blockIdx.x * PC_NSUM + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
 
 __device__ __forceinline__ bool pc_participates(const PcParams& P, int i, int n)
 {
