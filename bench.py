@@ -93,18 +93,17 @@ def concurrent_sequences(n_seq, n_frames, reps=4):
             "trajectory_points_per_s": sum(pts) * reps / dt}
 
 
-def secondary_track_optimize(ctx):
-    """track_optimize (chaining + Ceres-compatible path-consistency solve) on a synthetic stand-in of configs[2]
-    (Sintel alley_1 shape: 436x1024, 50 frames, sample_ratio 2): GPU time per sequence and the CPU oracle on the
-    first 6 flows of the same tensors, with the parity of those 6 flows checked on the spot."""
+def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="configs[2] shape"):
+    """track_optimize (chaining + Ceres-compatible path-consistency solve) on a synthetic sequence -- by default a
+    stand-in of configs[2] (Sintel alley_1 shape: 436x1024, 50 frames, sample_ratio 2): GPU time per sequence and the
+    CPU oracle on the first k flows of the same tensors, with the parity of those flows checked on the spot."""
     import numpy as np
     import torch
     import psfm_synth
     from oracle import oracle as orc
     from point_trajectory.utils import flow_check_device
     from point_trajectory.trajectory import run_track, _result_to_host
-    h, w, t, r = 436, 1024, 50, 2
-    d = psfm_synth.synth_sequence_torch(t, h, w, seed=2, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
+    d = psfm_synth.synth_sequence_torch(t, h, w, seed=seed, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
     ctx.set_profiling(0)
 
     from point_trajectory.trajectory import run_connect
@@ -123,7 +122,6 @@ def secondary_track_optimize(ctx):
     ms = 1e3 * (time.perf_counter() - t0) / n
     _, occ = flow_check_device(d["flows_f"], d["flows_b"], THRES)
     _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], THRES)
-    k = 6
     ff, f2 = list(d["flows_f"][:k].cpu().numpy()), list(d["flows_f2"][:k - 1].cpu().numpy())
     oo, o2 = list(occ[:k].cpu().numpy()), list(occ2[:k - 1].cpu().numpy())
     t0 = time.perf_counter()
@@ -131,10 +129,11 @@ def secondary_track_optimize(ctx):
     cpu_s = time.perf_counter() - t0
     Rg = _result_to_host(ctx, run_track(d["flows_f"][:k], occ[:k], d["flows_f2"][:k - 1], occ2[:k - 1], r, return_device=True))
     same = bool(np.array_equal(Rg.birth, Rc.birth) and np.array_equal(Rg.length, Rc.length))
-    return {"workload": "configs[2] shape: synthetic 436x1024 x 50 frames, sample_ratio=2, flow_check x2 + track_optimize",
+    return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check x2 + track_optimize" % (label, h, w, t, r),
             "ms_per_sequence": ms, "trajectory_points_per_s": info.n_points / (ms * 1e-3), "points": int(info.n_points),
             "solves": int(info.n_solves), "trust_region_iterations": int(info.solver_iterations),
-            "cpu_port_points_per_s": Rc.n_points / cpu_s, "cpu_port_sample": "first %d flows, 1 core, %.2f s" % (k, cpu_s),
+            "cpu_port_points_per_s": Rc.n_points / cpu_s,
+            "gpu_over_cpu_port": (info.n_points / (ms * 1e-3)) / (Rc.n_points / cpu_s), "cpu_port_sample": "first %d flows, 1 core, %.2f s" % (k, cpu_s),
             "parity_first_flows": {"ids_lengths_equal": same,
                                    "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None,
                                    "tolerance_px": 1e-4}}
@@ -336,6 +335,9 @@ def main():
             if not args.no_extras:
                 out["secondary"] = secondary_track_optimize(ctx)
                 del flows_b
+                # north_star's target workload for the path-consistency path: the headline shape with the solver on
+                out["secondary_1080p"] = secondary_track_optimize(ctx, H, W, n_frames, RATIO, seed=5, k=10,
+                                                                  label="headline shape with path consistency")
                 out["concurrent"] = concurrent_sequences(3, n_frames)
         print(json.dumps(out), flush=True)
     if world > 1:
