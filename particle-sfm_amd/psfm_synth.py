@@ -114,3 +114,20 @@ def synth_sequence_torch(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluder
             noisy(out["flows_b2"][t], -(u + u2), -(v + v2))
             occlude(out["flows_b2"][t], torch.stack([u + u2, v + v2], -1))
     return out
+
+
+NONFINITE_VALUES = (float("nan"), float("inf"), float("-inf"), 1e30, -1e30, 3e38, 1e10, -1e10, 2147483648.0, -2147483904.0)
+
+
+def poison_nonfinite(d, seed, per_field=40):
+    """Overwrite `per_field` random components of every flow field of a synth_sequence() result with NaN, +-Inf and
+    huge finite values (what a broken flow network could emit).  Returns the same dict, arrays modified in place."""
+    rng = np.random.default_rng(seed)
+    vals = np.array(NONFINITE_VALUES, np.float32)
+    for k in sorted(d):
+        for a in d[k]:
+            H, W = a.shape[:2]
+            for _ in range(per_field):
+                a[rng.integers(0, H), rng.integers(0, W), rng.integers(0, 2)] = vals[rng.integers(0, len(vals))]
+    return d
+

@@ -51,9 +51,27 @@ def input_hash(d):
     return h.hexdigest()
 
 
+def make_nonfinite(ref):
+    """NaN / Inf / huge flow components: the reference's torch ops define what happens (NaN errors compare false, a
+    track whose next position is not finite fails the strict bounds test and ends) and nothing may fault."""
+    T, H, W, r, seed = 7, 40, 56, 2, 41
+    d = psfm_synth.poison_nonfinite(psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=0.2, n_occluders=1, stride2=False),
+                                    seed=seed + 1)
+    err, occ = ref.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    tr = ref.track(d["flows_f"], occ, r)
+    b, l, off, xy = ref_shim.trajs_to_csr(tr)
+    np.savez_compressed(os.path.join(HERE, "nonfinite_40x56_r2.npz"), T=T, H=H, W=W, ratio=r, seed=seed, sigma=0.2,
+                        n_occluders=1, input_hash=input_hash(d), fc_err=np.stack(err), fc_occ=np.packbits(np.stack(occ)),
+                        birth=b, length=l, xy=xy)
+    print("nonfinite", len(tr), "tracks,", int(l.sum()), "points,", int(np.isnan(np.stack(err)).sum()), "NaN errors,",
+          int((~np.isfinite(np.concatenate([np.ravel(a) for a in d["flows_f"]]))).sum()), "non-finite forward components")
+
+
 def main():
     import torch
     ref = ref_shim.load()
+    if sys.argv[1:] == ["nonfinite"]:
+        return make_nonfinite(ref)
     out = {}
 
     # ---- 1. sampler known answers (trajectory.py:25-37) -------------------
@@ -133,6 +151,8 @@ def main():
         d2 = (gy[..., None] - ys) ** 2 + (gx[..., None] - xs) ** 2
         assert ((d2.min(-1) > r * r) == ref_mask).all(), r
     print("EDT == integer-disc rule verified for r=1..5")
+
+    make_nonfinite(ref)
 
 
 if __name__ == "__main__":

@@ -84,6 +84,36 @@ def test_track_golden(pt, name):
     assert_csr_equal(R.birth, R.length, R.xy, g)
 
 
+def test_nonfinite_flows_golden(pt):
+    """NaN / +-Inf / huge flow components against the fixture made by the reference's torch ops: same error maps (NaN
+    bit patterns included), masks and trajectories through every entry point, and no fault on the saturated taps."""
+    import ctypes
+    import torch
+    g = golden("nonfinite_40x56_r2")
+    T, H, W, r = int(g["T"]), int(g["H"]), int(g["W"]), int(g["ratio"])
+    d = psfm_synth.poison_nonfinite(psfm_synth.synth_sequence(T, H, W, seed=int(g["seed"]), sigma=float(g["sigma"]),
+                                                              n_occluders=int(g["n_occluders"]), stride2=False),
+                                    seed=int(g["seed"]) + 1)
+    err, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    ge, e = g["fc_err"], np.stack(err)
+    assert np.array_equal(np.isnan(e), np.isnan(ge))
+    assert np.array_equal(e[~np.isnan(ge)].view(np.uint32), ge[~np.isnan(ge)].view(np.uint32))
+    assert np.array_equal(np.packbits(np.stack(occ)), g["fc_occ"])
+    R = pt.track(d["flows_f"], occ, r)
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+    hip = pt.hip
+    ff = torch.from_numpy(np.stack(d["flows_f"])).cuda()
+    fb = torch.from_numpy(np.stack(d["flows_b"])).cuda()
+    R = pt.trajectory.run_connect(ff, fb, None, None, 1.0, r)
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+    # mask-only flow_check (the squared-threshold form) and the maps psfm_connect hands back
+    occ_out = torch.full((T - 1, H, W), 9, dtype=torch.uint8, device="cuda")
+    info = hip.TrackInfo()
+    hip.check(hip.lib().psfm_connect(hip.context().handle, hip.ptr(ff), hip.ptr(fb), None, None, T - 1, H, W, 1.0, r,
+                                     hip.ptr(occ_out), None, ctypes.byref(info), hip.current_stream_ptr()))
+    assert np.array_equal(np.packbits(occ_out.cpu().numpy().astype(bool)), g["fc_occ"])
+
+
 def test_track_all_tracks_die(pt):
     g = golden("track_alldie_24x30_r2")
     d = regen_inputs(g, stride2=False)

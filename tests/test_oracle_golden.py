@@ -71,6 +71,29 @@ def test_track_all_tracks_die():
     assert_csr_equal(R.birth, R.length, R.xy, g)
 
 
+def _nonfinite_inputs(g):
+    d = psfm_synth.poison_nonfinite(psfm_synth.synth_sequence(int(g["T"]), int(g["H"]), int(g["W"]), seed=int(g["seed"]),
+                                                              sigma=float(g["sigma"]), n_occluders=int(g["n_occluders"]),
+                                                              stride2=False), seed=int(g["seed"]) + 1)
+    from _common import input_hash
+    assert input_hash(d) == str(g["input_hash"])
+    return d
+
+
+def test_nonfinite_flows_bit_exact():
+    """NaN / +-Inf / huge flow components (fixture made by the reference's torch ops): NaN errors stay NaN and compare
+    false, tracks stepping to a non-finite position end there; ids, lengths, positions equal."""
+    g = golden("nonfinite_40x56_r2")
+    d = _nonfinite_inputs(g)
+    err, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    assert np.array_equal(np.stack(err).view(np.uint32), g["fc_err"].view(np.uint32))
+    assert np.isnan(g["fc_err"]).sum() > 50
+    assert np.array_equal(np.packbits(np.stack(occ)), g["fc_occ"])
+    R = orc.track(d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+    assert np.isfinite(R.xy).all()
+
+
 @pytest.mark.parametrize("name", ["opt_48x64_r2", "opt_45x70_r3"])
 def test_track_optimize_orchestration(name):
     """Buffer / index / scale semantics are the reference's (pinned); the solver iterate inside is the
