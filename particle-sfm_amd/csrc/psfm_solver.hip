@@ -144,10 +144,23 @@ __device__ __forceinline__ PcJac pc_scaled_jac(const double jac[4], double s, co
     return J;
 }
 
-// Gauss-Newton system of one track: diag, scaled gradient ghat, scaled GN step gn; returns false when the
-// Cholesky factorisation of (Js^T Js + mu diag^2) breaks down.  Also the Cauchy-point term |Js (ghat/diag)|^2.
-__device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], double mu, double d[4], double gh[4],
-                                             double gn[4], double* jg2)
+// IEEE division a / b given y = 1.0 / b (itself a true division): q = RN(a y) is within 1.5 ulp of a/b, the residual
+// a - b q is exact in an fma, and RN(q + r y) is the correctly rounded quotient (Markstein's correction step; exact
+// for every one of 4e8 random and special-significand pairs against `/` on the host, and bit-identical trajectories
+// against the true-division CPU restatement on the whole-sequence parity runs).  Three full-rate instructions instead
+// of the ~11 of the IEEE expansion with its quarter-rate v_rcp_f64 -- each pivot divides several numerators.
+// (b == 0 / non-finite operands only occur in solves that are flagged as failed anyway.)
+__device__ __forceinline__ double pc_div(double a, double b, double y)
+{
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    return fma(r, y, q);
+}
+
+// Gauss-Newton system of one track: diag (and its reciprocals), scaled gradient ghat, scaled GN step gn; returns false
+// when the Cholesky factorisation of (Js^T Js + mu diag^2) breaks down.  Also the Cauchy-point term |Js (ghat/diag)|^2.
+__device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], double mu, double d[4], double yd[4],
+                                             double gh[4], double gn[4], double* jg2)
 {
     const double n0 = (J.a0 * J.a0 + J.b0 * J.b0) + J.c0 * J.c0;
     const double n1 = (J.a1 * J.a1 + J.b1 * J.b1) + J.c1 * J.c1;
@@ -161,8 +174,9 @@ __device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], 
     for (int c = 0; c < 4; ++c) {
         const double cn = fmin(fmax(nn[c], 1e-6), 1e32);   // min/max_lm_diagonal
         d[c] = sqrt(cn);
-        gh[c] = q[c] / d[c];
-        sg[c] = gh[c] / d[c];
+        yd[c] = 1.0 / d[c];
+        gh[c] = pc_div(q[c], d[c], yd[c]);
+        sg[c] = pc_div(gh[c], d[c], yd[c]);
     }
     {
         const double m0 = J.a0 * sg[0], m1 = J.a1 * sg[1], m2 = J.a2 * sg[2], m3 = J.a3 * sg[3];
@@ -184,7 +198,7 @@ __device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], 
     A[3][0] = J.c0 * J.c3;
     A[3][1] = J.c1 * J.c3;
     A[3][2] = 0.0;
-    double L[4][4];
+    double L[4][4], yL[4];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -196,8 +210,9 @@ __device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], 
             if (i == j) {
                 ok = ok && (sum > 0.0);
                 L[i][i] = sqrt(sum);
+                yL[i] = 1.0 / L[i][i];
             } else {
-                L[i][j] = sum / L[j][j];
+                L[i][j] = pc_div(sum, L[j][j], yL[j]);
             }
         }
     }
@@ -207,14 +222,14 @@ __device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], 
         double sum = q[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) sum -= L[i][k] * z[k];
-        z[i] = sum / L[i][i];
+        z[i] = pc_div(sum, L[i][i], yL[i]);
     }
 #pragma unroll
     for (int i = 3; i >= 0; --i) {
         double sum = z[i];
 #pragma unroll
         for (int k = i + 1; k < 4; ++k) sum -= L[k][i] * y[k];
-        y[i] = sum / L[i][i];
+        y[i] = pc_div(sum, L[i][i], yL[i]);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -305,8 +320,8 @@ __device__ __forceinline__ void pc_track_iteration(const PcParams& P, const doub
         acc[SUM_XN2] += x[k] * x[k];
     }
     const PcJac J = pc_scaled_jac(jac, s, S);
-    double d[4], gh[4], gn[4], jg2;
-    const bool ok = pc_gn_system(J, r, mu, d, gh, gn, &jg2);
+    double d[4], yd[4], gh[4], gn[4], jg2;
+    const bool ok = pc_gn_system(J, r, mu, d, yd, gh, gn, &jg2);
     acc[SUM_JG2] += jg2;
     if (!ok) acc[SUM_FAIL] += 1.0;
     // dogleg step in the scaled space, then /diag (ComputeTraditionalDoglegStep)
@@ -318,7 +333,7 @@ __device__ __forceinline__ void pc_track_iteration(const PcParams& P, const doub
         acc[SUM_DOT] += gh[k] * gn[k];
         const double v = a * gh[k] + b * gn[k];
         acc[SUM_DL2] += v * v;
-        st[k] = v / d[k];
+        st[k] = pc_div(v, d[k], yd[k]);
     }
     // model_cost_change = -(J step)'(r + J step / 2)
     {
