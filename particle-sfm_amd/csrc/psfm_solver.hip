@@ -510,10 +510,13 @@ __device__ __forceinline__ void pc_choose_dogleg(PsfmSolveCtrl& C)
         C.dl_case = 2; C.dl_a = -(C.radius / gnorm); C.dl_b = 0.0; C.dl_norm = C.radius;
     } else {
         const double b_dot_a = -alpha * C.dot;
-        const double a2 = pow(alpha * gnorm, 2.0);
-        const double bma2 = a2 - 2 * b_dot_a + pow(gnn, 2);
+        // dogleg_strategy.cc writes these squares as pow(x, 2.0): host compilers fold that into x * x (exactly rounded);
+        // the device library's pow is a log/exp evaluation within 1 ulp, which moved the coefficients by an ulp
+        const double ag = alpha * gnorm;
+        const double a2 = ag * ag;
+        const double bma2 = a2 - 2 * b_dot_a + gnn * gnn;
         const double c = b_dot_a - a2;
-        const double dd = sqrt(c * c + bma2 * (pow(C.radius, 2.0) - a2));
+        const double dd = sqrt(c * c + bma2 * (C.radius * C.radius - a2));
         const double beta = (c <= 0) ? (dd - c) / bma2 : (C.radius * C.radius - a2) / (dd + c);
         C.dl_case = 3; C.dl_a = -alpha * (1.0 - beta); C.dl_b = beta; C.dl_norm = -1.0;
     }

@@ -56,6 +56,11 @@ def test_optimize_location_vs_oracle(pt, H, W, n, seed, sigma, kink):
     assert st_g["dogleg_nonGN"] == st_o["dogleg_nonGN"]
     assert abs(st_g["final_cost"] - st_o["final_cost"]) <= 1e-9 * max(1.0, st_o["final_cost"])
     assert float(np.abs(out_g - out_o).max()) <= 1e-8
+    # stronger than the 1e-4 px bar: every per-track operation rounds like the C restatement (true IEEE divisions there,
+    # reciprocal + fma correction here), so pure Gauss-Newton solves give the same bits; an interpolated dogleg step
+    # takes its two coefficients from sums over all tracks, whose order differs (tree vs sequential) by design
+    if st_o["dogleg_nonGN"] == 0:
+        assert np.array_equal(out_g, out_o)
 
 
 def test_optimize_location_exercises_dogleg(pt):
