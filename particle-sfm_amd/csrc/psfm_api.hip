@@ -426,6 +426,9 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     if (optimize) {
         if ((st = c->sol_stats.ensure(sizeof(psfm_solve_stats) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
     }
+    // (tests: PSFM_SOLVE_UNROLL=1 makes every solve that needs more than two iterations stall and resume)
+    const char* unroll_env = getenv("PSFM_SOLVE_UNROLL");
+    const int unroll_fixed = unroll_env ? (atoi(unroll_env) < 1 ? 1 : atoi(unroll_env)) : 0;
     int f = 0;
     while (f < n_flows) {
         // track.py:31-47 / track_optimize.py:31-50, one loop iteration:
@@ -438,7 +441,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
             c->prof.begin(PSFM_PROF_SOLVER, s);
             st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
                                           flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
-                                          c->solve_unroll, s);
+                                          unroll_fixed > 0 ? unroll_fixed : c->solve_unroll, s);
             c->prof.end(s);
             if (st != PSFM_OK) return st;
         }

@@ -103,6 +103,25 @@ def test_track_optimize_vs_oracle(pt, H, W, T, r, seed, sigma, nocc):
     assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
 
 
+def test_track_optimize_stalled_solves_are_resumed(pt, monkeypatch):
+    """With ONE unrolled iteration per frame every solve runs out of launches: its write-back raises the device-side
+    stall flag (everything enqueued behind turns into no-ops), the next checkpoint resumes it with host polling and
+    re-enqueues the frames after it.  Same trajectories, same per-solve statistics."""
+    from oracle import oracle as orc
+    monkeypatch.setenv("PSFM_SOLVE_UNROLL", "1")
+    for (H, W, T, r, seed, sigma) in [(90, 140, 8, 3, 52, 0.3), (64, 96, 21, 1, 54, 0.15)]:
+        d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=2, stride2=True)
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+        O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        assert max(s["iterations"] for s in O.solves) > 2          # more than init + one launch can do
+        R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+        assert float(np.abs(R.xy - O.xy).max()) <= TOL
+        assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+        assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
+
+
 def test_track_optimize_two_flows_only(pt):
     """n_flows = 2: exactly one solve; n_flows = 1: none (the stride-2 stack is empty)."""
     from oracle import oracle as orc
