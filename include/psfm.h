@@ -45,7 +45,7 @@ typedef enum psfm_status {
     PSFM_ERR_ARG = 1,       /* bad argument */
     PSFM_ERR_HIP = 2,       /* HIP runtime error (no device, OOM, launch failure) */
     PSFM_ERR_CAPACITY = 3,  /* lane / trajectory tables too small: raise psfm_ctx_set_capacity and retry */
-    PSFM_ERR_SOLVER = 4     /* the trust-region solver reported failure (Ceres would return FAILURE) */
+    PSFM_ERR_SOLVER = 4     /* the trust-region loop did not terminate (a solve Ceres would end in FAILURE is NOT an error: like the reference, the parameters stay as they came in and psfm_solve_stats.termination says 5) */
 } psfm_status;
 
 typedef struct psfm_ctx psfm_ctx;

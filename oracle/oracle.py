@@ -129,8 +129,7 @@ def optimize_location(uv12, ref1, ref2, scale, flow12_map, total_num=None, width
     st = SolveStats()
     rc = lib().orc_optimize_location(_ptr(uv12), _ptr(ref1), _ptr(ref2), _ptr(scale), _ptr(fm), n, W, H,
                                      _ptr(out), ctypes.byref(st))
-    if rc != 0:
-        raise RuntimeError("oracle optimize_location: solver failure")
+    # rc != 0: Ceres' FAILURE -- ignored like the reference does (trajectory_optimize.cpp:81-82); `out` then equals uv12
     return (out, st.as_dict()) if return_stats else out
 
 

@@ -531,7 +531,9 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
         }
     }
     st.final_cost = minimum_cost;
-    memcpy(out, best, sizeof(double) * P);
+    /* solver.cc Minimize(): the user's parameters are only updated when Summary::IsSolutionUsable() -- after a FAILURE
+     * Ceres restores the values it was called with; the reference ignores the failure (trajectory_optimize.cpp:81-82) */
+    memcpy(out, st.termination == 5 ? uv12 : best, sizeof(double) * P);
     if (stats) *stats = st;
     free(x); free(xc); free(res); free(jac); free(S); free(diag); free(ghat); free(gn); free(step); free(best);
     return st.termination == 5 ? 1 : 0;

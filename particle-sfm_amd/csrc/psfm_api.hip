@@ -465,10 +465,8 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
             }
             int max_it = 0;
             for (int k = first_unchecked; k <= last_ok; ++k) {
-                if (hstats[k].termination == PSFM_TERM_FAILURE) {
-                    psfm_set_error("path-consistency solver: FAILURE at frame %d", k);
-                    return PSFM_ERR_SOLVER;
-                }
+                // (termination 5 = Ceres' FAILURE: the reference ignores it, trajectory_optimize.cpp:81-82, and carries on
+                // with the positions it had -- so does the device; the caller sees it in the solve statistics)
                 if (hstats[k].termination >= 0) {   // -1: no track had a full buffer, nothing was solved
                     c->solve_stats.push_back(hstats[k]);
                     total_iters += hstats[k].iterations;

@@ -674,15 +674,23 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P,
         P.stats_dev[P.frame] = st;
     }
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
-    const double2* xc1 = C.cur ? P.x1b : P.x1a;
-    const double2* xc2 = C.cur ? P.x2b : P.x2a;
+    // A failed solve is not an error (the reference ignores Ceres' FAILURE, trajectory_optimize.cpp:81-82) and Ceres
+    // hands the parameters back as they came in (solver.cc Minimize(), Summary::IsSolutionUsable()).  The failure that
+    // can happen here is the one at iteration 0 -- non-finite residuals: nothing was accepted, C.cur == 0, buffer 0
+    // still holds the initial values.  (A breakdown after accepted steps would need the 4x4 SPD system
+    // Js^T Js + mu diag^2 to lose definiteness, or an accepted iterate with finite cost and a non-finite Jacobian over
+    // the same four taps; the current iterate is what comes out then.)
+    const int cur = C.cur;
+    if (cur == 0 && !out_rows) return;
+    const double2* xc1 = cur ? P.x1b : P.x1a;
+    const double2* xc2 = cur ? P.x2b : P.x2a;
     for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
         if (!pc_participates(P, i, n)) continue;
         const double2 p1 = xc1[i], p2 = xc2[i];
         if (out_rows) {
             out_rows[4 * (int64_t)i + 0] = p1.x; out_rows[4 * (int64_t)i + 1] = p1.y;
             out_rows[4 * (int64_t)i + 2] = p2.x; out_rows[4 * (int64_t)i + 3] = p2.y;
-        } else if (C.cur) {
+        } else {
             P.x1a[i] = p1; P.x2a[i] = p2;
         }
     }
@@ -751,7 +759,8 @@ static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double
     hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, out_rows);
     PSFM_HIP(hipGetLastError());
     if (st) pc_fill_stats(hctrl, st);
-    if (hctrl->failed) { psfm_set_error("path-consistency solver: FAILURE (invalid steps / Cholesky breakdown)"); return PSFM_ERR_SOLVER; }
+    // (a failed solve -- invalid steps / Cholesky breakdown / non-finite residuals -- is not an error: like the reference,
+    // which ignores Ceres' FAILURE at trajectory_optimize.cpp:81-82, the parameters stay as they came in; stats say 5)
     return PSFM_OK;
 }
 

@@ -103,6 +103,45 @@ def test_track_optimize_vs_oracle(pt, H, W, T, r, seed, sigma, nocc):
     assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
 
 
+def test_failed_solve_leaves_parameters_untouched(pt):
+    """A solve Ceres would end in FAILURE (here: non-finite residuals at iteration 0, and a map that is NaN where the
+    tracks walk to after a few accepted steps) is ignored by the reference (trajectory_optimize.cpp:81-82) and Ceres
+    hands the parameters back as they came in (solver.cc Minimize / IsSolutionUsable): same here, status OK,
+    termination 5 in the statistics."""
+    from oracle import oracle as orc
+    uv, ref1, ref2, scale, flow12 = _batch(60, 80, 3000, 7, 0.05)
+    bad = flow12.copy()
+    bad[20:30, 30:50, :] = np.nan
+    out_o, st_o = orc.optimize_location(uv, ref1, ref2, scale, bad, return_stats=True)
+    out_g = pt.particlesfm.optimize_location(uv, ref1, ref2, scale, bad, uv.shape[0], 80, 60)
+    st_g = pt.particlesfm.optimize_location.last_stats
+    assert st_o["termination"] == 5 and st_g["termination"] == 5
+    assert np.array_equal(out_o, uv) and np.array_equal(out_g, uv)
+    # and the next solve on the same context is unaffected
+    out_o, st_o = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+    out_g = pt.particlesfm.optimize_location(uv, ref1, ref2, scale, flow12, uv.shape[0], 80, 60)
+    assert st_o["termination"] != 5 and pt.particlesfm.optimize_location.last_stats["termination"] == st_o["termination"]
+    assert float(np.abs(out_g - out_o).max()) <= 1e-8
+
+
+def test_track_optimize_carries_on_after_failed_solves(pt):
+    """Non-finite flow components in all four stacks: the frames whose solve fails keep their chained positions, the
+    sequence goes on -- ids, lengths, positions and per-solve terminations as in the CPU restatement."""
+    from oracle import oracle as orc
+    T, H, W, r = 9, 60, 84, 2
+    d = psfm_synth.poison_nonfinite(psfm_synth.synth_sequence(T, H, W, seed=77, sigma=0.1, n_occluders=1, stride2=True),
+                                    seed=78, per_field=6)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    assert 5 in [s["termination"] for s in O.solves]
+    assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+    both = np.isfinite(O.xy)
+    assert np.array_equal(np.isfinite(R.xy), both) and float(np.abs(R.xy[both] - O.xy[both]).max()) <= TOL
+
+
 def test_track_optimize_stalled_solves_are_resumed(pt, monkeypatch):
     """With ONE unrolled iteration per frame every solve runs out of launches: its write-back raises the device-side
     stall flag (everything enqueued behind turns into no-ops), the next checkpoint resumes it with host polling and
