@@ -58,7 +58,7 @@ __device__ __forceinline__ uint8_t psfm_flow_check_px(const float2* __restrict__
     return (uint8_t)((s2 > q.t2) | oob);
 }
 
-struct PsfmStep { bool alive; double2 next; };
+struct PsfmStep { bool alive; double2 next; float2 flow; };   // flow: the sampled (fx, fy), next = p + (double)flow
 
 // One chain step split in two so that the caller can issue the gathers of several steps back to back and keep
 // them in flight across the block's bookkeeping: psfm_step_issue() computes the tap geometry and performs the eight
@@ -113,6 +113,7 @@ __device__ __forceinline__ PsfmStep psfm_step_finish(const A& a, double2 p, cons
     const bool valid = (nx > 0.0) & (nx < (double)(a.W - 1)) & (ny > 0.0) & (ny < (double)(a.H - 1));
     PsfmStep s;
     s.next = make_double2(nx, ny);
+    s.flow = make_float2(fx, fy);
     s.alive = valid & !(oc > 0.1f);
     return s;
 }

@@ -163,14 +163,117 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* 
     const int maxlen = s_maxlen;
     const int j = tid & (TILE_J - 1);   // track within the tile (read phase: lanes fastest)
     const int q = tid / TILE_J;         // 0..3
+    constexpr int NLD = TILE_K * TILE_J / PSFM_BLOCK;   // tile entries a thread loads per chunk
+    const int lj = s_len[j];
+    const int64_t col = s_lane[j];
+    const int bj = s_birth[j];
+    // read: for a fixed time, 64 consecutive ids -> (mostly) consecutive lanes of one slab; the loads of chunk c+1 are
+    // issued before chunk c is written out, so the read latency hides behind the writes
+    double2 r[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int t = q + u * (PSFM_BLOCK / TILE_J);
+        r[u] = t < lj ? log[(int64_t)(bj + t) * cap + col] : make_double2(0.0, 0.0);
+    }
     for (int k0 = 0; k0 < maxlen; k0 += TILE_K) {
-        // read: for a fixed time, 64 consecutive ids -> (mostly) consecutive lanes of one slab
-        const int lj = s_len[j];
-        const int64_t col = s_lane[j];
-        const int bj = s_birth[j];
-        for (int k = q; k < TILE_K; k += PSFM_BLOCK / TILE_J) {
-            const int t = k0 + k;
-            if (t < lj) tile[j][k] = log[(int64_t)(bj + t) * cap + col];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) tile[j][q + u * (PSFM_BLOCK / TILE_J)] = r[u];
+        __syncthreads();
+        if (k0 + TILE_K < maxlen) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int t = k0 + TILE_K + q + u * (PSFM_BLOCK / TILE_J);
+                r[u] = t < lj ? log[(int64_t)(bj + t) * cap + col] : make_double2(0.0, 0.0);
+            }
+        }
+        // write: for a fixed track, TILE_K consecutive times -> contiguous run of the result
+        const int kk = tid & (TILE_K - 1);
+        for (int jj = tid / TILE_K; jj < TILE_J; jj += PSFM_BLOCK / TILE_K) {
+            const int t = k0 + kk;
+            if (t < s_len[jj]) out[s_off[jj] + t] = tile[jj][kk];
+        }
+        __syncthreads();
+    }
+}
+
+// The persistent loop logs the sampled flow of every survived step instead of positions (half the bytes, written once,
+// read once): a trajectory is its birth grid point plus the running f64 sum of its column -- the additions the loop
+// itself performed, p(t+1) = p(t) + (double)flow, re-run here in the same order (one thread walks one trajectory's
+// chunk serially through LDS; a parallel scan would round differently whenever an addition is inexact).
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_delta_kernel(const float2* __restrict__ dlog, int64_t cap,
+                                                                       const int* __restrict__ lanes,
+                                                                       const int* __restrict__ birth,
+                                                                       const int* __restrict__ len,
+                                                                       const int64_t* __restrict__ off, int64_t n,
+                                                                       const void* __restrict__ keys, int use32, int shift_b,
+                                                                       int GW, int ratio, double2* __restrict__ out)
+{
+    __shared__ float2 dtile[TILE_J][TILE_K + 1];
+    __shared__ double2 tile[TILE_J][TILE_K + 1];
+    __shared__ double2 s_pos[TILE_J];
+    __shared__ int s_lane[TILE_J], s_birth[TILE_J], s_len[TILE_J];
+    __shared__ int64_t s_off[TILE_J];
+    __shared__ int s_maxlen;
+    const int tid = threadIdx.x;
+    const int64_t id0 = (int64_t)blockIdx.x * TILE_J;
+    if (tid == 0) s_maxlen = 0;
+    __syncthreads();
+    if (tid < TILE_J) {
+        const int64_t id = id0 + tid;
+        const bool ok = id < n;
+        s_lane[tid] = ok ? lanes[id] : 0;
+        s_birth[tid] = ok ? birth[id] : 0;
+        s_len[tid] = ok ? len[id] : 0;
+        s_off[tid] = ok ? off[id] : 0;
+        if (ok) {
+            atomicMax(&s_maxlen, s_len[tid]);
+            const unsigned long long mask = (1ull << shift_b) - 1ull;
+            const int idx = (int)((use32 ? (unsigned long long)((const unsigned*)keys)[id] : ((const unsigned long long*)keys)[id]) & mask);
+            const int gy = idx / GW, gx = idx - gy * GW;
+            s_pos[tid] = make_double2((double)(gx * ratio), (double)(gy * ratio));   // trajectory.py:110-115
+        }
+    }
+    __syncthreads();
+    const int maxlen = s_maxlen;
+    const int j = tid & (TILE_J - 1);
+    const int q = tid / TILE_J;
+    constexpr int NLD = TILE_K * TILE_J / PSFM_BLOCK;   // tile entries a thread loads per chunk
+    const int lj = s_len[j];
+    const int64_t col = s_lane[j];
+    const int bj = s_birth[j];
+    // point t >= 1 of a trajectory born at b needs the flow of step b + t - 1 (slab b + t - 1, its column)
+    float2 r[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int t = q + u * (PSFM_BLOCK / TILE_J);
+        r[u] = (t >= 1 && t < lj) ? dlog[(int64_t)(bj + t - 1) * cap + col] : make_float2(0.f, 0.f);
+    }
+    for (int k0 = 0; k0 < maxlen; k0 += TILE_K) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) dtile[j][q + u * (PSFM_BLOCK / TILE_J)] = r[u];
+        __syncthreads();
+        // the next chunk's flows travel while this one is accumulated and written
+        if (k0 + TILE_K < maxlen) {
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int t = k0 + TILE_K + q + u * (PSFM_BLOCK / TILE_J);
+                r[u] = (t < lj) ? dlog[(int64_t)(bj + t - 1) * cap + col] : make_float2(0.f, 0.f);
+            }
+        }
+        // accumulate: one thread per trajectory, in time order (entries outside [1, len) are zero-filled and skipped)
+        if (tid < TILE_J) {
+            double2 pos = s_pos[tid];
+            const int l = s_len[tid];
+            float2 f[TILE_K];
+#pragma unroll
+            for (int k = 0; k < TILE_K; ++k) f[k] = dtile[tid][k];
+#pragma unroll
+            for (int k = 0; k < TILE_K; ++k) {
+                const int t = k0 + k;
+                if (t >= 1 && t < l) { pos.x = pos.x + (double)f[k].x; pos.y = pos.y + (double)f[k].y; }
+                tile[tid][k] = pos;
+            }
+            s_pos[tid] = pos;
         }
         __syncthreads();
         // write: for a fixed track, TILE_K consecutive times -> contiguous run of the result
@@ -201,7 +304,7 @@ static PsfmKeyFmt psfm_key_fmt(const PsfmTrackDims& d, unsigned* end_bit)
 
 // common tail: (key, lane) records already compacted into the SECOND halves of sort_keys / sort_lanes (keys in the
 // format psfm_key_fmt() chose: n 8-byte or n 4-byte entries behind the first n entries of the same width)
-static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int64_t n, int64_t npts, hipStream_t s)
+static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int64_t n, int64_t npts, bool delta_log, hipStream_t s)
 {
     psfm_status st;
     unsigned end_bit = 0;
@@ -243,9 +346,15 @@ static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int
     c->res_n_points = npts;
     // transpose the frame-major log into the id-ordered CSR
     if ((st = c->res_xy.ensure(sizeof(double2) * (size_t)(npts > 0 ? npts : 1))) != PSFM_OK) return st;
-    hipLaunchKernelGGL(psfm_gather_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
-                       c->log.as<double2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
-                       c->res_len.as<int>(), c->res_off.as<int64_t>(), n, c->res_xy.as<double2>());
+    if (delta_log)
+        hipLaunchKernelGGL(psfm_gather_delta_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
+                           c->log.as<float2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
+                           c->res_len.as<int>(), c->res_off.as<int64_t>(), n, (const void*)c->sort_keys.p, fmt.use32,
+                           d.shift_b, d.GW, d.ratio, c->res_xy.as<double2>());
+    else
+        hipLaunchKernelGGL(psfm_gather_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
+                           c->log.as<double2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
+                           c->res_len.as<int>(), c->res_off.as<int64_t>(), n, c->res_xy.as<double2>());
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
@@ -295,7 +404,7 @@ psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
                        c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), d.shard_cap, so,
                        kdst, c->sort_lanes.as<int>() + n, fmt);
     PSFM_HIP(hipGetLastError());
-    return psfm_finalize_sorted(c, d, n, npts, s);
+    return psfm_finalize_sorted(c, d, n, npts, false, s);
 }
 
 // ---- persistent frame loop: records sit in one private segment per block (+ a shared tail) ----
@@ -362,5 +471,5 @@ psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fal
                        c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), c->seg_table.as<PsfmSegRow>(),
                        kdst, c->sort_lanes.as<int>() + n, fmt);
     PSFM_HIP(hipGetLastError());
-    return psfm_finalize_sorted(c, d, n, npts, s);
+    return psfm_finalize_sorted(c, d, n, npts, true, s);   // the persistent loop logs flows, not positions
 }

@@ -74,7 +74,9 @@ struct PsfmPersistArgs {
     int64_t occ_pitch; PsfmFastDiv wdiv;
     int H, W; float cw, ch, rcw, rch;
     int ratio, GW, GH, G;
-    double2* log; int cap;                     // (n_flows+1, cap): cap = gridDim.x * (256 + PP_GUESTS) columns
+    float2* dlog; int cap;                     // (n_flows, cap) sampled flow of every SURVIVED step: slab t, column = lane.  A
+                                               // trajectory is its birth grid point plus the running f64 sum of its column's
+                                               // entries (finalize re-runs the same additions); cap = gridDim.x * (256 + PP_GUESTS)
     int cap_main;                              // gridDim.x * 256 thread lanes (columns [cap_main, cap) are the guests)
     uint8_t* maps;                             // 3 x G, 0/1, zeroed: marks of step t go to map t % 3
     unsigned* survsh;                          // 2 x 64 words (128 B apart): frame+1 of the last step a block of the shard had a survivor in
@@ -246,7 +248,6 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         const int gy = (int)psfm_fastdiv((unsigned)L, a.gwdiv), gx = L - gy * a.GW;
         p = make_double2((double)(gx * ratio), (double)(gy * ratio));
         bf = 0;
-        a.log[L] = p;
         s_npts[tid] = 1;
     }
     s_xf[tid] = 0;
@@ -274,8 +275,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         v.flow = a.flows + (size_t)t * P; v.occ = a.occ + (size_t)t * a.occ_pitch;
         v.H = a.H; v.W = a.W; v.cw = a.cw; v.ch = a.ch; v.rcw = a.rcw; v.rch = a.rch; v.ratio = a.ratio; v.GW = a.GW; v.GH = a.GH; v.rdiv = a.rdiv;
         v.blocked_cur = a.maps + (size_t)(t % 3) * a.G; v.stamp_cur = 1;
-        double2* log_cur = a.log + (size_t)t * a.cap;
-        double2* log_next = a.log + (size_t)(t + 1) * a.cap;
+        float2* dlog_t = a.dlog + (size_t)t * a.cap;
         const int cur = t & 1, prev = cur ^ 1;
 
         PP_TL(0);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
             const int slot1 = psfm_record_slot(&s_rec_cnt, !s1.alive);
             if (live) {
                 if (s1.alive) {
-                    if (PP_CHK(L, a.cap, 1)) log_next[L] = s1.next;
+                    if (PP_CHK(L, a.cap, 1)) dlog_t[L] = s1.flow;
                     psfm_block_grid<R, PP_COH_MARKS>(v, (int)s1.next.x, (int)s1.next.y);
                     p = s1.next;
                     any_alive = true;
@@ -535,10 +535,10 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                     if (Lt >= a.cap_main) Lt = -1;
                 }
                 if (Lt >= 0) {
-                    if (PP_CHK(Lt, a.cap, 2)) log_cur[Lt] = q;
+                    (void)PP_CHK(Lt, a.cap, 2);
                     ++npts;
                     if (s2.alive) {
-                        if (PP_CHK(Lt, a.cap, 3)) log_next[Lt] = s2.next;
+                        if (PP_CHK(Lt, a.cap, 3)) dlog_t[Lt] = s2.flow;
                         psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
                         any_alive = true;
                         ++npts;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                 const PsfmStep s2 = psfm_step_finish(v, q, l2);
                 const int Lo = blockIdx.x * PP_BLOCK + e.ex;
                 if (s2.alive) {
-                    if (PP_CHK(Lo, a.cap, 4)) log_next[Lo] = s2.next;
+                    if (PP_CHK(Lo, a.cap, 4)) dlog_t[Lo] = s2.flow;
                     psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
                     any_alive = true;
                     ++npts;
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                 const PsfmStep s2 = psfm_step_finish(v, q, l2);
                 const int Lg = a.cap_main + blockIdx.x * PP_GUESTS + e.ex;
                 if (s2.alive) {
-                    if (PP_CHK(Lg, a.cap, 5)) log_next[Lg] = s2.next;
+                    if (PP_CHK(Lg, a.cap, 5)) dlog_t[Lg] = s2.flow;
                     psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
                     any_alive = true;
                     ++npts;
@@ -718,7 +718,7 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
     a.wdiv = psfm_fastdiv_make((unsigned)d.W);
     a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch; a.rcw = psfm_rcp_host(d.cw); a.rch = psfm_rcp_host(d.ch);
     a.ratio = d.ratio; a.GW = d.GW; a.GH = d.GH; a.G = (int)d.G;
-    a.log = c->log.as<double2>(); a.cap = (int)d.cap; a.cap_main = d.nblk * PP_BLOCK;
+    a.dlog = c->log.as<float2>(); a.cap = (int)d.cap; a.cap_main = d.nblk * PP_BLOCK;
     a.maps = c->occupied.as<uint8_t>();
     a.ctr = c->counters.as<PsfmCounters>();
     a.shards = c->shards.as<PsfmShard>();
