@@ -27,7 +27,11 @@
  *     describes it.  Nothing throws across this boundary and there is no CPU fallback:
  *     without a GPU every compute entry point fails with PSFM_ERR_HIP.
  *   - a psfm_ctx owns the device workspace (trajectory log, lane tables, results); it is
- *     not thread-safe, use one per host thread / stream.  No hidden global state.
+ *     not thread-safe, use one per host thread / stream.  The library keeps ONE piece of
+ *     process-wide state: a shared/exclusive gate per device -- every entry point that launches
+ *     work holds it shared, the persistent frame loop (psfm_ctx_set_chain_mode) holds it
+ *     exclusively for its few milliseconds, because all of its blocks must be resident at once.
+ *     Contexts on different devices never interact; last-error text is thread local.
  */
 #ifndef PSFM_H_
 #define PSFM_H_

@@ -363,7 +363,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
 
     for (;;) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue */
-        if (step_successful && x_cost <= minimum_cost) { /* parameters_ = x_ when cost improved */
+        if (step_successful && x_cost < minimum_cost) { /* trust_region_minimizer.cc: `if (x_cost_ < minimum_cost_)` -- strictly */
             minimum_cost = x_cost;
             memcpy(best, x, sizeof(double) * P);
         }

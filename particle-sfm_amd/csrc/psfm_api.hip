@@ -10,25 +10,9 @@
 #include "psfm_internal.h"
 
 static thread_local char g_err[512] = "";
-// Per device: every entry point that launches kernels holds this gate SHARED; the persistent frame loop needs it
-// EXCLUSIVE.  All blocks of that kernel must be resident at once, and with another queue feeding the device they may
-// never be (measured: a second host thread running psfm_connect alongside stalls the loop until its spin limit) -- so it
-// only runs when no other psfm call of this process is in flight on the device, and calls that arrive meanwhile wait for
-// it (<= a few ms).  A call that finds the device busy uses per-frame launches, which overlap well with other sequences.
+// The per-device gate of psfm_internal.h (the one piece of process-wide state in the library, documented in psfm.h).
 static std::shared_mutex g_dev_gate[16];
-struct PsfmGate {
-    std::shared_mutex& m;
-    bool exclusive = false;
-    PsfmGate(int device, int want_exclusive /* 0 no, 1 if free, 2 wait for it */) : m(g_dev_gate[device & 15])
-    {
-        if (want_exclusive == 2) { m.lock(); exclusive = true; }
-        else if (want_exclusive == 1 && m.try_lock()) exclusive = true;
-        else m.lock_shared();
-    }
-    ~PsfmGate() { if (exclusive) m.unlock(); else m.unlock_shared(); }
-    PsfmGate(const PsfmGate&) = delete;
-    PsfmGate& operator=(const PsfmGate&) = delete;
-};
+std::shared_mutex& psfm_device_gate(int device) { return g_dev_gate[device & 15]; }
 // Would this call run the persistent loop?  0 no, 1 yes if the device is free, 2 yes, wait for the device.
 // Mode 0 decides by shape, from measurements on MI355X (scripts/probe_shapes.py; 100 frames, flow_check + recurrence +
 // finalize, persistent / per-frame): the loop costs ~14 us per frame whatever the frame size (a barrier and five
@@ -605,6 +589,7 @@ extern "C" psfm_status psfm_result_copy(psfm_ctx* c, int32_t* birth_host, int32_
                                         double* xy_host, void* stream)
 {
     PSFM_CHECK_CTX(c);
+    PsfmGate gate(c->device, 0);
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = c->res_n_traj, np = c->res_n_points;
     if (n > 0) {

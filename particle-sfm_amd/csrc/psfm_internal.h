@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,28 @@ void psfm_set_error(const char* fmt, ...);
             return PSFM_ERR_HIP;                                                                \
         }                                                                                       \
     } while (0)
+
+// Per device and process: every entry point that launches kernels or copies holds this gate SHARED; the persistent frame
+// loop needs it EXCLUSIVE.  All blocks of that kernel must be resident at once, and with another queue feeding the device
+// they may never be (measured: a second host thread running psfm_connect alongside stalls the loop until its spin limit)
+// -- so it only runs when no other psfm call of this process is in flight on the device, and calls that arrive meanwhile
+// wait for it (<= a few ms).  A call that finds the device busy uses per-frame launches, which overlap well with other
+// sequences.  (Other PROCESSES on the device are not covered: there the loop's bounded spin and its hand-over to
+// per-frame launches are the safety net.)
+std::shared_mutex& psfm_device_gate(int device);
+struct PsfmGate {
+    std::shared_mutex& m;
+    bool exclusive = false;
+    PsfmGate(int device, int want_exclusive /* 0 no, 1 if free, 2 wait for it */) : m(psfm_device_gate(device))
+    {
+        if (want_exclusive == 2) { m.lock(); exclusive = true; }
+        else if (want_exclusive == 1 && m.try_lock()) exclusive = true;
+        else m.lock_shared();
+    }
+    ~PsfmGate() { if (exclusive) m.unlock(); else m.unlock_shared(); }
+    PsfmGate(const PsfmGate&) = delete;
+    PsfmGate& operator=(const PsfmGate&) = delete;
+};
 
 // grow-only device buffer
 struct PsfmBuf {

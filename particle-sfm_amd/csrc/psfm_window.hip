@@ -90,6 +90,7 @@ extern "C" psfm_status psfm_window_sample(psfm_ctx* c, int frame0, int n_frames,
 {
     if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
     PSFM_HIP(hipSetDevice(c->device));
+    PsfmGate gate(c->device, 0);
     if (n_frames < 1 || max_num_tracks < 0 || capacity < 0 || !k_host || (xy_norm && (raw_h < 1 || raw_w < 1 || in_h < 1 || in_w < 1))) {
         psfm_set_error("psfm_window_sample: bad argument (n_frames=%d max_num_tracks=%lld capacity=%lld)", n_frames,
                        (long long)max_num_tracks, (long long)capacity);
@@ -200,6 +201,7 @@ extern "C" psfm_status psfm_result_filter(psfm_ctx* c, int traj_min_len, int64_t
 {
     if (!c || !n_traj_host || !n_points_host) { psfm_set_error("psfm_result_filter: NULL argument"); return PSFM_ERR_ARG; }
     PSFM_HIP(hipSetDevice(c->device));
+    PsfmGate gate(c->device, 0);
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = c->res_n_traj;
     *n_traj_host = 0; *n_points_host = 0;
@@ -259,6 +261,7 @@ extern "C" psfm_status psfm_result_filtered_copy(psfm_ctx* c, int32_t* ids_host,
 {
     if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
     PSFM_HIP(hipSetDevice(c->device));
+    PsfmGate gate(c->device, 0);
     hipStream_t s = (hipStream_t)stream;
     const int64_t k = c->flt_n_traj, np_keep = c->flt_n_points;
     if (k > 0) {

@@ -136,6 +136,7 @@ class Context:
 
 
 _contexts = {}
+_contexts_lock = __import__("threading").Lock()   # batch.py worker threads create and release contexts concurrently
 
 
 def context(device=None):
@@ -150,22 +151,30 @@ def context(device=None):
         device = torch.cuda.current_device()
     device = int(device)
     key = (device, threading.get_ident())
-    if key not in _contexts:
-        _contexts[key] = Context(device)
-    return _contexts[key]
+    with _contexts_lock:
+        ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = Context(device)            # (outside the lock: creating a context allocates pinned memory)
+        with _contexts_lock:
+            _contexts[key] = ctx
+    return ctx
 
 
 def release_thread_contexts():
     """Destroy the calling thread's contexts (worker threads call this before they exit)."""
     import threading
     tid = threading.get_ident()
-    for key in [k for k in _contexts if k[1] == tid]:
-        _contexts.pop(key).close()
+    with _contexts_lock:
+        mine = [_contexts.pop(k) for k in [k for k in _contexts if k[1] == tid]]
+    for ctx in mine:
+        ctx.close()
 
 
-def current_stream_ptr():
+def current_stream_ptr(device=None):
+    """torch's current stream ON `device` (default: the current device) -- pass the context's device when it may differ
+    from the current one: a stream belongs to one device."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def ptr(t):

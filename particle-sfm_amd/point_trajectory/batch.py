@@ -15,8 +15,10 @@ from .main_connect_point_trajectories import main_connect_point_trajectories
 
 
 def connect_sequences(flow_dirs, traj_dirs, sample_ratio=2, flow_check_thres=1.0, traj_min_len=3,
-                      skip_path_consistency=False, skip_exists=False, concurrency=2, rank=None, world=None):
-    """main_connect_point_trajectories for a list of sequences; returns the indices this rank processed."""
+                      skip_path_consistency=False, skip_exists=False, concurrency=2, rank=None, world=None, layout="csr"):
+    """main_connect_point_trajectories for a list of sequences; returns the indices this rank processed.
+    layout: pickle state of the track.npy files -- "csr" (default here: the batch driver is this package's own entry
+    point and its files are read back through this package) or "reference" (files for an unmodified checkout)."""
     import torch
     import psfm_dist
     if rank is None or world is None:
@@ -44,7 +46,8 @@ def connect_sequences(flow_dirs, traj_dirs, sample_ratio=2, flow_check_thres=1.0
                         k = todo.pop(0)
                     main_connect_point_trajectories(flow_dirs[k], traj_dirs[k], sample_ratio=sample_ratio,
                                                     flow_check_thres=flow_check_thres, traj_min_len=traj_min_len,
-                                                    skip_path_consistency=skip_path_consistency, skip_exists=skip_exists)
+                                                    skip_path_consistency=skip_path_consistency, skip_exists=skip_exists,
+                                                    layout=layout)
                 stream.synchronize()
         except Exception as e:   # surface the first failure in the caller
             with lock:

@@ -11,8 +11,13 @@ from .trajectory import run_connect, result_to_trajectory_set, save_track_npy
 
 
 def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_check_thres=1.0, traj_min_len=3,
-                                    skip_path_consistency=False, skip_exists=False):
+                                    skip_path_consistency=False, skip_exists=False, layout=None):
+    """Reference signature (:27) plus `layout`: the pickle state of track.npy -- "reference" (default; the file an
+    unmodified particle-sfm checkout, pybind module included, reads) or "csr" (this package's compact arrays;
+    PSFM_TRACK_LAYOUT=csr selects it for callers that cannot pass the argument)."""
     import torch
+    if layout is None:
+        layout = os.environ.get("PSFM_TRACK_LAYOUT", "reference")
     os.makedirs(traj_dir, exist_ok=True)
     output_npy_fname = os.path.join(traj_dir, "track.npy")
     if skip_exists and os.path.exists(output_npy_fname):
@@ -33,7 +38,7 @@ def main_connect_point_trajectories(flow_dir, traj_dir, sample_ratio=2, flow_che
     # save the outputs (:56-62): ids are indices into the full list, short trajectories dropped -- filtered on the
     # device, staged through pinned memory, written as the same .npy/pickle container np.save produces
     trajectories = result_to_trajectory_set(_hip.context(), info, traj_min_len, reuse_pinned=True)
-    save_track_npy(output_npy_fname, trajectories)
+    save_track_npy(output_npy_fname, trajectories, layout=layout)
 
 
 def main(args):

@@ -7,8 +7,11 @@ pybind11 module (optimize/src/bindings.cc:27-77), backed by libpsfm_hip.so inste
 
 Because the classes live at the reference's module path, `np.load("track.npy", allow_pickle=True).item()`
 in the unmodified consumers (motion_seg/load_cut_seq.py:46, sfm/matches_from_flow.py:56,
-motion_seg/eval_traj_iou.py:28) resolves to them, and files written by either implementation load in the
-other: the pickle state is `{id: {"frame_ids", "locations", "labels"}}` (bindings.cc:39-46,64-71).
+motion_seg/eval_traj_iou.py:28) resolves to them.  The DEFAULT pickle state is the reference's
+`{id: {"frame_ids", "locations", "labels"}}` (bindings.cc:39-46,64-71), so files written by either implementation load
+in the other -- also with the original pybind module on the path.  The compact CSR state (array-speed save / load,
+readable by this class only) is opt-in: `TrajectorySet.pickle_layout = "csr"` on the object, which
+`save_track_npy(..., layout="csr")` sets.
 """
 import numpy as np
 
@@ -42,7 +45,7 @@ def optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num,
     st = _hip.SolveStats()
     _hip.check(_hip.lib().psfm_optimize_location(ctx.handle, _hip.ptr(uv), _hip.ptr(r1), _hip.ptr(r2), _hip.ptr(sc),
                                                  _hip.ptr(fmt), n, int(width), int(height), _hip.ptr(out),
-                                                 ctypes.byref(st), _hip.current_stream_ptr()))
+                                                 ctypes.byref(st), _hip.current_stream_ptr(ctx.device)))
     optimize_location.last_stats = st.as_dict()
     return out.cpu().numpy()
 
@@ -175,10 +178,12 @@ class TrajectorySet:
     materialised on demand.  At cfg-2 scale the reference layout means ~5e7 per-point Python objects; the CSR
     form keeps `np.save`, `build_invert_indexes` and `sample_inside_window` array-speed.
 
-    Pickle state: by default the compact CSR (loadable by this class, which is what resolves at
-    `point_trajectory.optimize.build.particlesfm.TrajectorySet` whenever this package is on the path); with
-    PSFM_LEGACY_PICKLE=1 the reference's `{id: {"frame_ids","locations","labels"}}` (bindings.cc:64-71), which the
-    original pybind module can load as well.  `__setstate__` accepts both."""
+    Pickle state: by default the reference's `{id: {"frame_ids","locations","labels"}}` (bindings.cc:64-71), which the
+    original pybind module loads as well; with `pickle_layout = "csr"` on the object (or PSFM_TRACK_LAYOUT=csr in the
+    environment for objects that do not say) the compact CSR arrays, loadable by this class only.  `__setstate__`
+    accepts both."""
+
+    pickle_layout = None    # None: PSFM_TRACK_LAYOUT or "reference"; "reference" | "csr"
 
     def __init__(self, trajs=None):
         self._csr = None
@@ -306,11 +311,25 @@ class TrajectorySet:
 
     # ---- pickle (bindings.cc:64-71) ----
     def _legacy_state(self):
+        """The reference's state (bindings.cc:64-71 over Trajectory::as_dict, trajectory_base.cpp:47-53):
+        {id: {"frame_ids": [int], "locations": (n,2) f64 rows, "labels": [bool]}} -- straight from the CSR when that is
+        the backing (no Trajectory objects; `locations` is a view of the point array, which pybind's vector<V2D> caster
+        and np.array() both take row by row)."""
+        if self._csr is not None and self._map is None:
+            ids, birth, length, off, xy, labels = self._csr
+            ids_l, b_l, o_l = ids.tolist(), birth.tolist(), off.tolist()
+            state = {}
+            for j in range(len(ids_l)):
+                s, e = o_l[j], o_l[j + 1]
+                state[ids_l[j]] = {"frame_ids": list(range(b_l[j], b_l[j] + e - s)), "locations": xy[s:e],
+                                   "labels": [False] * (e - s) if labels is None else labels[s:e].tolist()}
+            return state
         return {k: v._state() for k, v in self.trajs.items()}
 
     def __getstate__(self):
         import os
-        if self._csr is not None and self._map is None and not os.environ.get("PSFM_LEGACY_PICKLE"):
+        layout = self.pickle_layout or os.environ.get("PSFM_TRACK_LAYOUT", "reference")
+        if layout == "csr" and self._csr is not None and self._map is None:
             ids, birth, length, off, xy, labels = self._csr
             return {"__psfm_csr__": 1, "ids": ids, "birth": birth, "length": length, "off": off, "xy": xy,
                     "labels": labels}

@@ -26,7 +26,7 @@ def grid_sample(data, xy):
     pts = torch.from_numpy(np.ascontiguousarray(np.asarray(xy, dtype=np.float64).reshape(-1, 2))).to(dev)
     out = torch.empty((pts.shape[0], C), dtype=torch.float32, device=dev)
     _hip.check(_hip.lib().psfm_grid_sample(ctx.handle, _hip.ptr(m), C, H, W, _hip.ptr(pts), pts.shape[0],
-                                           _hip.ptr(out), _hip.current_stream_ptr()))
+                                           _hip.ptr(out), _hip.current_stream_ptr(ctx.device)))
     return out.cpu().numpy()
 
 
@@ -103,7 +103,7 @@ def _result_to_host(ctx, info):
     xy = b_xy.view(np.float64).reshape(-1, 2)
     _hip.check(_hip.lib().psfm_result_copy(ctx.handle, birth.ctypes.data_as(ctypes.c_void_p),
                                            length.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p),
-                                           xy.ctypes.data_as(ctypes.c_void_p), _hip.current_stream_ptr()))
+                                           xy.ctypes.data_as(ctypes.c_void_p), _hip.current_stream_ptr(ctx.device)))
     stats = []
     if info.n_solves:
         arr = (_hip.SolveStats * int(info.n_solves))()
@@ -121,7 +121,7 @@ def result_to_trajectory_set(ctx, info, traj_min_len=3, reuse_pinned=False):
     import torch
     L = _hip.lib()
     k, npt = ctypes.c_int64(0), ctypes.c_int64(0)
-    _hip.check(L.psfm_result_filter(ctx.handle, int(traj_min_len), ctypes.byref(k), ctypes.byref(npt), _hip.current_stream_ptr()))
+    _hip.check(L.psfm_result_filter(ctx.handle, int(traj_min_len), ctypes.byref(k), ctypes.byref(npt), _hip.current_stream_ptr(ctx.device)))
     k, npt = int(k.value), int(npt.value)
     sizes = [4 * k, 4 * k, 4 * k, 8 * (k + 1), 16 * npt]
     offs = np.concatenate([[0], np.cumsum([(x + 63) // 64 * 64 for x in sizes])])
@@ -139,15 +139,22 @@ def result_to_trajectory_set(ctx, info, traj_min_len=3, reuse_pinned=False):
     off = raw[offs[3]:offs[3] + sizes[3]].view(np.int64)
     xy = raw[offs[4]:offs[4] + sizes[4]].view(np.float64).reshape(-1, 2)
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    _hip.check(L.psfm_result_filtered_copy(ctx.handle, vp(ids), vp(birth), vp(length), vp(off), vp(xy), _hip.current_stream_ptr()))
+    _hip.check(L.psfm_result_filtered_copy(ctx.handle, vp(ids), vp(birth), vp(length), vp(off), vp(xy), _hip.current_stream_ptr(ctx.device)))
     return particlesfm.TrajectorySet._from_csr(ids.astype(np.int64), birth, length, off, xy)
 
 
-def save_track_npy(path, trajectories):
+def save_track_npy(path, trajectories, layout="reference"):
     """np.save(path, trajectories) for consumers that np.load(path, allow_pickle=True).item(): the same .npy container
-    (object array header + pickle), written with pickle protocol 5 so that the CSR arrays stream to the file without an
-    intermediate bytes copy."""
+    (object array header + pickle), written with pickle protocol 5 so that the point array streams to the file without an
+    intermediate bytes copy.
+    layout "reference" (default): the pickle state of the reference's pybind class (bindings.cc:64-71) -- the file loads
+    with the original module as well; "csr": this package's compact array state (array-speed save / load at 1e6+
+    trajectories, readable only where this package provides `point_trajectory.optimize.build.particlesfm`)."""
     import pickle
+    if layout not in ("reference", "csr"):
+        raise ValueError("save_track_npy: layout must be 'reference' or 'csr'")
+    if isinstance(trajectories, particlesfm.TrajectorySet):
+        trajectories.pickle_layout = layout
     arr = np.empty((), dtype=object)
     arr[()] = trajectories
     with open(path if str(path).endswith(".npy") else str(path) + ".npy", "wb") as fp:
@@ -208,7 +215,7 @@ def run_connect(flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, retur
         ctx._capacity[cap_key] = (lane_f, traj_f)      # remembered per shape: a sequence that needed larger tables keeps them
         st = _hip.lib().psfm_connect(ctx.handle, _hip.ptr(flows_f), _hip.ptr(flows_b), _hip.ptr(f2), _hip.ptr(b2), n, H, W,
                                      float(thres), int(sample_ratio), None, None, ctypes.byref(info),
-                                     _hip.current_stream_ptr())
+                                     _hip.current_stream_ptr(ctx.device))
         if st != _hip.PSFM_ERR_CAPACITY:
             break
         lane_f, traj_f = lane_f * 2.0, traj_f * 4.0
@@ -245,7 +252,7 @@ def run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio, return_devic
         ctx.set_capacity(lane_f, traj_f)
         ctx._capacity[cap_key] = (lane_f, traj_f)
         st = _hip.lib().psfm_track(ctx.handle, _hip.ptr(fl), _hip.ptr(oc), _hip.ptr(f2), _hip.ptr(o2), n, H, W,
-                                   int(sample_ratio), ctypes.byref(info), _hip.current_stream_ptr())
+                                   int(sample_ratio), ctypes.byref(info), _hip.current_stream_ptr(ctx.device))
         if st != _hip.PSFM_ERR_CAPACITY:
             break
         if os.environ.get("PSFM_VERBOSE"):

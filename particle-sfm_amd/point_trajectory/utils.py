@@ -116,7 +116,7 @@ def flow_check_device(flows, flows_b, thres, want_error=False):
     occ = torch.empty((n, H, W), dtype=torch.uint8, device=flows.device)
     err = torch.empty((n, H, W), dtype=torch.float32, device=flows.device) if want_error else None
     _hip.check(_hip.lib().psfm_flow_check(ctx.handle, _hip.ptr(flows), _hip.ptr(flows_b), n, H, W, float(thres),
-                                          _hip.ptr(occ), _hip.ptr(err), _hip.current_stream_ptr()))
+                                          _hip.ptr(occ), _hip.ptr(err), _hip.current_stream_ptr(ctx.device)))
     return err, occ
 
 

@@ -29,7 +29,7 @@ def sample_window_device(ctx, frame0, n_frames, raw_hw, input_size, traj_max_num
     import torch
     L = _hip.lib()
     k = ctypes.c_int64(0)
-    sp = _hip.current_stream_ptr()
+    sp = _hip.current_stream_ptr(ctx.device)
     args = (int(frame0), int(n_frames), int(traj_min_len), int(min_length), int(traj_max_num), int(seed),
             int(raw_hw[0]), int(raw_hw[1]), int(input_size[0]), int(input_size[1]))
     _hip.check(L.psfm_window_sample(ctx.handle, *args, 0, None, None, None, None, ctypes.byref(k), sp))   # count

@@ -19,9 +19,8 @@ for key, sub in (("flows_f", "flow_f"), ("flows_b", "flow_b"), ("flows_f2", "flo
         write_flo(os.path.join(fd, sub, "%05d.flo" % i), f)
 out = os.path.join(ROOT, "gpurun_out", "track_fixture")
 os.makedirs(out, exist_ok=True)
-main_connect_point_trajectories(fd, os.path.join(tmp, "traj"), sample_ratio=r)
+main_connect_point_trajectories(fd, os.path.join(tmp, "traj"), sample_ratio=r, layout="csr")
 shutil.copy(os.path.join(tmp, "traj", "track.npy"), os.path.join(out, "track.npy"))
-os.environ["PSFM_LEGACY_PICKLE"] = "1"
-main_connect_point_trajectories(fd, os.path.join(tmp, "traj_legacy"), sample_ratio=r)
+main_connect_point_trajectories(fd, os.path.join(tmp, "traj_legacy"), sample_ratio=r)   # default: reference layout
 shutil.copy(os.path.join(tmp, "traj_legacy", "track.npy"), os.path.join(out, "track_legacy.npy"))
 print("ok", os.listdir(out))

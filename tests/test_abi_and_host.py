@@ -6,6 +6,7 @@ import io
 import os
 import pickle
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -205,18 +206,22 @@ def test_trajectory_set_csr_vs_map_and_reference_semantics(tmp_path, monkeypatch
         assert out["traj_ids"] == ids
         assert np.array_equal(out["locations"][0], X) and np.array_equal(out["locations"][1], Y)
         assert np.array_equal(out["masks"], M)
-    # default pickle state is the compact CSR; the legacy layout is what the pybind module writes/reads
-    fn = str(tmp_path / "track.npy")
-    np.save(fn, ts)
-    back = np.load(fn, allow_pickle=True).item()
-    assert sorted(back.trajs) == kept and np.array_equal(np.array(back.trajs[kept[0]].xys), ref[kept[0]][1])
-    monkeypatch.setenv("PSFM_LEGACY_PICKLE", "1")
+    # default pickle state = the reference's layout (what the pybind module writes/reads); the compact CSR is opt-in
+    monkeypatch.delenv("PSFM_TRACK_LAYOUT", raising=False)
     st = ts.__getstate__()
     assert sorted(st) == kept and set(st[kept[0]]) == {"frame_ids", "locations", "labels"}
     assert st[kept[0]]["frame_ids"] == ref[kept[0]][0]
     fn2 = str(tmp_path / "legacy.npy")
     np.save(fn2, ts)
+    assert b"__psfm_csr__" not in open(fn2, "rb").read()
     back2 = np.load(fn2, allow_pickle=True).item()
+    ts.pickle_layout = "csr"
+    fn = str(tmp_path / "track.npy")
+    np.save(fn, ts)
+    assert b"__psfm_csr__" in open(fn, "rb").read()
+    back = np.load(fn, allow_pickle=True).item()
+    assert sorted(back.trajs) == kept and np.array_equal(np.array(back.trajs[kept[0]].xys), ref[kept[0]][1])
+    ts.pickle_layout = None
     d1, d2 = back.as_dict(), back2.as_dict()
     assert sorted(d1) == sorted(d2)
     for k in kept[:20]:
@@ -245,7 +250,7 @@ def test_fast_division_and_threshold_shortcuts_are_exact():
 def test_window_ranges_and_track_npy_writer(tmp_path):
     """Host logic that needs no GPU: the window cut of load_cut_seq.py:50-73 and the protocol-5 track.npy writer (same
     container as np.save: consumers np.load(..., allow_pickle=True).item())."""
-    from motion_seg.load_cut_seq import window_ranges
+    from psfm_motion_seg.load_cut_seq import window_ranges
     from point_trajectory.trajectory import save_track_npy
     from point_trajectory.optimize.build.particlesfm import TrajectorySet
     assert window_ranges(23, 10) == [(0, 10), (10, 10), (13, 10)]
@@ -257,8 +262,10 @@ def test_window_ranges_and_track_npy_writer(tmp_path):
     off = np.array([0, 3, 7, 10], np.int64)
     xy = np.arange(20, dtype=np.float64).reshape(10, 2)
     ts = TrajectorySet._from_csr(ids, birth, length, off, xy)
-    save_track_npy(str(tmp_path / "track.npy"), ts)
-    np.save(str(tmp_path / "ref.npy"), ts)
+    save_track_npy(str(tmp_path / "track.npy"), ts, layout="csr")
+    save_track_npy(str(tmp_path / "ref.npy"), ts)                       # default: the reference's state layout
+    assert b"__psfm_csr__" in open(str(tmp_path / "track.npy"), "rb").read()
+    assert b"__psfm_csr__" not in open(str(tmp_path / "ref.npy"), "rb").read()
     a = np.load(str(tmp_path / "track.npy"), allow_pickle=True).item()
     b = np.load(str(tmp_path / "ref.npy"), allow_pickle=True).item()
     assert a.as_dict().keys() == b.as_dict().keys() == {0, 3, 4}
@@ -267,3 +274,59 @@ def test_window_ranges_and_track_npy_writer(tmp_path):
     a.build_invert_indexes()
     out = a.sample_inside_window([2, 3, 4], min_length=3)
     assert out["traj_ids"] == [3, 4]
+
+
+def test_default_track_npy_loads_with_a_pybind_module_that_only_knows_the_reference_contract(tmp_path):
+    """bindings.cc:64-71: the reference's TrajectorySet unpickles from std::map<int, py::dict> and Trajectory from the
+    three casts of trajectory_base.cpp:39-46.  tests/pybind_standin/ implements exactly that contract as a REAL pybind11
+    module (g++ + the pip pybind11 headers); it is installed at point_trajectory/optimize/build/ in a scratch tree without
+    this package on the path, and must load the DEFAULT output of save_track_npy / np.save."""
+    import subprocess
+    import sysconfig
+    import textwrap
+    pybind11 = pytest.importorskip("pybind11")
+    from point_trajectory.trajectory import save_track_npy, TrajectoryList
+    rng = np.random.default_rng(5)
+    n = 50
+    birth = rng.integers(0, 9, n).astype(np.int32)
+    length = rng.integers(1, 9, n).astype(np.int32)
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum(length)
+    xy = rng.uniform(0, 100, (int(off[-1]), 2))
+    ts = TrajectoryList(birth, length, off, xy).to_trajectory_set(3)     # CSR-backed, as the stage entry produces it
+    save_track_npy(str(tmp_path / "track.npy"), ts)
+    np.save(str(tmp_path / "track_np_save.npy"), ts)
+    tree = tmp_path / "refpkg" / "point_trajectory" / "optimize" / "build"
+    tree.mkdir(parents=True)
+    for d in (tree, tree.parent, tree.parent.parent):
+        (d / "__init__.py").write_text("")
+    so = tree / ("particlesfm" + sysconfig.get_config_var("EXT_SUFFIX"))
+    src = os.path.join(ROOT, "tests", "pybind_standin", "particlesfm_standin.cpp")
+    inc = ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
+    subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-std=c++17"] + inc + [src, "-o", str(so)], check=True, timeout=300)
+    code = textwrap.dedent("""
+        import sys, json
+        import numpy as np
+        sys.path.insert(0, %r)
+        out = {}
+        for name in ("track.npy", "track_np_save.npy"):
+            ts = np.load(%r + "/" + name, allow_pickle=True).item()
+            assert type(ts).__module__ == "point_trajectory.optimize.build.particlesfm", type(ts).__module__
+            assert "pybind11" in str(type(type(ts))), type(type(ts))
+            d = ts.as_dict()
+            out[name] = {str(k): [v["frame_ids"], np.asarray(v["locations"]).tolist(), v["labels"]] for k, v in d.items()}
+        print(json.dumps(out))
+    """) % (str(tmp_path / "refpkg"), str(tmp_path))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    kept = [i for i in range(n) if length[i] >= 3]
+    for name in ("track.npy", "track_np_save.npy"):
+        g = got[name]
+        assert sorted(int(k) for k in g) == kept
+        for i in kept:
+            fr, loc, lab = g[str(i)]
+            assert fr == list(range(birth[i], birth[i] + length[i])) and lab == [False] * int(length[i])
+            assert np.array_equal(np.array(loc), xy[off[i]:off[i + 1]])

@@ -474,7 +474,7 @@ def test_motion_seg_window_tensors(pt):
     """SURVEY f-4: psfm_window_sample (device) against the host path the reference takes --
     TrajectorySet.sample_inside_window per window (trajectory_base.cpp:127-185) + resize_point_traj / normalize_point_traj
     (motion_seg/core/dataset/data_utils.py:74-89), restated in NumPy below."""
-    from motion_seg.load_cut_seq import cut_trajectory_windows, window_ranges, sample_window_device
+    from psfm_motion_seg.load_cut_seq import cut_trajectory_windows, window_ranges, sample_window_device
     T, H, W, r = 23, 96, 128, 2
     d = psfm_synth.synth_sequence_torch(T, H, W, seed=31, sigma=0.3, n_occluders=2, stride2=False)
     R = pt.trajectory.run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, r)      # result stays in the context

@@ -60,10 +60,10 @@ def test_reference_traj_to_matches_consumes_our_track_npy(tmp_path, fname):
 
 @pytest.mark.parametrize("fname,remove_dynamic", [("track_gpu_60x80.npy", True), ("track_gpu_60x80_legacy.npy", False)])
 def test_vectorised_traj_to_matches_equals_reference(tmp_path, fname, remove_dynamic):
-    """particle-sfm_amd/sfm/matches_from_flow.py (NumPy index arithmetic on the CSR) against the
+    """particle-sfm_amd/psfm_sfm/matches_from_flow.py (NumPy index arithmetic on the CSR) against the
     reference's loops, element for element -- keypoints, match lists, dict ordering, pair file."""
     import time
-    from sfm import matches_from_flow as ours      # particle-sfm_amd/sfm (conftest puts it on sys.path)
+    from psfm_sfm import matches_from_flow as ours   # particle-sfm_amd/psfm_sfm (conftest puts it on sys.path)
     traj_dir = tmp_path / "trajectories"
     img_dir = tmp_path / "images"
     traj_dir.mkdir(); img_dir.mkdir()
@@ -90,7 +90,7 @@ def test_vectorised_traj_to_matches_equals_reference(tmp_path, fname, remove_dyn
 
 def test_vectorised_traj_to_matches_long_tracks_and_dynamic_labels(tmp_path):
     """Trajectories longer than sample_k = 20 (strided sampling) and dynamic labels (motion-seg output is a plain dict)."""
-    from sfm import matches_from_flow as ours
+    from psfm_sfm import matches_from_flow as ours
     rng = np.random.default_rng(0)
     n_img = 60
     trajs = {}
@@ -114,3 +114,32 @@ def test_vectorised_traj_to_matches_long_tracks_and_dynamic_labels(tmp_path):
             for k in A[name].match_pairs:
                 assert A[name].match_pairs[k] == B[name].match_pairs[k]
         assert open(str(tmp_path / "a.txt")).read() == open(str(tmp_path / "b.txt")).read()
+
+
+def test_launcher_resolves_point_trajectory_here_and_the_other_stages_in_the_checkout(tmp_path):
+    """`python run_particlesfm.py` puts the checkout at sys.path[0] ahead of PYTHONPATH; particle-sfm_amd/run_with_psfm.py
+    fixes the order explicitly.  The driver's three package imports (run_particlesfm.py:21,61,78) must then resolve:
+    point_trajectory -> this package; motion_seg, sfm -> the checkout (this package ships no package of those names)."""
+    import subprocess
+    import textwrap
+    pkg = os.path.join(os.path.dirname(GOLDEN), "..", "particle-sfm_amd")
+    launcher = os.path.abspath(os.path.join(pkg, "run_with_psfm.py"))
+    probe = tmp_path / "probe.py"
+    probe.write_text(textwrap.dedent("""
+        import importlib.util, json, sys
+        out = {n: importlib.util.find_spec(n).origin for n in ("point_trajectory", "motion_seg", "sfm")}
+        from point_trajectory import main_connect_point_trajectories
+        out["entry"] = main_connect_point_trajectories.__module__
+        out["argv"] = sys.argv[1:]
+        print(json.dumps(out))
+    """))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, launcher, "--ref", REF, str(probe), "--flag", "x"], capture_output=True, text=True,
+                       env=env, cwd=REF, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert os.path.abspath(out["point_trajectory"]).startswith(os.path.abspath(pkg))
+    assert os.path.abspath(out["motion_seg"]).startswith(os.path.abspath(REF))
+    assert os.path.abspath(out["sfm"]).startswith(os.path.abspath(REF))
+    assert out["entry"] == "point_trajectory.main_connect_point_trajectories" and out["argv"] == ["--flag", "x"]
