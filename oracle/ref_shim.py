@@ -93,16 +93,27 @@ def _optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num
     return oracle.optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num, width, height)
 
 
-_loaded = None
+_loaded = {}
 
 
-def load():
+def load_reference(root=None, particlesfm_module=None, optimize_location=None):
+    """load() with a different `particlesfm`: the REAL pybind module (tests/test_ref_ceres.py) or the stand-in with
+    another optimize_location (the NumPy restatement, tests/test_oracle_golden.py)."""
+    global REFERENCE_ROOT
+    if root:
+        REFERENCE_ROOT = root
+    return load(particlesfm_module=particlesfm_module, optimize_location=optimize_location)
+
+
+def load(particlesfm_module=None, optimize_location=None):
     """Returns a namespace with the reference's flow_check, track, track_optimize, grid_sample, ..."""
-    global _loaded
-    if _loaded is not None:
-        return _loaded
+    global ALIAS
+    key = (id(particlesfm_module), id(optimize_location))
+    if key in _loaded:
+        return _loaded[key]
     if not available():
         raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    ALIAS = "psfm_reference_pt" if not _loaded else "psfm_reference_pt_%d" % len(_loaded)
     if "cv2" not in sys.modules:
         sys.modules["cv2"] = types.ModuleType("cv2")
     if "tqdm" not in sys.modules:
@@ -122,7 +133,9 @@ def load():
     standin = types.ModuleType(ALIAS + ".optimize.build.particlesfm")
     standin.Trajectory = Trajectory
     standin.TrajectorySet = TrajectorySet
-    standin.optimize_location = _optimize_location
+    standin.optimize_location = optimize_location or _optimize_location
+    if particlesfm_module is not None:
+        standin = particlesfm_module
     bld.particlesfm = standin
     opt.build = bld
     pkg.optimize = opt
@@ -147,7 +160,7 @@ def load():
         track=track.track, track_optimize=track_optimize.track_optimize,
         particlesfm=standin,
     )
-    _loaded = ns
+    _loaded[key] = ns
     return ns
 
 

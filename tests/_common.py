@@ -41,3 +41,28 @@ def assert_csr_equal(birth, length, xy, g, tol=0.0):
         assert np.array_equal(xy, g["xy"]), float(np.abs(xy - g["xy"]).max())
     else:
         assert float(np.abs(xy - g["xy"]).max()) <= tol
+
+
+def solver_batch(H, W, n, seed, sigma, kink=False):
+    """A batch for optimize_location: (uv12 (n,4), ref1, ref2, scale (n,1), flow12 (H,W,2) f32).  kink: points outside
+    the image too (Grid2D clamping); 20 % of the scales are exactly 0."""
+    rng = np.random.default_rng(seed)
+    d = psfm_synth.synth_sequence(3, H, W, seed=seed, sigma=sigma, stride2=True)
+    flow12 = d["flows_f"][1]
+    p0 = rng.uniform([-2, -2], [W + 1, H + 1], size=(n, 2)) if kink else rng.uniform([2, 2], [W - 3, H - 3], size=(n, 2))
+    ref1 = p0 + rng.normal(0, 1.0, size=(n, 2))
+    ref2 = ref1 + rng.normal(0, 1.5, size=(n, 2))
+    uv = np.concatenate([ref1 + rng.normal(0, 0.5, (n, 2)), ref2 + rng.normal(0, 0.5, (n, 2))], 1)
+    scale = rng.uniform(0, 1, size=(n, 1)).astype(np.float32).astype(np.float64)
+    scale[rng.uniform(size=n) < 0.2] = 0.0
+    return uv, ref1, ref2, scale, flow12
+
+
+# the batches every solver test runs (GPU vs oracle, oracle vs the second restatement, real Ceres when available)
+SOLVER_BATCHES = [
+    (60, 80, 3000, 1, 0.02, False),
+    (60, 80, 3000, 2, 0.5, False),      # noisy flow: rejected steps, dogleg interpolation
+    (45, 70, 5000, 3, 0.3, True),       # points outside the image: Grid2D clamping
+    (270, 480, 100000, 4, 0.05, False),
+    (33, 47, 1, 5, 0.1, False),         # a single track
+]

@@ -4,7 +4,7 @@ sides run the same Ceres-compatible control flow in f64 and differ only in summa
 import numpy as np
 import pytest
 
-from _common import golden, regen_inputs, assert_csr_equal
+from _common import golden, regen_inputs, assert_csr_equal, solver_batch, SOLVER_BATCHES
 import psfm_synth
 
 pytestmark = pytest.mark.gpu
@@ -25,26 +25,10 @@ def pt():
     return ns
 
 
-def _batch(H, W, n, seed, sigma, kink=False):
-    rng = np.random.default_rng(seed)
-    d = psfm_synth.synth_sequence(3, H, W, seed=seed, sigma=sigma, stride2=True)
-    flow12 = d["flows_f"][1]
-    p0 = rng.uniform([-2, -2], [W + 1, H + 1], size=(n, 2)) if kink else rng.uniform([2, 2], [W - 3, H - 3], size=(n, 2))
-    ref1 = p0 + rng.normal(0, 1.0, size=(n, 2))
-    ref2 = ref1 + rng.normal(0, 1.5, size=(n, 2))
-    uv = np.concatenate([ref1 + rng.normal(0, 0.5, (n, 2)), ref2 + rng.normal(0, 0.5, (n, 2))], 1)
-    scale = rng.uniform(0, 1, size=(n, 1)).astype(np.float32).astype(np.float64)
-    scale[rng.uniform(size=n) < 0.2] = 0.0
-    return uv, ref1, ref2, scale, flow12
+_batch = solver_batch
 
 
-@pytest.mark.parametrize("H,W,n,seed,sigma,kink", [
-    (60, 80, 3000, 1, 0.02, False),
-    (60, 80, 3000, 2, 0.5, False),      # noisy flow: rejected steps, dogleg interpolation
-    (45, 70, 5000, 3, 0.3, True),       # points outside the image: Grid2D clamping
-    (270, 480, 100000, 4, 0.05, False),
-    (33, 47, 1, 5, 0.1, False),         # a single track
-])
+@pytest.mark.parametrize("H,W,n,seed,sigma,kink", SOLVER_BATCHES)
 def test_optimize_location_vs_oracle(pt, H, W, n, seed, sigma, kink):
     from oracle import oracle as orc
     uv, ref1, ref2, scale, flow12 = _batch(H, W, n, seed, sigma, kink)

@@ -1,0 +1,75 @@
+"""Hook for pinning the Ceres-defined part of the path against the REAL reference module.
+
+Skipped unless PSFM_REF_PARTICLESFM_SO points at a built point_trajectory/optimize/build/particlesfm*.so of the
+reference (recipe: oracle/_ref/BUILD.md; impossible in the build image -- no Ceres / Eigen / glog, no network).  With it,
+the batches of tests/test_gpu_solver.py go through the real `optimize_location` (optimize/src/bindings.cc:31 ->
+trajectory_optimize.cpp:30-96, Ceres 2.0.0) and are compared with the C oracle, the second (NumPy) restatement and, on
+a GPU box, libpsfm_hip: <= 1e-4 px (north_star), iteration-level decisions reported.
+"""
+import importlib.machinery
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from _common import solver_batch, SOLVER_BATCHES
+import psfm_synth
+
+SO = os.environ.get("PSFM_REF_PARTICLESFM_SO", "")
+pytestmark = pytest.mark.skipif(not (SO and os.path.isfile(SO)),
+                                reason="real reference module not available (set PSFM_REF_PARTICLESFM_SO, see oracle/_ref/BUILD.md)")
+TOL = 1e-4
+
+
+def _real_module():
+    loader = importlib.machinery.ExtensionFileLoader("particlesfm", SO)
+    spec = importlib.util.spec_from_file_location("particlesfm", SO, loader=loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("H,W,n,seed,sigma,kink", SOLVER_BATCHES)
+def test_real_ceres_vs_both_restatements(H, W, n, seed, sigma, kink):
+    from oracle import oracle as orc
+    from oracle import ceres_tr_numpy as ct
+    real = _real_module()
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, seed, sigma, kink)
+    out_r = np.asarray(real.optimize_location(uv, ref1, ref2, scale, flow12.astype(np.float64), n, W, H))
+    out_c = orc.optimize_location(uv, ref1, ref2, scale, flow12)
+    out_n, _ = ct.optimize_location(uv, ref1, ref2, scale, flow12, n, W, H)
+    assert float(np.abs(out_r - out_c).max()) <= TOL
+    assert float(np.abs(out_r - out_n).max()) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,n,seed,sigma,kink", SOLVER_BATCHES)
+def test_real_ceres_vs_hip(H, W, n, seed, sigma, kink):
+    from point_trajectory.optimize.build import particlesfm as ours
+    real = _real_module()
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, seed, sigma, kink)
+    out_r = np.asarray(real.optimize_location(uv, ref1, ref2, scale, flow12.astype(np.float64), n, W, H))
+    out_g = ours.optimize_location(uv, ref1, ref2, scale, flow12, n, W, H)
+    assert float(np.abs(out_r - out_g).max()) <= TOL
+
+
+def test_reference_track_optimize_with_the_real_module():
+    """The reference's own Python (track_optimize.py:24-53, trajectory.py:161-194) with the REAL pybind module in place
+    of the stand-in of oracle/ref_shim.py, against the C oracle: ids / lengths equal, positions <= 1e-4 px."""
+    ref_root = os.environ.get("PSFM_REFERENCE_ROOT", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "point_trajectory")):
+        pytest.skip("reference tree not present")
+    from oracle import oracle as orc
+    from oracle import ref_shim
+    ref = ref_shim.load_reference(ref_root, particlesfm_module=_real_module())
+    d = psfm_synth.synth_sequence(8, 90, 140, seed=52, sigma=0.3, n_occluders=3, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 3)
+    full = ref.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 3)
+    assert len(full) == O.n_traj
+    for i, t in enumerate(full):
+        assert t.length() == O.length[i] and t.times[0] == O.birth[i]
+        assert float(np.abs(np.array(t.xys) - O.xy[O.off[i]:O.off[i + 1]]).max()) <= TOL
