@@ -107,6 +107,19 @@ psfm_status psfm_ctx_set_capacity(psfm_ctx* ctx, double lane_factor, double traj
  * Results are identical in every mode.  track_optimize always uses one launch per frame (the solves sit in between). */
 psfm_status psfm_ctx_set_chain_mode(psfm_ctx* ctx, int mode);
 
+/* How psfm_track / psfm_connect run the path-consistency solve of a frame (track_optimize.py:49-50 ->
+ * trajectory_optimize.cpp:74-82) -- the results do not depend on it:
+ *   mode 0 (default) adaptive: the FUSED solve -- one launch per frame that speculates k trust-region iterations taking
+ *     the Gauss-Newton step and being accepted, and replays Ceres' control flow over their sums -- while the solves of a
+ *     sequence go that way; the launch CHAIN (one launch per trust-region iteration, any dogleg case, rejections) for
+ *     windows of frames whose solves do not; a fused solve that meets anything it did not speculate is redone by the chain;
+ *   mode 1 the chain always;  mode 2 the fused solve always (+ redo).
+ *   k: iterations per fused launch, 0 = follow what the sequence needs (accepted steps + 1), at most 8. */
+psfm_status psfm_ctx_set_solver(psfm_ctx* ctx, int mode, int k);
+/* Solves of the last psfm_track / psfm_connect by how they ran: fused and done in one launch, fused then redone by
+ * the chain, chain.  k_now: the adaptive iterations per fused launch after that sequence.  Any pointer may be NULL. */
+psfm_status psfm_solver_counters(psfm_ctx* ctx, int64_t* fused, int64_t* fused_redone, int64_t* chain, int32_t* k_now);
+
 /* utils.py:94-105.  flows_f, flows_b: (n_pairs,H,W,2) f32 stacks in the .flo-native interleaved
  * layout.  occ_out: (n_pairs,H,W) u8 0/1.  err_out: (n_pairs,H,W) f32 or NULL (the reference
  * pipeline never consumes it).  Bit-exact with the reference's torch-CPU arithmetic. */

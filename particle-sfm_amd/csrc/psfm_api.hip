@@ -153,7 +153,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
                        &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
-                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->occ_own, &c->occ2_own,
+                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->sol_fused, &c->occ_own, &c->occ2_own,
                        &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar, &c->win_ws, &c->flt_ids, &c->flt_birth, &c->flt_len, &c->flt_off, &c->flt_xy};
     for (auto b : bufs) b->release();
     c->prof.destroy();
@@ -176,6 +176,27 @@ extern "C" psfm_status psfm_ctx_set_chain_mode(psfm_ctx* c, int mode)
 {
     if (!c || mode < 0 || mode > 2) { psfm_set_error("psfm_ctx_set_chain_mode: mode must be 0 (auto), 1 (per-frame launches) or 2 (persistent loop)"); return PSFM_ERR_ARG; }
     c->chain_mode = mode;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_ctx_set_solver(psfm_ctx* c, int mode, int k)
+{
+    if (!c || mode < 0 || mode > 2 || k < 0 || k > psfm_solve_kmax()) {
+        psfm_set_error("psfm_ctx_set_solver: mode must be 0 (adaptive), 1 (launch chain) or 2 (fused solve), k in [0, %d]", psfm_solve_kmax());
+        return PSFM_ERR_ARG;
+    }
+    c->solver_mode = mode;
+    c->solver_K = k;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_solver_counters(psfm_ctx* c, int64_t* fused, int64_t* fused_redone, int64_t* chain, int32_t* k_now)
+{
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    if (fused) *fused = c->n_fused_ok;
+    if (fused_redone) *fused_redone = c->n_fused_redone;
+    if (chain) *chain = c->n_chain;
+    if (k_now) *k_now = c->solve_K;
     return PSFM_OK;
 }
 
@@ -413,19 +434,31 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // (tests: PSFM_SOLVE_UNROLL=1 makes every solve that needs more than two iterations stall and resume)
     const char* unroll_env = getenv("PSFM_SOLVE_UNROLL");
     const int unroll_fixed = unroll_env ? (atoi(unroll_env) < 1 ? 1 : atoi(unroll_env)) : 0;
+    // How a frame's solve is enqueued (psfm_ctx_set_solver): the fused solve -- ONE launch that speculates solve_K
+    // Gauss-Newton iterations -- or the launch chain (init + solve_unroll iterations + write-back).  Adaptive: a
+    // window (the frames between two checkpoints) whose solves rejected steps / left the Gauss-Newton path sends the next
+    // window to the chain, a clean window brings the fused solve back; solve_K follows the accepted steps seen.
+    c->n_fused_ok = c->n_fused_redone = c->n_chain = 0;
+    if (optimize && (st = psfm_solve_prepare(c, d)) != PSFM_OK) return st;
     int f = 0;
     while (f < n_flows) {
         // track.py:31-47 / track_optimize.py:31-50, one loop iteration:
         // one launch = births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
         if (pipe && (st = pipe->need(f, false, s)) != PSFM_OK) return st;
-        st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * occ_pitch, f, s);
+        st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * occ_pitch, f, optimize, s);
         if (st != PSFM_OK) return st;
+        const bool fused_now = c->solver_mode == 2 || (c->solver_mode == 0 && c->solve_mode == 0);
         if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
             if (pipe && (st = pipe->need(f - 1, true, s)) != PSFM_OK) return st;
             c->prof.begin(PSFM_PROF_SOLVER, s);
-            st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
-                                          flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
-                                          unroll_fixed > 0 ? unroll_fixed : c->solve_unroll, s);
+            if (fused_now)
+                st = psfm_solve_frame_fused(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
+                                            flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
+                                            c->solver_K > 0 ? c->solver_K : c->solve_K, s);
+            else
+                st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
+                                              flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
+                                              unroll_fixed > 0 ? unroll_fixed : c->solve_unroll, s);
             c->prof.end(s);
             if (st != PSFM_OK) return st;
         }
@@ -447,15 +480,32 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                 hstats[fs] = ss;
                 last_ok = fs;
             }
-            int max_it = 0;
+            int max_it = 0, n_solved = 0, n_unclean = 0, k_need = 2;
             for (int k = first_unchecked; k <= last_ok; ++k) {
                 // (termination 5 = Ceres' FAILURE: the reference ignores it, trajectory_optimize.cpp:81-82, and carries on
                 // with the positions it had -- so does the device; the caller sees it in the solve statistics)
                 if (hstats[k].termination >= 0) {   // -1: no track had a full buffer, nothing was solved
                     c->solve_stats.push_back(hstats[k]);
                     total_iters += hstats[k].iterations;
+                    // "clean": every iteration but the terminating one took the Gauss-Newton step and was accepted --
+                    // what the fused solve speculates; it then needs successful_steps + 1 iterations in its launch
+                    const psfm_solve_stats& q = hstats[k];
+                    const bool clean = q.dogleg_nonGN == 0 && q.termination != PSFM_TERM_FAILURE &&
+                                       (q.iterations == q.successful_steps + 1 ||
+                                        (q.termination == PSFM_TERM_GRADIENT_TOL && q.iterations == q.successful_steps)) &&
+                                       q.successful_steps + 1 <= psfm_solve_kmax();
+                    ++n_solved;
+                    if (!clean) ++n_unclean;
+                    else if (q.successful_steps + 1 > k_need) k_need = q.successful_steps + 1;
+                    if (!fused_now) ++c->n_chain;
+                    else if (hc->stall && k == hc->stall - 1) ++c->n_fused_redone;
+                    else ++c->n_fused_ok;
                 }
                 if (hstats[k].iterations > max_it) max_it = hstats[k].iterations;
+            }
+            if (n_solved > 0) {
+                c->solve_mode = (n_unclean * 8 > n_solved) ? 1 : 0;
+                c->solve_K = k_need > c->solve_K ? k_need : c->solve_K - (c->solve_K - k_need + 1) / 2;
             }
             // adapt the unroll to what this sequence needs, within [4, 64]: a solve of k iterations needs k-1 pc_iter
             // launches (pc_init does the first), so max+1 leaves two spare launches for the slowest solve seen in the
@@ -469,6 +519,8 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         }
         ++f;
     }
+    // the positions of the last fused solve are still in their iterate buffer (no chain step followed to move them)
+    if (optimize && n_flows >= 2 && (st = psfm_solve_flush(c, d, n_flows - 1, s)) != PSFM_OK) return st;
     c->prof.begin(PSFM_PROF_FINALIZE, s);
     st = psfm_finalize(c, d, s);
     c->prof.end(s);

@@ -58,7 +58,9 @@ struct PsfmCounters {
     int stall;        // != 0: solve of frame stall-1 ran out of unrolled iterations; later launches are no-ops
     int abort;        // persistent frame loop: a block gave up (spin limit); every block leaves at its next barrier
     int spill_cnt;    // persistent frame loop: records written to the shared tail behind the private segments
-    int pad[11];
+    int sel;          // track_optimize: iterate buffer that holds the accepted positions (times f, f+1) of the last fused
+                      // solve; 0 = they are in the log.  The next chain step copies them on its way (psfm_solver.hip)
+    int pad[10];
 };
 
 // Death records and free lanes are published through PSFM_NSHARD independent tables so that the
@@ -124,7 +126,11 @@ struct psfm_ctx {
     PsfmBuf res_birth, res_len, res_off, res_xy;
     int64_t res_n_traj = 0, res_n_points = 0;
     // solver workspace
-    PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats;
+    PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats, sol_fused;
+    int solve_K = 4;        // fused solve: trust-region iterations speculated per launch (adapted at checkpoints)
+    int solve_mode = 0;     // 0 fused solve (one launch per frame), 1 launch chain (sequences whose solves reject steps)
+    int solver_mode = 0, solver_K = 0;   // psfm_ctx_set_solver: 0 adaptive / 1 chain / 2 fused; K 0 = adaptive
+    int64_t n_fused_ok = 0, n_fused_redone = 0, n_chain = 0;   // solves of the last psfm_track by how they ran
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
     PsfmBuf occ_own, occ2_own;           // occlusion maps of psfm_connect when the caller passes none
     PsfmBuf win_ws;                      // psfm_window_sample / psfm_result_filter workspace
@@ -156,7 +162,7 @@ struct PsfmTrackDims {
 
 psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
-                                   int frame, hipStream_t s);
+                                   int frame, bool optimize, hipStream_t s);
 
 // ---- persistent frame loop (psfm_persist.hip) ---------------------------------------------------
 int psfm_persist_max_blocks(psfm_ctx* c);
@@ -178,6 +184,11 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
 psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                     const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
                                     hipStream_t s);
+psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                   const float* flow02, const uint8_t* occ02, int frame, int K, hipStream_t s);
+psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
+psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d);   // every solver buffer of a sequence, up front
+int psfm_solve_kmax(void);
 // Batch API form (psfm_optimize_location).
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
                              const double* scale, const float* flow12, int64_t n, int w, int h, double* out,

@@ -27,6 +27,7 @@
 // All arithmetic f64 without contraction; reductions have a fixed order (bitwise reproducible for a
 // given lane assignment).
 #include <string.h>
+#include <stdlib.h>
 
 #include "psfm_device.h"
 #include "psfm_internal.h"
@@ -41,6 +42,8 @@
                              // tracks per thread; capped to 128 VGPRs / 4 waves with 14 spills: 78 ms)
 #endif
 #define PC_NSUM 13
+#define PC_KMAX 8            // fused solve: most trust-region iterations speculated in one launch
+#define PC_GROUP 32          // fused solve: blocks per first-level reduction group
 
 
 struct PsfmSolveCtrl {
@@ -64,8 +67,11 @@ struct PcParams {
     int max_birth;            // track participates iff 0 <= birth_frame <= max_birth
     const int* n_lanes_ptr;   // device count of lanes (frame mode) or NULL
     int n_rows;               // upper bound of the index range (cap or batch n)
-    // ping-pong iterate: buffer 0 = (x1a, x2a), buffer 1 = (x1b, x2b)
-    double2 *x1a, *x2a, *x1b, *x2b;
+    // iterate buffers: buffer 0 = (x1a, x2a) -- the caller's values (frame mode: the log slabs), never overwritten before
+    // the write-back; buffer m >= 1 = (xs + (2m-2) * xs_stride, xs + (2m-1) * xs_stride).  The launch chain ping-pongs
+    // between buffers 1 and 2; the fused solve stores the iterate after m accepted steps in buffer m.
+    double2 *x1a, *x2a;
+    double2* xs; int64_t xs_stride;
     const double2* p0;        // frame mode: log slab f-1
     // per-track constants
     double2 *ref1, *ref2;
@@ -82,7 +88,17 @@ struct PcParams {
     unsigned* ticket;         // last-block detection
     int frame;                // frame index of this solve (stall value / stats slot)
     psfm_solve_stats* stats_dev;   // per-frame statistics (frame mode) or NULL
+    // fused solve (psfm_pc_fused_kernel)
+    int K;                    // speculated trust-region iterations per launch (<= PC_KMAX)
+    double* gpart;            // [groups][PC_KMAX][PC_NSUM] sums of PC_GROUP consecutive blocks
+    unsigned* gticket;        // [groups] + 1 (top)
+    int* sel;                 // PsfmCounters::sel: buffer that holds the accepted iterate of the last solve (0: the log)
 };
+
+__device__ __forceinline__ double2* pc_buf1(const PcParams& P, int m) { return m == 0 ? P.x1a : P.xs + (int64_t)(2 * m - 2) * P.xs_stride; }
+__device__ __forceinline__ double2* pc_buf2(const PcParams& P, int m) { return m == 0 ? P.x2a : P.xs + (int64_t)(2 * m - 1) * P.xs_stride; }
+// the launch chain's candidate buffer while the iterate sits in buffer `cur`
+__device__ __forceinline__ int pc_other(int cur) { return cur == 1 ? 2 : 1; }
 
 // ---- f64 clamp-to-edge bilinear interpolation (linear_interpolation.h:97-123 over ceres::Grid2D) ----
 __device__ __forceinline__ void pc_bilerp(const float2* __restrict__ flow, int H, int W, double r, double c,
@@ -390,6 +406,9 @@ __device__ __forceinline__ bool pc_is_last_block(unsigned* ticket)
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
 {
     if (*P.stall) return;
+    // the chain step in front of this solve has consumed PsfmCounters::sel (positions of an earlier fused solve): the launch
+    // chain works in buffer 0 from here on, whatever becomes of it
+    if (P.sel && blockIdx.x == 0 && threadIdx.x == 0) *P.sel = 0;
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
     double acc[PC_NSUM];
 #pragma unroll
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
         P.jscale[i] = make_double2(S[0], S[1]);
         acc[SUM_CNT] += 1.0;
         double c_at_x;
-        pc_track_iteration(P, x, r1, r2, s, S, mu, 0.0, 1.0, P.x1b, P.x2b, i, acc, &c_at_x);   // iteration 1, speculated
+        pc_track_iteration(P, x, r1, r2, s, S, mu, 0.0, 1.0, pc_buf1(P, 1), pc_buf2(P, 1), i, acc, &c_at_x);   // iteration 1, speculated
         acc[SUM_COST0] += c_at_x;
     }
     pc_block_reduce(acc, P.partials);
@@ -464,10 +483,10 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
     PC_TL(0);
 #endif
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
-    const double2* xc1 = C.cur ? P.x1b : P.x1a;
-    const double2* xc2 = C.cur ? P.x2b : P.x2a;
-    double2* xn1 = C.cur ? P.x1a : P.x1b;
-    double2* xn2 = C.cur ? P.x2a : P.x2b;
+    const double2* xc1 = pc_buf1(P, C.cur);
+    const double2* xc2 = pc_buf2(P, C.cur);
+    double2* xn1 = pc_buf1(P, pc_other(C.cur));
+    double2* xn2 = pc_buf2(P, pc_other(C.cur));
     const double a = C.dl_fixed ? C.dl_a : 0.0, b = C.dl_fixed ? C.dl_b : 1.0;
     double acc[PC_NSUM];
 #pragma unroll
@@ -522,6 +541,98 @@ __device__ __forceinline__ void pc_choose_dogleg(PsfmSolveCtrl& C)
     }
 }
 
+// Ceres' scalar control logic for ONE trust-region iteration whose global sums are tot[PC_NSUM] (thread 0 of the last
+// block).  accept_buf: the buffer that holds the candidate, i.e. where the iterate lives if the step is accepted.
+__device__ __forceinline__ void pc_control_step(PsfmSolveCtrl& C, const double* tot, int is_init, int accept_buf)
+{
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double min_relative_decrease = 1e-3, min_radius = 1e-32;
+    const double min_mu = 1e-8, mu_increase = 10.0;
+    const int max_iter = 200, max_invalid = 5;
+    if (is_init) {
+        memset(&C, 0, sizeof(C));
+        C.radius = 1e4; C.mu = min_mu;
+        C.n_tracks = (int)tot[SUM_CNT];
+        C.x_cost = tot[SUM_COST0]; C.initial_cost = C.x_cost;
+        C.termination = PSFM_TERM_MAX_ITER;
+        C.fresh_x = 1;   // iteration 0 counts as a successful step: its gradient test is due now
+        if (C.n_tracks == 0) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
+    }
+    if (!C.done && tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+    if (!C.done) {
+        // quantities of the CURRENT iterate evaluated by this launch
+        C.x_norm = sqrt(tot[SUM_XN2]);
+        C.gmax = tot[SUM_GMAX];
+        C.g2 = tot[SUM_G2]; C.jg2 = tot[SUM_JG2]; C.gn2 = tot[SUM_GN2]; C.dot = tot[SUM_DOT];
+        if (C.fresh_x) {   // FinalizeIterationAndCheckIfMinimizerCanContinue after a successful step (max_iter and
+            C.fresh_x = 0; // radius were tested when the step was accepted; the gradient is only known now)
+            if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
+        }
+    }
+    if (!C.done) {
+        // Which step did the launch take, and which one does the dogleg prescribe for this radius?
+        const bool used_fixed = C.dl_fixed != 0;
+        const double used_a = C.dl_a, used_b = C.dl_b;
+        pc_choose_dogleg(C);
+        const bool step_ok = (C.dl_case == 1) ? !used_fixed : (used_fixed && used_a == C.dl_a && used_b == C.dl_b);
+        if (!step_ok) {
+            C.dl_fixed = (C.dl_case != 1);   // re-issue this iteration with the prescribed coefficients
+        } else {
+            bool rejected = false;
+            C.iteration += 1;
+            if (C.dl_case != 1) C.nonGN += 1;
+            const double mcc = -tot[SUM_MCC];
+            const double dogleg_step_norm = C.dl_norm >= 0.0 ? C.dl_norm : sqrt(tot[SUM_DL2]);
+            if (!(mcc > 0.0)) {
+                // HandleInvalidStep / StepIsInvalid: the next launch re-solves with the larger mu
+                if (++C.n_invalid >= max_invalid) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+                C.mu *= mu_increase;
+                C.dl_fixed = 0;
+            } else {
+                C.n_invalid = 0;
+                const double cand = tot[SUM_COST];
+                const double step_norm = sqrt(tot[SUM_STEP2]);
+                if (step_norm <= parameter_tolerance * (C.x_norm + parameter_tolerance)) {
+                    C.done = 1; C.termination = PSFM_TERM_PARAMETER_TOL;
+                } else if (fabs(C.x_cost - cand) <= function_tolerance * C.x_cost) {
+                    C.done = 1; C.termination = PSFM_TERM_FUNCTION_TOL;
+                } else {
+                    const double rho = (C.x_cost - cand) / mcc;
+                    if (rho > min_relative_decrease) {
+                        // HandleSuccessfulStep + DoglegStrategy::StepAccepted
+                        C.cur = accept_buf;
+                        C.x_cost = cand;
+                        C.successful += 1;
+                        if (rho < 0.25) C.radius *= 0.5;
+                        if (rho > 0.75) C.radius = fmax(C.radius, 3.0 * dogleg_step_norm);
+                        C.mu = fmax(min_mu, 2.0 * C.mu / mu_increase);
+                        C.fresh_x = 1;
+                        C.dl_fixed = 0;
+                    } else {
+                        rejected = true;
+                    }
+                }
+            }
+            // FinalizeIterationAndCheckIfMinimizerCanContinue (the gradient test of an accepted step is deferred)
+            if (!C.done) {
+                if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
+                else if (!rejected && C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
+            }
+            // StepRejected: radius /= 2 and the SAME Gauss-Newton system.  While the shrunken region still contains
+            // the Gauss-Newton step the dogleg returns the same step, hence the same candidate and the same
+            // rejection: replay those iterations here instead of relaunching.
+            while (rejected && !C.done) {
+                C.radius *= 0.5;
+                if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; break; }
+                pc_choose_dogleg(C);
+                if (C.dl_case != 1) { C.dl_fixed = 1; break; }
+                C.iteration += 1;   // identical step, identical rho: rejected again
+                if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
+            }
+        }
+    }
+}
+
 // Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket after an agent-scope
 // release; the reading block acquires before touching the other blocks' partials -- cdna_hip_programming.md G16):
 // fixed-order reduction of the per-block partials, then the scalar control step on thread 0.
@@ -564,95 +675,314 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
     }
     if (threadIdx.x != 0) return;
     PsfmSolveCtrl C = *ctrl;
-    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-    const double min_relative_decrease = 1e-3, min_radius = 1e-32;
-    const double min_mu = 1e-8, mu_increase = 10.0;
-    const int max_iter = 200, max_invalid = 5;
-    if (is_init) {
-        memset(&C, 0, sizeof(C));
-        C.radius = 1e4; C.mu = min_mu;
-        C.n_tracks = (int)s_tot[SUM_CNT];
-        C.x_cost = s_tot[SUM_COST0]; C.initial_cost = C.x_cost;
-        C.termination = PSFM_TERM_MAX_ITER;
-        C.fresh_x = 1;   // iteration 0 counts as a successful step: its gradient test is due now
-        if (C.n_tracks == 0) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
-    }
-    if (!C.done && s_tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
-    if (!C.done) {
-        // quantities of the CURRENT iterate evaluated by this launch
-        C.x_norm = sqrt(s_tot[SUM_XN2]);
-        C.gmax = s_tot[SUM_GMAX];
-        C.g2 = s_tot[SUM_G2]; C.jg2 = s_tot[SUM_JG2]; C.gn2 = s_tot[SUM_GN2]; C.dot = s_tot[SUM_DOT];
-        if (C.fresh_x) {   // FinalizeIterationAndCheckIfMinimizerCanContinue after a successful step (max_iter and
-            C.fresh_x = 0; // radius were tested when the step was accepted; the gradient is only known now)
-            if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
-        }
-    }
-    if (!C.done) {
-        // Which step did the launch take, and which one does the dogleg prescribe for this radius?
-        const bool used_fixed = C.dl_fixed != 0;
-        const double used_a = C.dl_a, used_b = C.dl_b;
-        pc_choose_dogleg(C);
-        const bool step_ok = (C.dl_case == 1) ? !used_fixed : (used_fixed && used_a == C.dl_a && used_b == C.dl_b);
-        if (!step_ok) {
-            C.dl_fixed = (C.dl_case != 1);   // re-issue this iteration with the prescribed coefficients
-        } else {
-            bool rejected = false;
-            C.iteration += 1;
-            if (C.dl_case != 1) C.nonGN += 1;
-            const double mcc = -s_tot[SUM_MCC];
-            const double dogleg_step_norm = C.dl_norm >= 0.0 ? C.dl_norm : sqrt(s_tot[SUM_DL2]);
-            if (!(mcc > 0.0)) {
-                // HandleInvalidStep / StepIsInvalid: the next launch re-solves with the larger mu
-                if (++C.n_invalid >= max_invalid) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
-                C.mu *= mu_increase;
-                C.dl_fixed = 0;
-            } else {
-                C.n_invalid = 0;
-                const double cand = s_tot[SUM_COST];
-                const double step_norm = sqrt(s_tot[SUM_STEP2]);
-                if (step_norm <= parameter_tolerance * (C.x_norm + parameter_tolerance)) {
-                    C.done = 1; C.termination = PSFM_TERM_PARAMETER_TOL;
-                } else if (fabs(C.x_cost - cand) <= function_tolerance * C.x_cost) {
-                    C.done = 1; C.termination = PSFM_TERM_FUNCTION_TOL;
-                } else {
-                    const double rho = (C.x_cost - cand) / mcc;
-                    if (rho > min_relative_decrease) {
-                        // HandleSuccessfulStep + DoglegStrategy::StepAccepted
-                        C.cur ^= 1;
-                        C.x_cost = cand;
-                        C.successful += 1;
-                        if (rho < 0.25) C.radius *= 0.5;
-                        if (rho > 0.75) C.radius = fmax(C.radius, 3.0 * dogleg_step_norm);
-                        C.mu = fmax(min_mu, 2.0 * C.mu / mu_increase);
-                        C.fresh_x = 1;
-                        C.dl_fixed = 0;
-                    } else {
-                        rejected = true;
-                    }
-                }
-            }
-            // FinalizeIterationAndCheckIfMinimizerCanContinue (the gradient test of an accepted step is deferred)
-            if (!C.done) {
-                if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
-                else if (!rejected && C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
-            }
-            // StepRejected: radius /= 2 and the SAME Gauss-Newton system.  While the shrunken region still contains
-            // the Gauss-Newton step the dogleg returns the same step, hence the same candidate and the same
-            // rejection: replay those iterations here instead of relaunching.
-            while (rejected && !C.done) {
-                C.radius *= 0.5;
-                if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; break; }
-                pc_choose_dogleg(C);
-                if (C.dl_case != 1) { C.dl_fixed = 1; break; }
-                C.iteration += 1;   // identical step, identical rho: rejected again
-                if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
-            }
-        }
-    }
+    pc_control_step(C, s_tot, is_init, is_init ? 1 : pc_other(C.cur));   // (init: the candidate of iteration 1 is in buffer 1)
     C.launches += 1;
     *ctrl = C;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// pc_fused: the WHOLE solve of a frame in one launch, speculating that every trust-region iteration takes the pure
+// Gauss-Newton step at mu = min_mu and is accepted -- which is what Ceres does on every solve that converges without a
+// rejection.  Under that assumption nothing a track computes depends on the global scalars: thread = track runs K
+// iterations in registers (the residuals / Jacobian evaluated at a candidate for its cost ARE the next iteration's
+// evaluation at x: K + 1 interpolations instead of 2 K), stores the iterate after m accepted steps in buffer m, and
+// every iteration's 13 sums are reduced block -> group of PC_GROUP blocks -> grid (two tickets, fixed order).  The last
+// block replays Ceres' control flow over iterations 1..K with those sums, exactly as the launch chain would have
+// (pc_control_step), and stops believing the speculation at the first decision that is not "Gauss-Newton step
+// accepted": termination -> done, the accepted iterate is buffer `cur` (PsfmCounters::sel tells the next chain step, which
+// copies it into the log on its way); anything else (rejection, dogleg interpolation, invalid step, more than K
+// iterations) raises the stall flag and the host redoes this solve with the launch chain from the untouched buffer 0.
+// ------------------------------------------------------------------------------------------------
+struct PcTrack {            // one track's solve state in registers
+    double x[4], r[6], jac[4];
+    double2 r1, r2;
+    double s, S0, S1, S2;
+};
+
+// sums of one trust-region iteration at T.x (already evaluated: T.r, T.jac) into v[]; the candidate goes to (xn1, xn2)[i]
+// and becomes T.x, evaluated.  Same arithmetic, operation for operation, as pc_track_iteration with (a, b) = (0, 1).
+__device__ __forceinline__ void pc_fused_iteration(const PcParams& P, PcTrack& T, double mu, double2* xn1, double2* xn2, int i,
+                                                   double v[PC_NSUM])
+{
+    const double* x = T.x; const double* r = T.r; const double* jac = T.jac;
+    const double s = T.s;
+    const double S[4] = {T.S0, T.S1, T.S2, T.S2};
+    const double g[4] = {(r[0] + jac[0] * r[4]) + jac[2] * r[5], (r[1] + jac[1] * r[4]) + jac[3] * r[5],
+                         s * r[2] + r[4], s * r[3] + r[5]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[SUM_GMAX] = fmax(v[SUM_GMAX], fabs(x[k] - (x[k] + (-g[k]))));
+        v[SUM_XN2] += x[k] * x[k];
+    }
+    const PcJac J = pc_scaled_jac(jac, s, S);
+    double d[4], yd[4], gh[4], gn[4], jg2;
+    const bool ok = pc_gn_system(J, r, mu, d, yd, gh, gn, &jg2);
+    v[SUM_JG2] += jg2;
+    if (!ok) v[SUM_FAIL] += 1.0;
+    double st[4], xp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[SUM_G2] += gh[k] * gh[k];
+        v[SUM_GN2] += gn[k] * gn[k];
+        v[SUM_DOT] += gh[k] * gn[k];
+        const double w = 0.0 * gh[k] + 1.0 * gn[k];
+        v[SUM_DL2] += w * w;
+        st[k] = pc_div(w, d[k], yd[k]);
+    }
+    {
+        const double m0 = J.a0 * st[0], m1 = J.a1 * st[1], m2 = J.a2 * st[2], m3 = J.a3 * st[3];
+        const double m4 = (J.b0 * st[0] + J.b1 * st[1]) + J.b2 * st[2];
+        const double m5 = (J.c0 * st[0] + J.c1 * st[1]) + J.c3 * st[3];
+        v[SUM_MCC] += ((((m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0)) + m2 * (r[2] + m2 / 2.0)) +
+                        m3 * (r[3] + m3 / 2.0)) + m4 * (r[4] + m4 / 2.0)) + m5 * (r[5] + m5 / 2.0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xp[k] = x[k] + st[k] * S[k];
+        const double dd = x[k] - xp[k];
+        v[SUM_STEP2] += dd * dd;
+    }
+    if (xn1) {
+        xn1[i] = make_double2(xp[0], xp[1]);
+        xn2[i] = make_double2(xp[2], xp[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T.x[k] = xp[k];
+    pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, s, T.r, T.jac);
+    v[SUM_COST] += 0.5 * (((((T.r[0] * T.r[0] + T.r[1] * T.r[1]) + T.r[2] * T.r[2]) + T.r[3] * T.r[3]) + T.r[4] * T.r[4]) +
+                          T.r[5] * T.r[5]);
+}
+
+// Sums of one iteration over the 64 tracks of a WAVE, through LDS, without a block barrier (the four waves of a block
+// stay independent inside the iteration loop): every lane parks its 13 values; lane 4k+q adds the values of lanes
+// q, q+4, ... of slot k in lane order; lanes k < 13 add the four quarter sums.  Fixed order.  LDS operations of one wave
+// execute in order, so the wave only has to wait for its own stores.
+#define PC_NW (PC_BLOCK / PSFM_WAVE)
+#define PC_WROW 66          // row pitch in doubles: 2-way instead of 13-way bank conflicts in the quarter sums
+struct PcWaveRed {
+    double park[PC_NW][PC_NSUM][PC_WROW];
+    double quarter[PC_NW][PC_NSUM][4];
+    double wsum[PC_NW][PC_KMAX][PC_NSUM];
+};
+__device__ __forceinline__ void pc_wave_reduce(PcWaveRed& R, const double v[PC_NSUM], int iter)
+{
+    const int lane = threadIdx.x & (PSFM_WAVE - 1), w = threadIdx.x / PSFM_WAVE;
+#pragma unroll
+    for (int k = 0; k < PC_NSUM; ++k) R.park[w][k][lane] = v[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int k = lane >> 2, q = lane & 3;
+    if (k < PC_NSUM) {
+        double t = R.park[w][k][q];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t = (k == SUM_GMAX) ? fmax(t, R.park[w][k][4 * j + q]) : t + R.park[w][k][4 * j + q];
+        R.quarter[w][k][q] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < PC_NSUM) {
+        double t = R.quarter[w][lane][0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) t = (lane == SUM_GMAX) ? fmax(t, R.quarter[w][lane][j]) : t + R.quarter[w][lane][j];
+        R.wsum[w][iter][lane] = t;
+    }
+    // (the next iteration's park stores come behind these loads in the wave's LDS queue)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// drain this block's write-through stores, then take a ticket: true for the last of `members` arrivals (which also
+// resets the counter for the next launch)
+__device__ __forceinline__ bool pc_last_arrival(unsigned* ticket, unsigned members)
+{
+    __shared__ int s_last2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last2 = (t == members - 1u);
+        if (s_last2) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last2 != 0;
+}
+
+// WAVES: waves per SIMD the register allocation targets (3: 136 VGPRs, no spill; 4: 128 VGPRs, 4 spilled)
+template <int WAVES>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void psfm_pc_fused_kernel(PcParams P)
+{
+    if (*P.stall) return;
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    const int n_active = (n + PC_BLOCK - 1) / PC_BLOCK;        // blocks with a lane below the high-water mark
+    if ((int)blockIdx.x >= n_active) return;
+    const int K = P.K;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * PC_BLOCK + tid;
+    // (state loaded alongside the birth frame that decides whether the lane takes part: one round trip less)
+    double2 p0 = make_double2(0.0, 0.0), p1 = p0, p2 = p0;
+    if (i < n) { p0 = P.p0[i]; p1 = P.x1a[i]; p2 = P.x2a[i]; }
+    const bool part = pc_participates(P, i, n);
+    const double mu = 1e-8;
+    // Where the iterates live.  A solve that goes as speculated accepts e = K - 1 steps and terminates in iteration K, so
+    // iterate e is written straight into buffer 0 -- the log slabs, where the next chain step and finalize read -- and
+    // the values the solve started from are kept in buffer e instead; every other iterate m sits in buffer m.
+    const int e = K - 1;
+#define PC_PHYS(m) ((m) == e ? 0 : ((m) == 0 ? e : (m)))
+    __shared__ PcWaveRed s_red;
+    PcTrack T;
+    double c0 = 0.0;
+    if (part) {
+        if (e != 0) { pc_buf1(P, e)[i] = p1; pc_buf2(P, e)[i] = p2; }
+        const PsfmTaps t = psfm_taps((float)p0.x, (float)p0.y, P.cw, P.ch, P.H, P.W);
+        const PsfmTapIdx k = psfm_tap_idx(P.H, P.W, t);
+        const float2 f01 = psfm_sample_flow(P.flow01, k, t);
+        const float2 f02 = psfm_sample_flow(P.flow02, k, t);
+        const float o02 = psfm_sample_mask(P.occ02, k, t);
+        // (trajectory.py:173-183, as in psfm_pc_init_kernel)
+        const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
+        const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
+        T.s = (double)sf;
+        T.r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
+        T.r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
+        T.x[0] = p1.x; T.x[1] = p1.y; T.x[2] = p2.x; T.x[3] = p2.y;
+        pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, T.s, T.r, T.jac);
+        // Jacobi scaling from the Jacobian at x0 (jac[] holds exactly the entries psfm_pc_init_kernel rebuilds)
+        const double q0 = (1.0 + T.jac[0] * T.jac[0]) + T.jac[2] * T.jac[2];
+        const double q1 = (1.0 + T.jac[1] * T.jac[1]) + T.jac[3] * T.jac[3];
+        const double q2 = T.s * T.s + 1.0;
+        T.S0 = 1.0 / (1.0 + sqrt(q0)); T.S1 = 1.0 / (1.0 + sqrt(q1)); T.S2 = 1.0 / (1.0 + sqrt(q2));
+        double ss = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ss += T.r[q] * T.r[q];
+        c0 = 0.5 * ss;
+    }
+    for (int j = 0; j < K; ++j) {
+        double v[PC_NSUM];
+#pragma unroll
+        for (int q = 0; q < PC_NSUM; ++q) v[q] = 0.0;
+        if (part) {
+            // (the K-th candidate is never read: were it accepted, the solve would not be over and is redone)
+            const bool keep = j + 1 < K;
+            pc_fused_iteration(P, T, mu, keep ? pc_buf1(P, PC_PHYS(j + 1)) : nullptr, keep ? pc_buf2(P, PC_PHYS(j + 1)) : nullptr, i, v);
+            if (j == 0) { v[SUM_CNT] = 1.0; v[SUM_COST0] = c0; }
+        }
+        pc_wave_reduce(s_red, v, j);
+    }
+    __syncthreads();
+    if (tid < K * PC_NSUM) {   // the block's sums: its waves in order
+        const int j = tid / PC_NSUM, k = tid - j * PC_NSUM;
+        double t = s_red.wsum[0][j][k];
+#pragma unroll
+        for (int w = 1; w < PC_NW; ++w) t = (k == SUM_GMAX) ? fmax(t, s_red.wsum[w][j][k]) : t + s_red.wsum[w][j][k];
+        __hip_atomic_store(&P.partials[((int64_t)blockIdx.x * PC_KMAX + j) * PC_NSUM + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+
+    // ---- level 1: the last block of each group of PC_GROUP consecutive blocks adds the group's partials ----
+    const int n_groups = (n_active + PC_GROUP - 1) / PC_GROUP;
+    const int grp = blockIdx.x / PC_GROUP;
+    const int members = min(PC_GROUP, n_active - grp * PC_GROUP);
+    if (!pc_last_arrival(P.gticket + 1 + grp, (unsigned)members)) return;
+    __shared__ double s_half[2][PC_KMAX * PC_NSUM];
+    __shared__ double s_tot[PC_KMAX][PC_NSUM];
+    const int slot = tid & 127, half = tid >> 7;      // slot = j * PC_NSUM + k
+    const int nslot = K * PC_NSUM;
+    {
+        double t = 0.0;
+        if (slot < nslot) {
+            const int j = slot / PC_NSUM, k = slot - j * PC_NSUM;
+            double pv[PC_GROUP / 2];
+#pragma unroll
+            for (int u = 0; u < PC_GROUP / 2; ++u) {
+                const int b = half * (PC_GROUP / 2) + u;
+                pv[u] = b < members ? __hip_atomic_load(&P.partials[((int64_t)(grp * PC_GROUP + b) * PC_KMAX + j) * PC_NSUM + k],
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                    : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < PC_GROUP / 2; ++u) t = (k == SUM_GMAX) ? fmax(t, pv[u]) : t + pv[u];
+            s_half[half][slot] = t;
+        }
+        __syncthreads();
+        if (tid < nslot) {
+            const int j = tid / PC_NSUM, k = tid - j * PC_NSUM;
+            const double a = s_half[0][tid], b = s_half[1][tid];
+            __hip_atomic_store(&P.gpart[((int64_t)grp * PC_KMAX + j) * PC_NSUM + k], (k == SUM_GMAX) ? fmax(a, b) : a + b,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // ---- level 2: the last group adds the group sums in group order and runs the control flow ----
+    if (!pc_last_arrival(P.gticket, (unsigned)n_groups)) return;
+    {
+        double t = 0.0;
+        if (slot < nslot) {
+            const int j = slot / PC_NSUM, k = slot - j * PC_NSUM;
+            for (int g0 = half * 16; g0 < n_groups; g0 += 32) {
+                double pv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    pv[u] = g0 + u < n_groups ? __hip_atomic_load(&P.gpart[((int64_t)(g0 + u) * PC_KMAX + j) * PC_NSUM + k],
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                              : 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t = (k == SUM_GMAX) ? fmax(t, pv[u]) : t + pv[u];
+            }
+            s_half[half][slot] = t;
+        }
+        __syncthreads();
+        if (tid < nslot) {
+            const int j = tid / PC_NSUM, k = tid - j * PC_NSUM;
+            const double a = s_half[0][tid], b = s_half[1][tid];
+            s_tot[j][k] = (k == SUM_GMAX) ? fmax(a, b) : a + b;
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    PsfmSolveCtrl C = *P.ctrl;
+    for (int j = 1; j <= K; ++j) {
+        pc_control_step(C, s_tot[j - 1], j == 1, j);
+        if (C.done) break;
+        // iteration j + 1 was computed at buffer j with the Gauss-Newton step at min_mu: only valid behind an accepted step
+        if (!(C.fresh_x && C.cur == j && C.dl_fixed == 0 && C.mu == 1e-8)) break;
+    }
+    C.launches += 1;
+    *P.ctrl = C;
+    if (!C.done) {      // not what was speculated: the launch chain redoes this solve from the values it started from,
+        *P.sel = PC_PHYS(0);   // which psfm_solve_frame_resume first moves back into buffer 0
+        *P.stall = P.frame + 1;
+        return;
+    }
+    // (a failed solve hands the parameters back as they came in: nothing was accepted, C.cur == 0 -- see the write-back)
+    *P.sel = PC_PHYS(C.cur);
+#undef PC_PHYS
+    if (P.stats_dev) {
+        psfm_solve_stats st;
+        st.iterations = C.iteration; st.successful_steps = C.successful;
+        st.termination = C.n_tracks == 0 ? -1 : C.termination; st.dogleg_nonGN = C.nonGN;
+        st.initial_cost = C.initial_cost; st.final_cost = C.x_cost;
+        if (C.failed) st.termination = PSFM_TERM_FAILURE;
+        P.stats_dev[P.frame] = st;
+    }
+}
+
+// Copy the accepted iterate of the last fused solve from buffer *sel into the log (what the next chain step does on
+// its way; needed behind the LAST solve of a sequence, whose positions no chain step picks up).
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_flush_kernel(PcParams P)
+{
+    if (*P.stall) return;
+    const int m = *P.sel;
+    if (m == 0) return;
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    const int i = blockIdx.x * PC_BLOCK + threadIdx.x;
+    if (pc_participates(P, i, n)) {
+        P.x1a[i] = pc_buf1(P, m)[i];
+        P.x2a[i] = pc_buf2(P, m)[i];
+    }
+}
+__global__ void psfm_pc_clear_sel_kernel(int* sel, const int* stall) { if (!*stall) *sel = 0; }
 
 // final: if the accepted iterate lives in the scratch pair, copy it back (frame mode: into the log)
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P, double* out_rows)
@@ -681,9 +1011,10 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P,
     // Js^T Js + mu diag^2 to lose definiteness, or an accepted iterate with finite cost and a non-finite Jacobian over
     // the same four taps; the current iterate is what comes out then.)
     const int cur = C.cur;
+    if (P.sel && blockIdx.x == 0 && threadIdx.x == 0) *P.sel = 0;   // the iterate is (being) copied into buffer 0 right here
     if (cur == 0 && !out_rows) return;
-    const double2* xc1 = cur ? P.x1b : P.x1a;
-    const double2* xc2 = cur ? P.x2b : P.x2a;
+    const double2* xc1 = pc_buf1(P, cur);
+    const double2* xc2 = pc_buf2(P, cur);
     for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
         if (!pc_participates(P, i, n)) continue;
         const double2 p1 = xc1[i], p2 = xc2[i];
@@ -764,11 +1095,11 @@ static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double
     return PSFM_OK;
 }
 
-static psfm_status pc_workspace(psfm_ctx* c, int64_t rows)
+static psfm_status pc_workspace(psfm_ctx* c, int64_t rows, int n_buf)
 {
     psfm_status rc;
-    // x1b, x2b, ref1, ref2, jscale (double2 each) + scale (double)
-    if ((rc = c->sol_x.ensure(sizeof(double2) * rows * 2)) != PSFM_OK) return rc;
+    // iterate buffers 1..n_buf (two double2 arrays each); ref1, ref2, jscale (double2 each) + scale (double)
+    if ((rc = c->sol_x.ensure(sizeof(double2) * rows * 2 * n_buf)) != PSFM_OK) return rc;
     if ((rc = c->sol_state.ensure(sizeof(double2) * rows * 3 + sizeof(double) * rows)) != PSFM_OK) return rc;
     return PSFM_OK;
 }
@@ -777,7 +1108,7 @@ static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const fl
                                    const float* flow02, const uint8_t* occ02, int frame, PcParams& P, hipStream_t s)
 {
     psfm_status rc;
-    if ((rc = pc_workspace(c, d.cap)) != PSFM_OK) return rc;
+    if ((rc = pc_workspace(c, d.cap, PC_KMAX)) != PSFM_OK) return rc;
     if ((rc = c->sol_stats.ensure(sizeof(psfm_solve_stats) * (size_t)(d.n_flows + 1))) != PSFM_OK) return rc;
     memset(&P, 0, sizeof(P));
     P.H = d.H; P.W = d.W; P.cw = d.cw; P.ch = d.ch;
@@ -791,8 +1122,8 @@ static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const fl
     P.p0 = lg + (int64_t)(frame - 1) * d.cap;
     P.x1a = lg + (int64_t)frame * d.cap;
     P.x2a = lg + (int64_t)(frame + 1) * d.cap;
-    P.x1b = c->sol_x.as<double2>();
-    P.x2b = P.x1b + d.cap;
+    P.xs = c->sol_x.as<double2>(); P.xs_stride = d.cap;
+    P.sel = &ctr->sel;
     P.ref1 = c->sol_state.as<double2>();
     P.ref2 = P.ref1 + d.cap;
     P.jscale = P.ref2 + d.cap;
@@ -829,7 +1160,70 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
     if (rc != PSFM_OK) return rc;
     PSFM_HIP(hipMemsetAsync(P.stall, 0, sizeof(int), s));
-    return pc_finish_sync(c, P, pc_blocks((int)d.cap), nullptr, st, s);
+    // from the top: the launch chain never writes buffer 0 (the log slabs) before its write-back; a fused solve that gave
+    // up left the values it started from in the iterate buffer PsfmCounters::sel names -- back into the log first
+    {
+        const int nb = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+        hipLaunchKernelGGL(psfm_pc_flush_kernel, dim3(nb), dim3(PC_BLOCK), 0, s, P);
+        hipLaunchKernelGGL(psfm_pc_clear_sel_kernel, dim3(1), dim3(1), 0, s, P.sel, (const int*)P.stall);
+    }
+    const int n_blocks = pc_blocks((int)d.cap);
+    hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    PSFM_HIP(hipGetLastError());
+    return pc_finish_sync(c, P, n_blocks, nullptr, st, s);
+}
+
+int psfm_solve_kmax(void) { return PC_KMAX; }
+
+// the chain steps of track_optimize capture the iterate-buffer pointer: allocate before the first one is enqueued
+psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d)
+{
+    psfm_status rc;
+    if ((rc = pc_workspace(c, d.cap, PC_KMAX)) != PSFM_OK) return rc;
+    return c->sol_stats.ensure(sizeof(psfm_solve_stats) * (size_t)(d.n_flows + 1));
+}
+
+// One frame's solve as ONE launch that speculates K Gauss-Newton iterations (psfm_pc_fused_kernel).  No host
+// synchronisation: a solve that does not go as speculated raises the stall flag like a launch chain that ran out of
+// iterations.  The accepted iterate stays in an iterate buffer; the next chain step (or psfm_solve_flush) moves it.
+psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                   const float* flow02, const uint8_t* occ02, int frame, int K, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+    const int n_groups = (n_blocks + PC_GROUP - 1) / PC_GROUP;
+    if ((rc = c->sol_partials.ensure(sizeof(double) * (size_t)n_blocks * PC_KMAX * PC_NSUM)) != PSFM_OK) return rc;
+    // tickets first (their place must not depend on the shape: they are zeroed once and every launch leaves them at zero)
+    const size_t tbytes = 4096 * sizeof(unsigned), gbytes = sizeof(double) * (size_t)n_groups * PC_KMAX * PC_NSUM;
+    if (n_groups + 1 > 4096) { psfm_set_error("psfm_track: lane table too large for the fused solve"); return PSFM_ERR_ARG; }
+    void* before = c->sol_fused.p;
+    if ((rc = c->sol_fused.ensure(tbytes + gbytes)) != PSFM_OK) return rc;
+    if (c->sol_fused.p != before) PSFM_HIP(hipMemsetAsync(c->sol_fused.p, 0, tbytes, s));
+    P.partials = c->sol_partials.as<double>();
+    P.gticket = c->sol_fused.as<unsigned>();
+    P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
+    P.K = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
+    static const int waves = getenv("PSFM_FUSED_WAVES") ? atoi(getenv("PSFM_FUSED_WAVES")) : 3;   // (measured: 11.0 vs 11.7 ms per 1080p sequence)
+    if (waves == 3) hipLaunchKernelGGL(psfm_pc_fused_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    else hipLaunchKernelGGL(psfm_pc_fused_kernel<4>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// Behind the last solve of a sequence: the accepted iterate into the log (no chain step follows to do it).
+psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, nullptr, nullptr, nullptr, nullptr, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+    hipLaunchKernelGGL(psfm_pc_flush_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    hipLaunchKernelGGL(psfm_pc_clear_sel_kernel, dim3(1), dim3(1), 0, s, P.sel, (const int*)P.stall);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
 }
 
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
@@ -839,7 +1233,7 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     if (n == 0) return PSFM_OK;
     if (n > 0x3fffffff) { psfm_set_error("psfm_optimize_location: n too large"); return PSFM_ERR_ARG; }
     psfm_status rc;
-    if ((rc = pc_workspace(c, n)) != PSFM_OK) return rc;
+    if ((rc = pc_workspace(c, n, 2)) != PSFM_OK) return rc;
     if ((rc = c->sol_misc.ensure(sizeof(double2) * n * 2)) != PSFM_OK) return rc;
     PcParams P;
     memset(&P, 0, sizeof(P));
@@ -848,8 +1242,7 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     P.n_rows = (int)n;
     P.x1a = c->sol_misc.as<double2>();
     P.x2a = P.x1a + n;
-    P.x1b = c->sol_x.as<double2>();
-    P.x2b = P.x1b + n;
+    P.xs = c->sol_x.as<double2>(); P.xs_stride = n;
     P.ref1 = c->sol_state.as<double2>();
     P.ref2 = P.ref1 + n;
     P.jscale = P.ref2 + n;

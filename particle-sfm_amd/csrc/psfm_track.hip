@@ -155,7 +155,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
                                                                      PsfmShard* __restrict__ shards)
 {
     const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
-    if (i == 0) { ctr->n_lanes = (int)G; ctr->overflow = 0; ctr->stall = 0; }
+    if (i == 0) { ctr->n_lanes = (int)G; ctr->overflow = 0; ctr->stall = 0; ctr->sel = 0; }
     if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; shards[i].points = (i == 0) ? (unsigned)G : 0u; }
     if (i >= cap) return;
     if (i < G) {
@@ -221,6 +221,10 @@ struct PsfmChainArgs {
     int cap, shard_cap, free_cap, frame, shift_b, shift_d;
     int nsh;                   // free-lane stacks in use: min(PSFM_NSHARD, blocks of the grid) -- a small grid must not probe stacks nobody fills
     PsfmFastDiv gwdiv, rdiv;   // division by GW (grid index -> row/col) and by the sample ratio
+    // track_optimize (OPT kernels): the fused solve of the previous frame leaves the accepted positions of its tracks
+    // (times frame-1, frame) in iterate buffer ctr->sel (0: already in the log); this launch moves them into the log
+    // slabs on its way and steps from them
+    double2* log_prev; const double2* xs; int64_t xs_stride;
 };
 
 #ifndef PSFM_CHAIN_BLOCK
@@ -260,7 +264,7 @@ extern "C" int psfm_debug_timeline(int frame, unsigned long long* out_host, int 
 #define PSFM_TL(k) do {} while (0)
 #endif
 
-template <int R>
+template <int R, bool OPT>
 __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_step_kernel(PsfmChainArgs a)
 {
     __shared__ int s_births[PSFM_CHAIN_NSEG], s_pend[PSFM_CHAIN_NSEG];
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
     }
 #endif
     if (a.ctr->stall) return;   // an earlier path-consistency solve is unfinished: this launch will be re-enqueued
+    const int sel = OPT ? a.ctr->sel : 0;   // (same cache line as `stall`)
     // tiles past both the lane high-water mark and the grid have nothing to do (lanes handed out during
     // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
     if (tile >= max(a.ctr->n_lanes, a.G)) return;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
 
     // ---- independent early loads: lane state, (speculative) tail position, respawn byte ----
     int bf[PSFM_LPT];
-    double2 p[PSFM_LPT];
+    double2 p[PSFM_LPT], sx1[PSFM_LPT], sx2[PSFM_LPT];
     bool birth[PSFM_LPT], live[PSFM_LPT], pend[PSFM_LPT];
     int pend_idx[PSFM_LPT];
     unsigned long long bm[PSFM_LPT], pm[PSFM_LPT];
@@ -302,6 +307,10 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
         bf[u] = -1;
         p[u] = make_double2(0.0, 0.0);
         if (i < a.cap) { bf[u] = psfm_ld(a.birth_frame, (unsigned)i * 4u); p[u] = psfm_ld(a.log_cur, (unsigned)i * 16u); }
+        if (OPT && sel != 0 && i < a.cap) {   // (speculative like the tail: whether this lane took part is known with bf)
+            sx1[u] = a.xs[(int64_t)(2 * sel - 2) * a.xs_stride + i];
+            sx2[u] = a.xs[(int64_t)(2 * sel - 1) * a.xs_stride + i];
+        }
         birth[u] = false;
         if (frame > 0 && i < a.G) {
             if (surv_prev == 0) {
@@ -320,6 +329,11 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
         // is a death recorded by the previous launch
         live[u] = (bf[u] >= 0) & ((bf[u] < frame) | (frame == 0));
         pend[u] = (bf[u] <= -2) & ((-2 - bf[u]) < frame);
+        if (OPT && sel != 0 && live[u] && bf[u] <= frame - 2) {   // took part in the solve of frame-1 (three buffered points)
+            p[u] = sx2[u];
+            psfm_st(a.log_cur, (unsigned)i * 16u, sx2[u]);
+            psfm_st(a.log_prev, (unsigned)i * 16u, sx1[u]);
+        }
         pend_idx[u] = 0;
         // ---- block-level counts; the births' grid indices and the just-died lanes are compacted through LDS ----
         bm[u] = __ballot(birth[u]);
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_clear_map_kernel(const PsfmCo
 }
 
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
-                                   int frame, hipStream_t s)
+                                   int frame, bool optimize, hipStream_t s)
 {
     PsfmChainArgs a;
     a.flow = (const float2*)flow; a.occ = occ;
@@ -579,14 +593,25 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
     a.cap = (int)d.cap; a.shard_cap = d.shard_cap; a.free_cap = d.free_cap; a.frame = frame; a.nsh = d.nsh;
     a.shift_b = d.shift_b; a.shift_d = d.shift_d;
     a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
+    a.log_prev = lg + (int64_t)(frame > 0 ? frame - 1 : 0) * d.cap;
+    a.xs = c->sol_x.as<double2>(); a.xs_stride = d.cap;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     c->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1);
     const dim3 grid((unsigned)((d.cap + PSFM_CHAIN_TILE - 1) / PSFM_CHAIN_TILE)), block(PSFM_CHAIN_BLOCK);
-    switch (d.ratio) {
-        case 1: hipExtLaunchKernelGGL(psfm_chain_step_kernel<1>, grid, block, 0, s, e0, e1, 0, a); break;
-        case 2: hipExtLaunchKernelGGL(psfm_chain_step_kernel<2>, grid, block, 0, s, e0, e1, 0, a); break;
-        case 4: hipExtLaunchKernelGGL(psfm_chain_step_kernel<4>, grid, block, 0, s, e0, e1, 0, a); break;
-        default: hipExtLaunchKernelGGL(psfm_chain_step_kernel<0>, grid, block, 0, s, e0, e1, 0, a); break;
+    if (optimize) {
+        switch (d.ratio) {
+            case 1: hipExtLaunchKernelGGL((psfm_chain_step_kernel<1, true>), grid, block, 0, s, e0, e1, 0, a); break;
+            case 2: hipExtLaunchKernelGGL((psfm_chain_step_kernel<2, true>), grid, block, 0, s, e0, e1, 0, a); break;
+            case 4: hipExtLaunchKernelGGL((psfm_chain_step_kernel<4, true>), grid, block, 0, s, e0, e1, 0, a); break;
+            default: hipExtLaunchKernelGGL((psfm_chain_step_kernel<0, true>), grid, block, 0, s, e0, e1, 0, a); break;
+        }
+    } else {
+        switch (d.ratio) {
+            case 1: hipExtLaunchKernelGGL((psfm_chain_step_kernel<1, false>), grid, block, 0, s, e0, e1, 0, a); break;
+            case 2: hipExtLaunchKernelGGL((psfm_chain_step_kernel<2, false>), grid, block, 0, s, e0, e1, 0, a); break;
+            case 4: hipExtLaunchKernelGGL((psfm_chain_step_kernel<4, false>), grid, block, 0, s, e0, e1, 0, a); break;
+            default: hipExtLaunchKernelGGL((psfm_chain_step_kernel<0, false>), grid, block, 0, s, e0, e1, 0, a); break;
+        }
     }
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;

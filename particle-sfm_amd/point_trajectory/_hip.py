@@ -18,6 +18,7 @@ EXPORTS = [
     "psfm_connect",
     "psfm_result_device", "psfm_result_copy", "psfm_result_solve_stats", "psfm_ctx_set_profiling",
     "psfm_profile_get", "psfm_ctx_set_chain_mode", "psfm_window_sample", "psfm_result_filter", "psfm_result_filtered_copy",
+    "psfm_ctx_set_solver", "psfm_solver_counters",
 ]
 
 
@@ -76,6 +77,8 @@ def lib():
     L.psfm_result_solve_stats.argtypes = [vp, ctypes.POINTER(SolveStats), i32, ctypes.POINTER(ctypes.c_int32)]
     L.psfm_ctx_set_profiling.argtypes = [vp, i32]
     L.psfm_ctx_set_chain_mode.argtypes = [vp, i32]
+    L.psfm_ctx_set_solver.argtypes = [vp, i32, i32]
+    L.psfm_solver_counters.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
     L.psfm_result_filter.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), vp]
     L.psfm_result_filtered_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.psfm_window_sample.argtypes = [vp, i32, i32, i32, i32, i64, ctypes.c_uint64, i32, i32, i32, i32, i64, vp, vp, vp, vp,
@@ -111,6 +114,16 @@ class Context:
     def set_chain_mode(self, mode):
         """0 auto (persistent frame loop when the grid fits the device), 1 per-frame launches, 2 persistent loop only."""
         check(lib().psfm_ctx_set_chain_mode(self._h, int(mode)))
+
+    def set_solver(self, mode, k=0):
+        """track_optimize: 0 adaptive (fused solve, launch chain for windows whose solves reject steps), 1 launch chain,
+        2 fused solve; k = trust-region iterations per fused launch (0: adaptive)."""
+        check(lib().psfm_ctx_set_solver(self._h, int(mode), int(k)))
+
+    def solver_counters(self):
+        a, b, c_, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+        check(lib().psfm_solver_counters(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c_), ctypes.byref(k)))
+        return {"fused": a.value, "fused_redone": b.value, "chain": c_.value, "k": k.value}
 
     def set_profiling(self, enable):
         check(lib().psfm_ctx_set_profiling(self._h, int(enable)))   # 0 off, 1 every launch, N>1 every N-th chain_step

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""track_optimize end to end (psfm_connect with the stride-2 stacks) under the solver modes of psfm_ctx_set_solver.
+
+    python scripts/probe_solver.py [H W T r] ; PSFM_FUSED_WAVES=3|4 selects the fused kernel's register target
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
+    sys.path.insert(0, p)
+import torch
+import psfm_synth
+from point_trajectory import _hip
+from point_trajectory.trajectory import run_connect
+
+H, W, T, r = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (1080, 1920, 101, 2)
+d = psfm_synth.synth_sequence_torch(T, H, W, seed=5, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
+ctx = _hip.context()
+out = {"shape": [H, W, T, r], "fused_waves": os.environ.get("PSFM_FUSED_WAVES", "4")}
+for name, mode, k in (("chain", 1, 0), ("fused", 2, 0), ("adaptive", 0, 0), ("fused_k4", 2, 4)):
+    ctx.set_solver(mode, k)
+    for _ in range(3):
+        info = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], 1.0, r, return_device=True)
+    n = 5
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        info = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], 1.0, r, return_device=True)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    ctx.set_profiling(1)
+    for _ in range(n):
+        info = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], 1.0, r, return_device=True)
+    torch.cuda.synchronize()
+    pr = ctx.profile()
+    ctx.set_profiling(0)
+    out[name] = {"ms_per_sequence": ms, "points": int(info.n_points), "iters": int(info.solver_iterations),
+                 "solves": int(info.n_solves), "counters": ctx.solver_counters(),
+                 "solver_ms_per_seq": pr["solver"]["total_ms"] / n, "chain_ms_per_seq": pr["chain_step"]["total_ms"] / n}
+ctx.set_solver(0, 0)
+print(json.dumps(out))

@@ -322,10 +322,11 @@ def test_connect_sequences_concurrently(pt, tmp_path):
     for a, b in zip(out_a, out_b):
         ta = np.load(a + "/track.npy", allow_pickle=True).item()
         tb = np.load(b + "/track.npy", allow_pickle=True).item()
-        assert ta.__getstate__().keys() == tb.__getstate__().keys()
-        sa, sb = ta.__getstate__(), tb.__getstate__()
-        for k in ("ids", "birth", "length", "off", "xy"):
-            assert np.array_equal(sa[k], sb[k]), k
+        # (the stage entry writes the reference's pickle state by default, the batch driver the CSR state: compare
+        # the trajectories, not the container)
+        ca, cb = ta._to_csr(), tb._to_csr()
+        for k, (xa, xb) in enumerate(zip(ca[:4], cb[:4])):
+            assert np.array_equal(xa, xb), ("ids", "off", "frames", "xy")[k]
 
 
 def test_chain_modes_report_what_ran(pt, chain_mode):

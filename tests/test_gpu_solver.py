@@ -28,6 +28,21 @@ def pt():
 _batch = solver_batch
 
 
+# How a frame's solve is run (psfm_ctx_set_solver): adaptive, the launch chain, the fused solve (one launch that
+# speculates k Gauss-Newton iterations), and the fused solve with k = 1 -- which no real solve fits, so every one of
+# them is redone by the chain from the untouched buffer.  The results must not depend on it.
+SOLVER_MODES = [(0, 0), (1, 0), (2, 0), (2, 1)]
+
+
+@pytest.fixture(params=SOLVER_MODES, ids=["adaptive", "launch-chain", "fused", "fused-k1-redone"])
+def solver_mode(request, pt):
+    from point_trajectory import _hip
+    ctx = _hip.context()
+    ctx.set_solver(*request.param)
+    yield request.param
+    ctx.set_solver(0, 0)
+
+
 @pytest.mark.parametrize("H,W,n,seed,sigma,kink", SOLVER_BATCHES)
 def test_optimize_location_vs_oracle(pt, H, W, n, seed, sigma, kink):
     from oracle import oracle as orc
@@ -56,7 +71,7 @@ def test_optimize_location_exercises_dogleg(pt):
 
 
 @pytest.mark.parametrize("name", ["opt_48x64_r2", "opt_45x70_r3"])
-def test_track_optimize_golden(pt, name):
+def test_track_optimize_golden(pt, solver_mode, name):
     g = golden(name)
     d = regen_inputs(g, stride2=True)
     _, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
@@ -72,7 +87,7 @@ def test_track_optimize_golden(pt, name):
     (436, 1024, 8, 2, 53, 0.05, 2),    # configs[2] shape (Sintel alley_1), fewer frames
     (64, 96, 20, 1, 54, 0.15, 1),
 ])
-def test_track_optimize_vs_oracle(pt, H, W, T, r, seed, sigma, nocc):
+def test_track_optimize_vs_oracle(pt, solver_mode, H, W, T, r, seed, sigma, nocc):
     from oracle import oracle as orc
     d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=True)
     _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
@@ -108,7 +123,7 @@ def test_failed_solve_leaves_parameters_untouched(pt):
     assert float(np.abs(out_g - out_o).max()) <= 1e-8
 
 
-def test_track_optimize_carries_on_after_failed_solves(pt):
+def test_track_optimize_carries_on_after_failed_solves(pt, solver_mode):
     """Non-finite flow components in all four stacks: the frames whose solve fails keep their chained positions, the
     sequence goes on -- ids, lengths, positions and per-solve terminations as in the CPU restatement."""
     from oracle import oracle as orc
@@ -127,11 +142,13 @@ def test_track_optimize_carries_on_after_failed_solves(pt):
 
 
 def test_track_optimize_stalled_solves_are_resumed(pt, monkeypatch):
-    """With ONE unrolled iteration per frame every solve runs out of launches: its write-back raises the device-side
-    stall flag (everything enqueued behind turns into no-ops), the next checkpoint resumes it with host polling and
-    re-enqueues the frames after it.  Same trajectories, same per-solve statistics."""
+    """With ONE unrolled iteration per frame every solve of the launch chain runs out of launches: its write-back raises
+    the device-side stall flag (everything enqueued behind turns into no-ops), the next checkpoint redoes it with host
+    polling and re-enqueues the frames after it.  Same trajectories, same per-solve statistics."""
     from oracle import oracle as orc
+    from point_trajectory import _hip
     monkeypatch.setenv("PSFM_SOLVE_UNROLL", "1")
+    _hip.context().set_solver(1, 0)
     for (H, W, T, r, seed, sigma) in [(90, 140, 8, 3, 52, 0.3), (64, 96, 21, 1, 54, 0.15)]:
         d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=2, stride2=True)
         _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
@@ -143,9 +160,49 @@ def test_track_optimize_stalled_solves_are_resumed(pt, monkeypatch):
         assert float(np.abs(R.xy - O.xy).max()) <= TOL
         assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
         assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
+    _hip.context().set_solver(0, 0)
 
 
-def test_track_optimize_two_flows_only(pt):
+def test_fused_solve_is_what_runs_on_clean_sequences(pt):
+    """Adaptive mode on a sequence whose solves converge without a rejection: (nearly) every solve is ONE fused launch,
+    k settles at accepted steps + 1; with k forced to 1 every solve is redone by the chain.  A noisy sequence (rejected
+    steps, dogleg interpolation) goes to the chain after its first window."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    ctx = _hip.context()
+    d = psfm_synth.synth_sequence(40, 72, 100, seed=91, sigma=0.03, n_occluders=1, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+    clean = [s["dogleg_nonGN"] == 0 and s["iterations"] == s["successful_steps"] + 1 for s in O.solves]
+    assert sum(clean) >= len(clean) - 2
+    ctx.set_solver(0, 0)
+    for _ in range(2):   # (the second run starts from the k the first one learnt)
+        R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+    cnt = ctx.solver_counters()
+    assert cnt["fused"] >= len(O.solves) - 4 and cnt["chain"] == 0, cnt
+    assert cnt["k"] == max(s["successful_steps"] for s in O.solves) + 1, cnt
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and float(np.abs(R.xy - O.xy).max()) <= TOL
+    assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+    ctx.set_solver(2, 1)
+    R1 = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+    cnt1 = ctx.solver_counters()
+    assert cnt1["fused"] == 0 and cnt1["fused_redone"] == len(O.solves), cnt1
+    assert np.array_equal(R1.xy, R.xy)
+    ctx.set_solver(0, 0)
+    dn = psfm_synth.synth_sequence(40, 72, 100, seed=92, sigma=0.5, n_occluders=2, stride2=True)
+    _, occ = orc.flow_check(dn["flows_f"], dn["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(dn["flows_f2"], dn["flows_b2"], 1.0)
+    On = orc.track_optimize(dn["flows_f"], dn["flows_f2"], occ, occ2, 2)
+    assert sum(s["iterations"] != s["successful_steps"] + 1 or s["dogleg_nonGN"] > 0 for s in On.solves) > len(On.solves) // 2
+    Rn = pt.track_optimize(dn["flows_f"], dn["flows_f2"], occ, occ2, 2)
+    cntn = ctx.solver_counters()
+    assert cntn["chain"] > cntn["fused"] + cntn["fused_redone"], cntn
+    assert np.array_equal(Rn.birth, On.birth) and np.array_equal(Rn.length, On.length) and float(np.abs(Rn.xy - On.xy).max()) <= TOL
+    assert [s["iterations"] for s in Rn.solve_stats] == [s["iterations"] for s in On.solves]
+
+
+def test_track_optimize_two_flows_only(pt, solver_mode):
     """n_flows = 2: exactly one solve; n_flows = 1: none (the stride-2 stack is empty)."""
     from oracle import oracle as orc
     d = psfm_synth.synth_sequence(3, 40, 60, seed=61, sigma=0.05, stride2=True)
