@@ -93,6 +93,56 @@ def concurrent_sequences(n_seq, n_frames, reps=4):
             "trajectory_points_per_s": sum(pts) * reps / dt}
 
 
+def solver_roofline(R, prof, cnt, h, w, n_flows):
+    """SURVEY 8(d) algorithmic bytes of the track_optimize kernels / their HIP-event launch time / 8 TB/s.
+    Per solve of frame f (N3 = tracks with three buffered points, k = trust-region iterations of that solve, P = H*W):
+      pc_prepare = 2 min(8P, 32 N3) + min(P, 4 N3) + 16 N3 + 40 N3        (refs + scale: flow01, flow02, occ02 at p0)
+      pc_solve   = k [ min(8P, 32 N3) + 72 N3 + 32 N3 ]                    (flow12 taps, state in, candidate out)
+    The fused solve (psfm_pc_fused_kernel) is ONE launch per solve doing both, so its bytes are their sum; the chain
+    step moves min(8P, 32A) + min(P, 4A) + 16A + 16A + A per frame (A = tracks alive at the step)."""
+    import numpy as np
+    P = float(h * w)
+    birth = R.birth.astype(np.int64)
+    last = birth + R.length - 1
+    out = {}
+    # N3 of the solve at loop index f (times f-1, f, f+1): born <= f-1, still there at f+1
+    tb = np.bincount(birth, minlength=n_flows + 3).cumsum()           # tracks born <= t
+    tl = np.bincount(last, minlength=n_flows + 3).cumsum()            # tracks whose last time <= t
+    its = [s["iterations"] for s in R.solve_stats]
+    frames = list(range(1, n_flows))
+    if len(its) == len(frames) and prof["solver"]["launches"] > 0:
+        tot = 0.0
+        for f, k in zip(frames, its):
+            n3 = float(tb[f - 1] - tl[f])          # born by f-1, last time >= f+1
+            prep = 2 * min(8 * P, 32 * n3) + min(P, 4 * n3) + 16 * n3 + 40 * n3
+            solve = k * (min(8 * P, 32 * n3) + 72 * n3 + 32 * n3)
+            tot += prep + solve
+        us = 1e3 * prof["solver"]["total_ms"] / prof["solver"]["launches"]
+        per_solve = tot / len(frames)
+        fused = cnt["fused"] + cnt["fused_redone"] > cnt["chain"]
+        out["solver"] = {"kernel": "psfm_pc_fused_kernel (one launch per solve)" if fused else "pc_init + pc_iter chain (one span per solve)",
+                         "bound": "hbm", "bytes_per_solve": per_solve, "avg_us_per_solve": us,
+                         "launches_timed": int(prof["solver"]["launches"]),
+                         "achieved": per_solve / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": per_solve / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "avg_iterations": float(np.mean(its)),
+                         "note": "f64 issue-bound, not bandwidth-bound: ~1e3 VALU instructions per track and iteration"}
+    alive_steps = float(R.n_points - int((last == n_flows).sum()))
+    A = alive_steps / n_flows
+    cb = min(8 * P, 32 * A) + min(P, 4 * A) + 16 * A + 16 * A + A
+    ch = prof["chain_step"]
+    if ch["launches"] > 0:
+        us = 1e3 * ch["total_ms"] / ch["launches"]
+        out["chain_step"] = {"kernel": "psfm_chain_step_kernel<R, OPT>", "bound": "hbm", "bytes_per_launch": cb, "avg_launch_us": us,
+                             "achieved": cb / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": cb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_alive_tracks": A}
+    fc = prof["flow_check"]
+    if fc["launches"] > 0:
+        out["flow_check_side_stream_ms"] = fc["total_ms"]
+    out["finalize_ms"] = prof["finalize"]["total_ms"]
+    return out
+
+
 def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="configs[2] shape"):
     """track_optimize (chaining + Ceres-compatible path-consistency solve) on a synthetic sequence -- by default a
     stand-in of configs[2] (Sintel alley_1 shape: 436x1024, 50 frames, sample_ratio 2): GPU time per sequence and the
@@ -120,6 +170,16 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
         info = step()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / n
+    # ---- per-kernel roofline of this path (HIP events on every launch, one more pass) ----
+    ctx.set_profiling(1)
+    info = step()
+    torch.cuda.synchronize()
+    pr = ctx.profile()
+    ctx.set_profiling(0)
+    cnt = ctx.solver_counters()
+    Rh = _result_to_host(ctx, info)
+    roof = solver_roofline(Rh, pr, cnt, h, w, t - 1)
+    del Rh
     _, occ = flow_check_device(d["flows_f"], d["flows_b"], THRES)
     _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], THRES)
     ff, f2 = list(d["flows_f"][:k].cpu().numpy()), list(d["flows_f2"][:k - 1].cpu().numpy())
@@ -132,6 +192,7 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check x2 + track_optimize" % (label, h, w, t, r),
             "ms_per_sequence": ms, "trajectory_points_per_s": info.n_points / (ms * 1e-3), "points": int(info.n_points),
             "solves": int(info.n_solves), "trust_region_iterations": int(info.solver_iterations),
+            "solver_counters": cnt, "roofline": roof,
             "cpu_port_points_per_s": Rc.n_points / cpu_s,
             "gpu_over_cpu_port": (info.n_points / (ms * 1e-3)) / (Rc.n_points / cpu_s), "cpu_port_sample": "first %d flows, 1 core, %.2f s" % (k, cpu_s),
             "parity_first_flows": {"ids_lengths_equal": same,

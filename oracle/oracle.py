@@ -75,8 +75,14 @@ def lib():
         L.orc_track.restype = ctypes.POINTER(_Result)
         L.orc_result_free.argtypes = [ctypes.POINTER(_Result)]
         L.orc_result_free.restype = None
+        L.orc_num_threads.restype = ctypes.c_int
         _lib = L
     return _lib
+
+
+def num_threads():
+    """Host threads the oracle's parallel loops use (OMP_NUM_THREADS; results do not depend on it)."""
+    return int(lib().orc_num_threads())
 
 
 def _f32(a):

@@ -6,9 +6,13 @@
  * library, and only as the checker / the timed CPU baseline.  The product path
  * (particle-sfm_amd/) never links, imports or falls back to it.
  *
- * Plain scalar C, one thread, written from the reference's semantics (SURVEY.md
- * Appendix A/B).  Every function cites the reference file:line it restates
- * (paths relative to the reference root).
+ * Plain scalar C written from the reference's semantics (SURVEY.md Appendix
+ * A/B).  Every function cites the reference file:line it restates (paths
+ * relative to the reference root).  OpenMP spreads loops over INDEPENDENT
+ * tracks / pixels / grid points over the host cores (OMP_NUM_THREADS; the
+ * reference itself runs Ceres with 8 threads, trajectory_optimize.cpp:79) --
+ * results do not depend on the thread count: sums over tracks are taken in
+ * fixed chunks (ORC_CHUNK), see orc_optimize_location.
  *
  * Pinning status:
  *   - sampler / flow_check / track / track_optimize orchestration: PINNED against
@@ -32,7 +36,21 @@
 #include <string.h>
 #include <float.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define ORC_API __attribute__((visibility("default")))
+
+/* host threads the parallel loops use (1 when built without OpenMP) */
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------- */
 /* A-1  bilinear sampler == point_trajectory/trajectory.py:25-37              */
@@ -126,6 +144,7 @@ ORC_API void orc_grid_sample(const float* map_hwc, int C, int H, int W,
 ORC_API void orc_flow_check(const float* F, const float* B, int H, int W, float thres,
                             uint8_t* occ, float* err)
 {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y) {
         for (int x = 0; x < W; ++x) {
             const int64_t p = (int64_t)y * W + x;
@@ -262,6 +281,8 @@ static inline void orc_build_js(const double* jac, double s, const double* S, or
     J->a[5][0] = jac[2] * S[0]; J->a[5][1] = jac[3] * S[1]; J->a[5][3] = 1.0 * S[3];
 }
 
+#define ORC_CHUNK 2048   /* tracks per summation chunk (see orc_optimize_location) */
+
 /* solver statistics (optional) */
 typedef struct {
     int32_t iterations;       /* trust-region iterations executed (excluding iteration 0) */
@@ -312,10 +333,19 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
     int n_invalid = 0;
 
     /* --- EvaluateGradientAndJacobian at iteration 0 (trust_region_minimizer.cc) --- */
+    /* Sums over all tracks are taken over chunks of ORC_CHUNK tracks, in track order inside a chunk, and the chunk sums
+     * are added in chunk order: the same bits whatever the number of threads, and exactly the plain sequential sum for
+     * n <= ORC_CHUNK (every committed golden vector).  OpenMP only spreads the chunks over the host cores -- the
+     * counterpart of the reference's solver_options.num_threads = 8 (trajectory_optimize.cpp:79). */
+    const int64_t n_chunks = (n + ORC_CHUNK - 1) / ORC_CHUNK;
+    double* part = (double*)malloc(sizeof(double) * 2 * (size_t)n_chunks);
 #define EVAL_AT_X(first)                                                              \
     do {                                                                              \
+        _Pragma("omp parallel for schedule(static)")                                  \
+        for (int64_t ch_ = 0; ch_ < n_chunks; ++ch_) {                                \
         double cs = 0.0, gm = 0.0;                                                    \
-        for (int64_t i = 0; i < n; ++i) {                                             \
+        const int64_t i1_ = (ch_ + 1) * ORC_CHUNK < n ? (ch_ + 1) * ORC_CHUNK : n;    \
+        for (int64_t i = ch_ * ORC_CHUNK; i < i1_; ++i) {                             \
             const double s_ = scale[i];                                               \
             double* r_ = res + 6 * i; double* j_ = jac + 4 * i;                       \
             orc_pc_eval(&grid, x + 4 * i, ref1 + 2 * i, ref2 + 2 * i, s_, r_, j_);    \
@@ -345,12 +375,28 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
                 if (d_ > gm) gm = d_;                                                 \
             }                                                                         \
         }                                                                             \
-        x_cost = cs; gmax = gm;                                                       \
+        part[2 * ch_] = cs; part[2 * ch_ + 1] = gm;                                   \
+        }                                                                             \
+        double cs_ = 0.0, gm_ = 0.0;                                                  \
+        for (int64_t ch_ = 0; ch_ < n_chunks; ++ch_) {                                \
+            cs_ += part[2 * ch_]; if (part[2 * ch_ + 1] > gm_) gm_ = part[2 * ch_ + 1]; \
+        }                                                                             \
+        x_cost = cs_; gmax = gm_;                                                     \
     } while (0)
 
 #define NORM_OF(v, outv)                                                              \
-    do { double a_ = 0.0; for (int64_t q = 0; q < P; ++q) a_ += (v)[q] * (v)[q];      \
-         (outv) = sqrt(a_); } while (0)
+    do {                                                                              \
+        _Pragma("omp parallel for schedule(static)")                                  \
+        for (int64_t ch_ = 0; ch_ < n_chunks; ++ch_) {                                \
+            double a_ = 0.0;                                                          \
+            const int64_t q1_ = 4 * ((ch_ + 1) * ORC_CHUNK < n ? (ch_ + 1) * ORC_CHUNK : n); \
+            for (int64_t q = 4 * ch_ * ORC_CHUNK; q < q1_; ++q) a_ += (v)[q] * (v)[q]; \
+            part[ch_] = a_;                                                           \
+        }                                                                             \
+        double t_ = 0.0;                                                              \
+        for (int64_t ch_ = 0; ch_ < n_chunks; ++ch_) t_ += part[ch_];                 \
+        (outv) = sqrt(t_);                                                            \
+    } while (0)
 
     NORM_OF(x, x_norm);            /* Init(): x_norm_ = x_.norm() */
     EVAL_AT_X(1);                  /* IterationZero() */
@@ -381,7 +427,11 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             reuse = 1;
             double g2 = 0.0, jg2 = 0.0;
             /* diagonal, gradient, Cauchy point (alpha) */
-            for (int64_t i = 0; i < n; ++i) {
+#pragma omp parallel for schedule(static)
+            for (int64_t ch = 0; ch < n_chunks; ++ch) {
+            double g2c = 0.0, jg2c = 0.0;
+            const int64_t i1 = (ch + 1) * ORC_CHUNK < n ? (ch + 1) * ORC_CHUNK : n;
+            for (int64_t i = ch * ORC_CHUNK; i < i1; ++i) {
                 orc_js_t J; orc_build_js(jac + 4 * i, scale[i], S + 4 * i, &J);
                 const double* r_ = res + 6 * i;
                 double d[4], gt[4], sg[4];
@@ -394,20 +444,26 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
                     sg[c] = gt[c] / d[c];
                     diag[4 * i + c] = d[c];
                     ghat[4 * i + c] = gt[c];
-                    g2 += gt[c] * gt[c];
+                    g2c += gt[c] * gt[c];
                 }
                 for (int q = 0; q < 6; ++q) {
                     double v = 0.0;
                     for (int c = 0; c < 4; ++c) v += J.a[q][c] * sg[c];
-                    jg2 += v * v;
+                    jg2c += v * v;
                 }
             }
+            part[2 * ch] = g2c; part[2 * ch + 1] = jg2c;
+            }
+            for (int64_t ch = 0; ch < n_chunks; ++ch) { g2 += part[2 * ch]; jg2 += part[2 * ch + 1]; }
             alpha = g2 / jg2;
             /* ComputeGaussNewtonStep: (Js^T Js + mu*diag^2) y = Js^T r, retry with mu*=10 */
             lin_fail = 1;
             while (mu < max_mu) {
                 int fail = 0;
-                for (int64_t i = 0; i < n && !fail; ++i) {
+#pragma omp parallel for schedule(static) reduction(|:fail)
+                for (int64_t ch = 0; ch < n_chunks; ++ch) {
+                const int64_t i1 = (ch + 1) * ORC_CHUNK < n ? (ch + 1) * ORC_CHUNK : n;
+                for (int64_t i = ch * ORC_CHUNK; i < i1 && !fail; ++i) {
                     orc_js_t J; orc_build_js(jac + 4 * i, scale[i], S + 4 * i, &J);
                     const double* r_ = res + 6 * i;
                     double A[4][4], b[4], y[4];
@@ -430,6 +486,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
                         gn[4 * i + c] = y[c] * (-diag[4 * i + c]); /* gauss_newton_step *= -diagonal */
                     }
                 }
+                }
                 if (fail) { mu *= mu_increase; continue; }
                 lin_fail = 0;
                 break;
@@ -442,6 +499,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             NORM_OF(ghat, gnorm);
             NORM_OF(gn, gnn);
             if (gnn <= radius) {
+#pragma omp parallel for schedule(static)
                 for (int64_t q = 0; q < P; ++q) step[q] = gn[q] / diag[q];
                 dogleg_step_norm = gnn;
             } else if (gnorm * alpha >= radius) {
@@ -468,15 +526,22 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             }
             /* model_cost_change = -(J*step)'(f + J*step/2)   (ComputeTrustRegionStep) */
             double mcc = 0.0;
-            for (int64_t i = 0; i < n; ++i) {
+#pragma omp parallel for schedule(static)
+            for (int64_t ch = 0; ch < n_chunks; ++ch) {
+            double mc = 0.0;
+            const int64_t i1 = (ch + 1) * ORC_CHUNK < n ? (ch + 1) * ORC_CHUNK : n;
+            for (int64_t i = ch * ORC_CHUNK; i < i1; ++i) {
                 orc_js_t J; orc_build_js(jac + 4 * i, scale[i], S + 4 * i, &J);
                 const double* r_ = res + 6 * i;
                 for (int q = 0; q < 6; ++q) {
                     double m = 0.0;
                     for (int c = 0; c < 4; ++c) m += J.a[q][c] * step[4 * i + c];
-                    mcc += m * (r_[q] + m / 2.0);
+                    mc += m * (r_[q] + m / 2.0);
                 }
             }
+            part[ch] = mc;
+            }
+            for (int64_t ch = 0; ch < n_chunks; ++ch) mcc += part[ch];
             model_cost_change = -mcc;
             step_valid = model_cost_change > 0.0;
         }
@@ -490,19 +555,26 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
         /* delta = step .* jacobian_scaling ; candidate = x + delta ; cost */
         {
             double cs = 0.0, sn2 = 0.0;
-            for (int64_t i = 0; i < n; ++i) {
+#pragma omp parallel for schedule(static)
+            for (int64_t ch = 0; ch < n_chunks; ++ch) {
+            double csc = 0.0, snc = 0.0;
+            const int64_t i1 = (ch + 1) * ORC_CHUNK < n ? (ch + 1) * ORC_CHUNK : n;
+            for (int64_t i = ch * ORC_CHUNK; i < i1; ++i) {
                 for (int c = 0; c < 4; ++c) {
                     const double delta = step[4 * i + c] * S[4 * i + c];
                     xc[4 * i + c] = x[4 * i + c] + delta;
                     const double dd = x[4 * i + c] - xc[4 * i + c];
-                    sn2 += dd * dd;
+                    snc += dd * dd;
                 }
                 double r_[6];
                 orc_pc_eval(&grid, xc + 4 * i, ref1 + 2 * i, ref2 + 2 * i, scale[i], r_, NULL);
                 double ss = 0.0;
                 for (int k = 0; k < 6; ++k) ss += r_[k] * r_[k];
-                cs += 0.5 * ss;
+                csc += 0.5 * ss;
             }
+            part[2 * ch] = csc; part[2 * ch + 1] = snc;
+            }
+            for (int64_t ch = 0; ch < n_chunks; ++ch) { cs += part[2 * ch]; sn2 += part[2 * ch + 1]; }
             cand_cost = cs;
             /* ParameterToleranceReached */
             const double step_norm = sqrt(sn2);
@@ -535,7 +607,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
      * Ceres restores the values it was called with; the reference ignores the failure (trajectory_optimize.cpp:81-82) */
     memcpy(out, st.termination == 5 ? uv12 : best, sizeof(double) * P);
     if (stats) *stats = st;
-    free(x); free(xc); free(res); free(jac); free(S); free(diag); free(ghat); free(gn); free(step); free(best);
+    free(x); free(xc); free(res); free(jac); free(S); free(diag); free(ghat); free(gn); free(step); free(best); free(part);
     return st.termination == 5 ? 1 : 0;
 #undef EVAL_AT_X
 #undef NORM_OF
@@ -620,6 +692,7 @@ ORC_API orc_result_t* orc_track(const float* const* flows, const uint8_t* const*
         const int64_t A = active.n;
         if (A > scratch_cap) { scratch_cap = A; nxt = (double*)realloc(nxt, sizeof(double) * 2 * A); flag = (uint8_t*)realloc(flag, A); }
         /* get_cur_pos + grid_sample(flow) + step_forward  (track.py:38-46, trajectory.py:45-62) */
+#pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < A; ++i) {
             const orc_traj_t* t = active.v[i];
             const double px = t->pts[2 * (t->len - 1)], py = t->pts[2 * (t->len - 1) + 1]; /* get_tail_location */
@@ -654,6 +727,7 @@ ORC_API orc_result_t* orc_track(const float* const* flows, const uint8_t* const*
          * == no occupied pixel with dx^2+dy^2 <= ratio^2 (SURVEY A-5).  With no occupied
          * pixel at all SciPy measures to a phantom feature at (y=-1,x=0): everything
          * but grid point (0,0) respawns. */
+#pragma omp parallel for schedule(static)
         for (int gy = 0; gy < GH; ++gy) {
             for (int gx = 0; gx < GW; ++gx) {
                 const int cx = gx * ratio, cy = gy * ratio;
@@ -685,10 +759,12 @@ ORC_API orc_result_t* orc_track(const float* const* flows, const uint8_t* const*
                 double* r2 = (double*)malloc(sizeof(double) * 2 * N);
                 double* sc = (double*)malloc(sizeof(double) * N);
                 double* o = (double*)malloc(sizeof(double) * 4 * N);
-                int64_t k = 0;
-                for (int64_t i = 0; i < active.n; ++i) {
-                    const orc_traj_t* t = active.v[i];
-                    if (t->len < buffer_size) continue;
+                /* row k of the batch = the k-th active track with a full buffer (trajectory.py:165-170) */
+                int64_t* row = (int64_t*)malloc(sizeof(int64_t) * (size_t)N);
+                { int64_t k = 0; for (int64_t i = 0; i < active.n; ++i) if (active.v[i]->len >= buffer_size) row[k++] = i; }
+#pragma omp parallel for schedule(static)
+                for (int64_t k = 0; k < N; ++k) {
+                    const orc_traj_t* t = active.v[row[k]];
                     const double* b0 = t->pts + 2 * (t->len - 3);
                     orc_taps_t tp;
                     orc_taps_f32((float)b0[0], (float)b0[1], H, W, &tp);
@@ -703,18 +779,16 @@ ORC_API orc_result_t* orc_track(const float* const* flows, const uint8_t* const*
                     r2[2 * k] = b0[0] + (double)f02[0]; r2[2 * k + 1] = b0[1] + (double)f02[1]; /* :183 */
                     sc[k] = (double)s;
                     uv12[4 * k] = b0[2]; uv12[4 * k + 1] = b0[3]; uv12[4 * k + 2] = b0[4]; uv12[4 * k + 3] = b0[5];
-                    k++;
                 }
                 orc_optimize_location(uv12, r1, r2, sc, flows[f], N, W, H, o, &R->solves[R->n_solves]);
                 R->n_solves++;
-                k = 0;
-                for (int64_t i = 0; i < active.n; ++i) {                    /* :190-194 set_buffer_xy(1|2) */
-                    orc_traj_t* t = active.v[i];
-                    if (t->len < buffer_size) continue;
+#pragma omp parallel for schedule(static)
+                for (int64_t k = 0; k < N; ++k) {                           /* :190-194 set_buffer_xy(1|2) */
+                    orc_traj_t* t = active.v[row[k]];
                     double* b0 = t->pts + 2 * (t->len - 3);
                     b0[2] = o[4 * k]; b0[3] = o[4 * k + 1]; b0[4] = o[4 * k + 2]; b0[5] = o[4 * k + 3];
-                    k++;
                 }
+                free(row);
                 free(uv12); free(r1); free(r2); free(sc); free(o);
             }
         }

@@ -450,16 +450,17 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         const bool fused_now = c->solver_mode == 2 || (c->solver_mode == 0 && c->solve_mode == 0);
         if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
             if (pipe && (st = pipe->need(f - 1, true, s)) != PSFM_OK) return st;
-            c->prof.begin(PSFM_PROF_SOLVER, s);
-            if (fused_now)
+            if (fused_now) {   // (timed inside: kernel begin / end events)
                 st = psfm_solve_frame_fused(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
                                             flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
                                             c->solver_K > 0 ? c->solver_K : c->solve_K, s);
-            else
+            } else {
+                c->prof.begin(PSFM_PROF_SOLVER, s);
                 st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
                                               flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
                                               unroll_fixed > 0 ? unroll_fixed : c->solve_unroll, s);
-            c->prof.end(s);
+                c->prof.end(s);
+            }
             if (st != PSFM_OK) return st;
         }
         const bool checkpoint = optimize && f >= 1 && ((f % PSFM_CHECK) == PSFM_CHECK - 1 || f == n_flows - 1);

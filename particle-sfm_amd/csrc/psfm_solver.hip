@@ -28,6 +28,7 @@
 // given lane assignment).
 #include <string.h>
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 
 #include "psfm_device.h"
 #include "psfm_internal.h"
@@ -1207,8 +1208,10 @@ psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const fl
     P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
     P.K = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
     static const int waves = getenv("PSFM_FUSED_WAVES") ? atoi(getenv("PSFM_FUSED_WAVES")) : 3;   // (measured: 11.0 vs 11.7 ms per 1080p sequence)
-    if (waves == 3) hipLaunchKernelGGL(psfm_pc_fused_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    else hipLaunchKernelGGL(psfm_pc_fused_kernel<4>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    c->prof.kernel_span(PSFM_PROF_SOLVER, &e0, &e1, true);   // (profiling on: exact begin / end of every fused launch)
+    if (waves == 3) hipExtLaunchKernelGGL(psfm_pc_fused_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, e0, e1, 0, P);
+    else hipExtLaunchKernelGGL(psfm_pc_fused_kernel<4>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, e0, e1, 0, P);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }

@@ -9,3 +9,4 @@ for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: whole BASELINE.json sequences against the one-core CPU oracle (minutes)")

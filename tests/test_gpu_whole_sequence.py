@@ -1,0 +1,82 @@
+"""Whole-sequence parity of the path-consistency path (flow_check x2 + track_optimize + id order) at BASELINE.json's
+full sizes, against the CPU oracle on the same tensors:
+
+    configs[2] shape   436 x 1024 x   50 frames, sample_ratio 2            (Sintel alley_1 stand-in)
+    configs[3] shape  1080 x 1920 x  401 frames, sample_ratio 2            (the 8-GPU config, here on ONE GPU)
+    configs[4] shape   480 x  640 x 1000 frames, sample_ratio 1, thres 3.0 (ScanNet stand-in, dense grid)
+
+Bar (north_star): ids / lengths bit-exact, |dxy| <= 1e-4 px on every point, and -- stronger -- every solve ends after the
+same number of trust-region iterations with the same termination as the oracle's Ceres-compatible loop.  The flows are
+synthesised on the device (seeded), the occlusion maps come from the device (spot-checked against the oracle's here,
+bit-exactly pinned in test_gpu_parity.py); the oracle walks the whole sequence on one host core (~2e6 points/s), which
+is what makes these the slow tests of the suite.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import psfm_synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+TOL = 1e-4
+
+CASES = [
+    pytest.param(436, 1024, 50, 2, 1.0, 3, id="configs2-436x1024x50-r2"),
+    pytest.param(1080, 1920, 401, 2, 1.0, 1, id="configs3-1080x1920x401-r2"),
+    pytest.param(480, 640, 1000, 1, 3.0, 4, id="configs4-480x640x1000-r1-thres3"),
+]
+
+
+def _host_bytes_needed(H, W, T, r):
+    G = ((H + r - 1) // r) * ((W + r - 1) // r)
+    return 2 * T * H * W * 8 + 2 * T * H * W + 5 * 16 * G * T       # two flow stacks, two mask stacks, points (oracle + copies)
+
+
+@pytest.mark.parametrize("H,W,T,r,thres,seed", CASES)
+def test_whole_sequence_track_optimize_vs_oracle(H, W, T, r, thres, seed):
+    import psutil
+    import torch
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    from point_trajectory.trajectory import run_connect
+    from point_trajectory.utils import flow_check_device
+    need = _host_bytes_needed(H, W, T, r)
+    if psutil.virtual_memory().available < 1.3 * need:
+        pytest.skip("host memory: %.1f GB needed for the oracle's copy of the sequence" % (need / 1e9))
+    ctx = _hip.context()
+    ctx.set_solver(0, 0)
+    d = psfm_synth.synth_sequence_torch(T, H, W, seed=seed, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
+    R = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], thres, r)
+    cnt = ctx.solver_counters()
+    _, occ = flow_check_device(d["flows_f"], d["flows_b"], thres)
+    _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], thres)
+    # the device's maps against the oracle's on a few pairs (first, middle, last of both strides)
+    for stack_f, stack_b, maps in ((d["flows_f"], d["flows_b"], occ), (d["flows_f2"], d["flows_b2"], occ2)):
+        for k in (0, len(maps) // 2, len(maps) - 1):
+            _, o = orc.flow_check([stack_f[k].cpu().numpy()], [stack_b[k].cpu().numpy()], thres)
+            assert np.array_equal(o[0], maps[k].cpu().numpy().astype(bool))
+    ff, f2 = d["flows_f"].cpu().numpy(), d["flows_f2"].cpu().numpy()
+    oo, o2 = occ.cpu().numpy(), occ2.cpu().numpy()
+    del d, occ, occ2
+    torch.cuda.empty_cache()
+    O = orc.track_optimize(list(ff), list(f2), list(oo), list(o2), r)
+    del ff, f2, oo, o2
+    assert len(R) == O.n_traj and R.n_points == O.n_points
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+    err = float(np.abs(R.xy - O.xy).max())
+    assert err <= TOL, err
+    assert len(R.solve_stats) == len(O.solves) == T - 2
+    assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+    assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
+    assert [s["successful_steps"] for s in R.solve_stats] == [s["successful_steps"] for s in O.solves]
+    # what ran: the fused solve on (nearly) every frame of these well-behaved sequences
+    assert cnt["fused"] + cnt["fused_redone"] + cnt["chain"] == T - 2
+    out = os.environ.get("PSFM_WHOLE_SEQ_REPORT")
+    if out:
+        import json
+        with open(out, "a") as fh:
+            fh.write(json.dumps({"shape": [H, W, T, r], "thres": thres, "trajectories": int(O.n_traj), "points": int(O.n_points),
+                                 "ids_lengths_equal": True, "max_abs_dxy_px": err, "solves": T - 2,
+                                 "trust_region_iterations": int(sum(s["iterations"] for s in O.solves)),
+                                 "iterations_and_terminations_equal": True, "solver_counters": cnt}) + "\n")
