@@ -199,6 +199,24 @@ psfm_status psfm_window_sample(psfm_ctx* ctx, int frame0, int n_frames, int traj
                                int64_t capacity, int32_t* ids_out, double* xy_raw, double* xy_norm, double* mask_absent,
                                int64_t* k_host, void* stream);
 
+/* sfm/matches_from_flow.py:51-118 (traj_to_matches) from the saved set that psfm_result_filter left in HBM -- the
+ * reference's per-trajectory Python loops as index arithmetic on the device (no track.npy round trip):
+ *   keypoints  image i lists the kept points observed in frame i in trajectory (id) order (:67-81); labels_dev: optional
+ *              (n_points of the saved set) u8 DEVICE array, 1 = dynamic point, dropped (remove_dynamic, :71-74), NULL = keep all
+ *   matches    point j of a trajectory with n kept points pairs with every other point when n <= sample_k (20 in the
+ *              reference, :52), else with the points at k * (n / sample_k), itself skipped (:83-101); a match is the row
+ *              [keypoint index of j, keypoint index of the target] under the image pair (frame of j, frame of the target)
+ * n_img = number of images (every frame index must be < n_img).  Returns the table sizes; synchronises `stream`.
+ * psfm_matches_copy copies the tables to HOST buffers (any may be NULL):
+ *   kp_off (n_img+1) i64, kp_xy (n_kp,2) f64 -- keypoints of image i = kp_xy[kp_off[i] .. kp_off[i+1])
+ *   pair_key (n_pairs) i64 = src_image * n_img + tgt_image, ascending;  pair_off (n_pairs+1) i64 into rows;
+ *   pair_first (n_pairs) i64 = position of the pair's first match in the reference's loop order (its dict order);
+ *   rows (n_matches,2) i32, inside a pair in the reference's loop order. */
+psfm_status psfm_traj_to_matches(psfm_ctx* ctx, int n_img, int sample_k, const uint8_t* labels_dev, int64_t* n_kp_host,
+                                 int64_t* n_matches_host, int64_t* n_pairs_host, void* stream);
+psfm_status psfm_matches_copy(psfm_ctx* ctx, int64_t* kp_off_host, double* kp_xy_host, int64_t* pair_key_host,
+                              int64_t* pair_off_host, int64_t* pair_first_host, int32_t* rows_host, void* stream);
+
 /* Per-kernel device time of the last psfm_track / psfm_flow_check when profiling is enabled with
  * psfm_ctx_set_profiling(ctx, 1): HIP events recorded on the launch stream around every launch of
  * the named kernel family (enable = N > 1: only every N-th per-frame chain_step launch is timed, which keeps the

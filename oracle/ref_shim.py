@@ -87,6 +87,35 @@ class TrajectorySet:
     def as_dict(self):
         return {k: v.as_dict() for k, v in sorted(self.trajs.items())}
 
+    # ---- what motion_seg/load_cut_seq.py:46-79 calls; restated from trajectory_base.cpp:115-185 (the C++ cannot be
+    # built here).  std::map iteration = ascending keys; std::random_shuffle is not restated: fixtures stay below the cap.
+    def build_invert_indexes(self):
+        self.invert_maps = {}
+        for traj_id in sorted(self.trajs):
+            t = self.trajs[traj_id]
+            for index, frame_id in enumerate(t.times):
+                self.invert_maps.setdefault(int(frame_id), {})[traj_id] = index
+
+    def sample_inside_window(self, frame_ids, min_length=3, max_num_tracks=100000):
+        if not getattr(self, "invert_maps", None):
+            raise RuntimeError("Error! The inverted index maps have not been built!")
+        counter = {}
+        for frame_id in frame_ids:
+            for traj_id in sorted(self.invert_maps.get(int(frame_id), {})):
+                counter[traj_id] = counter.get(traj_id, 0) + 1
+        traj_ids = [i for i in sorted(counter) if counter[i] >= min_length]
+        if len(traj_ids) > max_num_tracks:
+            raise NotImplementedError("std::random_shuffle (unseeded) is not restated")
+        K, L = len(traj_ids), len(frame_ids)
+        X, Y, M = np.zeros((K, L)), np.zeros((K, L)), np.zeros((K, L), np.int32)
+        for i, traj_id in enumerate(traj_ids):
+            for j, frame_id in enumerate(frame_ids):
+                fm = self.invert_maps.get(int(frame_id))
+                if fm is not None and traj_id in fm:
+                    xy = (self.trajs[traj_id].xys + self.trajs[traj_id].buffer_xys)[fm[traj_id]]
+                    X[i, j], Y[i, j], M[i, j] = xy[0], xy[1], 1
+        return {"locations": (X, Y), "masks": M, "traj_ids": traj_ids}
+
 
 def _optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num, width, height):
     from . import oracle  # noqa: PLC0415
@@ -162,6 +191,39 @@ def load(particlesfm_module=None, optimize_location=None):
     )
     _loaded[key] = ns
     return ns
+
+
+def load_consumers():
+    """The reference's consumers of track.npy, imported UNMODIFIED: sfm/matches_from_flow.py (traj_to_matches) and
+    motion_seg/load_cut_seq.py (+ core/dataset/data_utils.py resize / normalise).  cv2 and cvbase are absent: cv2 gets a
+    stub whose image functions return blank arrays of the right shape (the image / depth tensors are not what the
+    fixtures pin), cvbase a stub module."""
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    cv2 = sys.modules.get("cv2") or types.ModuleType("cv2")
+    cv2.COLOR_BGR2RGB = 4
+    cv2.imread = lambda name, flag=1: np.zeros((48, 64, 3), np.uint8) if flag != -1 else np.zeros((48, 64), np.float64)
+    cv2.cvtColor = lambda img, code: img
+    cv2.resize = lambda img, wh: np.zeros((wh[1], wh[0]) + tuple(img.shape[2:]), img.dtype)
+    sys.modules["cv2"] = cv2
+    for name in ("cvbase", "cvbase.optflow", "cvbase.optflow.visualize"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["cvbase.optflow.visualize"].flow2rgb = None
+    import importlib.util
+
+    def _load(alias, path, extra_path=None):
+        if extra_path and extra_path not in sys.path:
+            sys.path.append(extra_path)
+        spec = importlib.util.spec_from_file_location(alias, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    mff = _load("psfm_reference_matches_from_flow", os.path.join(REFERENCE_ROOT, "sfm", "matches_from_flow.py"))
+    mff.tqdm = lambda it, *a, **k: it
+    lcs = _load("psfm_reference_load_cut_seq", os.path.join(REFERENCE_ROOT, "motion_seg", "load_cut_seq.py"),
+                os.path.join(REFERENCE_ROOT, "motion_seg"))
+    return types.SimpleNamespace(traj_to_matches=mff.traj_to_matches, load_cut_seq=lcs.load_cut_seq, cv2=cv2)
 
 
 def trajs_to_csr(trajs):

@@ -136,6 +136,10 @@ struct psfm_ctx {
     PsfmBuf win_ws;                      // psfm_window_sample / psfm_result_filter workspace
     PsfmBuf flt_ids, flt_birth, flt_len, flt_off, flt_xy;   // psfm_result_filter: the saved set (length >= traj_min_len), CSR
     int64_t flt_n_traj = 0, flt_n_points = 0;
+    // psfm_traj_to_matches (psfm_matches.hip): keypoint / match tables of the saved set
+    PsfmBuf mt_kp_off, mt_q, mt_pts, mt_kp_ind, mt_kp_xy, mt_moff, mt_keys, mt_rows, mt_gid, mt_pairs;
+    int64_t mt_n_kp = 0, mt_n_m = 0, mt_n_pairs = 0;
+    int mt_n_img = 0;
     hipStream_t side_stream = nullptr;   // flow_check of psfm_connect runs here, ahead of the frame loop
     std::vector<psfm_solve_stats> solve_stats;
     PsfmProfiler prof;

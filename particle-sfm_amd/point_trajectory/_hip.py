@@ -18,7 +18,7 @@ EXPORTS = [
     "psfm_connect",
     "psfm_result_device", "psfm_result_copy", "psfm_result_solve_stats", "psfm_ctx_set_profiling",
     "psfm_profile_get", "psfm_ctx_set_chain_mode", "psfm_window_sample", "psfm_result_filter", "psfm_result_filtered_copy",
-    "psfm_ctx_set_solver", "psfm_solver_counters",
+    "psfm_ctx_set_solver", "psfm_solver_counters", "psfm_traj_to_matches", "psfm_matches_copy",
 ]
 
 
@@ -83,6 +83,8 @@ def lib():
     L.psfm_result_filtered_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.psfm_window_sample.argtypes = [vp, i32, i32, i32, i32, i64, ctypes.c_uint64, i32, i32, i32, i32, i64, vp, vp, vp, vp,
                                      ctypes.POINTER(i64), vp]
+    L.psfm_traj_to_matches.argtypes = [vp, i32, i32, vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64), vp]
+    L.psfm_matches_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.psfm_profile_get.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(i64)]
     for name in EXPORTS:
         if name != "psfm_last_error":

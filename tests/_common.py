@@ -24,6 +24,7 @@ def input_hash(d):
 def regen_inputs(g, stride2):
     """Re-synthesise a fixture's inputs from its seed and check they are the bytes it was made from."""
     d = psfm_synth.synth_sequence(int(g["T"]), int(g["H"]), int(g["W"]), seed=int(g["seed"]),
+                                  amp=float(g["amp"]) if "amp" in g else 3.0,
                                   sigma=float(g["sigma"]) if "sigma" in g else 0.05,
                                   n_occluders=int(g["n_occluders"]) if "n_occluders" in g else 0,
                                   stride2=stride2)
