@@ -198,3 +198,74 @@ def track(flows, occ_maps, sample_ratio):
 def track_optimize(flows, flows_f2, occ_maps, occ_maps_s2, sample_ratio):
     """track_optimize.py:24-53"""
     return _run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio)
+
+
+class ShardEngine:
+    """One process's share of a track-sharded run (orc_shard_* in psfm_oracle.c): the engine that tests hand to
+    psfm_dist.connect_sharded in place of the HIP engine -- same interface, the reference's semantics on the host."""
+
+    device = "cpu"
+
+    def __init__(self):
+        self._s = None
+        L = lib()
+        c_p, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        self._REDUCE = ctypes.CFUNCTYPE(None, ctypes.POINTER(ctypes.c_double), i32, ctypes.POINTER(i32), c_p)
+        L.orc_shard_begin.argtypes = [i32, i32, i32, i32, i64, i64, i32]
+        L.orc_shard_begin.restype = c_p
+        L.orc_shard_step.argtypes = [c_p, i32, c_p, c_p, c_p, ctypes.POINTER(i64)]
+        L.orc_shard_step.restype = None
+        L.orc_shard_set_blocked.argtypes = [c_p, c_p, i64]
+        L.orc_shard_set_blocked.restype = None
+        L.orc_shard_solve.argtypes = [c_p, i32, c_p, c_p, c_p, c_p, self._REDUCE, c_p]
+        L.orc_shard_solve.restype = None
+        L.orc_shard_finish.argtypes = [c_p]
+        L.orc_shard_finish.restype = ctypes.POINTER(_Result)
+
+    def begin(self, n_flows, H, W, ratio, g0, g1, optimize):
+        import torch
+        self.G = ((W + ratio - 1) // ratio) * ((H + ratio - 1) // ratio)
+        self._s = lib().orc_shard_begin(int(n_flows), int(H), int(W), int(ratio), int(g0), int(g1), 1 if optimize else 0)
+        self._x = torch.zeros(self.G + 1, dtype=torch.uint8)       # marks of this process + "a track survived" byte
+        self._optimize = bool(optimize)
+
+    def step(self, t, flow, occ):
+        """births of frame t on the own band + chain step; returns the exchange tensor (uint8, G marks + 1 survivor byte)"""
+        f = _f32(flow.numpy() if hasattr(flow, "numpy") else flow)
+        o = np.ascontiguousarray(occ.numpy() if hasattr(occ, "numpy") else occ, dtype=np.uint8)
+        n_alive = ctypes.c_int64(0)
+        buf = self._x.numpy()
+        lib().orc_shard_step(self._s, int(t), _ptr(f), _ptr(o), _ptr(buf), ctypes.byref(n_alive))
+        buf[self.G] = 1 if n_alive.value > 0 else 0
+        return self._x
+
+    def after_exchange(self, t, x):
+        buf = np.ascontiguousarray(x.numpy())
+        lib().orc_shard_set_blocked(self._s, _ptr(buf), int(buf[self.G]))
+
+    def solve(self, t, flow_prev, flow_cur, flow2_prev, occ2_prev, reduce):
+        import torch
+        arrs = [_f32(a.numpy() if hasattr(a, "numpy") else a) for a in (flow_prev, flow_cur, flow2_prev)]
+        o2 = np.ascontiguousarray(occ2_prev.numpy() if hasattr(occ2_prev, "numpy") else occ2_prev, dtype=np.uint8)
+
+        def cb(vals, n, is_max, user):
+            v = torch.from_numpy(np.ctypeslib.as_array(vals, (n,)))       # a view: reduce() works in place
+            reduce(v, [bool(is_max[i]) for i in range(n)])
+
+        fn = self._REDUCE(cb)
+        lib().orc_shard_solve(self._s, int(t), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(o2), fn, None)
+
+    def finish(self):
+        r = lib().orc_shard_finish(self._s)
+        self._s = None
+        try:
+            c = r.contents
+            nt, npnt = c.n_traj, c.n_points
+            birth = np.ctypeslib.as_array(c.birth, (max(nt, 1),))[:nt].copy()
+            length = np.ctypeslib.as_array(c.len, (max(nt, 1),))[:nt].copy()
+            off = np.ctypeslib.as_array(c.off, (nt + 1,)).copy()
+            xy = np.ctypeslib.as_array(c.xy, (max(npnt, 1) * 2,))[:npnt * 2].copy().reshape(-1, 2)
+            solves = [c.solves[i].as_dict() for i in range(c.n_solves)] if self._optimize else []
+        finally:
+            lib().orc_result_free(r)
+        return birth, length, off, xy, solves

@@ -283,6 +283,17 @@ static inline void orc_build_js(const double* jac, double s, const double* S, or
 
 #define ORC_CHUNK 2048   /* tracks per summation chunk (see orc_optimize_location) */
 
+/* Track-sharded runs (tests of psfm_dist.connect_sharded: the tracks of ONE sequence split over several processes):
+ * every scalar that Ceres forms over ALL residual blocks / parameters -- costs, norms, the model decrease, the
+ * linear-solver failure flag -- passes through this hook right after the local loop: vals[0..n) hold this process's
+ * part on entry and the value over all processes on return (is_max[i]: combine by max instead of sum).  NULL = the
+ * single-process run. */
+typedef void (*orc_reduce_fn)(double* vals, int n, const int* is_max, void* user);
+static __thread orc_reduce_fn orc_reduce_hook = NULL;
+static __thread void* orc_reduce_user = NULL;
+#define ORC_REDUCE1(v) do { if (orc_reduce_hook) { double rv_[1] = {(v)}; const int rm_[1] = {0}; orc_reduce_hook(rv_, 1, rm_, orc_reduce_user); (v) = rv_[0]; } } while (0)
+#define ORC_REDUCE2(a, b, amax, bmax) do { if (orc_reduce_hook) { double rv_[2] = {(a), (b)}; const int rm_[2] = {(amax), (bmax)}; orc_reduce_hook(rv_, 2, rm_, orc_reduce_user); (a) = rv_[0]; (b) = rv_[1]; } } while (0)
+
 /* solver statistics (optional) */
 typedef struct {
     int32_t iterations;       /* trust-region iterations executed (excluding iteration 0) */
@@ -302,7 +313,8 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
                                   double* out, orc_solve_stats_t* stats)
 {
     orc_solve_stats_t st; memset(&st, 0, sizeof(st));
-    if (n <= 0) { if (stats) *stats = st; return 0; }
+    if (n <= 0 && !orc_reduce_hook) { if (stats) *stats = st; return 0; }   /* (sharded: a process without tracks still takes part) */
+    if (n < 0) n = 0;
     const orc_grid_t grid = { flow12, h, w };
     const int64_t P = 4 * n;
 
@@ -338,7 +350,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
      * n <= ORC_CHUNK (every committed golden vector).  OpenMP only spreads the chunks over the host cores -- the
      * counterpart of the reference's solver_options.num_threads = 8 (trajectory_optimize.cpp:79). */
     const int64_t n_chunks = (n + ORC_CHUNK - 1) / ORC_CHUNK;
-    double* part = (double*)malloc(sizeof(double) * 2 * (size_t)n_chunks);
+    double* part = (double*)malloc(sizeof(double) * 2 * (size_t)(n_chunks > 0 ? n_chunks : 1));
 #define EVAL_AT_X(first)                                                              \
     do {                                                                              \
         _Pragma("omp parallel for schedule(static)")                                  \
@@ -381,6 +393,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
         for (int64_t ch_ = 0; ch_ < n_chunks; ++ch_) {                                \
             cs_ += part[2 * ch_]; if (part[2 * ch_ + 1] > gm_) gm_ = part[2 * ch_ + 1]; \
         }                                                                             \
+        ORC_REDUCE2(cs_, gm_, 0, 1);                                                  \
         x_cost = cs_; gmax = gm_;                                                     \
     } while (0)
 
@@ -395,6 +408,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
         }                                                                             \
         double t_ = 0.0;                                                              \
         for (int64_t ch_ = 0; ch_ < n_chunks; ++ch_) t_ += part[ch_];                 \
+        ORC_REDUCE1(t_);                                                              \
         (outv) = sqrt(t_);                                                            \
     } while (0)
 
@@ -455,6 +469,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             part[2 * ch] = g2c; part[2 * ch + 1] = jg2c;
             }
             for (int64_t ch = 0; ch < n_chunks; ++ch) { g2 += part[2 * ch]; jg2 += part[2 * ch + 1]; }
+            ORC_REDUCE2(g2, jg2, 0, 0);
             alpha = g2 / jg2;
             /* ComputeGaussNewtonStep: (Js^T Js + mu*diag^2) y = Js^T r, retry with mu*=10 */
             lin_fail = 1;
@@ -487,6 +502,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
                     }
                 }
                 }
+                { double ff = (double)fail; if (orc_reduce_hook) { const int m_[1] = {1}; orc_reduce_hook(&ff, 1, m_, orc_reduce_user); } fail = ff != 0.0; }
                 if (fail) { mu *= mu_increase; continue; }
                 lin_fail = 0;
                 break;
@@ -509,6 +525,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             } else {
                 double dot = 0.0;
                 for (int64_t q = 0; q < P; ++q) dot += ghat[q] * gn[q];
+                ORC_REDUCE1(dot);
                 const double b_dot_a = -alpha * dot;
                 const double a2 = pow(alpha * gnorm, 2.0);
                 const double bma2 = a2 - 2 * b_dot_a + pow(gnn, 2);
@@ -521,6 +538,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
                     sn += v * v;
                     step[q] = v / diag[q];
                 }
+                ORC_REDUCE1(sn);
                 dogleg_step_norm = sqrt(sn);
                 st.dogleg_nonGN++;
             }
@@ -542,6 +560,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             part[ch] = mc;
             }
             for (int64_t ch = 0; ch < n_chunks; ++ch) mcc += part[ch];
+            ORC_REDUCE1(mcc);
             model_cost_change = -mcc;
             step_valid = model_cost_change > 0.0;
         }
@@ -575,6 +594,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             part[2 * ch] = csc; part[2 * ch + 1] = snc;
             }
             for (int64_t ch = 0; ch < n_chunks; ++ch) { cs += part[2 * ch]; sn2 += part[2 * ch + 1]; }
+            ORC_REDUCE2(cs, sn2, 0, 0);
             cand_cost = cs;
             /* ParameterToleranceReached */
             const double step_norm = sqrt(sn2);
@@ -812,5 +832,177 @@ ORC_API orc_result_t* orc_track(const float* const* flows, const uint8_t* const*
         free(t->pts); free(t);
     }
     free(active.v); free(next_active.v); free(full.v); free(cand); free(occupied); free(nxt); free(flag);
+    return R;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Track-sharded stepping API (tests of psfm_dist.connect_sharded).           */
+/* The tracks of ONE sequence are split over processes by the row band of the */
+/* grid point they were born on; a process keeps the reference's active list  */
+/* for ITS tracks and performs, frame by frame, exactly the steps of orc_track */
+/* above -- what crosses processes is (a) which stride-r grid points lie       */
+/* within distance r of a surviving track's pixel (the EDT respawn rule,       */
+/* trajectory.py:150-152, at grid resolution) + whether any track survived,    */
+/* and (b) the global scalars of the solve (orc_reduce_hook).                   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int H, W, ratio, GW, GH, n_flows, optimize, buffer_size;
+    int64_t G, g0, g1;               /* this process owns the births on grid points [g0, g1) (whole rows) */
+    orc_list_t active, next_active, full;
+    uint8_t* cand;                   /* G: respawn candidates for the next frame (only [g0,g1) is used) */
+    orc_solve_stats_t* solves; int32_t n_solves;
+    double* nxt; uint8_t* flag; int64_t scratch_cap;
+} orc_shard_t;
+
+ORC_API orc_shard_t* orc_shard_begin(int n_flows, int H, int W, int ratio, int64_t g0, int64_t g1, int optimize)
+{
+    orc_shard_t* s = (orc_shard_t*)calloc(1, sizeof(orc_shard_t));
+    s->H = H; s->W = W; s->ratio = ratio; s->n_flows = n_flows; s->optimize = optimize;
+    s->buffer_size = optimize ? 3 : 0;
+    s->GW = (W + ratio - 1) / ratio; s->GH = (H + ratio - 1) / ratio;
+    s->G = (int64_t)s->GW * s->GH; s->g0 = g0; s->g1 = g1;
+    s->cand = (uint8_t*)malloc((size_t)s->G);
+    memset(s->cand, 1, (size_t)s->G);                      /* trajectory.py:108 */
+    if (optimize) s->solves = (orc_solve_stats_t*)calloc(n_flows > 0 ? n_flows : 1, sizeof(orc_solve_stats_t));
+    return s;
+}
+
+/* births of frame f on the own band + chain step + extend_all for the own tracks (orc_track, same lines).
+ * blocked_out[G]: 1 where a grid point has one of THIS process's survivors' pixels within distance ratio (all grid
+ * points, not only the own band); *n_alive_out = this process's survivors. */
+ORC_API void orc_shard_step(orc_shard_t* s, int f, const float* flow, const uint8_t* occ, uint8_t* blocked_out, int64_t* n_alive_out)
+{
+    const int H = s->H, W = s->W, ratio = s->ratio, GW = s->GW, GH = s->GH;
+    for (int64_t g = s->g0; g < s->g1; ++g) {
+        if (!s->cand[g]) continue;
+        orc_traj_t* t = (orc_traj_t*)calloc(1, sizeof(orc_traj_t));
+        t->birth = f;
+        orc_traj_extend(t, (double)((g % GW) * ratio), (double)((g / GW) * ratio));
+        orc_list_push(&s->active, t);
+    }
+    const int64_t A = s->active.n;
+    if (A > s->scratch_cap) { s->scratch_cap = A; s->nxt = (double*)realloc(s->nxt, sizeof(double) * 2 * A); s->flag = (uint8_t*)realloc(s->flag, A); }
+    double* nxt = s->nxt; uint8_t* flag = s->flag;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < A; ++i) {
+        const orc_traj_t* t = s->active.v[i];
+        const double px = t->pts[2 * (t->len - 1)], py = t->pts[2 * (t->len - 1) + 1];
+        orc_taps_t tp;
+        orc_taps_f32((float)px, (float)py, H, W, &tp);
+        float fl[2];
+        orc_sample_hwc(flow, 2, H, W, &tp, fl);
+        const float oc = orc_sample_u8(occ, H, W, &tp);
+        const int occ_c = oc > 0.1f;
+        const double nx = px + (double)fl[0], ny = py + (double)fl[1];
+        const int valid = (nx > 0) && (nx < (double)(W - 1)) && (ny > 0) && (ny < (double)(H - 1));
+        nxt[2 * i] = nx; nxt[2 * i + 1] = ny;
+        flag[i] = (uint8_t)(valid && !occ_c);
+    }
+    memset(blocked_out, 0, (size_t)s->G);
+    int64_t n_occ = 0;
+    s->next_active.n = 0;
+    for (int64_t i = 0; i < A; ++i) {
+        orc_traj_t* t = s->active.v[i];
+        if (!flag[i]) {
+            orc_list_push(&s->full, t);
+        } else {
+            /* occupied[int(y), int(x)] = 1 (trajectory.py:144), then every grid point whose disc of radius ratio holds it */
+            const int px = (int)nxt[2 * i], py = (int)nxt[2 * i + 1];
+            for (int gy = (py - ratio + ratio - 1) / ratio > 0 ? (py - ratio + ratio - 1) / ratio : 0; gy < GH && gy * ratio <= py + ratio; ++gy)
+                for (int gx = (px - ratio + ratio - 1) / ratio > 0 ? (px - ratio + ratio - 1) / ratio : 0; gx < GW && gx * ratio <= px + ratio; ++gx) {
+                    const int dx = gx * ratio - px, dy = gy * ratio - py;
+                    if (dx * dx + dy * dy <= ratio * ratio) blocked_out[(int64_t)gy * GW + gx] = 1;
+                }
+            n_occ++;
+            orc_traj_extend(t, nxt[2 * i], nxt[2 * i + 1]);
+            orc_list_push(&s->next_active, t);
+        }
+    }
+    { orc_list_t tmp = s->active; s->active = s->next_active; s->next_active = tmp; }
+    *n_alive_out = n_occ;
+}
+
+/* the respawn candidates of the next frame from the maps of ALL processes (OR) and the global survivor count */
+ORC_API void orc_shard_set_blocked(orc_shard_t* s, const uint8_t* blocked_global, int64_t n_alive_global)
+{
+    const int ratio = s->ratio, GW = s->GW;
+    for (int64_t g = s->g0; g < s->g1; ++g) {
+        const int cx = (int)(g % GW) * ratio, cy = (int)(g / GW) * ratio;
+        if (n_alive_global == 0) s->cand[g] = (uint8_t)!((cy + 1) * (cy + 1) + cx * cx <= ratio * ratio);   /* SciPy's phantom feature */
+        else s->cand[g] = (uint8_t)!blocked_global[g];
+    }
+}
+
+/* optimize_buffer of loop index f for the own tracks (orc_track, same lines); the solve's global scalars go through
+ * `reduce` (all processes call this together, also those without a track that has a full buffer) */
+ORC_API void orc_shard_solve(orc_shard_t* s, int f, const float* flow_prev, const float* flow_cur, const float* flow2_prev,
+                             const uint8_t* occ2_prev, orc_reduce_fn reduce, void* user)
+{
+    const int H = s->H, W = s->W, buffer_size = s->buffer_size;
+    int64_t N = 0;
+    for (int64_t i = 0; i < s->active.n; ++i) if (s->active.v[i]->len >= buffer_size) N++;
+    double nn = (double)N;
+    { const int m_[1] = {0}; if (reduce) reduce(&nn, 1, m_, user); }
+    if (nn == 0.0) return;                                  /* no track anywhere has a full buffer: no solve (orc_track) */
+    double* uv12 = (double*)malloc(sizeof(double) * 4 * (N ? N : 1));
+    double* r1 = (double*)malloc(sizeof(double) * 2 * (N ? N : 1));
+    double* r2 = (double*)malloc(sizeof(double) * 2 * (N ? N : 1));
+    double* sc = (double*)malloc(sizeof(double) * (N ? N : 1));
+    double* o = (double*)malloc(sizeof(double) * 4 * (N ? N : 1));
+    int64_t* row = (int64_t*)malloc(sizeof(int64_t) * (size_t)(N ? N : 1));
+    { int64_t k = 0; for (int64_t i = 0; i < s->active.n; ++i) if (s->active.v[i]->len >= buffer_size) row[k++] = i; }
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < N; ++k) {
+        const orc_traj_t* t = s->active.v[row[k]];
+        const double* b0 = t->pts + 2 * (t->len - 3);
+        orc_taps_t tp;
+        orc_taps_f32((float)b0[0], (float)b0[1], H, W, &tp);
+        float f01[2], f02[2];
+        orc_sample_hwc(flow_prev, 2, H, W, &tp, f01);
+        orc_sample_hwc(flow2_prev, 2, H, W, &tp, f02);
+        const float o02 = orc_sample_u8(occ2_prev, H, W, &tp);
+        const float nrm = sqrtf(f02[0] * f02[0] + f02[1] * f02[1]);
+        const float sf = (1.0f - o02) * (nrm < 20.0f ? 1.0f : 0.0f);
+        r1[2 * k] = b0[0] + (double)f01[0]; r1[2 * k + 1] = b0[1] + (double)f01[1];
+        r2[2 * k] = b0[0] + (double)f02[0]; r2[2 * k + 1] = b0[1] + (double)f02[1];
+        sc[k] = (double)sf;
+        uv12[4 * k] = b0[2]; uv12[4 * k + 1] = b0[3]; uv12[4 * k + 2] = b0[4]; uv12[4 * k + 3] = b0[5];
+    }
+    orc_reduce_hook = reduce; orc_reduce_user = user;
+    orc_optimize_location(uv12, r1, r2, sc, flow_cur, N, W, H, o, &s->solves[s->n_solves]);
+    orc_reduce_hook = NULL; orc_reduce_user = NULL;
+    s->n_solves++;
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < N; ++k) {
+        orc_traj_t* t = s->active.v[row[k]];
+        double* b0 = t->pts + 2 * (t->len - 3);
+        b0[2] = o[4 * k]; b0[3] = o[4 * k + 1]; b0[4] = o[4 * k + 2]; b0[5] = o[4 * k + 3];
+    }
+    free(uv12); free(r1); free(r2); free(sc); free(o); free(row);
+}
+
+/* clear_active + the own trajectories in the reference's order (dead ones by frame, then the still active ones) */
+ORC_API orc_result_t* orc_shard_finish(orc_shard_t* s)
+{
+    for (int64_t i = 0; i < s->active.n; ++i) orc_list_push(&s->full, s->active.v[i]);
+    orc_result_t* R = (orc_result_t*)calloc(1, sizeof(orc_result_t));
+    const orc_list_t full = s->full;
+    R->n_traj = full.n;
+    R->birth = (int32_t*)malloc(sizeof(int32_t) * (full.n ? full.n : 1));
+    R->len = (int32_t*)malloc(sizeof(int32_t) * (full.n ? full.n : 1));
+    R->off = (int64_t*)malloc(sizeof(int64_t) * (full.n + 1));
+    int64_t tot = 0;
+    for (int64_t i = 0; i < full.n; ++i) { R->off[i] = tot; tot += full.v[i]->len; }
+    R->off[full.n] = tot;
+    R->n_points = tot;
+    R->xy = (double*)malloc(sizeof(double) * 2 * (tot ? tot : 1));
+    for (int64_t i = 0; i < full.n; ++i) {
+        orc_traj_t* t = full.v[i];
+        R->birth[i] = t->birth; R->len[i] = t->len;
+        memcpy(R->xy + 2 * R->off[i], t->pts, sizeof(double) * 2 * t->len);
+        free(t->pts); free(t);
+    }
+    R->n_solves = s->n_solves; R->solves = s->solves;
+    free(s->active.v); free(s->next_active.v); free(s->full.v); free(s->cand); free(s->nxt); free(s->flag); free(s);
     return R;
 }

@@ -7,8 +7,16 @@ What shards exactly:
   * flow_check by frame pair (utils.py:94-105 is independent per pair) -- `flow_check_sharded`: every rank
     checks a contiguous slice of the pairs, then ONE all-gather of the bit-packed occlusion maps (H*W/8 bytes
     per pair: 259 KB at 1080p) gives every rank the full stack.  Bit-identical to the unsharded result.
-The frame recurrence itself has a loop-carried dependency (births at t+1 need every survivor of t), so it is
-NOT split across ranks; a rank that needs it for a sequence runs it whole.
+  * the frame recurrence of ONE sequence -- `connect_sharded`: it has a loop-carried dependency (births at t+1 need
+    every survivor of t; tails at t+1 are the optimised buffer of t), so frame ranges cannot be stitched exactly.  What
+    does split exactly is the set of TRACKS: rank r owns the tracks born on its row band of the stride-r grid and runs
+    every frame for them; per frame ONE all-reduce (max) of the grid-resolution `blocked` map (G bytes + a survivor
+    byte: which grid points have a surviving track's pixel within distance r -- the EDT respawn rule) tells every rank
+    where its band respawns; the path-consistency solve is block diagonal over tracks, its trust-region control needs
+    only global sums (13 per iteration), all-gathered and combined in rank order on every rank (replicated control);
+    ids follow from the keys (last valid time, birth frame, birth grid index) of all ranks.  Same trajectories, ids,
+    lengths and positions as one process; every message is latency-bound (<= 0.5 MB), so for chain-only runs this is
+    slower than one GPU -- it is the exact single-sequence mode north_star asks for, measured as such by bench.py.
 """
 import numpy as np
 
@@ -86,3 +94,124 @@ def reduce_totals(seconds, units, device=None, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         dist.all_reduce(u, op=dist.ReduceOp.SUM, group=group)
     return float(t.item()), float(u.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ONE sequence over several ranks, exactly (SURVEY.md 8e Stage A + Stage B)
+# ---------------------------------------------------------------------------------------------------------------
+def band_range(grid_h, grid_w, rank, world):
+    """Grid points [g0, g1) whose births `rank` owns: a contiguous band of whole grid rows (row-major grid indices)."""
+    lo, hi = shard_range(grid_h, rank, world)
+    return lo * int(grid_w), hi * int(grid_w)
+
+
+def make_reduce(group=None):
+    """reduce(vals, is_max): vals (1-D float64 tensor) = this rank's part on entry, the value over all ranks on return.
+    One all-gather; sums are added in rank order on every rank, so every rank holds the same bits."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def reduce(vals, is_max):
+        if world == 1:
+            return vals
+        flat = torch.empty(world * vals.numel(), dtype=vals.dtype, device=vals.device)
+        dist.all_gather_into_tensor(flat, vals.contiguous().reshape(-1), group=group)
+        parts = flat.reshape((world,) + tuple(vals.shape))
+        mx = torch.as_tensor(is_max, dtype=torch.bool, device=vals.device)
+        tot = parts[0].clone()
+        for r in range(1, world):
+            tot = torch.where(mx, torch.maximum(tot, parts[r]), tot + parts[r])
+        vals.copy_(tot)
+        return vals
+    return reduce
+
+
+def global_ids(birth, length, first_xy, n_flows, ratio, grid_w, group=None):
+    """Ids of this rank's trajectories in the order of the single-process run: rank of the key (last valid time, birth
+    frame, birth grid index) among the keys of all ranks (SURVEY a-17: dead tracks by frame, then the still active ones,
+    each group in active-list order = (birth frame, grid index)).  Returns (ids int64, total number of trajectories)."""
+    import torch
+    import torch.distributed as dist
+    birth = np.asarray(birth, np.int64)
+    last = birth + np.asarray(length, np.int64) - 1
+    gidx = (np.asarray(first_xy[:, 1], np.int64) // ratio) * int(grid_w) + np.asarray(first_xy[:, 0], np.int64) // ratio
+    key = (last << 51) | (birth << 40) | gidx                   # 11 + 11 + 40 bits
+    assert n_flows + 2 < (1 << 11) and (len(key) == 0 or (np.diff(key) > 0).all()), "local trajectories must come in key order"
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return np.arange(len(key), dtype=np.int64), len(key)
+    cnt = torch.tensor([len(key)], dtype=torch.int64)
+    cnts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    nmax = max(int(c.item()) for c in cnts)
+    pad = torch.full((max(nmax, 1),), np.iinfo(np.int64).max, dtype=torch.int64)
+    pad[:len(key)] = torch.from_numpy(key)
+    allk = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(allk, pad, group=group)
+    ids = np.zeros(len(key), np.int64)
+    for r in range(world):
+        ids += np.searchsorted(allk[r][:int(cnts[r].item())].numpy(), key, side="left")
+    return ids, int(sum(int(c.item()) for c in cnts))
+
+
+def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, check_fn, group=None):
+    """main_connect_point_trajectories.py:36-53 for ONE sequence on all ranks of `group`, exactly.
+
+    flows_*: (n,H,W,2) float32 tensors on every rank (flows_f2 / flows_b2 None: track() instead of track_optimize());
+    check_fn(f, b, thres) -> (k,H,W) uint8: flow_check of a slice (Stage A, frame-pair shards + all-gather);
+    engine: this rank's share of the recurrence -- point_trajectory.shard.HipShardEngine on a GPU (RCCL),
+    oracle.ShardEngine in the CPU tests (gloo):
+        begin(n_flows, H, W, ratio, g0, g1, optimize)
+        step(t, flow_t, occ_t) -> uint8 tensor (G marks of this rank's survivors + 1 survivor byte), exchanged here
+        after_exchange(t, x); solve(t, flow_{t-1}, flow_t, flow2_{t-1}, occ2_{t-1}, reduce); finish() -> CSR + stats
+    Returns {"birth","length","off","xy": this rank's trajectories; "ids": their ids in the single-process order;
+    "n_traj": trajectories over all ranks; "solve_stats"; "occ","occ2"}."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    optimize = flows_f2 is not None
+    n_flows, H, W = int(flows_f.shape[0]), int(flows_f.shape[1]), int(flows_f.shape[2])
+    r = int(sample_ratio)
+    GW, GH = (W + r - 1) // r, (H + r - 1) // r
+    # ---- Stage A: occlusion maps, frame-pair shards + one all-gather per stack ----
+    occ = flow_check_sharded(flows_f, flows_b, thres, check_fn, group)
+    occ2 = flow_check_sharded(flows_f2, flows_b2, thres, check_fn, group) if optimize and flows_f2.shape[0] > 0 else None
+    # ---- Stage B: the recurrence, tracks split by birth row band ----
+    g0, g1 = band_range(GH, GW, rank, world)
+    engine.begin(n_flows, H, W, r, g0, g1, optimize)
+    reduce = make_reduce(group)
+    for t in range(n_flows):
+        x = engine.step(t, flows_f[t], occ[t])                               # track.py:33-47 for the own tracks
+        if world > 1:
+            dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)            # marks of every rank's survivors
+        engine.after_exchange(t, x)
+        if optimize and t + 1 >= 2:                                          # track_optimize.py:49-50
+            engine.solve(t, flows_f[t - 1], flows_f[t], flows_f2[t - 1], occ2[t - 1], reduce)
+    birth, length, off, xy, stats = engine.finish()
+    first = xy[off[:-1]] if len(birth) else np.zeros((0, 2))
+    ids, n_traj = global_ids(birth, length, first, n_flows, r, GW, group)
+    return {"birth": birth, "length": length, "off": off, "xy": xy, "ids": ids, "n_traj": n_traj, "solve_stats": stats,
+            "occ": occ, "occ2": occ2, "band": (g0, g1)}
+
+
+def gather_result(part, group=None):
+    """The whole sequence's CSR in id order on every rank (tests, small runs): all-gather of the per-rank parts."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    parts = [part]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, {k: part[k] for k in ("birth", "length", "off", "xy", "ids")}, group=group)
+    n = part["n_traj"]
+    birth = np.zeros(n, np.int32); length = np.zeros(n, np.int32)
+    for p in parts:
+        birth[p["ids"]] = p["birth"]; length[p["ids"]] = p["length"]
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(length, out=off[1:])
+    xy = np.zeros((int(off[-1]), 2), np.float64)
+    for p in parts:
+        for j, i in enumerate(p["ids"]):
+            xy[off[i]:off[i + 1]] = p["xy"][p["off"][j]:p["off"][j + 1]]
+    return birth, length, off, xy

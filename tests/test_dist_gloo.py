@@ -56,6 +56,101 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _sharded_worker(rank, world, port, ret):
+    """psfm_dist.connect_sharded (the product's driver of the exact single-sequence multi-rank mode) over gloo, with
+    the oracle's ShardEngine as each rank's compute: Stage A frame-pair shards, Stage B tracks by birth row band."""
+    for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import psfm_dist
+        import psfm_synth
+        from oracle import oracle as orc
+
+        def check(f, b, thres):
+            _, occ = orc.flow_check(list(f.numpy()), list(b.numpy()), thres)
+            return torch.from_numpy(np.stack(occ).astype(np.uint8)) if len(occ) else torch.zeros((0,) + tuple(f.shape[1:3]), dtype=torch.uint8)
+
+        out = {}
+        # (T, H, W, ratio, seed, sigma, occluders, optimize): grid rows not divisible by the world size, deaths and
+        # respawns in every band, a noisy sequence whose solves reject steps (every dogleg case goes through the hook)
+        cases = [(7, 38, 52, 2, 11, 0.3, 2, False), (8, 45, 60, 3, 12, 0.1, 1, True), (6, 30, 44, 1, 13, 0.4, 2, True)]
+        for ci, (T, H, W, r, seed, sigma, nocc, optimize) in enumerate(cases):
+            d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=True)
+            tf = lambda k: torch.from_numpy(np.stack(d[k]))
+            part = psfm_dist.connect_sharded(orc.ShardEngine(), tf("flows_f"), tf("flows_b"),
+                                             tf("flows_f2") if optimize else None, tf("flows_b2") if optimize else None,
+                                             1.0, r, check)
+            birth, length, off, xy = psfm_dist.gather_result(part)
+            _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+            if optimize:
+                _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+                O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+            else:
+                O = orc.track(d["flows_f"], occ, r)
+            same_ids = bool(len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length))
+            err = float(np.abs(xy - O.xy).max()) if same_ids else None
+            stats_ok = [s["iterations"] for s in part["solve_stats"]] == [s["iterations"] for s in O.solves] and \
+                       [s["termination"] for s in part["solve_stats"]] == [s["termination"] for s in O.solves]
+            g0, g1 = part["band"]
+            GW = (W + r - 1) // r
+            first = part["xy"][part["off"][:-1]]
+            gidx = (first[:, 1].astype(np.int64) // r) * GW + first[:, 0].astype(np.int64) // r
+            own_band = bool(((gidx >= g0) & (gidx < g1)).all())
+            out[ci] = (same_ids, err, stats_ok, own_band, len(part["birth"]), O.n_traj)
+        # every track dies in one step (an all-occluded map): SciPy's phantom-feature respawn rule needs the GLOBAL
+        # "no survivor" flag
+        T, H, W, r = 5, 24, 30, 2
+        d = psfm_synth.synth_sequence(T, H, W, seed=31, sigma=0.05, stride2=False)
+
+        def check_dead(f, b, thres):
+            o = check(f, b, thres)
+            return o
+        ff, fb = torch.from_numpy(np.stack(d["flows_f"])), torch.from_numpy(np.stack(d["flows_b"]))
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        occ = [o.copy() for o in occ]
+        occ[1][:] = True
+        eng = orc.ShardEngine()
+        # (drive Stage B directly with the modified maps)
+        GW, GH = (W + r - 1) // r, (H + r - 1) // r
+        g0, g1 = psfm_dist.band_range(GH, GW, rank, world)
+        eng.begin(T - 1, H, W, r, g0, g1, False)
+        for t in range(T - 1):
+            x = eng.step(t, ff[t], torch.from_numpy(occ[t].astype(np.uint8)))
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            eng.after_exchange(t, x)
+        b_, l_, o_, xy_, _ = eng.finish()
+        ids, n = psfm_dist.global_ids(b_, l_, xy_[o_[:-1]], T - 1, r, GW)
+        Bd, Ld, Od, XYd = psfm_dist.gather_result({"birth": b_, "length": l_, "off": o_, "xy": xy_, "ids": ids, "n_traj": n})
+        O = orc.track(d["flows_f"], occ, r)
+        out["alldie"] = bool(n == O.n_traj and np.array_equal(Bd, O.birth) and np.array_equal(Ld, O.length) and np.array_equal(XYd, O.xy))
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_connect_sharded_gloo(world):
+    """ONE sequence over 2 and 3 ranks == the single-process oracle: ids / lengths / positions bit for bit, per-solve
+    iteration counts and terminations equal; every rank only holds tracks born on its own row band."""
+    port = 31500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        out = ret[r]
+        for ci in (0, 1, 2):
+            same_ids, err, stats_ok, own_band, n_local, n_total = out[ci]
+            assert same_ids and err == 0.0 and stats_ok and own_band, (r, ci, out[ci])
+            assert 0 < n_local < n_total
+        assert out["alldie"], (r, "alldie")
+
+
 def test_world2_gloo():
     world = 2
     port = 29500 + (os.getpid() % 2000)
