@@ -217,6 +217,30 @@ psfm_status psfm_traj_to_matches(psfm_ctx* ctx, int n_img, int sample_k, const u
 psfm_status psfm_matches_copy(psfm_ctx* ctx, int64_t* kp_off_host, double* kp_xy_host, int64_t* pair_key_host,
                               int64_t* pair_off_host, int64_t* pair_first_host, int32_t* rows_host, void* stream);
 
+/* ONE sequence over several processes / GPUs, exactly (psfm_dist.connect_sharded drives these).
+ * The tracks are split by the row band of the stride-r grid they are born on: this process owns the births on grid points
+ * [g0, g1) and runs every frame for its tracks.  `maps`: caller-owned DEVICE buffer of 2 x map_pitch bytes (map_pitch >=
+ * G + 1); after psfm_shard_step(frame) the slab (frame & 1) holds, stamped, the grid points within distance sample_ratio of
+ * one of this process's surviving tracks (+ byte G: a track survived) -- the caller all-reduces (max) those G + 1 bytes over
+ * the ranks before the next step reads them.  The solve of a frame runs as export (this process's sums: kind 0 the fused
+ * solve with k iterations -> k x 13 doubles, 1 / 2 the launch chain's first / next iteration -> 13) -> the caller combines the
+ * ranks' sums in rank order -> control on the totals (same numbers, same decision on every rank; synchronises and
+ * reports done / redo / statistics).  redo: a fused solve met something it did not speculate -> restore, then the chain
+ * (export 1, control, export 2, control, ... until done, write-back).  psfm_shard_finish leaves the own trajectories as the
+ * usual result (psfm_result_copy), sorted by (last valid time, birth frame, birth grid index); ids over all ranks follow
+ * from those keys.  No collective is issued by the library. */
+psfm_status psfm_shard_begin(psfm_ctx* ctx, int n_flows, int h, int w, int sample_ratio, int64_t g0, int64_t g1, int optimize,
+                             uint8_t* maps, int64_t map_pitch, void* stream);
+psfm_status psfm_shard_step(psfm_ctx* ctx, const float* flow, const uint8_t* occ, int frame, void* stream);
+psfm_status psfm_shard_solve_export(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02,
+                                    const uint8_t* occ02, int frame, int kind, int k, double* sums_out, void* stream);
+psfm_status psfm_shard_solve_control(psfm_ctx* ctx, int frame, int kind, int k, const double* totals, int32_t* done_host,
+                                     int32_t* redo_host, psfm_solve_stats* stats_host, void* stream);
+psfm_status psfm_shard_solve_restore(psfm_ctx* ctx, int frame, void* stream);
+psfm_status psfm_shard_solve_writeback(psfm_ctx* ctx, int frame, const psfm_solve_stats* stats, void* stream);
+psfm_status psfm_shard_solve_record(psfm_ctx* ctx, const psfm_solve_stats* stats);
+psfm_status psfm_shard_finish(psfm_ctx* ctx, psfm_track_info* info_host, void* stream);
+
 /* Per-kernel device time of the last psfm_track / psfm_flow_check when profiling is enabled with
  * psfm_ctx_set_profiling(ctx, 1): HIP events recorded on the launch stream around every launch of
  * the named kernel family (enable = N > 1: only every N-th per-frame chain_step launch is timed, which keeps the

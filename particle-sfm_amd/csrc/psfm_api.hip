@@ -274,6 +274,53 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
     return rc;
 }
 
+// Sizes of one run of the frame recurrence.  g_own < 0: the whole stride-r grid; otherwise the number of grid points whose
+// births this process owns (track-sharded runs): lane / record tables are sized for those, keys for the whole grid.
+psfm_status psfm_track_dims(psfm_ctx* c, int n_flows, int h, int w, int ratio, int64_t g_own, PsfmTrackDims& d)
+{
+    d.H = h; d.W = w; d.ratio = ratio; d.n_flows = n_flows;
+    d.GW = (w + ratio - 1) / ratio; d.GH = (h + ratio - 1) / ratio;   // trajectory.py:110-115
+    d.G = (int64_t)d.GW * d.GH;
+    const int64_t Gown = g_own < 0 ? d.G : (g_own > 0 ? g_own : 1);
+    d.cap = (int64_t)(c->lane_factor * (double)Gown);
+    d.cap = ((d.cap + 255) / 256) * 256;
+    const int64_t n_blocks = d.cap / 256;
+    {   // free-lane stacks: one per block of the grid up to PSFM_NSHARD (a small grid must not probe stacks nobody fills)
+        const int64_t gb = (Gown + 255) / 256;
+        d.nsh = (int)(gb < PSFM_NSHARD ? (gb > 0 ? gb : 1) : PSFM_NSHARD);
+    }
+    d.free_cap = (int)(((n_blocks + d.nsh - 1) / d.nsh) * 256) + 1024;   // per-stack entries: every lane of the blocks that push there
+    // records are spread over PSFM_NSHARD slices by block index: give every slice head-room
+    // trajectory records: traj_factor x G, but at least G x n_flows / 8 (one death in eight per frame and grid point)
+    const double tf = c->traj_factor > (double)n_flows / 8.0 ? c->traj_factor : (double)n_flows / 8.0;
+    d.shard_cap = (int)(((int64_t)(tf * (double)Gown) + d.cap) / PSFM_NSHARD) + 1024;
+    d.traj_cap = (int64_t)d.shard_cap * PSFM_NSHARD;
+    if (d.cap > 0x7fffffff / 2 || d.traj_cap > 0x7fffffff / 2) { psfm_set_error("psfm_track: grid too large"); return PSFM_ERR_ARG; }
+    d.shift_b = 1; while ((1ll << d.shift_b) < d.G) ++d.shift_b;
+    int tbits = 1; while ((1ll << tbits) < (long long)n_flows + 2) ++tbits;
+    d.shift_d = d.shift_b + tbits;
+    if (d.shift_d + tbits > 63) { psfm_set_error("psfm_track: key does not fit 64 bits"); return PSFM_ERR_ARG; }
+    d.cw = (float)((double)(w - 1) / 2.0); d.ch = (float)((double)(h - 1) / 2.0);
+    return PSFM_OK;
+}
+
+psfm_status psfm_track_alloc(psfm_ctx* c, const PsfmTrackDims& d)
+{
+    psfm_status st;
+    const int n_flows = d.n_flows;
+    if ((st = c->log.ensure(sizeof(double2) * (size_t)(n_flows + 1) * d.cap)) != PSFM_OK) return st;
+    if ((st = c->birth_frame.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
+    if ((st = c->birth_idx.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
+    if ((st = c->free_stack.ensure(sizeof(int) * (size_t)d.free_cap * PSFM_NSHARD * 2)) != PSFM_OK) return st;
+    if ((st = c->shards.ensure(sizeof(PsfmShard) * PSFM_NSHARD * 2)) != PSFM_OK) return st;
+    if ((st = c->fin_keys.ensure(sizeof(unsigned long long) * d.traj_cap)) != PSFM_OK) return st;
+    if ((st = c->fin_lanes.ensure(sizeof(int) * d.traj_cap)) != PSFM_OK) return st;
+    if ((st = c->occupied.ensure((size_t)d.G * 3 + 8)) != PSFM_OK) return st;   // (the persistent loop rotates three maps)
+    if ((st = c->counters.ensure(sizeof(PsfmCounters))) != PSFM_OK) return st;
+    if ((st = c->survivors.ensure(sizeof(int) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
+    return PSFM_OK;
+}
+
 // Occlusion maps produced on a side stream while the frame loop consumes them (psfm_connect): one event per chunk
 // of frame pairs; the loop waits for the chunk that contains the pair it is about to read.
 struct PsfmOccPipeline {
@@ -312,41 +359,10 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     if (ratio > 64) { psfm_set_error("psfm_track: sample_ratio %d > 64 unsupported", ratio); return PSFM_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     PsfmTrackDims d;
-    d.H = h; d.W = w; d.ratio = ratio; d.n_flows = n_flows;
-    d.GW = (w + ratio - 1) / ratio; d.GH = (h + ratio - 1) / ratio;   // trajectory.py:110-115
-    d.G = (int64_t)d.GW * d.GH;
-    d.cap = (int64_t)(c->lane_factor * (double)d.G);
-    d.cap = ((d.cap + 255) / 256) * 256;
-    const int64_t n_blocks = d.cap / 256;
-    {   // free-lane stacks: one per block of the grid up to PSFM_NSHARD (a small grid must not probe stacks nobody fills)
-        const int64_t gb = (d.G + 255) / 256;
-        d.nsh = (int)(gb < PSFM_NSHARD ? (gb > 0 ? gb : 1) : PSFM_NSHARD);
-    }
-    d.free_cap = (int)(((n_blocks + d.nsh - 1) / d.nsh) * 256) + 1024;   // per-stack entries: every lane of the blocks that push there
-    // records are spread over PSFM_NSHARD slices by block index: give every slice head-room
-    // trajectory records: traj_factor x G, but at least G x n_flows / 8 (one death in eight per frame and grid point)
-    const double tf = c->traj_factor > (double)n_flows / 8.0 ? c->traj_factor : (double)n_flows / 8.0;
-    d.shard_cap = (int)(((int64_t)(tf * (double)d.G) + d.cap) / PSFM_NSHARD) + 1024;
-    d.traj_cap = (int64_t)d.shard_cap * PSFM_NSHARD;
-    if (d.cap > 0x7fffffff / 2 || d.traj_cap > 0x7fffffff / 2) { psfm_set_error("psfm_track: grid too large"); return PSFM_ERR_ARG; }
-    d.shift_b = 1; while ((1ll << d.shift_b) < d.G) ++d.shift_b;
-    int tbits = 1; while ((1ll << tbits) < (long long)n_flows + 2) ++tbits;
-    d.shift_d = d.shift_b + tbits;
-    if (d.shift_d + tbits > 63) { psfm_set_error("psfm_track: key does not fit 64 bits"); return PSFM_ERR_ARG; }
-    d.cw = (float)((double)(w - 1) / 2.0); d.ch = (float)((double)(h - 1) / 2.0);
-
     psfm_status st;
+    if ((st = psfm_track_dims(c, n_flows, h, w, ratio, -1, d)) != PSFM_OK) return st;
     const int64_t P = (int64_t)h * w;
-    if ((st = c->log.ensure(sizeof(double2) * (size_t)(n_flows + 1) * d.cap)) != PSFM_OK) return st;
-    if ((st = c->birth_frame.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
-    if ((st = c->birth_idx.ensure(sizeof(int) * d.cap)) != PSFM_OK) return st;
-    if ((st = c->free_stack.ensure(sizeof(int) * (size_t)d.free_cap * PSFM_NSHARD * 2)) != PSFM_OK) return st;
-    if ((st = c->shards.ensure(sizeof(PsfmShard) * PSFM_NSHARD * 2)) != PSFM_OK) return st;
-    if ((st = c->fin_keys.ensure(sizeof(unsigned long long) * d.traj_cap)) != PSFM_OK) return st;
-    if ((st = c->fin_lanes.ensure(sizeof(int) * d.traj_cap)) != PSFM_OK) return st;
-    if ((st = c->occupied.ensure((size_t)d.G * 3 + 8)) != PSFM_OK) return st;   // (the persistent loop rotates three maps)
-    if ((st = c->counters.ensure(sizeof(PsfmCounters))) != PSFM_OK) return st;
-    if ((st = c->survivors.ensure(sizeof(int) * (size_t)(n_flows + 1))) != PSFM_OK) return st;
+    if ((st = psfm_track_alloc(c, d)) != PSFM_OK) return st;
 
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;

@@ -98,6 +98,8 @@ struct PsfmProfiler {
 // Device control block of the path-consistency solver (written by the last block of each kernel).
 struct PsfmSolveCtrl;
 
+struct PsfmTrackDims;
+
 struct psfm_ctx {
     int device = 0;
     double lane_factor = 2.0, traj_factor = 8.0;
@@ -131,6 +133,8 @@ struct psfm_ctx {
     int solve_mode = 0;     // 0 fused solve (one launch per frame), 1 launch chain (sequences whose solves reject steps)
     int solver_mode = 0, solver_K = 0;   // psfm_ctx_set_solver: 0 adaptive / 1 chain / 2 fused; K 0 = adaptive
     int64_t n_fused_ok = 0, n_fused_redone = 0, n_chain = 0;   // solves of the last psfm_track by how they ran
+    PsfmTrackDims* shard_dims = nullptr;   // psfm_shard_begin .. psfm_shard_finish
+    bool shard_optimize = false;
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
     PsfmBuf occ_own, occ2_own;           // occlusion maps of psfm_connect when the caller passes none
     PsfmBuf win_ws;                      // psfm_window_sample / psfm_result_filter workspace
@@ -162,8 +166,14 @@ struct PsfmTrackDims {
     int shift_b, shift_d;   // key = death<<shift_d | birth<<shift_b | grid index
     float cw, ch;
     int nblk = 0, seg_cap = 0, spill_cap = 0;   // persistent loop: blocks, records per private segment, shared tail
+    // track-sharded run (psfm_shard_*): births on grid points [g0, g0 + Gband) only; the two stamped blocked maps (+ the
+    // survivor byte at offset G) live in a caller-owned buffer, `shard_pitch` bytes apart, that the ranks all-reduce
+    int64_t g0 = 0, Gband = 0, shard_pitch = 0;
+    uint8_t* shard_maps = nullptr;
 };
 
+psfm_status psfm_track_dims(psfm_ctx* c, int n_flows, int h, int w, int ratio, int64_t g_own, PsfmTrackDims& d);
+psfm_status psfm_track_alloc(psfm_ctx* c, const PsfmTrackDims& d);
 psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
                                    int frame, bool optimize, hipStream_t s);
@@ -193,6 +203,13 @@ psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const fl
 psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d);   // every solver buffer of a sequence, up front
 int psfm_solve_kmax(void);
+// track-sharded runs (psfm_shard.hip)
+psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
+                              const uint8_t* occ02, int frame, int kind, int K, double* sums_out, hipStream_t s);
+psfm_status psfm_solve_control(psfm_ctx* c, const PsfmTrackDims& d, int frame, int kind, int K, const double* totals, hipStream_t s);
+psfm_status psfm_solve_state(psfm_ctx* c, int* done, int* stall, psfm_solve_stats* st, hipStream_t s);
+psfm_status psfm_solve_restore(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
+psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 // Batch API form (psfm_optimize_location).
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
                              const double* scale, const float* flow12, int64_t n, int w, int h, double* out,

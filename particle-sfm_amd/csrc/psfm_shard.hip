@@ -1,0 +1,137 @@
+// psfm_shard.hip -- ONE sequence over several processes / GPUs, exactly (SURVEY.md 8e Stage B; the driver is
+// particle-sfm_amd/psfm_dist.connect_sharded, the Python engine point_trajectory/shard.py).
+//
+// The frame recurrence (track.py:31-47 / track_optimize.py:31-50) cannot be cut into frame ranges -- births at t+1 need
+// every survivor of t -- but its TRACKS split exactly: this process owns the tracks born on grid points [g0, g1) (whole
+// rows of the stride-r grid) and runs every frame for them with the same kernels as a single-process run:
+//   psfm_shard_step            chain step + births of the own band (psfm_chain_step_kernel with the band offset).  The
+//                              stamped grid-resolution `blocked` map of the frame (+ the survivor byte at offset G) sits in
+//                              a caller-owned buffer: the ranks all-reduce(max) its G + 1 bytes before the next step reads it
+//   psfm_shard_solve_export    the solve of the frame for the own tracks, sums only (fused: K x 13; chain: 13)
+//   psfm_shard_solve_control   Ceres' control step on the totals over all ranks (replicated: same numbers on every rank)
+//   psfm_shard_finish          write-backs pending, finalize: the own trajectories as the usual CSR result, sorted by the
+//                              key (last valid time, birth frame, birth grid index) -- global ids follow from the keys
+// No collective is issued from here: the caller owns the process group (RCCL over xGMI, or gloo in tests).
+#include <string.h>
+
+#include "psfm_internal.h"
+
+#define PSFM_SHARD_CHECK(c)                                                                                  \
+    do {                                                                                                     \
+        if (!(c) || !(c)->shard_dims) { psfm_set_error("psfm_shard_*: no sharded run in progress"); return PSFM_ERR_ARG; } \
+        PSFM_HIP(hipSetDevice((c)->device));                                                                 \
+    } while (0)
+
+extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, int ratio, int64_t g0, int64_t g1, int optimize,
+                                        uint8_t* maps, int64_t map_pitch, void* stream)
+{
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    PSFM_HIP(hipSetDevice(c->device));
+    PsfmGate gate(c->device, 0);
+    if (n_flows < 1 || h < 2 || w < 2 || ratio < 1 || ratio > 64 || !maps) {
+        psfm_set_error("psfm_shard_begin: bad argument (n_flows=%d h=%d w=%d ratio=%d)", n_flows, h, w, ratio);
+        return PSFM_ERR_ARG;
+    }
+    PsfmTrackDims d;
+    psfm_status st;
+    const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
+    if (g0 < 0 || g1 < g0 || g1 > G || map_pitch < G + 1) {
+        psfm_set_error("psfm_shard_begin: band [%lld, %lld) of %lld grid points, map pitch %lld", (long long)g0, (long long)g1,
+                       (long long)G, (long long)map_pitch);
+        return PSFM_ERR_ARG;
+    }
+    if ((st = psfm_track_dims(c, n_flows, h, w, ratio, g1 - g0, d)) != PSFM_OK) return st;
+    d.g0 = g0; d.Gband = g1 - g0; d.shard_maps = maps; d.shard_pitch = map_pitch;
+    if ((st = psfm_track_alloc(c, d)) != PSFM_OK) return st;
+    if (optimize && (st = psfm_solve_prepare(c, d)) != PSFM_OK) return st;
+    c->solve_stats.clear();
+    c->res_n_traj = c->res_n_points = 0;
+    delete c->shard_dims;
+    c->shard_dims = new PsfmTrackDims(d);
+    c->shard_optimize = optimize != 0;
+    return psfm_launch_track_init(c, d, (hipStream_t)stream);
+}
+
+extern "C" psfm_status psfm_shard_step(psfm_ctx* c, const float* flow, const uint8_t* occ, int frame, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    const PsfmTrackDims& d = *c->shard_dims;
+    if (!flow || !occ || frame < 0 || frame >= d.n_flows) { psfm_set_error("psfm_shard_step: bad argument (frame %d)", frame); return PSFM_ERR_ARG; }
+    return psfm_launch_chain_step(c, d, flow, occ, frame, c->shard_optimize, (hipStream_t)stream);
+}
+
+extern "C" psfm_status psfm_shard_solve_export(psfm_ctx* c, const float* flow01, const float* flow12, const float* flow02,
+                                               const uint8_t* occ02, int frame, int kind, int k, double* sums_out, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    if (kind < 0 || kind > 2 || !sums_out || frame < 1) { psfm_set_error("psfm_shard_solve_export: bad argument"); return PSFM_ERR_ARG; }
+    return psfm_solve_export(c, *c->shard_dims, flow01, flow12, flow02, occ02, frame, kind, k, sums_out, (hipStream_t)stream);
+}
+
+extern "C" psfm_status psfm_shard_solve_control(psfm_ctx* c, int frame, int kind, int k, const double* totals, int32_t* done_host,
+                                                int32_t* redo_host, psfm_solve_stats* stats_host, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    hipStream_t s = (hipStream_t)stream;
+    psfm_status st = psfm_solve_control(c, *c->shard_dims, frame, kind, k, totals, s);
+    if (st != PSFM_OK) return st;
+    int done = 0, stall = 0;
+    psfm_solve_stats ss;
+    memset(&ss, 0, sizeof(ss));
+    if ((st = psfm_solve_state(c, &done, &stall, &ss, s)) != PSFM_OK) return st;
+    if (done_host) *done_host = done;
+    if (redo_host) *redo_host = stall != 0;     // the fused solve met something it had not speculated: redo with the chain
+    if (stats_host) *stats_host = ss;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_shard_solve_restore(psfm_ctx* c, int frame, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    return psfm_solve_restore(c, *c->shard_dims, frame, (hipStream_t)stream);
+}
+
+extern "C" psfm_status psfm_shard_solve_writeback(psfm_ctx* c, int frame, const psfm_solve_stats* stats, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    if (stats && stats->termination >= 0) c->solve_stats.push_back(*stats);
+    return psfm_solve_writeback(c, *c->shard_dims, frame, (hipStream_t)stream);
+}
+
+// a fused solve that finished in its launch: nothing to copy (the next chain step / the final flush picks the iterate up)
+extern "C" psfm_status psfm_shard_solve_record(psfm_ctx* c, const psfm_solve_stats* stats)
+{
+    if (!c || !stats) { psfm_set_error("psfm_shard_solve_record: NULL argument"); return PSFM_ERR_ARG; }
+    if (stats->termination >= 0) c->solve_stats.push_back(*stats);
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_shard_finish(psfm_ctx* c, psfm_track_info* info, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    hipStream_t s = (hipStream_t)stream;
+    const PsfmTrackDims d = *c->shard_dims;
+    delete c->shard_dims;
+    c->shard_dims = nullptr;
+    psfm_status st;
+    if (c->shard_optimize && d.n_flows >= 2 && (st = psfm_solve_flush(c, d, d.n_flows - 1, s)) != PSFM_OK) return st;
+    if ((st = psfm_finalize(c, d, s)) != PSFM_OK) return st;
+    PSFM_HIP(hipStreamSynchronize(s));
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->n_traj = c->res_n_traj;
+        info->n_points = c->res_n_points;
+        info->n_lanes_peak = ((PsfmCounters*)c->host_pinned)->n_lanes;
+        info->lane_capacity = d.cap;
+        info->n_solves = (int32_t)c->solve_stats.size();
+        for (auto& q : c->solve_stats) info->solver_iterations += q.iterations;
+        info->chain_mode = 1;
+    }
+    return PSFM_OK;
+}

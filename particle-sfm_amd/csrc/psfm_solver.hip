@@ -94,6 +94,10 @@ struct PcParams {
     double* gpart;            // [groups][PC_KMAX][PC_NSUM] sums of PC_GROUP consecutive blocks
     unsigned* gticket;        // [groups] + 1 (top)
     int* sel;                 // PsfmCounters::sel: buffer that holds the accepted iterate of the last solve (0: the log)
+    // track-sharded runs: the tracks of the solve are spread over several processes.  A launch then only EXPORTS its sums
+    // ([K or 1][PC_NSUM], this process's tracks); the ranks combine them (all-gather, rank order) and every rank runs the
+    // same control step on the totals (psfm_pc_control_kernel)
+    double* export_sums;
 };
 
 __device__ __forceinline__ double2* pc_buf1(const PcParams& P, int m) { return m == 0 ? P.x1a : P.xs + (int64_t)(2 * m - 2) * P.xs_stride; }
@@ -383,7 +387,7 @@ __device__ __forceinline__ void pc_track_iteration(const PcParams& P, const doub
 // (force-inlined: as a called function it dragged the call ABI's register budget into the kernels -- 248 VGPRs,
 // 2 waves/SIMD -- although the per-track code needs 152)
 __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
-                                                      int is_init);
+                                                      int is_init, double* export_sums);
 
 // Publish this block's partials and find out whether it is the last one to finish: write-through payload ->
 // drain -> ticket (device-scope atomic); the last block reads the payload with cache-bypassing loads.
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
         acc[SUM_COST0] += c_at_x;
     }
     pc_block_reduce(acc, P.partials);
-    if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1);
+    if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1, P.export_sums);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
     const bool last_block = pc_is_last_block(P.ticket);
     PC_TL(2);
     if (last_block) {
-        pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 0);
+        pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 0, P.export_sums);
         PC_TL(3);
 #ifdef PSFM_TIMELINE
         if (threadIdx.x == 0 && tl_slot >= 0) { g_pc_tl[((size_t)tl_slot * 1024 + 1023) * 4 + 0] = blockIdx.x; g_pc_tl_n = tl_slot + 1; }
@@ -638,7 +642,7 @@ __device__ __forceinline__ void pc_control_step(PsfmSolveCtrl& C, const double* 
 // release; the reading block acquires before touching the other blocks' partials -- cdna_hip_programming.md G16):
 // fixed-order reduction of the per-block partials, then the scalar control step on thread 0.
 __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
-                                                      int is_init)
+                                                      int is_init, double* export_sums)
 {
     // Fixed-order reduction of partials[n_blocks][PC_NSUM]: thread t owns slot (t % 16) of the block rows
     // t/16, t/16 + 16, ...; its loads are independent (issued back to back), summed in increasing row order; the 16
@@ -674,6 +678,10 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
         }
         __syncthreads();
     }
+    if (export_sums) {
+        if (threadIdx.x < PC_NSUM) export_sums[threadIdx.x] = s_tot[threadIdx.x];
+        return;
+    }
     if (threadIdx.x != 0) return;
     PsfmSolveCtrl C = *ctrl;
     pc_control_step(C, s_tot, is_init, is_init ? 1 : pc_other(C.cur));   // (init: the candidate of iteration 1 is in buffer 1)
@@ -695,6 +703,39 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
 // copies it into the log on its way); anything else (rejection, dogleg interpolation, invalid step, more than K
 // iterations) raises the stall flag and the host redoes this solve with the launch chain from the untouched buffer 0.
 // ------------------------------------------------------------------------------------------------
+// Ceres' control flow replayed over the sums of the K speculated iterations (thread 0 of the last block, or the control
+// kernel of a track-sharded run): tot[j * PC_NSUM + k].
+__device__ __forceinline__ void pc_fused_replay(const PcParams& P, const double* tot, int K)
+{
+    const int e = K - 1;
+#define PC_PHYS(m) ((m) == e ? 0 : ((m) == 0 ? e : (m)))
+    PsfmSolveCtrl C = *P.ctrl;
+    for (int j = 1; j <= K; ++j) {
+        pc_control_step(C, tot + (j - 1) * PC_NSUM, j == 1, j);
+        if (C.done) break;
+        // iteration j + 1 was computed at buffer j with the Gauss-Newton step at min_mu: only valid behind an accepted step
+        if (!(C.fresh_x && C.cur == j && C.dl_fixed == 0 && C.mu == 1e-8)) break;
+    }
+    C.launches += 1;
+    *P.ctrl = C;
+    if (!C.done) {      // not what was speculated: the launch chain redoes this solve from the values it started from,
+        *P.sel = PC_PHYS(0);   // which psfm_solve_frame_resume first moves back into buffer 0
+        *P.stall = P.frame + 1;
+        return;
+    }
+    // (a failed solve hands the parameters back as they came in: nothing was accepted, C.cur == 0 -- see the write-back)
+    *P.sel = PC_PHYS(C.cur);
+#undef PC_PHYS
+    if (P.stats_dev) {
+        psfm_solve_stats st;
+        st.iterations = C.iteration; st.successful_steps = C.successful;
+        st.termination = C.n_tracks == 0 ? -1 : C.termination; st.dogleg_nonGN = C.nonGN;
+        st.initial_cost = C.initial_cost; st.final_cost = C.x_cost;
+        if (C.failed) st.termination = PSFM_TERM_FAILURE;
+        P.stats_dev[P.frame] = st;
+    }
+}
+
 struct PcTrack {            // one track's solve state in registers
     double x[4], r[6], jac[4];
     double2 r1, r2;
@@ -941,32 +982,31 @@ void psfm_pc_fused_kernel(PcParams P)
         }
         __syncthreads();
     }
-    if (tid != 0) return;
-    PsfmSolveCtrl C = *P.ctrl;
-    for (int j = 1; j <= K; ++j) {
-        pc_control_step(C, s_tot[j - 1], j == 1, j);
-        if (C.done) break;
-        // iteration j + 1 was computed at buffer j with the Gauss-Newton step at min_mu: only valid behind an accepted step
-        if (!(C.fresh_x && C.cur == j && C.dl_fixed == 0 && C.mu == 1e-8)) break;
-    }
-    C.launches += 1;
-    *P.ctrl = C;
-    if (!C.done) {      // not what was speculated: the launch chain redoes this solve from the values it started from,
-        *P.sel = PC_PHYS(0);   // which psfm_solve_frame_resume first moves back into buffer 0
-        *P.stall = P.frame + 1;
+    if (P.export_sums) {      // track-sharded: the totals of THIS process; the control step follows the ranks' exchange
+        if (tid < nslot) P.export_sums[tid] = s_tot[tid / PC_NSUM][tid % PC_NSUM];
         return;
     }
-    // (a failed solve hands the parameters back as they came in: nothing was accepted, C.cur == 0 -- see the write-back)
-    *P.sel = PC_PHYS(C.cur);
+    if (tid != 0) return;
+    pc_fused_replay(P, &s_tot[0][0], K);
+}
+
 #undef PC_PHYS
-    if (P.stats_dev) {
-        psfm_solve_stats st;
-        st.iterations = C.iteration; st.successful_steps = C.successful;
-        st.termination = C.n_tracks == 0 ? -1 : C.termination; st.dogleg_nonGN = C.nonGN;
-        st.initial_cost = C.initial_cost; st.final_cost = C.x_cost;
-        if (C.failed) st.termination = PSFM_TERM_FAILURE;
-        P.stats_dev[P.frame] = st;
+
+// Track-sharded runs: the control step on the totals over all ranks (every rank runs it on the same numbers).
+// mode 0: replay over the K iterations of a fused launch; 1 / 2: one step behind pc_init / pc_iter.
+__global__ void psfm_pc_control_kernel(PcParams P, const double* totals, int K, int mode)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (mode == 0) {
+        if (*P.stall) return;
+        pc_fused_replay(P, totals, K);
+        return;
     }
+    PsfmSolveCtrl C = *P.ctrl;
+    if (mode == 2 && C.done) return;
+    pc_control_step(C, totals, mode == 1, mode == 1 ? 1 : pc_other(C.cur));
+    C.launches += 1;
+    *P.ctrl = C;
 }
 
 // Copy the accepted iterate of the last fused solve from buffer *sel into the log (what the next chain step does on
@@ -1212,6 +1252,87 @@ psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const fl
     c->prof.kernel_span(PSFM_PROF_SOLVER, &e0, &e1, true);   // (profiling on: exact begin / end of every fused launch)
     if (waves == 3) hipExtLaunchKernelGGL(psfm_pc_fused_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, e0, e1, 0, P);
     else hipExtLaunchKernelGGL(psfm_pc_fused_kernel<4>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, e0, e1, 0, P);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// ---- track-sharded runs (psfm_shard.hip): one launch of the solve of `frame` that only exports its sums
+//      (kind 0 fused with K iterations, 1 pc_init, 2 pc_iter), the control step on the combined totals, the write-back ----
+psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
+                              const uint8_t* occ02, int frame, int kind, int K, double* sums_out, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    P.export_sums = sums_out;
+    if (kind == 0) {
+        const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+        const int n_groups = (n_blocks + PC_GROUP - 1) / PC_GROUP;
+        if ((rc = c->sol_partials.ensure(sizeof(double) * (size_t)n_blocks * PC_KMAX * PC_NSUM)) != PSFM_OK) return rc;
+        const size_t tbytes = 4096 * sizeof(unsigned), gbytes = sizeof(double) * (size_t)n_groups * PC_KMAX * PC_NSUM;
+        if (n_groups + 1 > 4096) { psfm_set_error("lane table too large for the fused solve"); return PSFM_ERR_ARG; }
+        void* before = c->sol_fused.p;
+        if ((rc = c->sol_fused.ensure(tbytes + gbytes)) != PSFM_OK) return rc;
+        if (c->sol_fused.p != before) PSFM_HIP(hipMemsetAsync(c->sol_fused.p, 0, tbytes, s));
+        P.partials = c->sol_partials.as<double>();
+        P.gticket = c->sol_fused.as<unsigned>();
+        P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
+        P.K = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
+        hipLaunchKernelGGL(psfm_pc_fused_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    } else {
+        const int n_blocks = pc_blocks((int)d.cap);
+        if (kind == 1) hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+        else hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    }
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+psfm_status psfm_solve_control(psfm_ctx* c, const PsfmTrackDims& d, int frame, int kind, int K, const double* totals, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, nullptr, nullptr, nullptr, nullptr, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    hipLaunchKernelGGL(psfm_pc_control_kernel, dim3(1), dim3(64), 0, s, P, totals, K, kind);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// solver state after a control step: done flag, stall flag, statistics (synchronises)
+psfm_status psfm_solve_state(psfm_ctx* c, int* done, int* stall, psfm_solve_stats* st, hipStream_t s)
+{
+    PsfmSolveCtrl* hctrl = (PsfmSolveCtrl*)((char*)c->host_pinned + 512 + sizeof(PsfmShard) * PSFM_NSHARD);
+    PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
+    PSFM_HIP(hipMemcpyAsync(hctrl, c->sol_ctrl.p, sizeof(PsfmSolveCtrl), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    if (done) *done = hctrl->done;
+    if (stall) *stall = hc->stall;
+    if (st) pc_fill_stats(hctrl, st);
+    if (st && hctrl->failed) st->termination = PSFM_TERM_FAILURE;
+    return PSFM_OK;
+}
+
+// redo of a fused solve that gave up: the values it started from back into the log, stall flag cleared
+psfm_status psfm_solve_restore(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, nullptr, nullptr, nullptr, nullptr, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    PSFM_HIP(hipMemsetAsync(P.stall, 0, sizeof(int), s));
+    const int nb = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+    hipLaunchKernelGGL(psfm_pc_flush_kernel, dim3(nb), dim3(PC_BLOCK), 0, s, P);
+    hipLaunchKernelGGL(psfm_pc_clear_sel_kernel, dim3(1), dim3(1), 0, s, P.sel, (const int*)P.stall);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, nullptr, nullptr, nullptr, nullptr, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(pc_blocks((int)d.cap)), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }

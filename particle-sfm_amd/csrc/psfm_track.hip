@@ -147,7 +147,7 @@ psfm_status psfm_launch_grid_sample(const float* map, int c, int h, int w, const
 // ------------------------------------------------------------------------------------------------
 // init: frame-0 births on the full stride-r grid (trajectory.py:108,110-120; track.py:33-35)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap, int64_t G, int GW, int ratio,
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap, int64_t G, int64_t g0, int GW, int ratio,
                                                                      int* __restrict__ birth_frame,
                                                                      int* __restrict__ birth_idx,
                                                                      double2* __restrict__ log0,
@@ -158,10 +158,11 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
     if (i == 0) { ctr->n_lanes = (int)G; ctr->overflow = 0; ctr->stall = 0; ctr->sel = 0; }
     if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; shards[i].points = (i == 0) ? (unsigned)G : 0u; }
     if (i >= cap) return;
-    if (i < G) {
+    if (i < G) {   // (G = the grid points this process owns, [g0, g0 + G): the whole grid unless track-sharded)
+        const int64_t g = g0 + i;
         birth_frame[i] = 0;
-        birth_idx[i] = (int)i;
-        log0[i] = make_double2((double)((int)(i % GW) * ratio), (double)((int)(i / GW) * ratio));
+        birth_idx[i] = (int)g;
+        log0[i] = make_double2((double)((int)(g % GW) * ratio), (double)((int)(g / GW) * ratio));
     } else {
         birth_frame[i] = -1;
     }
@@ -169,10 +170,11 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
 
 psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
 {
-    PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.G * 2, s));
+    if (!d.shard_maps) PSFM_HIP(hipMemsetAsync(c->occupied.p, 0, (size_t)d.G * 2, s));
+    else PSFM_HIP(hipMemsetAsync(d.shard_maps, 0, (size_t)d.shard_pitch * 2, s));
     PSFM_HIP(hipMemsetAsync(c->survivors.p, 0, sizeof(int) * (size_t)(d.n_flows + 1), s));
     hipLaunchKernelGGL(psfm_track_init_kernel, dim3((unsigned)((d.cap + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
-                       0, s, d.cap, d.G, d.GW, d.ratio, c->birth_frame.as<int>(), c->birth_idx.as<int>(),
+                       0, s, d.cap, d.shard_maps ? d.Gband : d.G, d.shard_maps ? d.g0 : (int64_t)0, d.GW, d.ratio, c->birth_frame.as<int>(), c->birth_idx.as<int>(),
                        c->log.as<double2>(), c->counters.as<PsfmCounters>(), c->shards.as<PsfmShard>());
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
@@ -225,6 +227,10 @@ struct PsfmChainArgs {
     // (times frame-1, frame) in iterate buffer ctr->sel (0: already in the log); this launch moves them into the log
     // slabs on its way and steps from them
     double2* log_prev; const double2* xs; int64_t xs_stride;
+    // track-sharded runs (psfm_shard_*): this process owns the births on grid points [g0, g0 + Gband) -- thread i tests
+    // grid point g0 + i -- and the "a track survived" flag travels as byte G of the blocked maps (stamped like them), so
+    // that ONE all-reduce(max) of G + 1 bytes per frame carries everything the ranks owe each other
+    int g0, Gband, shard;
 };
 
 #ifndef PSFM_CHAIN_BLOCK
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
     const int sel = OPT ? a.ctr->sel : 0;   // (same cache line as `stall`)
     // tiles past both the lane high-water mark and the grid have nothing to do (lanes handed out during
     // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
-    if (tile >= max(a.ctr->n_lanes, a.G)) return;
+    if (tile >= max(a.ctr->n_lanes, a.Gband)) return;
     if (tid == 0) s_alive_any = 0;
 
     // ---- independent early loads: lane state, (speculative) tail position, respawn byte ----
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
     bool birth[PSFM_LPT], live[PSFM_LPT], pend[PSFM_LPT];
     int pend_idx[PSFM_LPT];
     unsigned long long bm[PSFM_LPT], pm[PSFM_LPT];
-    const int surv_prev = (frame > 0) ? *a.surv_prev : 1;
+    const int surv_prev = (frame > 0) ? (a.shard ? (int)(psfm_ld(a.blocked_prev, (unsigned)a.G) == a.stamp_prev) : *a.surv_prev) : 1;
 #pragma unroll
     for (int u = 0; u < PSFM_LPT; ++u) {
         const int i = tile + u * PSFM_CHAIN_BLOCK + tid;
@@ -312,13 +318,14 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
             sx2[u] = a.xs[(int64_t)(2 * sel - 1) * a.xs_stride + i];
         }
         birth[u] = false;
-        if (frame > 0 && i < a.G) {
+        if (frame > 0 && i < a.Gband) {
+            const int g = a.g0 + i;
             if (surv_prev == 0) {
-                const int gy = (int)psfm_fastdiv((unsigned)i, a.gwdiv), gx = i - gy * a.GW;
+                const int gy = (int)psfm_fastdiv((unsigned)g, a.gwdiv), gx = g - gy * a.GW;
                 const int cx = gx * ratio, cy = gy * ratio;
                 birth[u] = ((cy + 1) * (cy + 1) + cx * cx) > ratio * ratio;
             } else {
-                birth[u] = psfm_ld(a.blocked_prev, (unsigned)i) != a.stamp_prev;
+                birth[u] = psfm_ld(a.blocked_prev, (unsigned)g) != a.stamp_prev;
             }
         }
     }
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
         pm[u] = __ballot(pend[u]);
         const int seg = u * PSFM_CHAIN_NW + wave;
         if (lane == 0) { s_births[seg] = __popcll(bm[u]); s_pend[seg] = __popcll(pm[u]); }
-        if (birth[u]) s_new_g[seg * PSFM_WAVE + psfm_rank_in(bm[u])] = i;
+        if (birth[u]) s_new_g[seg * PSFM_WAVE + psfm_rank_in(bm[u])] = a.g0 + i;
         if (pend[u]) s_pend_lane[seg * PSFM_WAVE + psfm_rank_in(pm[u])] = i;
     }
 
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
     }
     PSFM_TL(5);
     __syncthreads();
-    if (tid == 0 && s_alive_any) *a.surv_cur = 1;
+    if (tid == 0 && s_alive_any) { if (a.shard) a.blocked_cur[a.G] = a.stamp_cur; else *a.surv_cur = 1; }
     PSFM_TL(6);
 }
 
@@ -566,17 +573,19 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
     a.log_next = lg + (int64_t)(frame + 1) * d.cap;
     a.birth_frame = c->birth_frame.as<int>(); a.birth_idx = c->birth_idx.as<int>();
     // blocked maps / free stacks / shard tables are double-buffered by frame parity; stamps wrap every 254 frames
-    uint8_t* maps = c->occupied.as<uint8_t>();
+    uint8_t* maps = d.shard_maps ? d.shard_maps : c->occupied.as<uint8_t>();
+    const int64_t pitch = d.shard_maps ? d.shard_pitch : d.G;
     const int cur = frame & 1, prev = cur ^ 1;
-    a.blocked_cur = maps + (int64_t)cur * d.G;
-    a.blocked_prev = maps + (int64_t)prev * d.G;
+    a.blocked_cur = maps + (int64_t)cur * pitch;
+    a.blocked_prev = maps + (int64_t)prev * pitch;
+    a.g0 = d.shard_maps ? (int)d.g0 : 0; a.Gband = d.shard_maps ? (int)d.Gband : (int)d.G; a.shard = d.shard_maps ? 1 : 0;
     a.stamp_cur = (uint8_t)((frame % 254) + 1);
     a.stamp_prev = (uint8_t)(((frame + 253) % 254) + 1);
     if (frame > 1 && (frame % 254) <= 1) {
         // the map about to be written last saw this stamp value 254 frames ago: clear it (with a kernel that
         // honours the stall flag -- a memset would also run for launches that are going to be re-enqueued)
-        hipLaunchKernelGGL(psfm_clear_map_kernel, dim3((unsigned)((d.G + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
-                           0, s, c->counters.as<PsfmCounters>(), a.blocked_cur, (int)d.G);
+        hipLaunchKernelGGL(psfm_clear_map_kernel, dim3((unsigned)((d.G + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
+                           0, s, c->counters.as<PsfmCounters>(), a.blocked_cur, (int)d.G + (d.shard_maps ? 1 : 0));
     }
     a.surv_prev = c->survivors.as<int>() + (frame > 0 ? frame - 1 : 0);
     a.surv_cur = c->survivors.as<int>() + frame;

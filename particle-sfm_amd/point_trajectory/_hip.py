@@ -19,6 +19,8 @@ EXPORTS = [
     "psfm_result_device", "psfm_result_copy", "psfm_result_solve_stats", "psfm_ctx_set_profiling",
     "psfm_profile_get", "psfm_ctx_set_chain_mode", "psfm_window_sample", "psfm_result_filter", "psfm_result_filtered_copy",
     "psfm_ctx_set_solver", "psfm_solver_counters", "psfm_traj_to_matches", "psfm_matches_copy",
+    "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
+    "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish",
 ]
 
 
@@ -85,6 +87,15 @@ def lib():
                                      ctypes.POINTER(i64), vp]
     L.psfm_traj_to_matches.argtypes = [vp, i32, i32, vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64), vp]
     L.psfm_matches_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.psfm_shard_begin.argtypes = [vp, i32, i32, i32, i32, i64, i64, i32, vp, i64, vp]
+    L.psfm_shard_step.argtypes = [vp, vp, vp, i32, vp]
+    L.psfm_shard_solve_export.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.psfm_shard_solve_control.argtypes = [vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                           ctypes.POINTER(SolveStats), vp]
+    L.psfm_shard_solve_restore.argtypes = [vp, i32, vp]
+    L.psfm_shard_solve_writeback.argtypes = [vp, i32, ctypes.POINTER(SolveStats), vp]
+    L.psfm_shard_solve_record.argtypes = [vp, ctypes.POINTER(SolveStats)]
+    L.psfm_shard_finish.argtypes = [vp, ctypes.POINTER(TrackInfo), vp]
     L.psfm_profile_get.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(i64)]
     for name in EXPORTS:
         if name != "psfm_last_error":

@@ -1,0 +1,105 @@
+"""This rank's share of a track-sharded run on its GPU: the engine psfm_dist.connect_sharded drives (one process per GPU,
+RCCL over xGMI).  Everything computes in libpsfm_hip.so (psfm_shard_* in include/psfm.h); this class only owns the two
+exchange tensors -- the stamped grid-resolution `blocked` maps (+ survivor byte) and the solver sums -- because they must
+be torch tensors for torch.distributed, and sequences the export -> reduce -> control steps of a solve.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _hip
+
+SUM_GMAX, N_SUM, K_MAX = 5, 13, 8          # csrc/psfm_solver.hip: slot combined by max, sums per iteration, fused iterations
+
+
+class HipShardEngine:
+    def __init__(self, ctx=None, k=4):
+        self.ctx = ctx or _hip.context()
+        self.k = int(k)                    # iterations speculated per fused solve; follows what the sequence needs
+        self.counters = {"fused": 0, "fused_redone": 0}
+
+    @property
+    def device(self):
+        import torch
+        return torch.device("cuda", self.ctx.device)
+
+    def _sp(self):
+        return _hip.current_stream_ptr(self.ctx.device)
+
+    def begin(self, n_flows, H, W, ratio, g0, g1, optimize):
+        import torch
+        self.G = ((W + ratio - 1) // ratio) * ((H + ratio - 1) // ratio)
+        self.pitch = (self.G + 1 + 255) // 256 * 256
+        self.maps = torch.zeros(2 * self.pitch, dtype=torch.uint8, device=self.device)
+        self.sums = torch.zeros(K_MAX * N_SUM, dtype=torch.float64, device=self.device)
+        self.n_flows, self.optimize = int(n_flows), bool(optimize)
+        _hip.check(_hip.lib().psfm_shard_begin(self.ctx.handle, int(n_flows), int(H), int(W), int(ratio), int(g0), int(g1),
+                                               1 if optimize else 0, _hip.ptr(self.maps), self.pitch, self._sp()))
+
+    def step(self, t, flow, occ):
+        """births of frame t on the own band + chain step; returns the tensor the ranks all-reduce (max)"""
+        assert flow.is_cuda and flow.is_contiguous() and occ.is_contiguous()
+        _hip.check(_hip.lib().psfm_shard_step(self.ctx.handle, _hip.ptr(flow), _hip.ptr(occ), int(t), self._sp()))
+        o = (int(t) & 1) * self.pitch
+        return self.maps[o:o + self.G + 1]
+
+    def after_exchange(self, t, x):
+        pass          # the reduced map is the buffer the next chain step reads
+
+    def _control(self, t, kind, k):
+        done, redo, st = ctypes.c_int32(0), ctypes.c_int32(0), _hip.SolveStats()
+        _hip.check(_hip.lib().psfm_shard_solve_control(self.ctx.handle, int(t), kind, k, _hip.ptr(self.sums), ctypes.byref(done),
+                                                       ctypes.byref(redo), ctypes.byref(st), self._sp()))
+        return bool(done.value), bool(redo.value), st
+
+    def solve(self, t, flow_prev, flow_cur, flow2_prev, occ2_prev, reduce):
+        """track_optimize.py:49-50 for the own tracks: fused export -> sums over the ranks -> control; the launch chain
+        (one export / reduce / control per trust-region iteration) redoes a solve that did not go as speculated."""
+        L, h = _hip.lib(), self.ctx.handle
+        p = (_hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ2_prev))
+        k = max(1, min(K_MAX, self.k))
+        mask = [(i % N_SUM) == SUM_GMAX for i in range(k * N_SUM)]
+        _hip.check(L.psfm_shard_solve_export(h, *p, int(t), 0, k, _hip.ptr(self.sums), self._sp()))
+        reduce(self.sums[:k * N_SUM], mask)
+        done, redo, st = self._control(t, 0, k)
+        if not redo:
+            assert done
+            _hip.check(L.psfm_shard_solve_record(h, ctypes.byref(st)))
+            self.counters["fused"] += 1
+        else:
+            self.counters["fused_redone"] += 1
+            _hip.check(L.psfm_shard_solve_restore(h, int(t), self._sp()))
+            kind, n = 1, 0
+            while True:
+                _hip.check(L.psfm_shard_solve_export(h, *p, int(t), kind, 1, _hip.ptr(self.sums), self._sp()))
+                reduce(self.sums[:N_SUM], mask[:N_SUM])
+                done, _, st = self._control(t, kind, 1)
+                if done:
+                    break
+                kind, n = 2, n + 1
+                if n > 2 * 200 + 64:
+                    raise RuntimeError("path-consistency solver did not terminate")
+            _hip.check(L.psfm_shard_solve_writeback(h, int(t), ctypes.byref(st), self._sp()))
+        # the next solve speculates what this one needed (same statistics, same choice on every rank)
+        clean = st.dogleg_nonGN == 0 and st.termination != 5 and (st.iterations == st.successful_steps + 1 or
+                                                                  (st.termination == 2 and st.iterations == st.successful_steps))
+        if st.termination >= 0 and clean:
+            need = min(K_MAX, st.successful_steps + 1)
+            self.k = need if need > self.k else max(need, self.k - 1)
+
+    def finish(self):
+        from .trajectory import _result_to_host
+        info = _hip.TrackInfo()
+        _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
+        R = _result_to_host(self.ctx, info)
+        return R.birth, R.length, R.off, R.xy, R.solve_stats
+
+
+def flow_check_slice(f, b, thres):
+    """check_fn for psfm_dist.flow_check_sharded on the GPU: (k,H,W) uint8 maps of a slice of frame pairs."""
+    import torch
+    from .utils import flow_check_device
+    if f.shape[0] == 0:
+        return torch.zeros((0,) + tuple(f.shape[1:3]), dtype=torch.uint8, device=f.device)
+    _, occ = flow_check_device(f.contiguous(), b.contiguous(), thres)
+    return occ.to(torch.uint8)

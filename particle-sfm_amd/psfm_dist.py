@@ -21,6 +21,50 @@ What shards exactly:
 import numpy as np
 
 
+class TorchComm:
+    """The collectives connect_sharded needs, over torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, gloo
+    on CPU).  Tests that emulate several ranks inside one process pass an object with the same five members."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.gpu_only = self.on and dist.get_backend(group) == "nccl"      # RCCL moves device memory only
+
+    def all_reduce_max_(self, t):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def all_gather_flat(self, t):
+        """(n,) tensor -> (world * n,) tensor, rank-major."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return t.reshape(-1).clone()
+        host = self.gpu_only and not t.is_cuda
+        if host:
+            t = t.cuda()
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous().reshape(-1), group=self.group)
+        return out.cpu() if host else out
+
+    def all_gather_object(self, obj):
+        import torch.distributed as dist
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+
+def _comm(comm, group=None):
+    return comm if comm is not None else TorchComm(group)
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced slice [lo, hi) of n_items for `rank` of `world` (first n_items % world ranks get one more)."""
     base, extra = divmod(int(n_items), int(world))
@@ -53,7 +97,7 @@ def unpack_bits(packed, H, W):
     return bits.reshape(packed.shape[0], -1)[:, :H * W].reshape(-1, H, W)
 
 
-def flow_check_sharded(flows_f, flows_b, thres, check_fn, group=None):
+def flow_check_sharded(flows_f, flows_b, thres, check_fn, group=None, comm=None):
     """Frame-pair-sharded flow_check with an all-gather stitch.
 
     flows_f / flows_b: (n,H,W,2) tensors present on every rank (or at least this rank's slice valid);
@@ -61,9 +105,8 @@ def flow_check_sharded(flows_f, flows_b, thres, check_fn, group=None):
     point_trajectory.utils.flow_check_device; in the CPU tests: the oracle).  Returns the full (n,H,W) uint8 stack
     on every rank."""
     import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    comm = _comm(comm, group)
+    world, rank = comm.world, comm.rank
     n, H, W = int(flows_f.shape[0]), int(flows_f.shape[1]), int(flows_f.shape[2])
     lo, hi = shard_range(n, rank, world)
     mine = check_fn(flows_f[lo:hi], flows_b[lo:hi], thres) if hi > lo else torch.zeros((0, H, W), dtype=torch.uint8,
@@ -75,8 +118,7 @@ def flow_check_sharded(flows_f, flows_b, thres, check_fn, group=None):
     buf = torch.zeros((per, nbytes), dtype=torch.uint8, device=mine.device)
     if hi > lo:
         buf[:hi - lo] = pack_bits(mine)
-    out = torch.empty((world * per, nbytes), dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
+    out = comm.all_gather_flat(buf.reshape(-1)).reshape(world * per, nbytes)
     parts = []
     for r in range(world):
         l, h = shard_range(n, r, world)
@@ -105,19 +147,17 @@ def band_range(grid_h, grid_w, rank, world):
     return lo * int(grid_w), hi * int(grid_w)
 
 
-def make_reduce(group=None):
+def make_reduce(group=None, comm=None):
     """reduce(vals, is_max): vals (1-D float64 tensor) = this rank's part on entry, the value over all ranks on return.
     One all-gather; sums are added in rank order on every rank, so every rank holds the same bits."""
     import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    comm = _comm(comm, group)
+    world = comm.world
 
     def reduce(vals, is_max):
         if world == 1:
             return vals
-        flat = torch.empty(world * vals.numel(), dtype=vals.dtype, device=vals.device)
-        dist.all_gather_into_tensor(flat, vals.contiguous().reshape(-1), group=group)
-        parts = flat.reshape((world,) + tuple(vals.shape))
+        parts = comm.all_gather_flat(vals.reshape(-1)).reshape((world,) + tuple(vals.shape))
         mx = torch.as_tensor(is_max, dtype=torch.bool, device=vals.device)
         tot = parts[0].clone()
         for r in range(1, world):
@@ -127,83 +167,73 @@ def make_reduce(group=None):
     return reduce
 
 
-def global_ids(birth, length, first_xy, n_flows, ratio, grid_w, group=None):
+def global_ids(birth, length, first_xy, n_flows, ratio, grid_w, group=None, comm=None):
     """Ids of this rank's trajectories in the order of the single-process run: rank of the key (last valid time, birth
     frame, birth grid index) among the keys of all ranks (SURVEY a-17: dead tracks by frame, then the still active ones,
     each group in active-list order = (birth frame, grid index)).  Returns (ids int64, total number of trajectories)."""
     import torch
-    import torch.distributed as dist
+    comm = _comm(comm, group)
     birth = np.asarray(birth, np.int64)
     last = birth + np.asarray(length, np.int64) - 1
     gidx = (np.asarray(first_xy[:, 1], np.int64) // ratio) * int(grid_w) + np.asarray(first_xy[:, 0], np.int64) // ratio
     key = (last << 51) | (birth << 40) | gidx                   # 11 + 11 + 40 bits
     assert n_flows + 2 < (1 << 11) and (len(key) == 0 or (np.diff(key) > 0).all()), "local trajectories must come in key order"
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world = comm.world
     if world == 1:
         return np.arange(len(key), dtype=np.int64), len(key)
-    cnt = torch.tensor([len(key)], dtype=torch.int64)
-    cnts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    nmax = max(int(c.item()) for c in cnts)
-    pad = torch.full((max(nmax, 1),), np.iinfo(np.int64).max, dtype=torch.int64)
+    cnts = comm.all_gather_flat(torch.tensor([len(key)], dtype=torch.int64)).tolist()
+    nmax = max(max(cnts), 1)
+    pad = torch.full((nmax,), np.iinfo(np.int64).max, dtype=torch.int64)
     pad[:len(key)] = torch.from_numpy(key)
-    allk = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(allk, pad, group=group)
+    allk = comm.all_gather_flat(pad).reshape(world, nmax).numpy()
     ids = np.zeros(len(key), np.int64)
     for r in range(world):
-        ids += np.searchsorted(allk[r][:int(cnts[r].item())].numpy(), key, side="left")
-    return ids, int(sum(int(c.item()) for c in cnts))
+        ids += np.searchsorted(allk[r][:cnts[r]], key, side="left")
+    return ids, int(sum(cnts))
 
 
-def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, check_fn, group=None):
+def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, check_fn, group=None, comm=None):
     """main_connect_point_trajectories.py:36-53 for ONE sequence on all ranks of `group`, exactly.
 
     flows_*: (n,H,W,2) float32 tensors on every rank (flows_f2 / flows_b2 None: track() instead of track_optimize());
     check_fn(f, b, thres) -> (k,H,W) uint8: flow_check of a slice (Stage A, frame-pair shards + all-gather);
     engine: this rank's share of the recurrence -- point_trajectory.shard.HipShardEngine on a GPU (RCCL),
-    oracle.ShardEngine in the CPU tests (gloo):
+    the engine of the CPU oracle in the gloo tests:
         begin(n_flows, H, W, ratio, g0, g1, optimize)
         step(t, flow_t, occ_t) -> uint8 tensor (G marks of this rank's survivors + 1 survivor byte), exchanged here
         after_exchange(t, x); solve(t, flow_{t-1}, flow_t, flow2_{t-1}, occ2_{t-1}, reduce); finish() -> CSR + stats
     Returns {"birth","length","off","xy": this rank's trajectories; "ids": their ids in the single-process order;
     "n_traj": trajectories over all ranks; "solve_stats"; "occ","occ2"}."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    comm = _comm(comm, group)
+    world, rank = comm.world, comm.rank
     optimize = flows_f2 is not None
     n_flows, H, W = int(flows_f.shape[0]), int(flows_f.shape[1]), int(flows_f.shape[2])
     r = int(sample_ratio)
     GW, GH = (W + r - 1) // r, (H + r - 1) // r
     # ---- Stage A: occlusion maps, frame-pair shards + one all-gather per stack ----
-    occ = flow_check_sharded(flows_f, flows_b, thres, check_fn, group)
-    occ2 = flow_check_sharded(flows_f2, flows_b2, thres, check_fn, group) if optimize and flows_f2.shape[0] > 0 else None
+    occ = flow_check_sharded(flows_f, flows_b, thres, check_fn, comm=comm)
+    occ2 = flow_check_sharded(flows_f2, flows_b2, thres, check_fn, comm=comm) if optimize and flows_f2.shape[0] > 0 else None
     # ---- Stage B: the recurrence, tracks split by birth row band ----
     g0, g1 = band_range(GH, GW, rank, world)
     engine.begin(n_flows, H, W, r, g0, g1, optimize)
-    reduce = make_reduce(group)
+    reduce = make_reduce(comm=comm)
     for t in range(n_flows):
         x = engine.step(t, flows_f[t], occ[t])                               # track.py:33-47 for the own tracks
-        if world > 1:
-            dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)            # marks of every rank's survivors
+        comm.all_reduce_max_(x)                                              # marks of every rank's survivors
         engine.after_exchange(t, x)
         if optimize and t + 1 >= 2:                                          # track_optimize.py:49-50
             engine.solve(t, flows_f[t - 1], flows_f[t], flows_f2[t - 1], occ2[t - 1], reduce)
     birth, length, off, xy, stats = engine.finish()
     first = xy[off[:-1]] if len(birth) else np.zeros((0, 2))
-    ids, n_traj = global_ids(birth, length, first, n_flows, r, GW, group)
+    ids, n_traj = global_ids(birth, length, first, n_flows, r, GW, comm=comm)
     return {"birth": birth, "length": length, "off": off, "xy": xy, "ids": ids, "n_traj": n_traj, "solve_stats": stats,
             "occ": occ, "occ2": occ2, "band": (g0, g1)}
 
 
-def gather_result(part, group=None):
+def gather_result(part, group=None, comm=None):
     """The whole sequence's CSR in id order on every rank (tests, small runs): all-gather of the per-rank parts."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    parts = [part]
-    if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, {k: part[k] for k in ("birth", "length", "off", "xy", "ids")}, group=group)
+    comm = _comm(comm, group)
+    parts = comm.all_gather_object({k: part[k] for k in ("birth", "length", "off", "xy", "ids")})
     n = part["n_traj"]
     birth = np.zeros(n, np.int32); length = np.zeros(n, np.int32)
     for p in parts:

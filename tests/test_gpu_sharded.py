@@ -1,0 +1,72 @@
+"""The exact single-sequence multi-rank mode on the GPU: psfm_dist.connect_sharded with the HIP engine
+(point_trajectory/shard.py -> psfm_shard_* in libpsfm_hip.so) against the single-process oracle.  world = 1 is the plain
+product path; world = 2, 3 run one thread per "rank" on the box's single GPU (tests/_thread_comm.py) -- same driver,
+same kernels, same exchange as one process per GPU over RCCL, whose collectives this box cannot host."""
+import numpy as np
+import pytest
+
+import psfm_synth
+from _thread_comm import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+# T, H, W, ratio, seed, sigma, occluders, optimize
+CASES = [(9, 58, 76, 2, 21, 0.3, 2, False),
+         (10, 60, 84, 2, 22, 0.05, 1, True),       # clean solves: the fused export / control path
+         (8, 45, 63, 3, 23, 0.4, 2, True),         # noisy: every solve is redone by the chain (export per iteration)
+         (7, 40, 56, 1, 24, 0.15, 1, True)]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("T,H,W,r,seed,sigma,nocc,optimize", CASES)
+def test_connect_sharded_hip_engine(world, T, H, W, r, seed, sigma, nocc, optimize):
+    import torch
+    import psfm_dist
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    from point_trajectory.shard import HipShardEngine, flow_check_slice
+    d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=True)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stack = {k: torch.from_numpy(np.stack(d[k])).to(dev) for k in ("flows_f", "flows_b", "flows_f2", "flows_b2")}
+    torch.cuda.synchronize()
+
+    def rank_fn(comm):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            try:
+                eng = HipShardEngine()
+                part = psfm_dist.connect_sharded(eng, stack["flows_f"], stack["flows_b"], stack["flows_f2"] if optimize else None,
+                                                 stack["flows_b2"] if optimize else None, 1.0, r, flow_check_slice, comm=comm)
+                full = psfm_dist.gather_result(part, comm=comm)
+                return part, full, dict(eng.counters)
+            finally:
+                _hip.release_thread_contexts()
+
+    res = run_ranks(world, rank_fn)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    if optimize:
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+        O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    else:
+        O = orc.track(d["flows_f"], occ, r)
+    GW = (W + r - 1) // r
+    n_local = 0
+    for rank, (part, (birth, length, off, xy), cnt) in enumerate(res):
+        assert len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
+        assert float(np.abs(xy - O.xy).max()) <= 1e-4
+        if not optimize:
+            assert np.array_equal(xy, O.xy)
+        assert [s["iterations"] for s in part["solve_stats"]] == [s["iterations"] for s in O.solves]
+        assert [s["termination"] for s in part["solve_stats"]] == [s["termination"] for s in O.solves]
+        g0, g1 = part["band"]
+        first = part["xy"][part["off"][:-1]]
+        gidx = (first[:, 1].astype(np.int64) // r) * GW + first[:, 0].astype(np.int64) // r
+        assert ((gidx >= g0) & (gidx < g1)).all()
+        n_local += len(part["birth"])
+        if optimize:
+            assert cnt["fused"] + cnt["fused_redone"] == len(O.solves)
+    assert n_local == O.n_traj
+    if optimize and sigma <= 0.05:
+        assert res[0][2]["fused"] >= len(O.solves) - 3          # clean sequence: (nearly) every solve in one launch
+    if optimize and sigma >= 0.4:
+        assert res[0][2]["fused_redone"] >= len(O.solves) // 2  # noisy sequence: the chain protocol did the work
