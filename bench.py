@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def cpu_baseline(flows_f, flows_b, n_pairs):
-    """The CPU oracle ("port": plain scalar C restatement of the reference path, 1 thread) on the first
-    n_pairs frame pairs of the same tensors."""
+    """The CPU oracle ("port": C restatement of the reference path, OpenMP over independent tracks / pixels with
+    OMP_NUM_THREADS or all host cores) on the first n_pairs frame pairs of the same tensors."""
     import numpy as np
     from oracle import oracle as orc
     ff = [f for f in flows_f[:n_pairs].cpu().numpy()]
@@ -40,9 +40,22 @@ def cpu_baseline(flows_f, flows_b, n_pairs):
     _, occ = orc.flow_check(ff, fb, THRES)
     R = orc.track(ff, occ, RATIO)
     dt = time.perf_counter() - t0
-    return {"value": R.n_points / dt, "unit": "trajectory-points/s", "cores": 1, "kind": "port",
-            "sample": "first %d of %d frame pairs at 1080p, sample_ratio=2: flow_check + track + id order; %d points in %.1f s"
-                      % (n_pairs, N_FRAMES - 1, R.n_points, dt)}, R
+    out = {"value": R.n_points / dt, "unit": "trajectory-points/s", "cores": orc.num_threads(), "host_cores": os.cpu_count(),
+           "kind": "port",
+           "sample": "first %d of %d frame pairs at 1080p, sample_ratio=2: flow_check + track + id order; %d points in %.1f s "
+                     "(C restatement, OpenMP over tracks / pixels; the per-track list bookkeeping of extend_all is serial)"
+                     % (n_pairs, N_FRAMES - 1, R.n_points, dt)}
+    ref = os.path.join(ROOT, "BASELINE_MEASURED.json")
+    if os.path.exists(ref):     # the reference's own Python, timed in the build container (scripts/measure_reference_baseline.py)
+        try:
+            m = json.load(open(ref))
+            out["reference_python_build_container"] = {
+                "track_points_per_s": m["track"]["points_per_s"], "track_optimize_points_per_s": m["track_optimize"]["points_per_s"],
+                "flow_check_s_per_pair": m["flow_check_s_per_pair"], "host": m["host"], "frames": m["workload"]["frames"],
+                "note": "unmodified reference Python through oracle/ref_shim.py, not this box: see BASELINE_MEASURED.json"}
+        except Exception:
+            pass
+    return out, R
 
 
 def concurrent_sequences(n_seq, n_frames, reps=4):
@@ -91,6 +104,81 @@ def concurrent_sequences(n_seq, n_frames, reps=4):
         c.close()
     return {"sequences_in_flight": n_seq, "ms_per_sequence": 1e3 * dt / (reps * n_seq),
             "trajectory_points_per_s": sum(pts) * reps / dt}
+
+
+def single_sequence_sharded(dev, rank, world, frames, reps=2):
+    """BASELINE.json configs[3]: ONE 1080p sequence with the full path-consistency optimize over all ranks, exactly
+    (psfm_dist.connect_sharded: flow_check by frame pair + all-gather, tracks by birth row band, one all-reduce(max) of
+    the blocked map per frame, solver sums all-gathered per launch; RCCL when world > 1).  Every rank synthesises the same
+    seeded sequence.  Beside it, on rank 0, the same sequence through the one-GPU product call (psfm_connect)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import psfm_dist
+    import psfm_synth
+    from point_trajectory import _hip
+    from point_trajectory.shard import HipShardEngine, flow_check_slice
+    from point_trajectory.trajectory import run_connect
+    torch.cuda.set_device(dev)
+    d = psfm_synth.synth_sequence_torch(frames, H, W, seed=1, sigma=0.05, n_occluders=2, stride2=True, device=dev)
+    comm = psfm_dist.TorchComm()
+    eng = HipShardEngine()
+
+    def once():
+        return psfm_dist.connect_sharded(eng, d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], THRES, RATIO,
+                                         flow_check_slice, comm=comm, keep_on_device=True)   # result left in HBM, like the headline step
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    part = once()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        part = once()
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    dt, pts = psfm_dist.reduce_totals(dt, float(part["n_points_local"]), device=dev)
+    out = {"mode": "single-sequence", "world_size": dist.get_world_size() if world > 1 else 1,
+           "backend": (dist.get_backend() if world > 1 else None),
+           "workload": "configs[3] shape: synthetic %dx(1920x1080) flow pairs + stride-2 stacks, sample_ratio=2, flow_check x2 + "
+                       "track_optimize, ONE sequence over %d rank(s)" % (frames - 1, world),
+           "partition": "flow_check by frame pair (all-gather of bit-packed maps); tracks by birth row band; per frame one "
+                        "all-reduce(max) of %d bytes; per fused solve one all-gather of k x 13 doubles" % (((W + RATIO - 1) // RATIO) * ((H + RATIO - 1) // RATIO) + 1),
+           "ms_per_sequence": 1e3 * dt, "trajectory_points_per_s": pts / dt, "points": int(pts), "trajectories": int(part["n_traj"]),
+           "solves": part["n_solves"], "trust_region_iterations": part["solver_iterations"],
+           "solver_counters": dict(eng.counters), "local_trajectories_rank0": int(part["ids"].numel())}
+    if rank == 0:   # the one-GPU product call on the same tensors: time and counts
+        info = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], THRES, RATIO, return_device=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], THRES, RATIO, return_device=True)
+        torch.cuda.synchronize()
+        out["one_gpu_psfm_connect_ms_per_sequence"] = 1e3 * (time.perf_counter() - t0)
+        out["counts_equal_one_gpu"] = bool(int(info.n_traj) == int(part["n_traj"]) and int(info.n_points) == int(pts))
+    return out
+
+
+def guarded(fn, timeout_s):
+    """fn() on a helper thread with a deadline: (result, hung).  A collective that never completes (a rank that died)
+    must not take the headline line with it."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except BaseException as e:     # noqa: BLE001
+            box["r"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return {"error": "no result after %d s" % timeout_s}, True
+    return box["r"], False
 
 
 def solver_roofline(R, prof, cnt, h, w, n_flows):
@@ -208,6 +296,7 @@ def main():
     ap.add_argument("--frames", type=int, default=N_FRAMES, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-pairs", type=int, default=100, help=argparse.SUPPRESS)   # whole workload: ~10 s of CPU
     ap.add_argument("--no-cpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-seq-frames", type=int, default=401, help=argparse.SUPPRESS)   # configs[3]: 400 pairs
     ap.add_argument("--no-extras", action="store_true",
                     help="only warm-up + timed steps (what profiles/*_kernel_stats.csv is collected with): skips the figures "
                          "measured outside the timed region (overlapped psfm_connect, track_optimize, concurrent sequences)")
@@ -305,6 +394,13 @@ def main():
     import psfm_dist
     dt_max, total_points = psfm_dist.reduce_totals(dt, points, device=dev)   # max time, summed units over ranks
 
+    # ---- ONE sequence over all ranks (exact track-sharded mode), outside the timed region ----
+    single, hung = None, False
+    if not args.no_extras or world > 1:
+        if world > 1:
+            dist.barrier()
+        single, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, args.single_seq_frames), 600)
+
     if rank == 0:
         # ---- roofline of the flow-chaining kernel (K2): algorithmic bytes per launch / avg duration ----
         # chain_step/frame = min(8P,32A) + min(P,4A) + 16A + 16A + A, A = tracks alive at the step.
@@ -379,6 +475,9 @@ def main():
             },
         }
         out["kernels"].pop("respawn_avg_us", None)   # respawn is fused into chain_step
+        out["config"]["world_size"] = dist.get_world_size() if world > 1 else 1
+        if single is not None:
+            out["single_sequence"] = single
         if world == 1 and not args.no_cpu:
             n_cpu = min(args.cpu_pairs, n_flows)
             cb, Rc = cpu_baseline(flows_f, flows_b, n_cpu)
@@ -401,6 +500,9 @@ def main():
                                                                   label="headline shape with path consistency")
                 out["concurrent"] = concurrent_sequences(3, n_frames)
         print(json.dumps(out), flush=True)
+    if hung:            # a rank is stuck in a collective of the extra mode: the line is out, leave without the barrier
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

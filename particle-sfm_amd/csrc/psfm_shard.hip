@@ -135,3 +135,31 @@ extern "C" psfm_status psfm_shard_finish(psfm_ctx* c, psfm_track_info* info, voi
     }
     return PSFM_OK;
 }
+
+// key (last valid time, birth frame, birth grid index) of every trajectory of the result, in result order (ascending):
+// what psfm_dist.global_ids ranks over all processes.  Layout: last << 51 | birth << 40 | grid index.
+__global__ __launch_bounds__(256) void psfm_shard_keys_kernel(const int* __restrict__ birth, const int* __restrict__ len,
+                                                             const int64_t* __restrict__ off, const double2* __restrict__ xy, int64_t n,
+                                                             int ratio, int GW, int64_t* __restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double2 p = xy[off[i]];
+    const int64_t g = (int64_t)((int)p.y / ratio) * GW + (int)p.x / ratio;
+    keys[i] = ((int64_t)(birth[i] + len[i] - 1) << 51) | ((int64_t)birth[i] << 40) | g;
+}
+
+extern "C" psfm_status psfm_result_keys(psfm_ctx* c, int ratio, int w, int64_t* keys_dev, void* stream)
+{
+    if (!c || !keys_dev || ratio < 1 || w < 1) { psfm_set_error("psfm_result_keys: bad argument"); return PSFM_ERR_ARG; }
+    PSFM_HIP(hipSetDevice(c->device));
+    PsfmGate gate(c->device, 0);
+    const int64_t n = c->res_n_traj;
+    if (n > 0) {
+        hipLaunchKernelGGL(psfm_shard_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           c->res_birth.as<int>(), c->res_len.as<int>(), c->res_off.as<int64_t>(), c->res_xy.as<double2>(), n, ratio,
+                           (w + ratio - 1) / ratio, keys_dev);
+        PSFM_HIP(hipGetLastError());
+    }
+    return PSFM_OK;
+}

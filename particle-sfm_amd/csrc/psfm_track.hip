@@ -27,8 +27,9 @@
 
 // ------------------------------------------------------------------------------------------------
 // K1  flow_check (utils.py:58-105).  Algorithmic bytes per pair: 8P (F, streamed) + 8P (B, gathered
-// near p+F) + P (occ) = 17P.  Vector form: a thread owns 4 consecutive pixels -> F arrives as two
-// 16-byte loads, the mask leaves as one 4-byte store; blockIdx.y = frame pair (one launch for all pairs).
+// near p+F) + P (occ) = 17P.  blockIdx.y = frame pair (one launch for all pairs).  Three kernels: one pixel per thread
+// (tiny maps), four pixels per thread strided by the block (8-byte loads; keeps the reference API's error map), and two
+// ADJACENT pixels per lane with 16-byte loads (psfm_flow_check_x2v_kernel, the mask-only default).
 // ------------------------------------------------------------------------------------------------
 template <bool NEED_ERR>
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_kernel(
@@ -77,6 +78,69 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x4_kernel(
     }
 }
 
+
+// Two ADJACENT pixels per lane and step: F arrives as one 16-byte load per lane (the access width the memory system is
+// fastest at), the two horizontally adjacent taps of a row of B as one 16-byte load (2 loads per pixel instead of 4), the
+// mask leaves as one 2-byte store.  PSFM_FC2_UNROLL pairs per thread, block-strided like the x4 kernel.
+#define PSFM_FC2_UNROLL 2
+__device__ __forceinline__ uint8_t psfm_flow_check_px16(const float2* __restrict__ B, int x, int y, float2 f, const PsfmFcParams& q)
+{
+    const float X = __fadd_rn((float)x, f.x), Y = __fadd_rn((float)y, f.y);
+    const PsfmTaps t = psfm_taps_t<true>(X, Y, q.cw, q.ch, q.rcw, q.rch, q.H, q.W);
+    const int x0 = t.x0, y0 = t.y0;
+    const int xc = min(max(x0, 0), q.W - 2);                         // the pair (xc, xc + 1) lies inside the row
+    const int rn = min(max(y0, 0), q.H - 1), rs = min(max(y0 + 1, 0), q.H - 1);
+    const float4 n4 = *(const float4*)((const char*)B + ((unsigned)(rn * q.W + xc)) * 8u);
+    const float4 s4 = *(const float4*)((const char*)B + ((unsigned)(rs * q.W + xc)) * 8u);
+    const bool xw = (x0 >= 0) & (x0 < q.W), xe = (x0 + 1 >= 0) & (x0 + 1 < q.W);
+    const bool yn = (y0 >= 0) & (y0 < q.H), ys = (y0 + 1 >= 0) & (y0 + 1 < q.H);
+    const bool wlo = x0 == xc, elo = x0 + 1 == xc;                   // which half of the pair a tap is
+    const float z = 0.0f;
+    const float nwx = (xw & yn) ? (wlo ? n4.x : n4.z) : z, nwy = (xw & yn) ? (wlo ? n4.y : n4.w) : z;
+    const float nex = (xe & yn) ? (elo ? n4.x : n4.z) : z, ney = (xe & yn) ? (elo ? n4.y : n4.w) : z;
+    const float swx = (xw & ys) ? (wlo ? s4.x : s4.z) : z, swy = (xw & ys) ? (wlo ? s4.y : s4.w) : z;
+    const float sex = (xe & ys) ? (elo ? s4.x : s4.z) : z, sey = (xe & ys) ? (elo ? s4.y : s4.w) : z;
+    const float bx = psfm_blend(nwx, nex, swx, sex, t), by = psfm_blend(nwy, ney, swy, sey, t);
+    const float eu = __fadd_rn(bx, f.x), ev = __fadd_rn(by, f.y);
+    const float s2 = __fmaf_rn(ev, ev, __fmul_rn(eu, eu));
+    const bool oob = (X < 0.0f) | (X > (float)(q.W - 1)) | (Y < 0.0f) | (Y > (float)(q.H - 1));
+    return (uint8_t)((s2 > q.t2) | oob);
+}
+
+template <bool NT>     // NT: non-temporal F loads / mask stores (streamed once: keep them out of the way of the B taps in L2)
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_kernel(
+    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q, uint8_t* __restrict__ occ_out, PsfmFastDiv wdiv)
+{
+    const int P = q.H * q.W;                      // (even: the launcher falls back to the x4 kernel otherwise)
+    const int64_t base = (int64_t)blockIdx.y * P;
+    const float2* __restrict__ F = flows_f + base;
+    const float2* __restrict__ B = flows_b + base;
+    const int p0 = (blockIdx.x * (PSFM_BLOCK * PSFM_FC2_UNROLL) + threadIdx.x) * 2;
+    float4 f[PSFM_FC2_UNROLL];
+#pragma unroll
+    for (int k = 0; k < PSFM_FC2_UNROLL; ++k) {
+        const int p = p0 + k * PSFM_BLOCK * 2;
+        typedef float psfm_v4f __attribute__((ext_vector_type(4)));
+        const float4* src = (const float4*)((const char*)F + (unsigned)p * 8u);
+        if (p >= P) f[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (NT) { const psfm_v4f v = __builtin_nontemporal_load((const psfm_v4f*)src); f[k] = make_float4(v.x, v.y, v.z, v.w); }
+        else f[k] = *src;
+    }
+#pragma unroll
+    for (int k = 0; k < PSFM_FC2_UNROLL; ++k) {
+        const int p = p0 + k * PSFM_BLOCK * 2;
+        if (p >= P) break;
+        const int y = (int)psfm_fastdiv((unsigned)p, wdiv), x = p - y * q.W;
+        int x1 = x + 1, y1 = y;
+        if (x1 >= q.W) { x1 = 0; ++y1; }
+        uchar2 o;
+        o.x = psfm_flow_check_px16(B, x, y, make_float2(f[k].x, f[k].y), q);
+        o.y = psfm_flow_check_px16(B, x1, y1, make_float2(f[k].z, f[k].w), q);
+        if (NT) __builtin_nontemporal_store(*(unsigned short*)&o, (unsigned short*)(occ_out + base + p));
+        else *(uchar2*)(occ_out + base + p) = o;
+    }
+}
+
 PsfmFcParams psfm_fc_params(int h, int w, float thres)
 {
     PsfmFcParams q;
@@ -93,7 +157,18 @@ psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs
     if (n_pairs <= 0) return PSFM_OK;
     const int64_t P = (int64_t)h * w;
     const PsfmFcParams q = psfm_fc_params(h, w, thres);
-    if (P >= PSFM_BLOCK * PSFM_FC_UNROLL) {
+    static const int fc_kernel = getenv("PSFM_FC_KERNEL") ? atoi(getenv("PSFM_FC_KERNEL")) : 2;
+    if (!err && fc_kernel >= 2 && (P % 2) == 0 && P >= PSFM_BLOCK * PSFM_FC2_UNROLL * 2 && ((uintptr_t)ff % 16) == 0 &&
+        ((uintptr_t)fb % 16) == 0 && ((uintptr_t)occ % 2) == 0) {
+        const int64_t per_block = (int64_t)PSFM_BLOCK * PSFM_FC2_UNROLL * 2;
+        dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)n_pairs);
+        if (fc_kernel == 3)
+            hipLaunchKernelGGL(psfm_flow_check_x2v_kernel<true>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb, q, occ,
+                               psfm_fastdiv_make((unsigned)w));
+        else
+            hipLaunchKernelGGL(psfm_flow_check_x2v_kernel<false>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb, q, occ,
+                               psfm_fastdiv_make((unsigned)w));
+    } else if (P >= PSFM_BLOCK * PSFM_FC_UNROLL) {
         dim3 grid((unsigned)((P + PSFM_BLOCK * PSFM_FC_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_UNROLL)), (unsigned)n_pairs);
         if (err)
             hipLaunchKernelGGL(psfm_flow_check_x4_kernel<true>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,

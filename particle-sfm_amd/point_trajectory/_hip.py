@@ -20,7 +20,7 @@ EXPORTS = [
     "psfm_profile_get", "psfm_ctx_set_chain_mode", "psfm_window_sample", "psfm_result_filter", "psfm_result_filtered_copy",
     "psfm_ctx_set_solver", "psfm_solver_counters", "psfm_traj_to_matches", "psfm_matches_copy",
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
-    "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish",
+    "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
     L.psfm_shard_solve_writeback.argtypes = [vp, i32, ctypes.POINTER(SolveStats), vp]
     L.psfm_shard_solve_record.argtypes = [vp, ctypes.POINTER(SolveStats)]
     L.psfm_shard_finish.argtypes = [vp, ctypes.POINTER(TrackInfo), vp]
+    L.psfm_result_keys.argtypes = [vp, i32, i32, vp, vp]
     L.psfm_profile_get.argtypes = [vp, i32, ctypes.POINTER(f64), ctypes.POINTER(i64)]
     for name in EXPORTS:
         if name != "psfm_last_error":

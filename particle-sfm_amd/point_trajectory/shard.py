@@ -16,6 +16,7 @@ class HipShardEngine:
     def __init__(self, ctx=None, k=4):
         self.ctx = ctx or _hip.context()
         self.k = int(k)                    # iterations speculated per fused solve; follows what the sequence needs
+        self._need = []                    # ... = the most a clean solve of the last 16 frames needed
         self.counters = {"fused": 0, "fused_redone": 0}
 
     @property
@@ -84,15 +85,25 @@ class HipShardEngine:
         clean = st.dogleg_nonGN == 0 and st.termination != 5 and (st.iterations == st.successful_steps + 1 or
                                                                   (st.termination == 2 and st.iterations == st.successful_steps))
         if st.termination >= 0 and clean:
-            need = min(K_MAX, st.successful_steps + 1)
-            self.k = need if need > self.k else max(need, self.k - 1)
+            self._need = (self._need + [min(K_MAX, st.successful_steps + 1)])[-16:]
+            self.k = max(self._need)
 
     def finish(self):
+        """the own trajectories on the HOST: (birth, length, off, xy, solve statistics)"""
         from .trajectory import _result_to_host
         info = _hip.TrackInfo()
         _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
         R = _result_to_host(self.ctx, info)
         return R.birth, R.length, R.off, R.xy, R.solve_stats
+
+    def finish_device(self, ratio, width):
+        """the own trajectories stay in HBM (psfm_result_device); returns (track info, their order keys as a device tensor)"""
+        import torch
+        info = _hip.TrackInfo()
+        _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
+        keys = torch.empty(int(info.n_traj), dtype=torch.int64, device=self.device)
+        _hip.check(_hip.lib().psfm_result_keys(self.ctx.handle, int(ratio), int(width), _hip.ptr(keys), self._sp()))
+        return info, keys
 
 
 def flow_check_slice(f, b, thres):

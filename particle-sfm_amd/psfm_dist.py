@@ -192,7 +192,26 @@ def global_ids(birth, length, first_xy, n_flows, ratio, grid_w, group=None, comm
     return ids, int(sum(cnts))
 
 
-def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, check_fn, group=None, comm=None):
+def global_ids_device(keys, comm):
+    """global_ids on device tensors: keys (n,) int64 ascending (HipShardEngine.finish_device) -> (ids (n,) int64 on the same
+    device, total number of trajectories).  One all-gather of the counts, one of the padded keys."""
+    import torch
+    world = comm.world
+    if world == 1:
+        return torch.arange(keys.numel(), dtype=torch.int64, device=keys.device), int(keys.numel())
+    cnts = comm.all_gather_flat(torch.tensor([keys.numel()], dtype=torch.int64, device=keys.device)).tolist()
+    nmax = max(max(cnts), 1)
+    pad = torch.full((nmax,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=keys.device)
+    pad[:keys.numel()] = keys
+    allk = comm.all_gather_flat(pad).reshape(world, nmax)
+    ids = torch.zeros(keys.numel(), dtype=torch.int64, device=keys.device)
+    for r in range(world):
+        ids += torch.searchsorted(allk[r][:cnts[r]].contiguous(), keys, right=False)
+    return ids, int(sum(cnts))
+
+
+def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, check_fn, group=None, comm=None,
+                    keep_on_device=False):
     """main_connect_point_trajectories.py:36-53 for ONE sequence on all ranks of `group`, exactly.
 
     flows_*: (n,H,W,2) float32 tensors on every rank (flows_f2 / flows_b2 None: track() instead of track_optimize());
@@ -223,6 +242,11 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
         engine.after_exchange(t, x)
         if optimize and t + 1 >= 2:                                          # track_optimize.py:49-50
             engine.solve(t, flows_f[t - 1], flows_f[t], flows_f2[t - 1], occ2[t - 1], reduce)
+    if keep_on_device:      # the trajectories stay in the engine's HBM (psfm_result_device); only their ids are formed
+        info, keys = engine.finish_device(r, W)
+        ids, n_traj = global_ids_device(keys, comm)
+        return {"info": info, "ids": ids, "n_traj": n_traj, "n_points_local": int(info.n_points), "n_solves": int(info.n_solves),
+                "solver_iterations": int(info.solver_iterations), "occ": occ, "occ2": occ2, "band": (g0, g1)}
     birth, length, off, xy, stats = engine.finish()
     first = xy[off[:-1]] if len(birth) else np.zeros((0, 2))
     ids, n_traj = global_ids(birth, length, first, n_flows, r, GW, comm=comm)

@@ -530,7 +530,10 @@ def test_saved_set_filtered_on_the_device(pt, tmp_path):
     np.save(str(tmp_path / "track_ref.npy"), host)
     a = np.load(str(tmp_path / "track.npy"), allow_pickle=True).item()
     b = np.load(str(tmp_path / "track_ref.npy"), allow_pickle=True).item()
-    for x, y in zip(a._csr[:5], b._csr[:5]):
+    # (the files carry the reference's pickle state by default: compare the trajectories, whatever backs the sets)
+    for x, y in zip(a._to_csr()[:4], b._to_csr()[:4]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a._to_csr()[:4], dev._to_csr()[:4]):
         assert np.array_equal(x, y)
     a.build_invert_indexes()
     assert sorted(a.as_dict()) == sorted(b.as_dict())
