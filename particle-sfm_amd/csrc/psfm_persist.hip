@@ -747,6 +747,26 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
     hipEvent_t e0 = nullptr, e1 = nullptr;
     c->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1, true);
     const dim3 grid((unsigned)d.nblk), block(PP_BLOCK);
+    // PSFM_PERSIST_COOP=1: a COOPERATIVE launch -- the runtime refuses it when the grid cannot be co-resident on the device
+    // (instead of the loop discovering that after its barrier spin limit) and runs it on the device's cooperative queue.
+    // Measured on MI355X: +50 us per 100-frame 1080p sequence (2.73 vs 2.68 ms per step), which is why the plain launch
+    // behind the residency query + the per-device gate stays the default; the bounded spin and the hand-over to per-frame
+    // launches remain the safety net in both forms.
+    const bool coop = getenv("PSFM_PERSIST_COOP") && atoi(getenv("PSFM_PERSIST_COOP")) != 0;
+    const void* fn = d.ratio == 1 ? (const void*)psfm_chain_persist_kernel<1> : d.ratio == 2 ? (const void*)psfm_chain_persist_kernel<2>
+                   : d.ratio == 4 ? (const void*)psfm_chain_persist_kernel<4> : (const void*)psfm_chain_persist_kernel<0>;
+    if (coop) {
+        void* kargs[] = {(void*)&a};
+        if (e0) PSFM_HIP(hipEventRecord(e0, s));
+        const hipError_t le = hipLaunchCooperativeKernel(fn, grid, block, kargs, 0, s);
+        if (le != hipSuccess) {
+            (void)hipGetLastError();
+            psfm_set_error("cooperative launch of the persistent frame loop refused: %s", hipGetErrorString(le));
+            return PSFM_ERR_CAPACITY;      // the caller reruns the sequence with one launch per frame
+        }
+        if (e1) PSFM_HIP(hipEventRecord(e1, s));
+        return PSFM_OK;
+    }
     switch (d.ratio) {
         case 1: hipExtLaunchKernelGGL(psfm_chain_persist_kernel<1>, grid, block, 0, s, e0, e1, 0, a); break;
         case 2: hipExtLaunchKernelGGL(psfm_chain_persist_kernel<2>, grid, block, 0, s, e0, e1, 0, a); break;

@@ -369,6 +369,21 @@ def test_persistent_loop_hands_over_to_per_frame_launches(pt, chain_mode, monkey
     assert np.array_equal(Rc.birth, O.birth) and np.array_equal(Rc.length, O.length) and np.array_equal(Rc.xy, O.xy)
 
 
+def test_persistent_loop_cooperative_launch(pt, chain_mode, monkeypatch):
+    """PSFM_PERSIST_COOP=1: the persistent frame loop as a cooperative launch (refused by the runtime when its grid cannot be
+    co-resident).  Same trajectories as the plain launch; chain_mode 2 reports that the loop ran."""
+    if chain_mode == 1:
+        pytest.skip("per-frame launches only")
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(9, 120, 160, seed=66, sigma=0.3, n_occluders=2, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    O = orc.track(d["flows_f"], occ, 2)
+    monkeypatch.setenv("PSFM_PERSIST_COOP", "1")
+    R = pt.track(d["flows_f"], occ, 2)
+    assert R.info["chain_mode"] == 2
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+
+
 def test_chain_mode_policy(pt):
     """Mode 2 runs the persistent loop wherever it can and per-frame launches elsewhere (grid larger than the resident
     lanes, track_optimize); mode 0 decides by shape: sample_ratio >= 2 with >= 100 k grid points for psfm_track,
