@@ -34,6 +34,7 @@ def cpu_baseline(flows_f, flows_b, n_pairs):
     OMP_NUM_THREADS or all host cores) on the first n_pairs frame pairs of the same tensors."""
     import numpy as np
     from oracle import oracle as orc
+    orc.set_num_threads(min(32, os.cpu_count() or 1))
     ff = [f for f in flows_f[:n_pairs].cpu().numpy()]
     fb = [f for f in flows_b[:n_pairs].cpu().numpy()]
     t0 = time.perf_counter()

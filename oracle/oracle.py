@@ -80,6 +80,14 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    """Cap the host threads of the oracle's parallel loops (beyond ~16-32 the fork/join per loop costs more than it gains)."""
+    L = lib()
+    L.orc_set_num_threads.argtypes = [ctypes.c_int]
+    L.orc_set_num_threads.restype = None
+    L.orc_set_num_threads(int(n))
+
+
 def num_threads():
     """Host threads the oracle's parallel loops use (OMP_NUM_THREADS; results do not depend on it)."""
     return int(lib().orc_num_threads())

@@ -42,6 +42,16 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* cap the host threads of the parallel loops (no-op without OpenMP; results do not depend on it) */
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* host threads the parallel loops use (1 when built without OpenMP) */
 ORC_API int orc_num_threads(void)
 {

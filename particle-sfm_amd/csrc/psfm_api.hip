@@ -468,23 +468,34 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         // track.py:31-47 / track_optimize.py:31-50, one loop iteration:
         // one launch = births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
         if (pipe && (st = pipe->need(f, false, s)) != PSFM_OK) return st;
-        st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * occ_pitch, f, optimize, s);
-        if (st != PSFM_OK) return st;
         const bool fused_now = c->solver_mode == 2 || (c->solver_mode == 0 && c->solve_mode == 0);
-        if (optimize && f + 1 >= 2) {   // track_optimize.py:49-50
+        const bool solve_now = optimize && f + 1 >= 2;   // track_optimize.py:49-50
+        // PSFM_MERGE_FRAME=0: chain step and fused solve as two launches (what the merged frame kernel is measured against)
+        static const bool merge = !(getenv("PSFM_MERGE_FRAME") && atoi(getenv("PSFM_MERGE_FRAME")) == 0);
+        if (solve_now && fused_now && merge) {
+            // ONE launch: chain step of the frame + the fused solve of its tracks
             if (pipe && (st = pipe->need(f - 1, true, s)) != PSFM_OK) return st;
-            if (fused_now) {   // (timed inside: kernel begin / end events)
-                st = psfm_solve_frame_fused(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
-                                            flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
-                                            c->solver_K > 0 ? c->solver_K : c->solve_K, s);
-            } else {
-                c->prof.begin(PSFM_PROF_SOLVER, s);
-                st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
-                                              flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
-                                              unroll_fixed > 0 ? unroll_fixed : c->solve_unroll, s);
-                c->prof.end(s);
-            }
+            st = psfm_launch_frame(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2, flows_f2 + (size_t)(f - 1) * P * 2,
+                                   occ + (size_t)f * occ_pitch, occ_s2 + (size_t)(f - 1) * P, f, c->solver_K > 0 ? c->solver_K : c->solve_K, s);
             if (st != PSFM_OK) return st;
+        } else {
+            st = psfm_launch_chain_step(c, d, flows + (size_t)f * P * 2, occ + (size_t)f * occ_pitch, f, optimize, s);
+            if (st != PSFM_OK) return st;
+            if (solve_now) {
+                if (pipe && (st = pipe->need(f - 1, true, s)) != PSFM_OK) return st;
+                if (fused_now) {   // (timed inside: kernel begin / end events)
+                    st = psfm_solve_frame_fused(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
+                                                flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
+                                                c->solver_K > 0 ? c->solver_K : c->solve_K, s);
+                } else {
+                    c->prof.begin(PSFM_PROF_SOLVER, s);
+                    st = psfm_solve_frame_enqueue(c, d, flows + (size_t)(f - 1) * P * 2, flows + (size_t)f * P * 2,
+                                                  flows_f2 + (size_t)(f - 1) * P * 2, occ_s2 + (size_t)(f - 1) * P, f,
+                                                  unroll_fixed > 0 ? unroll_fixed : c->solve_unroll, s);
+                    c->prof.end(s);
+                }
+                if (st != PSFM_OK) return st;
+            }
         }
         const bool checkpoint = optimize && f >= 1 && ((f % PSFM_CHECK) == PSFM_CHECK - 1 || f == n_flows - 1);
         if (checkpoint) {
@@ -494,12 +505,17 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                                     sizeof(psfm_solve_stats) * (size_t)(f - first_unchecked + 1), hipMemcpyDeviceToHost, s));
             PSFM_HIP(hipStreamSynchronize(s));
             int last_ok = f;
-            if (hc->stall) {
-                const int fs = hc->stall - 1;
+            const int stalled = hc->stall ? hc->stall - 1 : -1;   // (the redo below reuses the pinned block `hc` points at)
+            if (stalled >= 0) {
+                const int fs = stalled;
                 psfm_solve_stats ss;
                 memset(&ss, 0, sizeof(ss));
+                // (a fused solve that ran out of iterations is first retried with the most it can speculate; the chain
+                // takes what is left -- and every stalled solve of a chain window)
+                const int k_used = c->solver_K > 0 ? c->solver_K : c->solve_K;
                 st = psfm_solve_frame_resume(c, d, flows + (size_t)(fs - 1) * P * 2, flows + (size_t)fs * P * 2,
-                                             flows_f2 + (size_t)(fs - 1) * P * 2, occ_s2 + (size_t)(fs - 1) * P, fs, &ss, s);
+                                             flows_f2 + (size_t)(fs - 1) * P * 2, occ_s2 + (size_t)(fs - 1) * P, fs, &ss,
+                                             (fused_now && c->solver_K == 0 && k_used < psfm_solve_kmax()) ? psfm_solve_kmax() : 0, s);
                 if (st != PSFM_OK) return st;
                 hstats[fs] = ss;
                 last_ok = fs;
@@ -522,7 +538,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                     if (!clean) ++n_unclean;
                     else if (q.successful_steps + 1 > k_need) k_need = q.successful_steps + 1;
                     if (!fused_now) ++c->n_chain;
-                    else if (hc->stall && k == hc->stall - 1) ++c->n_fused_redone;
+                    else if (k == stalled) ++c->n_fused_redone;
                     else ++c->n_fused_ok;
                 }
                 if (hstats[k].iterations > max_it) max_it = hstats[k].iterations;

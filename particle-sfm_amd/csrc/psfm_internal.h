@@ -60,7 +60,9 @@ struct PsfmCounters {
     int spill_cnt;    // persistent frame loop: records written to the shared tail behind the private segments
     int sel;          // track_optimize: iterate buffer that holds the accepted positions (times f, f+1) of the last fused
                       // solve; 0 = they are in the log.  The next chain step copies them on its way (psfm_solver.hip)
-    int pad[10];
+    int n_lanes_snap; // n_lanes as the previous launch of the sequence left it (set by track_init, the merged frame kernel's
+                      // control thread and the solver's write-back): the tile bound every block of a merged launch agrees on
+    int pad[9];
 };
 
 // Death records and free lanes are published through PSFM_NSHARD independent tables so that the
@@ -197,9 +199,11 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
                                      const float* flow02, const uint8_t* occ02, int frame, int unroll, hipStream_t s);
 psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                     const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
-                                    hipStream_t s);
+                                    int try_fused_k, hipStream_t s);
 psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                    const float* flow02, const uint8_t* occ02, int frame, int K, hipStream_t s);
+psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
+                              const uint8_t* occ, const uint8_t* occ02, int frame, int K, hipStream_t s);
 psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d);   // every solver buffer of a sequence, up front
 int psfm_solve_kmax(void);

@@ -32,6 +32,7 @@
 
 #include "psfm_device.h"
 #include "psfm_internal.h"
+#include "psfm_chain_step.h"
 
 #define PC_BLOCK 256
 #ifndef PC_RED_ROWS
@@ -94,6 +95,7 @@ struct PcParams {
     double* gpart;            // [groups][PC_KMAX][PC_NSUM] sums of PC_GROUP consecutive blocks
     unsigned* gticket;        // [groups] + 1 (top)
     int* sel;                 // PsfmCounters::sel: buffer that holds the accepted iterate of the last solve (0: the log)
+    int* n_lanes_snap;        // PsfmCounters::n_lanes_snap (frame mode)
     // track-sharded runs: the tracks of the solve are spread over several processes.  A launch then only EXPORTS its sums
     // ([K or 1][PC_NSUM], this process's tracks); the ranks combine them (all-gather, rank order) and every rank runs the
     // same control step on the totals (psfm_pc_control_kernel)
@@ -180,22 +182,43 @@ __device__ __forceinline__ double pc_div(double a, double b, double y)
 
 // Gauss-Newton system of one track: diag (and its reciprocals), scaled gradient ghat, scaled GN step gn; returns false
 // when the Cholesky factorisation of (Js^T Js + mu diag^2) breaks down.  Also the Cauchy-point term |Js (ghat/diag)|^2.
-__device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], double mu, double d[4], double yd[4],
-                                             double gh[4], double gn[4], double* jg2)
+// PRE: columns 2 and 3 of the scaled Jacobian are per-track constants (a2 = a3 = s S2, b2 = c3 = S2), hence so are
+// their squared norm, its clamped root, the reciprocal and -- at a fixed mu -- the diagonal entries of the normal
+// equations: pre = {n2, d2, 1/d2, A22}, computed once per solve by the same expressions (pc_gn_pre), bit for bit.
+struct PcGnPre { double n2, d2, yd2, A22; };
+__device__ __forceinline__ PcGnPre pc_gn_pre(double s, double S2, double mu)
+{
+    PcGnPre q;
+    const double a2 = s * S2, b2 = 1.0 * S2;
+    q.n2 = a2 * a2 + b2 * b2;
+    const double cn = fmin(fmax(q.n2, 1e-6), 1e32);
+    q.d2 = sqrt(cn);
+    q.yd2 = 1.0 / q.d2;
+    const double D = q.d2 * sqrt(mu);
+    q.A22 = q.n2 + D * D;
+    return q;
+}
+
+template <bool PRE>
+__device__ __forceinline__ bool pc_gn_system_t(const PcJac& J, const double r[6], double mu, double d[4], double yd[4],
+                                               double gh[4], double gn[4], double* jg2, const PcGnPre& pre)
 {
     const double n0 = (J.a0 * J.a0 + J.b0 * J.b0) + J.c0 * J.c0;
     const double n1 = (J.a1 * J.a1 + J.b1 * J.b1) + J.c1 * J.c1;
-    const double n2 = J.a2 * J.a2 + J.b2 * J.b2;
-    const double n3 = J.a3 * J.a3 + J.c3 * J.c3;
+    const double n2 = PRE ? pre.n2 : J.a2 * J.a2 + J.b2 * J.b2;
+    const double n3 = PRE ? pre.n2 : J.a3 * J.a3 + J.c3 * J.c3;
     const double q[4] = {(J.a0 * r[0] + J.b0 * r[4]) + J.c0 * r[5], (J.a1 * r[1] + J.b1 * r[4]) + J.c1 * r[5],
                          J.a2 * r[2] + J.b2 * r[4], J.a3 * r[3] + J.c3 * r[5]};
     const double nn[4] = {n0, n1, n2, n3};
     double sg[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const double cn = fmin(fmax(nn[c], 1e-6), 1e32);   // min/max_lm_diagonal
-        d[c] = sqrt(cn);
-        yd[c] = 1.0 / d[c];
+        if (PRE && c >= 2) { d[c] = pre.d2; yd[c] = pre.yd2; }
+        else {
+            const double cn = fmin(fmax(nn[c], 1e-6), 1e32);   // min/max_lm_diagonal
+            d[c] = sqrt(cn);
+            yd[c] = 1.0 / d[c];
+        }
         gh[c] = pc_div(q[c], d[c], yd[c]);
         sg[c] = pc_div(gh[c], d[c], yd[c]);
     }
@@ -211,8 +234,11 @@ __device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], 
     double D;
     D = d[0] * smu; A[0][0] = n0 + D * D;
     D = d[1] * smu; A[1][1] = n1 + D * D;
-    D = d[2] * smu; A[2][2] = n2 + D * D;
-    D = d[3] * smu; A[3][3] = n3 + D * D;
+    if (PRE) { A[2][2] = pre.A22; A[3][3] = pre.A22; }
+    else {
+        D = d[2] * smu; A[2][2] = n2 + D * D;
+        D = d[3] * smu; A[3][3] = n3 + D * D;
+    }
     A[1][0] = J.b0 * J.b1 + J.c0 * J.c1;
     A[2][0] = J.b0 * J.b2;
     A[2][1] = J.b1 * J.b2;
@@ -258,6 +284,13 @@ __device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], 
         gn[c] = y[c] * (-d[c]);   // gauss_newton_step *= -diagonal
     }
     return ok;
+}
+
+__device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], double mu, double d[4], double yd[4],
+                                             double gh[4], double gn[4], double* jg2)
+{
+    const PcGnPre none = {0.0, 0.0, 0.0, 0.0};
+    return pc_gn_system_t<false>(J, r, mu, d, yd, gh, gn, jg2, none);
 }
 
 // sums slots
@@ -740,6 +773,7 @@ struct PcTrack {            // one track's solve state in registers
     double x[4], r[6], jac[4];
     double2 r1, r2;
     double s, S0, S1, S2;
+    PcGnPre pre;
 };
 
 // sums of one trust-region iteration at T.x (already evaluated: T.r, T.jac) into v[]; the candidate goes to (xn1, xn2)[i]
@@ -759,7 +793,7 @@ __device__ __forceinline__ void pc_fused_iteration(const PcParams& P, PcTrack& T
     }
     const PcJac J = pc_scaled_jac(jac, s, S);
     double d[4], yd[4], gh[4], gn[4], jg2;
-    const bool ok = pc_gn_system(J, r, mu, d, yd, gh, gn, &jg2);
+    const bool ok = pc_gn_system_t<true>(J, r, mu, d, yd, gh, gn, &jg2, T.pre);
     v[SUM_JG2] += jg2;
     if (!ok) v[SUM_FAIL] += 1.0;
     double st[4], xp[4];
@@ -853,21 +887,15 @@ __device__ __forceinline__ bool pc_last_arrival(unsigned* ticket, unsigned membe
 }
 
 // WAVES: waves per SIMD the register allocation targets (3: 136 VGPRs, no spill; 4: 128 VGPRs, 4 spilled)
-template <int WAVES>
-__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-void psfm_pc_fused_kernel(PcParams P)
+// The solve of lane i = blockIdx.x * PC_BLOCK + threadIdx.x (if `part`) from its three buffered positions, the sums of
+// the launch and -- in its last block -- the control flow.  n_active: the blocks of the launch that come here (every one
+// of them, whatever its lanes do: the tickets count them).
+__device__ __forceinline__ void pc_fused_body(const PcParams& P, bool part, double2 p0, double2 p1, double2 p2, int n_active,
+                                              int* n_lanes_snap, const int* n_lanes_live)
 {
-    if (*P.stall) return;
-    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
-    const int n_active = (n + PC_BLOCK - 1) / PC_BLOCK;        // blocks with a lane below the high-water mark
-    if ((int)blockIdx.x >= n_active) return;
     const int K = P.K;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * PC_BLOCK + tid;
-    // (state loaded alongside the birth frame that decides whether the lane takes part: one round trip less)
-    double2 p0 = make_double2(0.0, 0.0), p1 = p0, p2 = p0;
-    if (i < n) { p0 = P.p0[i]; p1 = P.x1a[i]; p2 = P.x2a[i]; }
-    const bool part = pc_participates(P, i, n);
     const double mu = 1e-8;
     // Where the iterates live.  A solve that goes as speculated accepts e = K - 1 steps and terminates in iteration K, so
     // iterate e is written straight into buffer 0 -- the log slabs, where the next chain step and finalize read -- and
@@ -897,6 +925,7 @@ void psfm_pc_fused_kernel(PcParams P)
         const double q1 = (1.0 + T.jac[1] * T.jac[1]) + T.jac[3] * T.jac[3];
         const double q2 = T.s * T.s + 1.0;
         T.S0 = 1.0 / (1.0 + sqrt(q0)); T.S1 = 1.0 / (1.0 + sqrt(q1)); T.S2 = 1.0 / (1.0 + sqrt(q2));
+        T.pre = pc_gn_pre(T.s, T.S2, mu);
         double ss = 0.0;
 #pragma unroll
         for (int q = 0; q < 6; ++q) ss += T.r[q] * T.r[q];
@@ -987,7 +1016,41 @@ void psfm_pc_fused_kernel(PcParams P)
         return;
     }
     if (tid != 0) return;
+    if (n_lanes_snap) *n_lanes_snap = *n_lanes_live;   // (every block is past its chain step: the count is final for this launch)
     pc_fused_replay(P, &s_tot[0][0], K);
+}
+#undef PC_PHYS
+
+template <int WAVES>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void psfm_pc_fused_kernel(PcParams P)
+{
+    if (*P.stall) return;
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    const int n_active = (n + PC_BLOCK - 1) / PC_BLOCK;        // blocks with a lane below the high-water mark
+    if ((int)blockIdx.x >= n_active) return;
+    const int i = blockIdx.x * PC_BLOCK + threadIdx.x;
+    // (state loaded alongside the birth frame that decides whether the lane takes part: one round trip less)
+    double2 p0 = make_double2(0.0, 0.0), p1 = p0, p2 = p0;
+    if (i < n) { p0 = P.p0[i]; p1 = P.x1a[i]; p2 = P.x2a[i]; }
+    pc_fused_body(P, pc_participates(P, i, n), p0, p1, p2, n_active, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The merged frame kernel of track_optimize (track_optimize.py:31-50, one loop iteration = ONE launch): the chain step
+// of the frame for the block's lanes (births, step, marks, records -- psfm_chain_step_body) and, for the tracks that
+// survive it with three buffered points, the whole path-consistency solve (pc_fused_body) -- their tail and next position
+// go from the step straight into the solve, the taps of both share a round trip, one launch boundary and one pass over
+// the lane state disappear.  Every block below the lane snapshot / the grid takes part in the solve's tickets.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void psfm_frame_kernel(PsfmChainArgs a, PcParams P)
+{
+    PsfmChainOut o;
+    if (!psfm_chain_step_body<R, true, true>(a, o)) return;
+    const int n_active = (max(a.ctr->n_lanes_snap, a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
+    pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &a.ctr->n_lanes_snap, &a.ctr->n_lanes);
 }
 
 #undef PC_PHYS
@@ -1052,7 +1115,10 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P,
     // Js^T Js + mu diag^2 to lose definiteness, or an accepted iterate with finite cost and a non-finite Jacobian over
     // the same four taps; the current iterate is what comes out then.)
     const int cur = C.cur;
-    if (P.sel && blockIdx.x == 0 && threadIdx.x == 0) *P.sel = 0;   // the iterate is (being) copied into buffer 0 right here
+    if (P.sel && blockIdx.x == 0 && threadIdx.x == 0) {
+        *P.sel = 0;                                   // the iterate is (being) copied into buffer 0 right here
+        if (P.n_lanes_snap) *P.n_lanes_snap = *P.n_lanes_ptr;   // (no chain step is running: the lane count is final)
+    }
     if (cur == 0 && !out_rows) return;
     const double2* xc1 = pc_buf1(P, cur);
     const double2* xc2 = pc_buf2(P, cur);
@@ -1165,6 +1231,7 @@ static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const fl
     P.x2a = lg + (int64_t)(frame + 1) * d.cap;
     P.xs = c->sol_x.as<double2>(); P.xs_stride = d.cap;
     P.sel = &ctr->sel;
+    P.n_lanes_snap = &ctr->n_lanes_snap;
     P.ref1 = c->sol_state.as<double2>();
     P.ref2 = P.ref1 + d.cap;
     P.jscale = P.ref2 + d.cap;
@@ -1195,7 +1262,7 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
 // The stalled solve of `frame`: clear the flag, iterate to termination with host polling, write back.
 psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                     const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
-                                    hipStream_t s)
+                                    int try_fused_k, hipStream_t s)
 {
     PcParams P;
     psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
@@ -1203,9 +1270,22 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     PSFM_HIP(hipMemsetAsync(P.stall, 0, sizeof(int), s));
     // from the top: the launch chain never writes buffer 0 (the log slabs) before its write-back; a fused solve that gave
     // up left the values it started from in the iterate buffer PsfmCounters::sel names -- back into the log first
-    {
-        const int nb = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
-        hipLaunchKernelGGL(psfm_pc_flush_kernel, dim3(nb), dim3(PC_BLOCK), 0, s, P);
+    const int nb_all = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+    hipLaunchKernelGGL(psfm_pc_flush_kernel, dim3(nb_all), dim3(PC_BLOCK), 0, s, P);
+    hipLaunchKernelGGL(psfm_pc_clear_sel_kernel, dim3(1), dim3(1), 0, s, P.sel, (const int*)P.stall);
+    if (try_fused_k > 0) {
+        // most redos are solves that needed one or two iterations more than the sequence's usual: the fused solve with
+        // try_fused_k iterations settles those in one launch; anything else falls through to the chain
+        psfm_status rc2 = psfm_solve_frame_fused(c, d, flow01, flow12, flow02, occ02, frame, try_fused_k, s);
+        if (rc2 != PSFM_OK) return rc2;
+        PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
+        psfm_solve_stats* hs = (psfm_solve_stats*)((char*)c->host_pinned + 288);
+        PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
+        PSFM_HIP(hipMemcpyAsync(hs, c->sol_stats.as<psfm_solve_stats>() + frame, sizeof(psfm_solve_stats), hipMemcpyDeviceToHost, s));
+        PSFM_HIP(hipStreamSynchronize(s));
+        if (!hc->stall) { if (st) *st = *hs; return PSFM_OK; }
+        PSFM_HIP(hipMemsetAsync(P.stall, 0, sizeof(int), s));
+        hipLaunchKernelGGL(psfm_pc_flush_kernel, dim3(nb_all), dim3(PC_BLOCK), 0, s, P);
         hipLaunchKernelGGL(psfm_pc_clear_sel_kernel, dim3(1), dim3(1), 0, s, P.sel, (const int*)P.stall);
     }
     const int n_blocks = pc_blocks((int)d.cap);
@@ -1333,6 +1413,41 @@ psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame,
     psfm_status rc = pc_frame_params(c, d, nullptr, nullptr, nullptr, nullptr, frame, P, s);
     if (rc != PSFM_OK) return rc;
     hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(pc_blocks((int)d.cap)), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// One loop iteration of track_optimize as ONE launch: chain step of `frame` + the fused solve of its tracks
+// (psfm_frame_kernel).  flow12 = the frame's own forward flow, occ = its occlusion map.
+psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
+                              const uint8_t* occ, const uint8_t* occ02, int frame, int K, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+    const int n_groups = (n_blocks + PC_GROUP - 1) / PC_GROUP;
+    if ((rc = c->sol_partials.ensure(sizeof(double) * (size_t)n_blocks * PC_KMAX * PC_NSUM)) != PSFM_OK) return rc;
+    const size_t tbytes = 4096 * sizeof(unsigned), gbytes = sizeof(double) * (size_t)n_groups * PC_KMAX * PC_NSUM;
+    if (n_groups + 1 > 4096) { psfm_set_error("psfm_track: lane table too large for the fused solve"); return PSFM_ERR_ARG; }
+    void* before = c->sol_fused.p;
+    if ((rc = c->sol_fused.ensure(tbytes + gbytes)) != PSFM_OK) return rc;
+    if (c->sol_fused.p != before) PSFM_HIP(hipMemsetAsync(c->sol_fused.p, 0, tbytes, s));
+    P.partials = c->sol_partials.as<double>();
+    P.gticket = c->sol_fused.as<unsigned>();
+    P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
+    P.K = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
+    PsfmChainArgs a;
+    psfm_fill_chain_args(c, d, flow12, occ, frame, a, s);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    c->prof.kernel_span(PSFM_PROF_SOLVER, &e0, &e1, true);
+    const dim3 grid((unsigned)n_blocks), block(PC_BLOCK);
+    switch (d.ratio) {
+        case 1: hipExtLaunchKernelGGL(psfm_frame_kernel<1>, grid, block, 0, s, e0, e1, 0, a, P); break;
+        case 2: hipExtLaunchKernelGGL(psfm_frame_kernel<2>, grid, block, 0, s, e0, e1, 0, a, P); break;
+        case 4: hipExtLaunchKernelGGL(psfm_frame_kernel<4>, grid, block, 0, s, e0, e1, 0, a, P); break;
+        default: hipExtLaunchKernelGGL(psfm_frame_kernel<0>, grid, block, 0, s, e0, e1, 0, a, P); break;
+    }
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }

@@ -46,6 +46,7 @@ def test_whole_sequence_track_optimize_vs_oracle(H, W, T, r, thres, seed):
         pytest.skip("host memory: %.1f GB needed for the oracle's copy of the sequence" % (need / 1e9))
     ctx = _hip.context()
     ctx.set_solver(0, 0)
+    orc.set_num_threads(min(16, os.cpu_count() or 1))      # (measured on a 256-core box: all cores are slower than 16)
     d = psfm_synth.synth_sequence_torch(T, H, W, seed=seed, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
     R = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], thres, r)
     cnt = ctx.solver_counters()
