@@ -199,6 +199,11 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
     tl = np.bincount(last, minlength=n_flows + 3).cumsum()            # tracks whose last time <= t
     its = [s["iterations"] for s in R.solve_stats]
     frames = list(range(1, n_flows))
+    alive_steps = float(R.n_points - int((last == n_flows).sum()))
+    A = alive_steps / n_flows
+    cb = min(8 * P, 32 * A) + min(P, 4 * A) + 16 * A + 16 * A + A
+    ch = prof["chain_step"]
+    merged = ch["launches"] * 2 < n_flows          # track_optimize ran the merged frame kernel: chain step inside the solve's launch
     if len(its) == len(frames) and prof["solver"]["launches"] > 0:
         tot = 0.0
         for f, k in zip(frames, its):
@@ -207,20 +212,19 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
             solve = k * (min(8 * P, 32 * n3) + 72 * n3 + 32 * n3)
             tot += prep + solve
         us = 1e3 * prof["solver"]["total_ms"] / prof["solver"]["launches"]
-        per_solve = tot / len(frames)
+        per_solve = tot / len(frames) + (cb if merged else 0.0)
         fused = cnt["fused"] + cnt["fused_redone"] > cnt["chain"]
-        out["solver"] = {"kernel": "psfm_pc_fused_kernel (one launch per solve)" if fused else "pc_init + pc_iter chain (one span per solve)",
-                         "bound": "hbm", "bytes_per_solve": per_solve, "avg_us_per_solve": us,
-                         "launches_timed": int(prof["solver"]["launches"]),
-                         "achieved": per_solve / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": per_solve / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "avg_iterations": float(np.mean(its)),
-                         "note": "f64 issue-bound, not bandwidth-bound: ~1e3 VALU instructions per track and iteration"}
-    alive_steps = float(R.n_points - int((last == n_flows).sum()))
-    A = alive_steps / n_flows
-    cb = min(8 * P, 32 * A) + min(P, 4 * A) + 16 * A + 16 * A + A
-    ch = prof["chain_step"]
-    if ch["launches"] > 0:
+        name = ("psfm_frame_kernel (ONE launch per frame: chain step + fused solve)" if merged else
+                "psfm_pc_fused_kernel (one launch per solve)") if fused else "pc_init + pc_iter chain (one span per solve)"
+        out["frame_kernel" if merged else "solver"] = {
+            "kernel": name, "bound": "hbm", "bytes_per_launch": per_solve,
+            "bytes_breakdown": {"pc_prepare + pc_solve (SURVEY 8d)": tot / len(frames), "chain_step": cb if merged else 0.0},
+            "avg_launch_us": us, "launches_timed": int(prof["solver"]["launches"]),
+            "achieved": per_solve / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": per_solve / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_iterations": float(np.mean(its)),
+            "note": "f64 issue-bound, not bandwidth-bound: ~940 VALU instructions per track and trust-region iteration; the "
+                    "timed launches include the few that overlap a flow_check chunk of the side stream (2x) and the retries"}
+    if ch["launches"] > 0 and not merged:
         us = 1e3 * ch["total_ms"] / ch["launches"]
         out["chain_step"] = {"kernel": "psfm_chain_step_kernel<R, OPT>", "bound": "hbm", "bytes_per_launch": cb, "avg_launch_us": us,
                              "achieved": cb / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
