@@ -448,7 +448,10 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // Frame loop.  In track_optimize mode nothing returns to the host inside a window of PSFM_CHECK frames: each
     // solve is enqueued with `solve_unroll` iterations; a solve that needs more raises a device-side stall flag that
     // turns every later launch into a no-op, and the checkpoint below resumes it and re-enqueues from there.
-    const int PSFM_CHECK = 16;   // (8: +1.5 % on the 401-frame 1080p run -- every checkpoint drains the queue; 32: no further gain)
+    // frames between two host checkpoints (every checkpoint drains the queue).  Round 1 (150 us per frame): 8 -> 16 gained
+    // 1.5 %, 32 nothing more; PSFM_CHECK_FRAMES overrides for measurements
+    static const int check_env = getenv("PSFM_CHECK_FRAMES") ? atoi(getenv("PSFM_CHECK_FRAMES")) : 0;
+    const int PSFM_CHECK = check_env >= 2 ? check_env : 16;
     std::vector<psfm_solve_stats> hstats((size_t)n_flows + 1);
     int first_unchecked = 1;
     if (optimize) {
