@@ -345,6 +345,9 @@ def main():
         _, occ = flow_check_device(flows_f, flows_b, THRES)
         return run_track(flows_f, occ, None, None, RATIO, return_device=True)
 
+    if os.environ.get("PSFM_BENCH_TWO_CALLS"):      # profiling only: the stand-alone flow_check + the loop on its maps as the step
+        step = step_two_calls
+
     def sync_all():
         if world > 1:
             dist.barrier()
