@@ -513,12 +513,12 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                 const int fs = stalled;
                 psfm_solve_stats ss;
                 memset(&ss, 0, sizeof(ss));
-                // (a fused solve that ran out of iterations is first retried with the most it can speculate; the chain
+                // (a fused solve that ran out of iterations is first retried with two iterations more; the chain
                 // takes what is left -- and every stalled solve of a chain window)
                 const int k_used = c->solver_K > 0 ? c->solver_K : c->solve_K;
                 st = psfm_solve_frame_resume(c, d, flows + (size_t)(fs - 1) * P * 2, flows + (size_t)fs * P * 2,
                                              flows_f2 + (size_t)(fs - 1) * P * 2, occ_s2 + (size_t)(fs - 1) * P, fs, &ss,
-                                             (fused_now && c->solver_K == 0 && k_used < psfm_solve_kmax()) ? psfm_solve_kmax() : 0, s);
+                                             (fused_now && c->solver_K == 0 && k_used < psfm_solve_kmax()) ? (k_used + 2 < psfm_solve_kmax() ? k_used + 2 : psfm_solve_kmax()) : 0, s);
                 if (st != PSFM_OK) return st;
                 hstats[fs] = ss;
                 last_ok = fs;
