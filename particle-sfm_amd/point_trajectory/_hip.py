@@ -60,6 +60,9 @@ def lib():
         raise RuntimeError(
             "libpsfm_hip.so not found at %s -- build it with `python particle-sfm_amd/build.py` "
             "(the HIP extension is mandatory, there is no CPU fallback)" % LIB_PATH)
+    # torch first: its bundled HIP runtime must be the one in the process.  Loaded before torch, libpsfm_hip.so would pull
+    # the system libamdhip64 in, torch would add its own copy, and the two runtimes do not see each other's devices.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
     L.psfm_last_error.restype = ctypes.c_char_p
