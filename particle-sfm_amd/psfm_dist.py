@@ -32,11 +32,17 @@ class TorchComm:
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.gpu_only = self.on and dist.get_backend(group) == "nccl"      # RCCL moves device memory only
+        self.cpu_only = self.on and not self.gpu_only                       # gloo: device tensors are staged through the host
 
     def all_reduce_max_(self, t):
         import torch.distributed as dist
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            if self.cpu_only and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
     def all_gather_flat(self, t):
@@ -45,12 +51,15 @@ class TorchComm:
         import torch.distributed as dist
         if self.world == 1:
             return t.reshape(-1).clone()
-        host = self.gpu_only and not t.is_cuda
-        if host:
+        to_dev, to_host = self.gpu_only and not t.is_cuda, self.cpu_only and t.is_cuda
+        dev = t.device
+        if to_dev:
             t = t.cuda()
+        elif to_host:
+            t = t.cpu()
         out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t.contiguous().reshape(-1), group=self.group)
-        return out.cpu() if host else out
+        return out.to(dev) if (to_dev or to_host) else out
 
     def all_gather_object(self, obj):
         import torch.distributed as dist

@@ -70,3 +70,53 @@ def test_connect_sharded_hip_engine(world, T, H, W, r, seed, sigma, nocc, optimi
         assert res[0][2]["fused"] >= len(O.solves) - 3          # clean sequence: (nearly) every solve in one launch
     if optimize and sigma >= 0.4:
         assert res[0][2]["fused_redone"] >= len(O.solves) // 2  # noisy sequence: the chain protocol did the work
+
+
+def _proc_worker(rank, world, port, ret):
+    """one PROCESS per rank on the box's single GPU, torch.distributed over gloo (device tensors staged through the host by
+    psfm_dist.TorchComm): the multi-process plumbing of connect_sharded with the HIP engine"""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import psfm_dist
+        import psfm_synth as synth
+        from point_trajectory.shard import HipShardEngine, flow_check_slice
+        torch.cuda.set_device(0)
+        T, H, W, r = 10, 60, 84, 2
+        d = synth.synth_sequence(T, H, W, seed=22, sigma=0.05, n_occluders=1, stride2=True)
+        st = {k: torch.from_numpy(np.stack(d[k])).cuda() for k in ("flows_f", "flows_b", "flows_f2", "flows_b2")}
+        part = psfm_dist.connect_sharded(HipShardEngine(), st["flows_f"], st["flows_b"], st["flows_f2"], st["flows_b2"], 1.0, r,
+                                         flow_check_slice)
+        birth, length, off, xy = psfm_dist.gather_result(part)
+        ret[rank] = (birth, length, xy, [s["iterations"] for s in part["solve_stats"]], len(part["birth"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_connect_sharded_two_processes_one_gpu():
+    import os
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_proc_worker, args=(world, 33500 + os.getpid() % 2000, ret), nprocs=world, join=True)
+    T, H, W, r = 10, 60, 84, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=22, sigma=0.05, n_occluders=1, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    assert len(ret) == world
+    for rank in range(world):
+        birth, length, xy, its, n_local = ret[rank]
+        assert np.array_equal(birth, O.birth) and np.array_equal(length, O.length) and float(np.abs(xy - O.xy).max()) <= 1e-4
+        assert its == [s["iterations"] for s in O.solves] and 0 < n_local < O.n_traj
