@@ -330,3 +330,27 @@ def test_default_track_npy_loads_with_a_pybind_module_that_only_knows_the_refere
             fr, loc, lab = g[str(i)]
             assert fr == list(range(birth[i], birth[i] + length[i])) and lab == [False] * int(length[i])
             assert np.array_equal(np.array(loc), xy[off[i]:off[i + 1]])
+
+
+def test_package_imports_from_a_git_archive(tmp_path):
+    """What `git archive HEAD` exports must be a working source tree: every module of the product package is tracked
+    (an unanchored ignore pattern once hid point_trajectory/optimize/build/) and `import point_trajectory` works from it."""
+    import shutil
+    import subprocess
+    if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout")
+    tar = tmp_path / "head.tar"
+    r = subprocess.run(["git", "-C", ROOT, "archive", "--format=tar", "-o", str(tar), "HEAD"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("git archive failed: " + r.stderr[:200])
+    out = tmp_path / "export"
+    out.mkdir()
+    subprocess.run(["tar", "-xf", str(tar), "-C", str(out)], check=True)
+    for rel in ("particle-sfm_amd/point_trajectory/optimize/build/particlesfm.py", "particle-sfm_amd/point_trajectory/shard.py",
+                "particle-sfm_amd/csrc/psfm_chain_step.h", "particle-sfm_amd/csrc/psfm_shard.hip", "particle-sfm_amd/csrc/psfm_matches.hip",
+                "include/psfm.h", "oracle/psfm_oracle.c", "tests/golden/matches_40x56_t12.npz"):
+        assert (out / rel).exists(), rel
+    code = ("import sys; sys.path.insert(0, %r); import point_trajectory; from point_trajectory.optimize.build import particlesfm; "
+            "import psfm_dist; from point_trajectory import shard; print('ok')" % str(out / "particle-sfm_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-800:]
