@@ -208,6 +208,7 @@ psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hip
 psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d);   // every solver buffer of a sequence, up front
 int psfm_solve_kmax(void);
 // track-sharded runs (psfm_shard.hip)
+void psfm_shard_abandon(psfm_ctx* c);   // a run that was begun and never finished (context teardown)
 psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
                               const uint8_t* occ02, int frame, int kind, int K, double* sums_out, hipStream_t s);
 psfm_status psfm_solve_control(psfm_ctx* c, const PsfmTrackDims& d, int frame, int kind, int K, const double* totals, hipStream_t s);

@@ -22,6 +22,12 @@
         PSFM_HIP(hipSetDevice((c)->device));                                                                 \
     } while (0)
 
+void psfm_shard_abandon(psfm_ctx* c)
+{
+    delete c->shard_dims;
+    c->shard_dims = nullptr;
+}
+
 extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, int ratio, int64_t g0, int64_t g1, int optimize,
                                         uint8_t* maps, int64_t map_pitch, void* stream)
 {

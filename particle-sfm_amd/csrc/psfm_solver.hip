@@ -10,18 +10,26 @@
 // (TrustRegionMinimizer + DoglegStrategy/TRADITIONAL_DOGLEG + Jacobi scaling + SPARSE_NORMAL_CHOLESKY,
 // max 200 iterations) is reproduced with its scalars reduced over all tracks:
 //
-//   pc_init   per track: refs/scale (fp32 sampler, trajectory.py:173-183), Jacobi scaling, and -- in the same launch --
-//             trust-region iteration 1 (below)
+//   fused     (track_optimize's default) ONE launch per solve -- per FRAME together with the chain step (psfm_frame_kernel):
+//             thread = track runs K trust-region iterations in registers, speculating what Ceres does on every solve that
+//             converges without a rejection (Gauss-Newton step inside the trust region, mu = min_mu, step accepted); the K
+//             x 13 sums are reduced wave -> block -> group -> grid and the last block REPLAYS the control flow below over
+//             them.  The first decision that is not "Gauss-Newton step accepted" ends the belief: termination = done, anything
+//             else = the solve is redone by the launch chain from the values it started with.
+//   pc_init   (launch chain) per track: refs/scale (fp32 sampler, trajectory.py:173-183), Jacobi scaling, and -- in the same
+//             launch -- trust-region iteration 1 (below)
 //   pc_iter   ONE launch per trust-region iteration, one pass per track: r, J at x (f64 bilinear gather), the
 //             4x4 block of the normal equations solved by a register-resident Cholesky, the step, the model decrease,
 //             the candidate x+ and its cost.  The dogleg case depends on GLOBAL norms that only exist after the
 //             launch, so the kernel speculates the overwhelmingly common case (pure Gauss-Newton step inside the trust
 //             region); when the reduced norms say otherwise the control step re-issues the iteration with the
-//             interpolation coefficients fixed.  x lives in a ping-pong pair (log slabs <-> scratch).
-//   control   (last block of each launch) deterministic reduction of the per-block partials + Ceres' scalar logic:
-//             accept / reject / radius / mu / the three tolerances.  Consecutive rejections whose shrunken radius
-//             still contains the Gauss-Newton step reproduce the same candidate, so they are replayed in the control
-//             step without relaunching (bit-identical to Ceres, which recomputes the same step each time).
+//             interpolation coefficients fixed.  x ping-pongs between iterate buffers 1 and 2; buffer 0 (the caller's
+//             values / the log slabs) is only written by the write-back.
+//   control   pc_control_step: Ceres' scalar logic for one iteration from its 13 global sums -- accept / reject / radius /
+//             mu / the three tolerances.  Consecutive rejections whose shrunken radius still contains the Gauss-Newton step
+//             reproduce the same candidate, so they are replayed without relaunching (bit-identical to Ceres, which
+//             recomputes the same step each time).  Run by the last block of each launch (ticket after write-through
+//             partials), or -- track-sharded runs -- by psfm_pc_control_kernel on the totals over all ranks.
 //             Nothing returns to the host inside the loop.
 //
 // All arithmetic f64 without contraction; reductions have a fixed order (bitwise reproducible for a
