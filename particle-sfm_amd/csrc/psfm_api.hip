@@ -467,15 +467,127 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // window to the chain, a clean window brings the fused solve back; solve_K follows the accepted steps seen.
     c->n_fused_ok = c->n_fused_redone = c->n_chain = 0;
     if (optimize && (st = psfm_solve_prepare(c, d)) != PSFM_OK) return st;
+    // PSFM_MERGE_FRAME=0: chain step and fused solve as two launches (what the merged frame kernel is measured against);
+    // PSFM_SEQ=0: host-paced frame kernels (one per frame, stall + redo when a solve needs more iterations than speculated)
+    static const bool merge = !(getenv("PSFM_MERGE_FRAME") && atoi(getenv("PSFM_MERGE_FRAME")) == 0);
+    static const bool seq_env = !(getenv("PSFM_SEQ") && atoi(getenv("PSFM_SEQ")) == 0);
+    bool seq_ok = optimize && merge && seq_env && unroll_fixed == 0;
+    int launch_id = 0;            // device-paced windows: id of the next psfm_seq_kernel launch (== PsfmCounters::pc_owner)
+    bool pc_in_step = true;       // the device's program counter is where the host thinks it is (track_init: frame 1, launch 0)
+    int* hpc = (int*)((char*)c->host_pinned + 320);     // pinned staging for {pc_frame, pc_phase, pc_owner, solve_K}
+    PsfmCounters* dctr = c->counters.as<PsfmCounters>();
+
+    // One checkpoint: counters + the window's statistics to the host, the stalled solve (if any) redone, statistics folded
+    // into the result and into the adaptation of mode / K / unroll.  f_hi: last frame whose launch has been enqueued.
+    // Returns the first frame that is NOT complete in *f_next.
+    auto checkpoint = [&](int f_hi, bool fused_now, bool seq, int* f_next) -> psfm_status {
+        PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
+        PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
+        PSFM_HIP(hipMemcpyAsync(hstats.data() + first_unchecked, c->sol_stats.as<psfm_solve_stats>() + first_unchecked,
+                                sizeof(psfm_solve_stats) * (size_t)(f_hi - first_unchecked + 1), hipMemcpyDeviceToHost, s));
+        PSFM_HIP(hipStreamSynchronize(s));
+        const int stalled = hc->stall ? hc->stall - 1 : -1;   // (the redo below reuses the pinned block `hc` points at)
+        int last_ok = f_hi;
+        if (seq) {      // frames below the device's program counter are complete (it may be in the middle of the next solve)
+            const int pcf = hc->pc_frame < n_flows ? hc->pc_frame : n_flows;
+            last_ok = pcf - 1;
+        }
+        if (stalled >= 0) {
+            const int fs = stalled;
+            psfm_solve_stats ss;
+            memset(&ss, 0, sizeof(ss));
+            // (a fused solve that ran out of iterations is first retried with two iterations more; the chain
+            // takes what is left -- and every stalled solve of a chain window)
+            const int k_used = c->solver_K > 0 ? c->solver_K : c->solve_K;
+            psfm_status st2 = psfm_solve_frame_resume(c, d, flows + (size_t)(fs - 1) * P * 2, flows + (size_t)fs * P * 2,
+                                                      flows_f2 + (size_t)(fs - 1) * P * 2, occ_s2 + (size_t)(fs - 1) * P, fs, &ss,
+                                                      (fused_now && !seq && c->solver_K == 0 && k_used < psfm_solve_kmax())
+                                                          ? (k_used + 2 < psfm_solve_kmax() ? k_used + 2 : psfm_solve_kmax()) : 0, s);
+            if (st2 != PSFM_OK) return st2;
+            hstats[fs] = ss;
+            last_ok = fs;
+            pc_in_step = false;     // the device's counter still points at the redone frame
+        }
+        int max_it = 0, n_solved = 0, n_unclean = 0, k_need = 2;
+        for (int k = first_unchecked; k <= last_ok; ++k) {
+            // (termination 5 = Ceres' FAILURE: the reference ignores it, trajectory_optimize.cpp:81-82, and carries on
+            // with the positions it had -- so does the device; the caller sees it in the solve statistics)
+            if (hstats[k].termination >= 0) {   // -1: no track had a full buffer, nothing was solved
+                c->solve_stats.push_back(hstats[k]);
+                total_iters += hstats[k].iterations;
+                // "clean": every iteration but the terminating one took the Gauss-Newton step and was accepted --
+                // what the fused solve speculates; it then needs successful_steps + 1 iterations in its launch
+                const psfm_solve_stats& q = hstats[k];
+                const bool clean = q.dogleg_nonGN == 0 && q.termination != PSFM_TERM_FAILURE &&
+                                   (q.iterations == q.successful_steps + 1 ||
+                                    (q.termination == PSFM_TERM_GRADIENT_TOL && q.iterations == q.successful_steps)) &&
+                                   q.successful_steps + 1 <= psfm_solve_kmax();
+                ++n_solved;
+                if (!clean) ++n_unclean;
+                else if (q.successful_steps + 1 > k_need) k_need = q.successful_steps + 1;
+                if (!fused_now) ++c->n_chain;
+                else if (k == stalled) ++c->n_fused_redone;
+                else ++c->n_fused_ok;
+            }
+            if (hstats[k].iterations > max_it) max_it = hstats[k].iterations;
+        }
+        if (n_solved > 0) {
+            c->solve_mode = (n_unclean * 8 > n_solved) ? 1 : 0;
+            if (seq) {
+                // device-paced: an iteration more than speculated costs one more launch, not a redo -- follow the MOST COMMON
+                // need of the window instead of its maximum
+                int hist[16] = {0};
+                for (int k = first_unchecked; k <= last_ok; ++k)
+                    if (hstats[k].termination >= 0) ++hist[hstats[k].successful_steps + 1 < 15 ? hstats[k].successful_steps + 1 : 15];
+                int best = 2;
+                for (int q = 2; q <= psfm_solve_kmax(); ++q) if (hist[q] > hist[best]) best = q;
+                c->solve_K = best;
+            } else {
+                c->solve_K = k_need > c->solve_K ? k_need : c->solve_K - (c->solve_K - k_need + 1) / 2;
+            }
+        }
+        // adapt the unroll to what this sequence needs, within [4, 64]: a solve of k iterations needs k-1 pc_iter
+        // launches (pc_init does the first), so max+1 leaves two spare launches for the slowest solve seen in the
+        // window (a spare launch is a no-op that costs < 1 us behind another one; a solve that still runs out raises the stall flag)
+        int want = max_it + 1;
+        want = want < 4 ? 4 : (want > 64 ? 64 : want);
+        c->solve_unroll = want > c->solve_unroll ? want : c->solve_unroll - (c->solve_unroll - want + 1) / 2;   // decays all the way
+        first_unchecked = last_ok + 1;
+        *f_next = last_ok + 1;   // after a stall: re-enqueue the (poisoned) frames behind the redone solve
+        return PSFM_OK;
+    };
+
     int f = 0;
     while (f < n_flows) {
+        const bool fused_now = c->solver_mode == 2 || (c->solver_mode == 0 && c->solve_mode == 0);
+        if (seq_ok && fused_now && f >= 1) {
+            // ---- a window of the device-paced sequence: launches that each do "the next thing" (psfm_seq_kernel) ----
+            const int k_now = c->solver_K > 0 ? c->solver_K : c->solve_K;
+            if (!pc_in_step) {       // behind a host-paced window or a redo: put the device's counter where the host is
+                hpc[0] = f; hpc[1] = 0; hpc[2] = launch_id; hpc[3] = k_now;
+                PSFM_HIP(hipMemcpyAsync(&dctr->pc_frame, hpc, 4 * sizeof(int), hipMemcpyHostToDevice, s));
+                pc_in_step = true;
+            } else {
+                hpc[3] = k_now;
+                PSFM_HIP(hipMemcpyAsync(&dctr->solve_K, hpc + 3, sizeof(int), hipMemcpyHostToDevice, s));
+            }
+            const int left = n_flows - f;
+            const int n_launch = (left < PSFM_CHECK ? left : PSFM_CHECK) + 2;   // two spare: continuation launches of the window
+            const int f_hi = f + n_launch - 1 < n_flows - 1 ? f + n_launch - 1 : n_flows - 1;   // the furthest the device can get
+            if (pipe && (st = pipe->need(f_hi, false, s)) != PSFM_OK) return st;
+            if (pipe && (st = pipe->need(f_hi - 1, true, s)) != PSFM_OK) return st;
+            if ((st = psfm_launch_seq(c, d, flows, occ, occ_pitch, flows_f2, occ_s2, n_launch, launch_id, s)) != PSFM_OK) return st;
+            launch_id += n_launch;
+            const int f_before = f;
+            if ((st = checkpoint(f_hi, true, true, &f)) != PSFM_OK) return st;
+            if (f == f_before) { seq_ok = false; pc_in_step = false; }   // (no frame completed: never expected -- host-paced from here)
+            continue;
+        }
+        pc_in_step = false;         // a host-paced frame: the device-side counter is not maintained
         // track.py:31-47 / track_optimize.py:31-50, one loop iteration:
         // one launch = births of frame f (new_traj_all) + chain step f (step_forward, extend_all)
         if (pipe && (st = pipe->need(f, false, s)) != PSFM_OK) return st;
-        const bool fused_now = c->solver_mode == 2 || (c->solver_mode == 0 && c->solve_mode == 0);
         const bool solve_now = optimize && f + 1 >= 2;   // track_optimize.py:49-50
-        // PSFM_MERGE_FRAME=0: chain step and fused solve as two launches (what the merged frame kernel is measured against)
-        static const bool merge = !(getenv("PSFM_MERGE_FRAME") && atoi(getenv("PSFM_MERGE_FRAME")) == 0);
         if (solve_now && fused_now && merge) {
             // ONE launch: chain step of the frame + the fused solve of its tracks
             if (pipe && (st = pipe->need(f - 1, true, s)) != PSFM_OK) return st;
@@ -501,64 +613,8 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                 if (st != PSFM_OK) return st;
             }
         }
-        const bool checkpoint = optimize && f >= 1 && ((f % PSFM_CHECK) == PSFM_CHECK - 1 || f == n_flows - 1);
-        if (checkpoint) {
-            PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
-            PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
-            PSFM_HIP(hipMemcpyAsync(hstats.data() + first_unchecked, c->sol_stats.as<psfm_solve_stats>() + first_unchecked,
-                                    sizeof(psfm_solve_stats) * (size_t)(f - first_unchecked + 1), hipMemcpyDeviceToHost, s));
-            PSFM_HIP(hipStreamSynchronize(s));
-            int last_ok = f;
-            const int stalled = hc->stall ? hc->stall - 1 : -1;   // (the redo below reuses the pinned block `hc` points at)
-            if (stalled >= 0) {
-                const int fs = stalled;
-                psfm_solve_stats ss;
-                memset(&ss, 0, sizeof(ss));
-                // (a fused solve that ran out of iterations is first retried with two iterations more; the chain
-                // takes what is left -- and every stalled solve of a chain window)
-                const int k_used = c->solver_K > 0 ? c->solver_K : c->solve_K;
-                st = psfm_solve_frame_resume(c, d, flows + (size_t)(fs - 1) * P * 2, flows + (size_t)fs * P * 2,
-                                             flows_f2 + (size_t)(fs - 1) * P * 2, occ_s2 + (size_t)(fs - 1) * P, fs, &ss,
-                                             (fused_now && c->solver_K == 0 && k_used < psfm_solve_kmax()) ? (k_used + 2 < psfm_solve_kmax() ? k_used + 2 : psfm_solve_kmax()) : 0, s);
-                if (st != PSFM_OK) return st;
-                hstats[fs] = ss;
-                last_ok = fs;
-            }
-            int max_it = 0, n_solved = 0, n_unclean = 0, k_need = 2;
-            for (int k = first_unchecked; k <= last_ok; ++k) {
-                // (termination 5 = Ceres' FAILURE: the reference ignores it, trajectory_optimize.cpp:81-82, and carries on
-                // with the positions it had -- so does the device; the caller sees it in the solve statistics)
-                if (hstats[k].termination >= 0) {   // -1: no track had a full buffer, nothing was solved
-                    c->solve_stats.push_back(hstats[k]);
-                    total_iters += hstats[k].iterations;
-                    // "clean": every iteration but the terminating one took the Gauss-Newton step and was accepted --
-                    // what the fused solve speculates; it then needs successful_steps + 1 iterations in its launch
-                    const psfm_solve_stats& q = hstats[k];
-                    const bool clean = q.dogleg_nonGN == 0 && q.termination != PSFM_TERM_FAILURE &&
-                                       (q.iterations == q.successful_steps + 1 ||
-                                        (q.termination == PSFM_TERM_GRADIENT_TOL && q.iterations == q.successful_steps)) &&
-                                       q.successful_steps + 1 <= psfm_solve_kmax();
-                    ++n_solved;
-                    if (!clean) ++n_unclean;
-                    else if (q.successful_steps + 1 > k_need) k_need = q.successful_steps + 1;
-                    if (!fused_now) ++c->n_chain;
-                    else if (k == stalled) ++c->n_fused_redone;
-                    else ++c->n_fused_ok;
-                }
-                if (hstats[k].iterations > max_it) max_it = hstats[k].iterations;
-            }
-            if (n_solved > 0) {
-                c->solve_mode = (n_unclean * 8 > n_solved) ? 1 : 0;
-                c->solve_K = k_need > c->solve_K ? k_need : c->solve_K - (c->solve_K - k_need + 1) / 2;
-            }
-            // adapt the unroll to what this sequence needs, within [4, 64]: a solve of k iterations needs k-1 pc_iter
-            // launches (pc_init does the first), so max+1 leaves two spare launches for the slowest solve seen in the
-            // window (a spare launch is a no-op that costs < 1 us behind another one; a solve that still runs out raises the stall flag)
-            int want = max_it + 1;
-            want = want < 4 ? 4 : (want > 64 ? 64 : want);
-            c->solve_unroll = want > c->solve_unroll ? want : c->solve_unroll - (c->solve_unroll - want + 1) / 2;   // decays all the way
-            first_unchecked = last_ok + 1;
-            f = last_ok + 1;   // after a stall: re-enqueue the (poisoned) frames behind the resumed solve
+        if (optimize && f >= 1 && ((f % PSFM_CHECK) == PSFM_CHECK - 1 || f == n_flows - 1)) {
+            if ((st = checkpoint(f, fused_now, false, &f)) != PSFM_OK) return st;
             continue;
         }
         ++f;

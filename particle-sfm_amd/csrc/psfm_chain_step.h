@@ -30,7 +30,31 @@ struct PsfmChainArgs {
     // grid point g0 + i -- and the "a track survived" flag travels as byte G of the blocked maps (stamped like them), so
     // that ONE all-reduce(max) of G + 1 bytes per frame carries everything the ranks owe each other
     int g0, Gband, shard;
+    // device-paced sequence (psfm_seq_kernel): no host-side clear of the blocked map at the stamp wrap -- the grid point's
+    // owner thread zeroes the byte it has just read when the map is about to be written with recycled stamps
+    int owner_clear;
 };
+
+// What changes from one frame to the next in the arguments of a chain step (everything else is per-sequence): strides of
+// the per-frame stacks.  psfm_chain_args_rebase turns the arguments of frame `a.frame` into those of frame f -- the
+// same values psfm_fill_chain_args computes on the host (checked there under PSFM_SEQ_CHECK).
+struct PsfmSeqStride { int64_t flow, occ, cap; };
+__host__ __device__ inline void psfm_chain_args_rebase(PsfmChainArgs& a, const PsfmSeqStride& st, int f)
+{
+    const int64_t df = (int64_t)f - a.frame;
+    a.flow += df * st.flow; a.occ += df * st.occ;
+    a.log_cur += df * st.cap; a.log_next += df * st.cap;
+    a.log_prev = a.log_cur - (f > 0 ? st.cap : 0);
+    if (df & 1) {
+        const uint8_t* bp = a.blocked_prev; a.blocked_prev = a.blocked_cur; a.blocked_cur = const_cast<uint8_t*>(bp);
+        PsfmShard* sp = a.sh_pop; a.sh_pop = a.sh_push; a.sh_push = sp;
+        const int* fp = a.free_pop; a.free_pop = a.free_push; a.free_push = const_cast<int*>(fp);
+    }
+    a.stamp_cur = (uint8_t)((f % 254) + 1);
+    a.stamp_prev = (uint8_t)(((f + 253) % 254) + 1);
+    a.surv_cur += df; a.surv_prev = a.surv_cur - (f > 0 ? 1 : 0);
+    a.frame = f;
+}
 
 #ifndef PSFM_CHAIN_BLOCK
 #define PSFM_CHAIN_BLOCK 256
@@ -72,6 +96,7 @@ extern "C" int psfm_debug_timeline(int frame, unsigned long long* out_host, int 
 
 void psfm_fill_chain_args(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ, int frame, PsfmChainArgs& a,
                           hipStream_t s);
+void psfm_fill_chain_args_nolaunch(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ, int frame, PsfmChainArgs& a);
 
 // What the merged frame kernel (psfm_solver.hip) takes over from the chain step of a thread's lane: does the lane's track
 // take part in the path-consistency solve of this frame (alive after the step, born at least two frames ago), and its
@@ -111,7 +136,7 @@ __device__ __forceinline__ bool psfm_chain_step_body(const PsfmChainArgs& a, Psf
     const int sel = OPT ? a.ctr->sel : 0;   // (same cache line as `stall`)
     // tiles past both the lane high-water mark and the grid have nothing to do (lanes handed out during
     // this launch are born at `frame` and are stepped by their allocator, not by their own thread)
-    if (tile >= max(MERGED ? a.ctr->n_lanes_snap : a.ctr->n_lanes, a.Gband)) return false;
+    if (tile >= max(MERGED ? a.ctr->n_lanes_snap[frame & 1] : a.ctr->n_lanes, a.Gband)) return false;
     if (tid == 0) s_alive_any = 0;
 
     // ---- independent early loads: lane state, (speculative) tail position, respawn byte ----
@@ -143,6 +168,8 @@ __device__ __forceinline__ bool psfm_chain_step_body(const PsfmChainArgs& a, Psf
             } else {
                 birth[u] = psfm_ld(a.blocked_prev, (unsigned)g) != a.stamp_prev;
             }
+            // (this map is written again at frame + 1; stamps come round every 254 frames: its reader wipes it in time)
+            if (a.owner_clear && ((frame + 1) % 254) <= 1) const_cast<uint8_t*>(a.blocked_prev)[g] = 0;
         }
     }
 #pragma unroll

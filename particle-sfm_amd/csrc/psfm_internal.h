@@ -60,9 +60,14 @@ struct PsfmCounters {
     int spill_cnt;    // persistent frame loop: records written to the shared tail behind the private segments
     int sel;          // track_optimize: iterate buffer that holds the accepted positions (times f, f+1) of the last fused
                       // solve; 0 = they are in the log.  The next chain step copies them on its way (psfm_solver.hip)
-    int n_lanes_snap; // n_lanes as the previous launch of the sequence left it (set by track_init, the merged frame kernel's
-                      // control thread and the solver's write-back): the tile bound every block of a merged launch agrees on
-    int pad[9];
+    int n_lanes_snap[2]; // n_lanes as the launch in front of frame f left it, in entry f & 1 (set by track_init, by the control
+                      // thread of the frame kernel of f-1 and by the solver's write-back): the tile bound every block of the frame
+                      // kernel of f agrees on -- n_lanes itself grows while that launch runs, and nothing it reads changes under it
+    // device-paced sequence (psfm_seq_kernel): which frame the next launch works on (pc_phase 0: its chain step + fused solve,
+    // 1: more iterations of its solve), which launch that is (a block of an earlier launch that starts after its control thread
+    // has moved on must not pick the new work up), iterations per fused launch
+    int pc_frame, pc_phase, pc_owner, solve_K;
+    int pad[4];
 };
 
 // Death records and free lanes are published through PSFM_NSHARD independent tables so that the
@@ -204,6 +209,8 @@ psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const fl
                                    const float* flow02, const uint8_t* occ02, int frame, int K, hipStream_t s);
 psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
                               const uint8_t* occ, const uint8_t* occ02, int frame, int K, hipStream_t s);
+psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
+                            const float* flows_f2, const uint8_t* occ_s2, int n_launches, int launch_id0, hipStream_t s);
 psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d);   // every solver buffer of a sequence, up front
 int psfm_solve_kmax(void);

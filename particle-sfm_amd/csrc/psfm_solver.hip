@@ -65,7 +65,8 @@ struct PsfmSolveCtrl {
     int dl_fixed, done, termination, iteration;   // dl_fixed == 0: the kernel speculates the Gauss-Newton step (0, 1)
     int n_invalid, cur, successful, nonGN;
     int n_tracks, failed, dl_case, launches;
-    int fresh_x, pad0;               // x was accepted by the previous control step: gradient test pending
+    int fresh_x, k_first;            // x was accepted by the previous control step: gradient test pending; iterations of the
+                                     // solve's first fused launch (fixes where its iterates live)
 };
 
 struct PcParams {
@@ -103,7 +104,7 @@ struct PcParams {
     double* gpart;            // [groups][PC_KMAX][PC_NSUM] sums of PC_GROUP consecutive blocks
     unsigned* gticket;        // [groups] + 1 (top)
     int* sel;                 // PsfmCounters::sel: buffer that holds the accepted iterate of the last solve (0: the log)
-    int* n_lanes_snap;        // PsfmCounters::n_lanes_snap (frame mode)
+    int* n_lanes_snap;        // PsfmCounters::n_lanes_snap[2] (frame mode)
     // track-sharded runs: the tracks of the solve are spread over several processes.  A launch then only EXPORTS its sums
     // ([K or 1][PC_NSUM], this process's tracks); the ranks combine them (all-gather, rank order) and every rank runs the
     // same control step on the totals (psfm_pc_control_kernel)
@@ -744,29 +745,46 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
 // copies it into the log on its way); anything else (rejection, dogleg interpolation, invalid step, more than K
 // iterations) raises the stall flag and the host redoes this solve with the launch chain from the untouched buffer 0.
 // ------------------------------------------------------------------------------------------------
-// Ceres' control flow replayed over the sums of the K speculated iterations (thread 0 of the last block, or the control
-// kernel of a track-sharded run): tot[j * PC_NSUM + k].
-__device__ __forceinline__ void pc_fused_replay(const PcParams& P, const double* tot, int K)
+// Where iterate m (the position after m accepted steps) of a fused solve lives.  A solve that goes as speculated accepts
+// e = k_first - 1 steps and terminates in iteration k_first, so iterate e is written straight into buffer 0 -- the log
+// slabs, where the next chain step and finalize read -- and the values the solve started from are kept in buffer e
+// instead; every other iterate m sits in buffer m.
+__device__ __forceinline__ int pc_phys(int m, int e) { return m == e ? 0 : (m == 0 ? e : m); }
+
+// Ceres' control flow replayed over the sums of `n_it` speculated iterations (thread 0 of the last block, or the control
+// kernel of a track-sharded run): tot[j * PC_NSUM + k].  first: the launch that started the solve (iteration 1 ..), else
+// a continuation behind `C.cur` accepted steps.  pc != NULL (device-paced sequence): the outcome also says what the NEXT
+// launch does -- the next frame, or more iterations of this solve when every one so far was accepted and none terminated.
+__device__ __forceinline__ void pc_fused_replay(const PcParams& P, const double* tot, int n_it, bool first, PsfmCounters* pc,
+                                                int launch_id)
 {
-    const int e = K - 1;
-#define PC_PHYS(m) ((m) == e ? 0 : ((m) == 0 ? e : (m)))
     PsfmSolveCtrl C = *P.ctrl;
-    for (int j = 1; j <= K; ++j) {
-        pc_control_step(C, tot + (j - 1) * PC_NSUM, j == 1, j);
+    const int base = first ? 0 : C.cur;
+    const int k_first = first ? n_it : C.k_first;
+    for (int j = 1; j <= n_it; ++j) {
+        pc_control_step(C, tot + (j - 1) * PC_NSUM, first && j == 1, base + j);
         if (C.done) break;
-        // iteration j + 1 was computed at buffer j with the Gauss-Newton step at min_mu: only valid behind an accepted step
-        if (!(C.fresh_x && C.cur == j && C.dl_fixed == 0 && C.mu == 1e-8)) break;
+        // iteration j + 1 was computed at iterate base + j with the Gauss-Newton step at min_mu: only valid behind an accepted step
+        if (!(C.fresh_x && C.cur == base + j && C.dl_fixed == 0 && C.mu == 1e-8)) break;
     }
+    C.k_first = k_first;
     C.launches += 1;
     *P.ctrl = C;
-    if (!C.done) {      // not what was speculated: the launch chain redoes this solve from the values it started from,
-        *P.sel = PC_PHYS(0);   // which psfm_solve_frame_resume first moves back into buffer 0
+    const int e = k_first - 1;
+    if (!C.done) {
+        const bool all_accepted = C.fresh_x && C.cur == base + n_it && C.dl_fixed == 0 && C.mu == 1e-8;
+        if (pc && all_accepted && C.cur + 1 <= PC_KMAX) {     // device-paced: the next launch continues this solve
+            pc->pc_phase = 1;
+            pc->pc_owner = launch_id + 1;
+            return;
+        }
+        // not what was speculated: the launch chain redoes this solve from the values it started from,
+        *P.sel = pc_phys(0, e);   // which psfm_solve_frame_resume first moves back into buffer 0
         *P.stall = P.frame + 1;
         return;
     }
     // (a failed solve hands the parameters back as they came in: nothing was accepted, C.cur == 0 -- see the write-back)
-    *P.sel = PC_PHYS(C.cur);
-#undef PC_PHYS
+    *P.sel = pc_phys(C.cur, e);
     if (P.stats_dev) {
         psfm_solve_stats st;
         st.iterations = C.iteration; st.successful_steps = C.successful;
@@ -775,6 +793,7 @@ __device__ __forceinline__ void pc_fused_replay(const PcParams& P, const double*
         if (C.failed) st.termination = PSFM_TERM_FAILURE;
         P.stats_dev[P.frame] = st;
     }
+    if (pc) { pc->pc_frame = P.frame + 1; pc->pc_phase = 0; pc->pc_owner = launch_id + 1; }
 }
 
 struct PcTrack {            // one track's solve state in registers
@@ -894,81 +913,65 @@ __device__ __forceinline__ bool pc_last_arrival(unsigned* ticket, unsigned membe
     return s_last2 != 0;
 }
 
-// WAVES: waves per SIMD the register allocation targets (3: 136 VGPRs, no spill; 4: 128 VGPRs, 4 spilled)
-// The solve of lane i = blockIdx.x * PC_BLOCK + threadIdx.x (if `part`) from its three buffered positions, the sums of
-// the launch and -- in its last block -- the control flow.  n_active: the blocks of the launch that come here (every one
-// of them, whatever its lanes do: the tickets count them).
-__device__ __forceinline__ void pc_fused_body(const PcParams& P, bool part, double2 p0, double2 p1, double2 p2, int n_active,
-                                              int* n_lanes_snap, const int* n_lanes_live)
+// (one LDS instance for every body that reduces per wave: a kernel that contains two of them must not pay for two)
+__device__ __forceinline__ PcWaveRed& pc_shared_red()
 {
-    const int K = P.K;
+    __shared__ PcWaveRed s_red_storage;
+    return s_red_storage;
+}
+
+// refs / scale (trajectory.py:173-183, as in psfm_pc_init_kernel) and the Jacobi scaling of a track: from its p0 and
+// the values x0 its solve starts from.  Leaves T.x = x0 evaluated (T.r, T.jac); returns the cost at x0.
+__device__ __forceinline__ double pc_track_setup(const PcParams& P, PcTrack& T, double2 p0, double2 p1, double2 p2, double mu)
+{
+    const PsfmTaps t = psfm_taps((float)p0.x, (float)p0.y, P.cw, P.ch, P.H, P.W);
+    const PsfmTapIdx k = psfm_tap_idx(P.H, P.W, t);
+    const float2 f01 = psfm_sample_flow(P.flow01, k, t);
+    const float2 f02 = psfm_sample_flow(P.flow02, k, t);
+    const float o02 = psfm_sample_mask(P.occ02, k, t);
+    const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
+    const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
+    T.s = (double)sf;
+    T.r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
+    T.r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
+    T.x[0] = p1.x; T.x[1] = p1.y; T.x[2] = p2.x; T.x[3] = p2.y;
+    pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, T.s, T.r, T.jac);
+    // Jacobi scaling from the Jacobian at x0 (jac[] holds exactly the entries psfm_pc_init_kernel rebuilds)
+    const double q0 = (1.0 + T.jac[0] * T.jac[0]) + T.jac[2] * T.jac[2];
+    const double q1 = (1.0 + T.jac[1] * T.jac[1]) + T.jac[3] * T.jac[3];
+    const double q2 = T.s * T.s + 1.0;
+    T.S0 = 1.0 / (1.0 + sqrt(q0)); T.S1 = 1.0 / (1.0 + sqrt(q1)); T.S2 = 1.0 / (1.0 + sqrt(q2));
+    T.pre = pc_gn_pre(T.s, T.S2, mu);
+    double ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) ss += T.r[q] * T.r[q];
+    return 0.5 * ss;
+}
+
+// The block's sums of n_it iterations (the waves' sums, in wave order) -> its partial row; then the two tickets: the
+// last block of each group of PC_GROUP consecutive blocks adds the group's rows, the last group adds the group sums in
+// group order.  Returns the totals ([n_it][PC_NSUM], in LDS) in the LAST block of the launch, NULL in every other block.
+// n_active: the blocks of the launch that come here.
+__device__ __forceinline__ const double* pc_grid_totals(const PcParams& P, PcWaveRed& s_red, int n_it, int n_active)
+{
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * PC_BLOCK + tid;
-    const double mu = 1e-8;
-    // Where the iterates live.  A solve that goes as speculated accepts e = K - 1 steps and terminates in iteration K, so
-    // iterate e is written straight into buffer 0 -- the log slabs, where the next chain step and finalize read -- and
-    // the values the solve started from are kept in buffer e instead; every other iterate m sits in buffer m.
-    const int e = K - 1;
-#define PC_PHYS(m) ((m) == e ? 0 : ((m) == 0 ? e : (m)))
-    __shared__ PcWaveRed s_red;
-    PcTrack T;
-    double c0 = 0.0;
-    if (part) {
-        if (e != 0) { pc_buf1(P, e)[i] = p1; pc_buf2(P, e)[i] = p2; }
-        const PsfmTaps t = psfm_taps((float)p0.x, (float)p0.y, P.cw, P.ch, P.H, P.W);
-        const PsfmTapIdx k = psfm_tap_idx(P.H, P.W, t);
-        const float2 f01 = psfm_sample_flow(P.flow01, k, t);
-        const float2 f02 = psfm_sample_flow(P.flow02, k, t);
-        const float o02 = psfm_sample_mask(P.occ02, k, t);
-        // (trajectory.py:173-183, as in psfm_pc_init_kernel)
-        const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
-        const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
-        T.s = (double)sf;
-        T.r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
-        T.r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
-        T.x[0] = p1.x; T.x[1] = p1.y; T.x[2] = p2.x; T.x[3] = p2.y;
-        pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, T.s, T.r, T.jac);
-        // Jacobi scaling from the Jacobian at x0 (jac[] holds exactly the entries psfm_pc_init_kernel rebuilds)
-        const double q0 = (1.0 + T.jac[0] * T.jac[0]) + T.jac[2] * T.jac[2];
-        const double q1 = (1.0 + T.jac[1] * T.jac[1]) + T.jac[3] * T.jac[3];
-        const double q2 = T.s * T.s + 1.0;
-        T.S0 = 1.0 / (1.0 + sqrt(q0)); T.S1 = 1.0 / (1.0 + sqrt(q1)); T.S2 = 1.0 / (1.0 + sqrt(q2));
-        T.pre = pc_gn_pre(T.s, T.S2, mu);
-        double ss = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) ss += T.r[q] * T.r[q];
-        c0 = 0.5 * ss;
-    }
-    for (int j = 0; j < K; ++j) {
-        double v[PC_NSUM];
-#pragma unroll
-        for (int q = 0; q < PC_NSUM; ++q) v[q] = 0.0;
-        if (part) {
-            // (the K-th candidate is never read: were it accepted, the solve would not be over and is redone)
-            const bool keep = j + 1 < K;
-            pc_fused_iteration(P, T, mu, keep ? pc_buf1(P, PC_PHYS(j + 1)) : nullptr, keep ? pc_buf2(P, PC_PHYS(j + 1)) : nullptr, i, v);
-            if (j == 0) { v[SUM_CNT] = 1.0; v[SUM_COST0] = c0; }
-        }
-        pc_wave_reduce(s_red, v, j);
-    }
     __syncthreads();
-    if (tid < K * PC_NSUM) {   // the block's sums: its waves in order
+    if (tid < n_it * PC_NSUM) {   // the block's sums: its waves in order
         const int j = tid / PC_NSUM, k = tid - j * PC_NSUM;
         double t = s_red.wsum[0][j][k];
 #pragma unroll
         for (int w = 1; w < PC_NW; ++w) t = (k == SUM_GMAX) ? fmax(t, s_red.wsum[w][j][k]) : t + s_red.wsum[w][j][k];
         __hip_atomic_store(&P.partials[((int64_t)blockIdx.x * PC_KMAX + j) * PC_NSUM + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-
-    // ---- level 1: the last block of each group of PC_GROUP consecutive blocks adds the group's partials ----
+    // ---- level 1 ----
     const int n_groups = (n_active + PC_GROUP - 1) / PC_GROUP;
     const int grp = blockIdx.x / PC_GROUP;
     const int members = min(PC_GROUP, n_active - grp * PC_GROUP);
-    if (!pc_last_arrival(P.gticket + 1 + grp, (unsigned)members)) return;
+    if (!pc_last_arrival(P.gticket + 1 + grp, (unsigned)members)) return nullptr;
     __shared__ double s_half[2][PC_KMAX * PC_NSUM];
     __shared__ double s_tot[PC_KMAX][PC_NSUM];
     const int slot = tid & 127, half = tid >> 7;      // slot = j * PC_NSUM + k
-    const int nslot = K * PC_NSUM;
+    const int nslot = n_it * PC_NSUM;
     {
         double t = 0.0;
         if (slot < nslot) {
@@ -993,8 +996,8 @@ __device__ __forceinline__ void pc_fused_body(const PcParams& P, bool part, doub
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    // ---- level 2: the last group adds the group sums in group order and runs the control flow ----
-    if (!pc_last_arrival(P.gticket, (unsigned)n_groups)) return;
+    // ---- level 2 ----
+    if (!pc_last_arrival(P.gticket, (unsigned)n_groups)) return nullptr;
     {
         double t = 0.0;
         if (slot < nslot) {
@@ -1019,15 +1022,91 @@ __device__ __forceinline__ void pc_fused_body(const PcParams& P, bool part, doub
         }
         __syncthreads();
     }
+    return &s_tot[0][0];
+}
+
+// The solve of lane i = blockIdx.x * PC_BLOCK + threadIdx.x (if `part`) from its three buffered positions, the sums of
+// the launch and -- in its last block -- the control flow.  n_active: the blocks of the launch that come here (every one
+// of them, whatever its lanes do: the tickets count them).  snap_next / n_lanes_live: the merged frame kernel leaves the
+// lane count for the next frame's launch.  pc / launch_id: device-paced sequence (see pc_fused_replay); there the K-th
+// candidate is stored too (a continuation launch starts from it).
+__device__ __forceinline__ void pc_fused_body(const PcParams& P, bool part, double2 p0, double2 p1, double2 p2, int n_active,
+                                              int* snap_next, const int* n_lanes_live, PsfmCounters* pc, int launch_id)
+{
+    const int K = P.K;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * PC_BLOCK + tid;
+    const double mu = 1e-8;
+    const int e = K - 1;            // (pc_phys: iterate e goes straight into the log slabs, the start values into buffer e)
+    PcWaveRed& s_red = pc_shared_red();
+    PcTrack T;
+    double c0 = 0.0;
+    if (part) {
+        if (e != 0) { pc_buf1(P, e)[i] = p1; pc_buf2(P, e)[i] = p2; }
+        c0 = pc_track_setup(P, T, p0, p1, p2, mu);
+    }
+    for (int j = 0; j < K; ++j) {
+        double v[PC_NSUM];
+#pragma unroll
+        for (int q = 0; q < PC_NSUM; ++q) v[q] = 0.0;
+        if (part) {
+            // (host-paced: the K-th candidate is never read -- were it accepted, the solve would not be over and is redone)
+            const bool keep = j + 1 < K || (pc != nullptr && K < PC_KMAX);
+            const int m = pc_phys(j + 1, e);
+            pc_fused_iteration(P, T, mu, keep ? pc_buf1(P, m) : nullptr, keep ? pc_buf2(P, m) : nullptr, i, v);
+            if (j == 0) { v[SUM_CNT] = 1.0; v[SUM_COST0] = c0; }
+        }
+        pc_wave_reduce(s_red, v, j);
+    }
+    const double* tot = pc_grid_totals(P, s_red, K, n_active);
+    if (!tot) return;
     if (P.export_sums) {      // track-sharded: the totals of THIS process; the control step follows the ranks' exchange
-        if (tid < nslot) P.export_sums[tid] = s_tot[tid / PC_NSUM][tid % PC_NSUM];
+        if (tid < K * PC_NSUM) P.export_sums[tid] = tot[tid];
         return;
     }
     if (tid != 0) return;
-    if (n_lanes_snap) *n_lanes_snap = *n_lanes_live;   // (every block is past its chain step: the count is final for this launch)
-    pc_fused_replay(P, &s_tot[0][0], K);
+    if (snap_next) *snap_next = *n_lanes_live;   // (every block is past its chain step: the count is final for this launch)
+    pc_fused_replay(P, tot, K, true, pc, launch_id);
 }
-#undef PC_PHYS
+
+// Device-paced sequence: MORE iterations of the solve of P.frame, behind a launch whose K iterations were all accepted
+// without terminating it.  The track state is rebuilt from p0 and the start values (kept in buffer k_first - 1), the
+// iterate is read from where the previous launch left it, up to two more iterations are speculated the same way.
+__device__ __forceinline__ void pc_more_body(const PcParams& P, int n_active, PsfmCounters* pc, int launch_id)
+{
+    const PsfmSolveCtrl C0 = *P.ctrl;
+    const int e = C0.k_first - 1, base = C0.cur;
+    const int n_it = min(2, PC_KMAX - base);
+    const int n = min(*P.n_lanes_ptr, P.n_rows);
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * PC_BLOCK + tid;
+    const double mu = 1e-8;
+    PcWaveRed& s_red = pc_shared_red();
+    const bool part = pc_participates(P, i, n);
+    PcTrack T;
+    if (part) {
+        const double2 p0 = P.p0[i];
+        const double2 s1 = pc_buf1(P, pc_phys(0, e))[i], s2 = pc_buf2(P, pc_phys(0, e))[i];      // the start values
+        (void)pc_track_setup(P, T, p0, s1, s2, mu);
+        const double2 c1 = pc_buf1(P, pc_phys(base, e))[i], c2 = pc_buf2(P, pc_phys(base, e))[i];  // the current iterate
+        T.x[0] = c1.x; T.x[1] = c1.y; T.x[2] = c2.x; T.x[3] = c2.y;
+        pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, T.s, T.r, T.jac);
+    }
+    for (int j = 0; j < n_it; ++j) {
+        double v[PC_NSUM];
+#pragma unroll
+        for (int q = 0; q < PC_NSUM; ++q) v[q] = 0.0;
+        if (part) {
+            const int m = pc_phys(base + j + 1, e);
+            const bool keep = base + j + 1 <= PC_KMAX;
+            pc_fused_iteration(P, T, mu, keep ? pc_buf1(P, m) : nullptr, keep ? pc_buf2(P, m) : nullptr, i, v);
+        }
+        pc_wave_reduce(s_red, v, j);
+    }
+    const double* tot = pc_grid_totals(P, s_red, n_it, n_active);
+    if (!tot || tid != 0) return;
+    pc_fused_replay(P, tot, n_it, false, pc, launch_id);
+}
 
 template <int WAVES>
 __global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
@@ -1041,7 +1120,7 @@ void psfm_pc_fused_kernel(PcParams P)
     // (state loaded alongside the birth frame that decides whether the lane takes part: one round trip less)
     double2 p0 = make_double2(0.0, 0.0), p1 = p0, p2 = p0;
     if (i < n) { p0 = P.p0[i]; p1 = P.x1a[i]; p2 = P.x2a[i]; }
-    pc_fused_body(P, pc_participates(P, i, n), p0, p1, p2, n_active, nullptr, nullptr);
+    pc_fused_body(P, pc_participates(P, i, n), p0, p1, p2, n_active, nullptr, nullptr, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1057,11 +1136,56 @@ void psfm_frame_kernel(PsfmChainArgs a, PcParams P)
 {
     PsfmChainOut o;
     if (!psfm_chain_step_body<R, true, true>(a, o)) return;
-    const int n_active = (max(a.ctr->n_lanes_snap, a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
-    pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &a.ctr->n_lanes_snap, &a.ctr->n_lanes);
+    const int n_active = (max(a.ctr->n_lanes_snap[a.frame & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
+    pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &a.ctr->n_lanes_snap[(a.frame + 1) & 1], &a.ctr->n_lanes, nullptr, 0);
 }
 
-#undef PC_PHYS
+// What changes from one frame to the next in the solver's arguments (frame mode)
+__host__ __device__ inline void pc_params_rebase(PcParams& P, const PsfmSeqStride& st, int64_t occ2_stride, int f)
+{
+    const int64_t df = (int64_t)f - P.frame;
+    P.p0 += df * st.cap; P.x1a += df * st.cap; P.x2a += df * st.cap;
+    P.flow01 += df * st.flow; P.flow12 += df * st.flow; P.flow02 += df * st.flow;
+    P.occ02 += df * occ2_stride;
+    P.frame = f;
+    P.max_birth = f - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The device-paced sequence of track_optimize: every launch is the same kernel with the same arguments (those of frame
+// 1 + the strides of the per-frame stacks) and does "the next thing" the device-side program counter names --
+//   phase 0  the frame kernel of pc_frame (chain step + fused solve with solve_K iterations), or
+//   phase 1  more iterations of that frame's solve, when all of them were accepted and none terminated it
+// -- and its control thread moves the counter on.  The host only keeps launches in the queue and looks at the counter
+// at its checkpoints: a solve that needs one iteration more than the sequence's usual costs one more launch instead of
+// a drained queue, a host-side redo and the no-op launches behind a stall flag.  (Solves that reject a step or leave the
+// Gauss-Newton path still raise the stall flag and are redone by the launch chain.)
+// launch_id: a block that is dispatched after the control thread has moved the counter on (only blocks beyond the lane
+// snapshot can be) sees pc_owner != launch_id and leaves.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void psfm_seq_kernel(PsfmChainArgs a, PcParams P, PsfmSeqStride st, int64_t occ2_stride, int n_flows, int launch_id)
+{
+    PsfmCounters* ctr = a.ctr;
+    if (ctr->stall || ctr->pc_owner != launch_id) return;
+    const int f = ctr->pc_frame, phase = ctr->pc_phase;
+    if (f >= n_flows) return;
+    psfm_chain_args_rebase(a, st, f);
+    pc_params_rebase(P, st, occ2_stride, f);
+    const int k = ctr->solve_K;
+    P.K = k < 1 ? 1 : (k > PC_KMAX ? PC_KMAX : k);
+    const int n_active = (max(ctr->n_lanes_snap[f & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
+    if (phase == 0) {
+        PsfmChainOut o;
+        if (!psfm_chain_step_body<R, true, true>(a, o)) return;
+        pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &ctr->n_lanes_snap[(f + 1) & 1], &ctr->n_lanes, ctr, launch_id);
+    } else {
+        if ((int)blockIdx.x >= n_active) return;
+        pc_more_body(P, n_active, ctr, launch_id);
+    }
+}
+
 
 // Track-sharded runs: the control step on the totals over all ranks (every rank runs it on the same numbers).
 // mode 0: replay over the K iterations of a fused launch; 1 / 2: one step behind pc_init / pc_iter.
@@ -1070,7 +1194,7 @@ __global__ void psfm_pc_control_kernel(PcParams P, const double* totals, int K, 
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (mode == 0) {
         if (*P.stall) return;
-        pc_fused_replay(P, totals, K);
+        pc_fused_replay(P, totals, K, true, nullptr, 0);
         return;
     }
     PsfmSolveCtrl C = *P.ctrl;
@@ -1125,7 +1249,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P,
     const int cur = C.cur;
     if (P.sel && blockIdx.x == 0 && threadIdx.x == 0) {
         *P.sel = 0;                                   // the iterate is (being) copied into buffer 0 right here
-        if (P.n_lanes_snap) *P.n_lanes_snap = *P.n_lanes_ptr;   // (no chain step is running: the lane count is final)
+        if (P.n_lanes_snap) P.n_lanes_snap[(P.frame + 1) & 1] = *P.n_lanes_ptr;   // (no chain step is running: the lane count is final)
     }
     if (cur == 0 && !out_rows) return;
     const double2* xc1 = pc_buf1(P, cur);
@@ -1239,7 +1363,7 @@ static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const fl
     P.x2a = lg + (int64_t)(frame + 1) * d.cap;
     P.xs = c->sol_x.as<double2>(); P.xs_stride = d.cap;
     P.sel = &ctr->sel;
-    P.n_lanes_snap = &ctr->n_lanes_snap;
+    P.n_lanes_snap = ctr->n_lanes_snap;
     P.ref1 = c->sol_state.as<double2>();
     P.ref2 = P.ref1 + d.cap;
     P.jscale = P.ref2 + d.cap;
@@ -1455,6 +1579,68 @@ psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* 
         case 2: hipExtLaunchKernelGGL(psfm_frame_kernel<2>, grid, block, 0, s, e0, e1, 0, a, P); break;
         case 4: hipExtLaunchKernelGGL(psfm_frame_kernel<4>, grid, block, 0, s, e0, e1, 0, a, P); break;
         default: hipExtLaunchKernelGGL(psfm_frame_kernel<0>, grid, block, 0, s, e0, e1, 0, a, P); break;
+    }
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// Device-paced sequence: `n_launches` launches of psfm_seq_kernel (ids launch_id0 ..), every one with the arguments of
+// frame 1 and the strides; what each of them does is decided on the device (PsfmCounters::pc_*).
+psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
+                            const float* flows_f2, const uint8_t* occ_s2, int n_launches, int launch_id0, hipStream_t s)
+{
+    const int64_t Pix = (int64_t)d.H * d.W;
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, flows, flows + Pix * 2, flows_f2, occ_s2, 1, P, s);
+    if (rc != PSFM_OK) return rc;
+    const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+    const int n_groups = (n_blocks + PC_GROUP - 1) / PC_GROUP;
+    if ((rc = c->sol_partials.ensure(sizeof(double) * (size_t)n_blocks * PC_KMAX * PC_NSUM)) != PSFM_OK) return rc;
+    const size_t tbytes = 4096 * sizeof(unsigned), gbytes = sizeof(double) * (size_t)n_groups * PC_KMAX * PC_NSUM;
+    if (n_groups + 1 > 4096) { psfm_set_error("psfm_track: lane table too large for the fused solve"); return PSFM_ERR_ARG; }
+    void* before = c->sol_fused.p;
+    if ((rc = c->sol_fused.ensure(tbytes + gbytes)) != PSFM_OK) return rc;
+    if (c->sol_fused.p != before) PSFM_HIP(hipMemsetAsync(c->sol_fused.p, 0, tbytes, s));
+    P.partials = c->sol_partials.as<double>();
+    P.gticket = c->sol_fused.as<unsigned>();
+    P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
+    PsfmChainArgs a;
+    psfm_fill_chain_args(c, d, flows + Pix * 2, occ + occ_pitch, 1, a, s);
+    a.owner_clear = 1;
+    PsfmSeqStride st;
+    st.flow = Pix; st.occ = occ_pitch; st.cap = d.cap;          // (float2 / byte / double2 elements per frame)
+    if (getenv("PSFM_SEQ_CHECK")) {     // the device-side rebase against the host's own per-frame arguments
+        const int fs[] = {2, 3, 17, 254, 255, 256, 509, 510};
+        for (int f : fs) {
+            if (f >= d.n_flows) continue;
+            PsfmChainArgs r = a, h;
+            psfm_chain_args_rebase(r, st, f);
+            // (no stream: the host version may launch the stamp-wrap clear, which the device-paced form does in-kernel)
+            psfm_fill_chain_args_nolaunch(c, d, flows + (size_t)f * Pix * 2, occ + (size_t)f * occ_pitch, f, h);
+            PcParams rp = P, hp;
+            pc_params_rebase(rp, st, Pix, f);
+            if ((rc = pc_frame_params(c, d, flows + (size_t)(f - 1) * Pix * 2, flows + (size_t)f * Pix * 2, flows_f2 + (size_t)(f - 1) * Pix * 2,
+                                      occ_s2 + (size_t)(f - 1) * Pix, f, hp, s)) != PSFM_OK) return rc;
+            const bool ok = r.flow == h.flow && r.occ == h.occ && r.log_cur == h.log_cur && r.log_next == h.log_next && r.log_prev == h.log_prev &&
+                            r.blocked_cur == h.blocked_cur && r.blocked_prev == h.blocked_prev && r.stamp_cur == h.stamp_cur &&
+                            r.stamp_prev == h.stamp_prev && r.surv_cur == h.surv_cur && r.surv_prev == h.surv_prev && r.sh_pop == h.sh_pop &&
+                            r.sh_push == h.sh_push && r.free_pop == h.free_pop && r.free_push == h.free_push && r.frame == h.frame &&
+                            rp.p0 == hp.p0 && rp.x1a == hp.x1a && rp.x2a == hp.x2a && rp.flow01 == hp.flow01 && rp.flow12 == hp.flow12 &&
+                            rp.flow02 == hp.flow02 && rp.occ02 == hp.occ02 && rp.frame == hp.frame && rp.max_birth == hp.max_birth;
+            if (!ok) { psfm_set_error("psfm_seq: rebased arguments of frame %d differ from the host's", f); return PSFM_ERR_ARG; }
+        }
+    }
+    const dim3 grid((unsigned)n_blocks), block(PC_BLOCK);
+    for (int k = 0; k < n_launches; ++k) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        c->prof.kernel_span(PSFM_PROF_SOLVER, &e0, &e1, true);
+        const int id = launch_id0 + k;
+        switch (d.ratio) {
+            case 1: hipExtLaunchKernelGGL(psfm_seq_kernel<1>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
+            case 2: hipExtLaunchKernelGGL(psfm_seq_kernel<2>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
+            case 4: hipExtLaunchKernelGGL(psfm_seq_kernel<4>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
+            default: hipExtLaunchKernelGGL(psfm_seq_kernel<0>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
+        }
     }
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;

@@ -230,7 +230,8 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_kernel(int64_t cap
                                                                      PsfmShard* __restrict__ shards)
 {
     const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
-    if (i == 0) { ctr->n_lanes = (int)G; ctr->n_lanes_snap = (int)G; ctr->overflow = 0; ctr->stall = 0; ctr->sel = 0; }
+    if (i == 0) { ctr->n_lanes = (int)G; ctr->n_lanes_snap[0] = ctr->n_lanes_snap[1] = (int)G; ctr->overflow = 0; ctr->stall = 0; ctr->sel = 0;
+                  ctr->pc_frame = 1; ctr->pc_phase = 0; ctr->pc_owner = 0; ctr->solve_K = 3; }
     if (i < 2 * PSFM_NSHARD) { shards[i].fin_cnt = 0; shards[i].free_top = 0; shards[i].points = (i == 0) ? (unsigned)G : 0u; }
     if (i >= cap) return;
     if (i < G) {   // (G = the grid points this process owns, [g0, g0 + G): the whole grid unless track-sharded)
@@ -301,8 +302,19 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_clear_map_kernel(const PsfmCo
 
 // the arguments of one chain step (also of the chain part of the merged frame kernel); launches the stamp-wrap clear of
 // the blocked map when it is due
+static void psfm_fill_chain_args_impl(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ, int frame,
+                                      PsfmChainArgs& a, hipStream_t s, bool launch_clear);
 void psfm_fill_chain_args(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ, int frame, PsfmChainArgs& a,
                           hipStream_t s)
+{
+    psfm_fill_chain_args_impl(c, d, flow, occ, frame, a, s, true);
+}
+void psfm_fill_chain_args_nolaunch(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ, int frame, PsfmChainArgs& a)
+{
+    psfm_fill_chain_args_impl(c, d, flow, occ, frame, a, nullptr, false);
+}
+static void psfm_fill_chain_args_impl(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ, int frame,
+                                      PsfmChainArgs& a, hipStream_t s, bool launch_clear)
 {
     a.flow = (const float2*)flow; a.occ = occ;
     a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch; a.rcw = psfm_rcp_host(d.cw); a.rch = psfm_rcp_host(d.ch);
@@ -320,7 +332,7 @@ void psfm_fill_chain_args(psfm_ctx* c, const PsfmTrackDims& d, const float* flow
     a.g0 = d.shard_maps ? (int)d.g0 : 0; a.Gband = d.shard_maps ? (int)d.Gband : (int)d.G; a.shard = d.shard_maps ? 1 : 0;
     a.stamp_cur = (uint8_t)((frame % 254) + 1);
     a.stamp_prev = (uint8_t)(((frame + 253) % 254) + 1);
-    if (frame > 1 && (frame % 254) <= 1) {
+    if (launch_clear && frame > 1 && (frame % 254) <= 1) {
         // the map about to be written last saw this stamp value 254 frames ago: clear it (with a kernel that
         // honours the stall flag -- a memset would also run for launches that are going to be re-enqueued)
         hipLaunchKernelGGL(psfm_clear_map_kernel, dim3((unsigned)((d.G + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK),
@@ -343,6 +355,7 @@ void psfm_fill_chain_args(psfm_ctx* c, const PsfmTrackDims& d, const float* flow
     a.gwdiv = psfm_fastdiv_make((unsigned)d.GW); a.rdiv = psfm_fastdiv_make((unsigned)d.ratio);
     a.log_prev = lg + (int64_t)(frame > 0 ? frame - 1 : 0) * d.cap;
     a.xs = c->sol_x.as<double2>(); a.xs_stride = d.cap;
+    a.owner_clear = 0;
 }
 
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
