@@ -470,7 +470,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // PSFM_MERGE_FRAME=0: chain step and fused solve as two launches (what the merged frame kernel is measured against);
     // PSFM_SEQ=0: host-paced frame kernels (one per frame, stall + redo when a solve needs more iterations than speculated)
     static const bool merge = !(getenv("PSFM_MERGE_FRAME") && atoi(getenv("PSFM_MERGE_FRAME")) == 0);
-    static const bool seq_env = !(getenv("PSFM_SEQ") && atoi(getenv("PSFM_SEQ")) == 0);
+    const bool seq_env = !(getenv("PSFM_SEQ") && atoi(getenv("PSFM_SEQ")) == 0);
     bool seq_ok = optimize && merge && seq_env && unroll_fixed == 0;
     int launch_id = 0;            // device-paced windows: id of the next psfm_seq_kernel launch (== PsfmCounters::pc_owner)
     bool pc_in_step = true;       // the device's program counter is where the host thinks it is (track_init: frame 1, launch 0)

@@ -31,15 +31,21 @@ _batch = solver_batch
 # How a frame's solve is run (psfm_ctx_set_solver): adaptive, the launch chain, the fused solve (one launch that
 # speculates k Gauss-Newton iterations), and the fused solve with k = 1 -- which no real solve fits, so every one of
 # them is redone by the chain from the untouched buffer.  The results must not depend on it.
-SOLVER_MODES = [(0, 0), (1, 0), (2, 0), (2, 1)]
+SOLVER_MODES = [(0, 0, 1), (1, 0, 1), (2, 0, 1), (2, 1, 1), (2, 0, 0), (2, 1, 0)]
 
 
-@pytest.fixture(params=SOLVER_MODES, ids=["adaptive", "launch-chain", "fused", "fused-k1-redone"])
+@pytest.fixture(params=SOLVER_MODES, ids=["adaptive", "launch-chain", "fused", "fused-k1-continued", "fused-host-paced", "fused-k1-redone"])
 def solver_mode(request, pt):
+    """(mode, k, device-paced): the last flag is PSFM_SEQ -- 0 keeps one host-parameterised frame kernel per frame, where a
+    solve that needs more iterations than speculated stalls and is redone (with k = 1: every solve)."""
+    import os
     from point_trajectory import _hip
     ctx = _hip.context()
-    ctx.set_solver(*request.param)
+    ctx.set_solver(request.param[0], request.param[1])
+    if not request.param[2]:
+        os.environ["PSFM_SEQ"] = "0"
     yield request.param
+    os.environ.pop("PSFM_SEQ", None)
     ctx.set_solver(0, 0)
 
 
@@ -184,11 +190,22 @@ def test_fused_solve_is_what_runs_on_clean_sequences(pt):
     assert cnt["k"] == max(s["successful_steps"] for s in O.solves) + 1, cnt
     assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and float(np.abs(R.xy - O.xy).max()) <= TOL
     assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+    # k forced to 1: the device-paced sequence finishes every solve with continuation launches (no redo) ...
     ctx.set_solver(2, 1)
     R1 = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
     cnt1 = ctx.solver_counters()
-    assert cnt1["fused"] == 0 and cnt1["fused_redone"] == len(O.solves), cnt1
+    assert cnt1["fused"] == len(O.solves) and cnt1["fused_redone"] == 0, cnt1
     assert np.array_equal(R1.xy, R.xy)
+    # ... and the host-paced form (PSFM_SEQ=0: one frame kernel per frame) has every one of them redone by the chain
+    import os
+    os.environ["PSFM_SEQ"] = "0"
+    try:
+        R2 = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+        cnt2 = ctx.solver_counters()
+    finally:
+        del os.environ["PSFM_SEQ"]
+    assert cnt2["fused"] == 0 and cnt2["fused_redone"] == len(O.solves), cnt2
+    assert np.array_equal(R2.xy, R.xy)
     ctx.set_solver(0, 0)
     dn = psfm_synth.synth_sequence(40, 72, 100, seed=92, sigma=0.5, n_occluders=2, stride2=True)
     _, occ = orc.flow_check(dn["flows_f"], dn["flows_b"], 1.0)
