@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PSFM_VERSION 110
+#define PSFM_VERSION 120
 
 typedef enum psfm_status {
     PSFM_OK = 0,
@@ -109,10 +109,12 @@ psfm_status psfm_ctx_set_chain_mode(psfm_ctx* ctx, int mode);
 
 /* How psfm_track / psfm_connect run the path-consistency solve of a frame (track_optimize.py:49-50 ->
  * trajectory_optimize.cpp:74-82) -- the results do not depend on it:
- *   mode 0 (default) adaptive: the FUSED solve -- one launch per frame that speculates k trust-region iterations taking
- *     the Gauss-Newton step and being accepted, and replays Ceres' control flow over their sums -- while the solves of a
- *     sequence go that way; the launch CHAIN (one launch per trust-region iteration, any dogleg case, rejections) for
- *     windows of frames whose solves do not; a fused solve that meets anything it did not speculate is redone by the chain;
+ *   mode 0 (default) adaptive: the FUSED solve -- one launch per frame (the frame's chain step included) that speculates k
+ *     trust-region iterations taking the Gauss-Newton step and being accepted, and replays Ceres' control flow over their
+ *     sums; a solve that is not over after k accepted iterations gets a continuation launch (decided on the device) --
+ *     while the solves of a sequence go that way; the launch CHAIN (one launch per trust-region iteration, any dogleg case,
+ *     rejections) for windows of frames whose solves do not; a fused solve that meets a rejection / a dogleg interpolation /
+ *     an invalid step is redone by the chain;
  *   mode 1 the chain always;  mode 2 the fused solve always (+ redo).
  *   k: iterations per fused launch, 0 = follow what the sequence needs (accepted steps + 1), at most 8. */
 psfm_status psfm_ctx_set_solver(psfm_ctx* ctx, int mode, int k);

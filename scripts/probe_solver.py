@@ -19,7 +19,7 @@ from point_trajectory.trajectory import run_connect
 H, W, T, r = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (1080, 1920, 101, 2)
 d = psfm_synth.synth_sequence_torch(T, H, W, seed=5, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
 ctx = _hip.context()
-out = {"shape": [H, W, T, r], "fused_waves": os.environ.get("PSFM_FUSED_WAVES", "4")}
+out = {"shape": [H, W, T, r], "fused_waves": os.environ.get("PSFM_FUSED_WAVES", "3")}
 MODES = {"chain": (1, 0), "fused": (2, 0), "adaptive": (0, 0), "fused_k4": (2, 4), "fused_k2": (2, 2), "fused_k5": (2, 5)}
 names = os.environ.get("PSFM_PROBE_MODES", "chain,fused,adaptive,fused_k4").split(",")
 for name, mode, k in [(n, *MODES[n]) for n in names]:
