@@ -214,7 +214,7 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
         us = 1e3 * prof["solver"]["total_ms"] / prof["solver"]["launches"]
         per_solve = tot / len(frames) + (cb if merged else 0.0)
         fused = cnt["fused"] + cnt["fused_redone"] > cnt["chain"]
-        name = ("psfm_frame_kernel (ONE launch per frame: chain step + fused solve)" if merged else
+        name = ("psfm_seq_kernel = the frame kernel, device-paced (ONE launch per frame: chain step + fused solve)" if merged else
                 "psfm_pc_fused_kernel (one launch per solve)") if fused else "pc_init + pc_iter chain (one span per solve)"
         out["frame_kernel" if merged else "solver"] = {
             "kernel": name, "bound": "hbm", "bytes_per_launch": per_solve,
