@@ -699,20 +699,35 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
     PSFM_HIP(hipEventRecord(e_in, s));
     PSFM_HIP(hipStreamWaitEvent(side, e_in, 0));
     PsfmOccPipeline pipe;
-    pipe.chunk = 10;
+    pipe.chunk = getenv("PSFM_FC_CHUNK") && atoi(getenv("PSFM_FC_CHUNK")) > 0 ? atoi(getenv("PSFM_FC_CHUNK")) : 10;
     c->prof.begin(PSFM_PROF_FLOW_CHECK, side);
+    // track_optimize: the first chunk at full occupancy (the frame loop waits for it), the others as the background form
+    // that shares the CUs with the frame kernel (PSFM_FC_BG=0: every chunk at full occupancy)
+    const bool bg = optimize && !(getenv("PSFM_FC_BG") && atoi(getenv("PSFM_FC_BG")) == 0);
+    int cus = 256;
+    if (bg) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        const int mult = getenv("PSFM_FC_BG_BLOCKS") ? atoi(getenv("PSFM_FC_BG_BLOCKS")) : 0;   // resident blocks per CU; 0: short-lived blocks
+        cus *= mult > 0 ? mult : 0;
+    }
     for (int p0 = 0; p0 < n_flows; p0 += pipe.chunk) {
         const int np = n_flows - p0 < pipe.chunk ? n_flows - p0 : pipe.chunk;
-        if ((st = psfm_launch_flow_check(flows_f + (size_t)p0 * P * 2, flows_b + (size_t)p0 * P * 2, np, h, w, thres,
-                                         occ + (size_t)p0 * P, nullptr, side)) != PSFM_OK) return st;
+        if (bg && p0 > 0) st = psfm_launch_flow_check_bg(flows_f + (size_t)p0 * P * 2, flows_b + (size_t)p0 * P * 2, np, h, w, thres,
+                                                        occ + (size_t)p0 * P, cus, side);
+        else st = psfm_launch_flow_check(flows_f + (size_t)p0 * P * 2, flows_b + (size_t)p0 * P * 2, np, h, w, thres,
+                                         occ + (size_t)p0 * P, nullptr, side);
+        if (st != PSFM_OK) return st;
         hipEvent_t e = c->prof.get();
         PSFM_HIP(hipEventRecord(e, side));
         pipe.ready.push_back(e);
         // the stride-2 maps of the same time range follow their stride-1 chunk (needed one frame later)
         if (p0 < n2) {
             const int np2 = n2 - p0 < pipe.chunk ? n2 - p0 : pipe.chunk;
-            if ((st = psfm_launch_flow_check(flows_f2 + (size_t)p0 * P * 2, flows_b2 + (size_t)p0 * P * 2, np2, h, w,
-                                             thres, occ_s2 + (size_t)p0 * P, nullptr, side)) != PSFM_OK) return st;
+            if (bg && p0 > 0) st = psfm_launch_flow_check_bg(flows_f2 + (size_t)p0 * P * 2, flows_b2 + (size_t)p0 * P * 2, np2, h, w, thres,
+                                                            occ_s2 + (size_t)p0 * P, cus, side);
+            else st = psfm_launch_flow_check(flows_f2 + (size_t)p0 * P * 2, flows_b2 + (size_t)p0 * P * 2, np2, h, w,
+                                             thres, occ_s2 + (size_t)p0 * P, nullptr, side);
+            if (st != PSFM_OK) return st;
             hipEvent_t e2 = c->prof.get();
             PSFM_HIP(hipEventRecord(e2, side));
             pipe.ready_s2.push_back(e2);

@@ -161,6 +161,8 @@ struct psfm_ctx {
 // ---- launchers (psfm_track.hip) -------------------------------------------------------------
 psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs, int h, int w, float thres,
                                    uint8_t* occ, float* err, hipStream_t s);
+psfm_status psfm_launch_flow_check_bg(const float* ff, const float* fb, int n_pairs, int h, int w, float thres, uint8_t* occ,
+                                      int n_blocks, hipStream_t s);
 psfm_status psfm_launch_grid_sample(const float* map, int c, int h, int w, const double* xy, int64_t n,
                                     float* out, hipStream_t s);
 

@@ -141,6 +141,72 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_kernel(
     }
 }
 
+PsfmFcParams psfm_fc_params(int h, int w, float thres);
+
+// Background form for the side stream of track_optimize: 32 VGPRs and a dynamic LDS reservation (PSFM_FC_BG_LDS_KB,
+// default 48 KB, never touched) -- exactly ONE such block fits on a CU BESIDE the three blocks of the frame kernel (3 waves x
+// 160 VGPRs + 32 <= 512 per SIMD lane; 3 x 37 KB + 48 KB <= 160 KB of LDS) and three when the CU is otherwise empty, so
+// flow_check runs in the issue slots and memory cycles the latency-bound solve leaves idle instead of taking CUs from it
+// in bursts (a frame kernel that overlaps a full-occupancy flow_check chunk takes 2x).  Measured, 1080p x 101 frames with
+// path consistency, ms per sequence on one box: full-occupancy chunks 10.28; this kernel without the reservation 10.28,
+// 20 KB 10.24, 40 KB 9.99-10.14, 44 KB 9.78, 48 KB 9.76-9.85, 52 KB 10.05, 56 / 64 KB 10.7 (two blocks per empty CU
+// starve it); persistent grid-stride blocks (1 / 2 / 4 per CU) 10.30 / 10.65 / 10.55 (they hold what they got).
+#define PSFM_FC_BG_LDS_KB_DEFAULT 48
+#define PSFM_FC_BG_UNROLL 2   // (32 VGPRs: 3 x 160 of the frame kernel + 32 = 512 per SIMD lane)
+__global__ __launch_bounds__(PSFM_BLOCK) __attribute__((amdgpu_num_vgpr(32))) void psfm_flow_check_bg_kernel(
+    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q, uint8_t* __restrict__ occ_out,
+    PsfmFastDiv wdiv, int n_pairs)
+{
+    extern __shared__ char psfm_fc_bg_reserve[];      // (occupancy control only)
+    const int P = q.H * q.W;
+    const int chunks = (P + PSFM_BLOCK * PSFM_FC_BG_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_BG_UNROLL);
+    // gridDim.y == 1: a few resident blocks walk over the whole chunk of pairs; gridDim.y == n_pairs: one short-lived
+    // block per 512 pixels (the LDS reservation then caps how many of them a CU hosts beside the frame kernel's blocks)
+    const int64_t w0 = gridDim.y > 1 ? (int64_t)blockIdx.y * chunks + blockIdx.x : blockIdx.x;
+    const int64_t wstep = gridDim.y > 1 ? (int64_t)chunks * n_pairs : gridDim.x;
+    for (int64_t w = w0; w < (int64_t)chunks * n_pairs; w += wstep) {
+        const int pair = (int)(w / chunks), ch = (int)(w - (int64_t)pair * chunks);
+        const int64_t base = (int64_t)pair * P;
+        const float2* __restrict__ F = flows_f + base;
+        const float2* __restrict__ B = flows_b + base;
+        const int p0 = ch * (PSFM_BLOCK * PSFM_FC_BG_UNROLL) + threadIdx.x;
+        float2 f[PSFM_FC_BG_UNROLL];
+#pragma unroll
+        for (int k = 0; k < PSFM_FC_BG_UNROLL; ++k) {
+            const int p = p0 + k * PSFM_BLOCK;
+            f[k] = p < P ? psfm_ld(F, (unsigned)p * 8u) : make_float2(0.f, 0.f);
+        }
+        int y = (int)psfm_fastdiv((unsigned)p0, wdiv), x = p0 - y * q.W;
+#pragma unroll
+        for (int k = 0; k < PSFM_FC_BG_UNROLL; ++k) {
+            const int p = p0 + k * PSFM_BLOCK;
+            if (p >= P) break;
+            float e = 0.f;
+            occ_out[base + p] = psfm_flow_check_px<false>(B, x, y, f[k], q, &e);
+            x += PSFM_BLOCK;
+            while (x >= q.W) { x -= q.W; ++y; }
+        }
+    }
+    if (threadIdx.x == 0xffff) psfm_fc_bg_reserve[0] = 0;
+}
+
+psfm_status psfm_launch_flow_check_bg(const float* ff, const float* fb, int n_pairs, int h, int w, float thres, uint8_t* occ,
+                                      int n_blocks, hipStream_t s)
+{
+    if (n_pairs <= 0) return PSFM_OK;
+    const PsfmFcParams q = psfm_fc_params(h, w, thres);
+    dim3 grid((unsigned)n_blocks);
+    if (n_blocks <= 0) {      // one short-lived block per PSFM_BLOCK * PSFM_FC_BG_UNROLL pixels
+        const int64_t P = (int64_t)h * w;
+        grid = dim3((unsigned)((P + PSFM_BLOCK * PSFM_FC_BG_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_BG_UNROLL)), (unsigned)n_pairs);
+    }
+    const int lds_kb = getenv("PSFM_FC_BG_LDS_KB") ? atoi(getenv("PSFM_FC_BG_LDS_KB")) : PSFM_FC_BG_LDS_KB_DEFAULT;
+    hipLaunchKernelGGL(psfm_flow_check_bg_kernel, grid, dim3(PSFM_BLOCK), (size_t)(lds_kb > 0 ? lds_kb : 0) * 1024, s, (const float2*)ff,
+                       (const float2*)fb, q, occ, psfm_fastdiv_make((unsigned)w), n_pairs);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
 PsfmFcParams psfm_fc_params(int h, int w, float thres)
 {
     PsfmFcParams q;
