@@ -224,7 +224,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
     __shared__ int s_gi[PP_BLOCK];          // birth grid index of the thread's live track (only needed when it dies)
     __shared__ int s_npts[PP_BLOCK];        // trajectory points written by the thread
     __shared__ int s_seg_start[PP_PROBE + 1], s_seg_end[PP_PROBE + 1];
-    __shared__ int s_nseg, s_base_free, s_ok, s_alive_any, s_rec_cnt;
+    __shared__ int s_nseg, s_base_free, s_ok, s_alive_any[2], s_rec_cnt, s_done;   // s_alive_any: two slots, by frame parity; s_done: waves of this frame whose stores are all acknowledged
     __shared__ double2 s_gp[PP_GUESTS];     // guest lanes: position at time t,
     __shared__ int s_gbf[PP_GUESTS];        // birth frame (-1 free),
     __shared__ int s_ggi[PP_GUESTS];        // birth grid index;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
     }
     s_xf[tid] = 0;
     if (tid < PP_GUESTS) s_gbf[tid] = -1;
-    if (tid == 0) { s_rec_cnt = 0; s_alive_any = 0; }
+    if (tid == 0) { s_rec_cnt = 0; s_alive_any[0] = 0; s_alive_any[1] = 0; s_done = 0; }
     // ---- prologue: the occlusion maps of the first two frame pairs, then barrier #0 ----
     int fc_next = 0;     // (per wave) frame pairs whose occlusion map this wave has finished its share of
     if (a.fc) {
@@ -279,34 +279,36 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         const int cur = t & 1, prev = cur ^ 1;
 
         PP_TL(0);
-        // ---- A: gathers of the live tracks (unconditional: idle lanes sample pixel (0,0)) ----
         const bool live = bf >= 0;
+        bool any_alive = false;          // a track of this thread survived step t
+        int npts = 0;
+        // one step (s = t or t + 1) of this thread's own track from the gathered taps `ld`: log entry, marks, or the death record
+        auto own_step = [&](const PsfmFrameView& vs, float2* slab, int s, const PsfmStepLoads& ld, bool mine, bool& alive_any) {
+            PsfmStep s1;
+            s1.alive = true;
+            if (mine) s1 = psfm_step_finish(vs, p, ld);
+            const int slot1 = psfm_record_slot(&s_rec_cnt, !s1.alive);
+            if (mine) {
+                if (s1.alive) {
+                    if (PP_CHK(L, a.cap, 1)) slab[L] = s1.flow;
+                    psfm_block_grid<R, PP_COH_MARKS>(vs, (int)s1.next.x, (int)s1.next.y);
+                    p = s1.next;
+                    alive_any = true;
+                    ++npts;
+                } else {
+                    psfm_put_record(a, slot1, psfm_key(s, bf, s_gi[tid], a.shift_b, a.shift_d), L);
+                    bf = PP_PEND;       // free from the next frame on (`live` keeps it out of this frame's PEND list)
+                    p = make_double2(0.0, 0.0);
+                }
+            }
+        };
+        // ---- A: gathers of the live tracks (unconditional: idle lanes sample pixel (0,0)) ----
         PsfmStepLoads l1 = psfm_step_issue(v, p);
 
         // ---- E: the live tracks' own step.  It needs nothing from other blocks, and its marks go to a map nobody reads
         // before barrier t (three maps), so the first PP_PRE_WAVES waves run it BEFORE waiting for barrier t-1 (their
         // ALU hides under the barrier latency) and the others behind the loads of C (under that round trip) ----
-        bool any_alive = false;
-        int npts = 0;
-        auto do_E = [&]() {
-            PsfmStep s1;
-            s1.alive = true;
-            if (live) s1 = psfm_step_finish(v, p, l1);
-            const int slot1 = psfm_record_slot(&s_rec_cnt, !s1.alive);
-            if (live) {
-                if (s1.alive) {
-                    if (PP_CHK(L, a.cap, 1)) dlog_t[L] = s1.flow;
-                    psfm_block_grid<R, PP_COH_MARKS>(v, (int)s1.next.x, (int)s1.next.y);
-                    p = s1.next;
-                    any_alive = true;
-                    ++npts;
-                } else {
-                    psfm_put_record(a, slot1, psfm_key(t, bf, s_gi[tid], a.shift_b, a.shift_d), L);
-                    bf = PP_PEND;       // free from t+1 on (`live` keeps it out of this frame's PEND list)
-                    p = make_double2(0.0, 0.0);
-                }
-            }
-        };
+        auto do_E = [&]() { own_step(v, dlog_t, t, l1, live, any_alive); };
         // (letting a block that finds barrier t-1 already released skip ahead and run E behind C made no difference)
         const bool e_first = wave < PP_PRE_WAVES;
         if (e_first) do_E();
@@ -509,100 +511,92 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                     }
                 }
             }
-            // ---- phase-2 results ----
+            // ---- phase-2 results: ONE finish for the three kinds.  The block's first wave holds all of them (newborns,
+            //      adopted tracks, live guests); three divergent copies of the blend / bounds / marks code would run one
+            //      after the other in exactly the wave every other wave of the block is waiting for ----
             psfm_step_pin<true>(l2);
             asm volatile("" : "+v"(e.ex));   // the entry's position is rebuilt, not carried across the barrier
-            if (e.kind == 1) {
-                const int gy = (int)psfm_fastdiv((unsigned)e.ex, a.gwdiv), gx = e.ex - gy * a.GW;
-                const double2 q = make_double2((double)(gx * ratio), (double)(gy * ratio));
-                const PsfmStep s2 = psfm_step_finish(v, q, l2);
-                // lane of the newborn: the block's k-th PEND lane, else a popped / fresh lane
-                int Lt;
-                int gs = -1;
-                if (k < matched) {
-                    Lt = blockIdx.x * PP_BLOCK + e.host;
-                } else if (k < matched + gmatched) {
-                    gs = s_gfree[k - matched];
-                    Lt = a.cap_main + blockIdx.x * PP_GUESTS + gs;
+            if (e.kind != 0) {
+                double2 q;
+                int bfk, gik, col, gs = -1;      // birth frame, birth grid index, log column (= lane) of the entry's track
+                if (e.kind == 1) {
+                    const int gy = (int)psfm_fastdiv((unsigned)e.ex, a.gwdiv), gx = e.ex - gy * a.GW;
+                    q = make_double2((double)(gx * ratio), (double)(gy * ratio));
+                    bfk = t; gik = e.ex;
+                    // lane of the newborn: the block's k-th PEND lane, else a free guest lane, else a popped / fresh lane
+                    if (k < matched) {
+                        col = blockIdx.x * PP_BLOCK + e.host;
+                    } else if (k < matched + gmatched) {
+                        gs = s_gfree[k - matched];
+                        col = a.cap_main + blockIdx.x * PP_GUESTS + gs;
+                    } else {
+                        const int* free_pop = a.free_stack + (size_t)cur * a.free_cap * PSFM_NSHARD;
+                        const int qq = k - matched - gmatched;
+                        int j = 0, pv = 0;
+                        while (j < s_nseg - 1 && qq >= s_seg_end[j]) { pv = s_seg_end[j]; ++j; }
+                        const int st = s_seg_start[j];
+                        if (st >= 0) (void)PP_CHK(st - (qq - pv), 2 * a.free_cap * PSFM_NSHARD, 9);
+                        col = st >= 0 ? psfm_coh_ld(free_pop + (st - (qq - pv))) : (-(st + 1) + (qq - pv));
+                        if (col >= a.cap_main) col = -1;
+                    }
+                } else if (e.kind == 2) {
+                    q = s_xp[e.ex];
+                    bfk = t - 1; gik = s_xg[e.ex];
+                    col = blockIdx.x * PP_BLOCK + e.ex;
                 } else {
-                    const int* free_pop = a.free_stack + (size_t)cur * a.free_cap * PSFM_NSHARD;
-                    const int qq = k - matched - gmatched;
-                    int j = 0, pv = 0;
-                    while (j < s_nseg - 1 && qq >= s_seg_end[j]) { pv = s_seg_end[j]; ++j; }
-                    const int st = s_seg_start[j];
-                    if (st >= 0) (void)PP_CHK(st - (qq - pv), 2 * a.free_cap * PSFM_NSHARD, 9);
-                    Lt = st >= 0 ? psfm_coh_ld(free_pop + (st - (qq - pv))) : (-(st + 1) + (qq - pv));
-                    if (Lt >= a.cap_main) Lt = -1;
+                    q = s_gp[e.ex];
+                    bfk = s_gbf[e.ex]; gik = s_ggi[e.ex];
+                    col = a.cap_main + blockIdx.x * PP_GUESTS + e.ex;
                 }
-                if (Lt >= 0) {
-                    (void)PP_CHK(Lt, a.cap, 2);
-                    ++npts;
+                if (col >= 0) {
+                    (void)PP_CHK(col, a.cap, 2);
+                    const PsfmStep s2 = psfm_step_finish(v, q, l2);
+                    if (e.kind == 1) ++npts;                  // the birth point itself
                     if (s2.alive) {
-                        if (PP_CHK(Lt, a.cap, 3)) dlog_t[Lt] = s2.flow;
+                        if (PP_CHK(col, a.cap, 3)) dlog_t[col] = s2.flow;
                         psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
                         any_alive = true;
                         ++npts;
-                    } else {   // born and lost in the same step: a length-1 trajectory
+                    } else {   // (a newborn lost in its first step is a length-1 trajectory)
                         const int slot = atomicAdd(&s_rec_cnt, 1);
-                        psfm_put_record(a, slot, psfm_key(t, t, e.ex, a.shift_b, a.shift_d), Lt);
+                        psfm_put_record(a, slot, psfm_key(t, bfk, gik, a.shift_b, a.shift_d), col);
                     }
-                    if (k >= matched + gmatched && s2.alive && t == a.n_flows - 1) {
-                        // born in the last frame on a popped lane: its owner never gets to adopt it, so the
-                        // "still active at the end" record (last valid time n_flows) is written here
-                        const int slot = atomicAdd(&s_rec_cnt, 1);
-                        psfm_put_record(a, slot, psfm_key(a.n_flows, t, e.ex, a.shift_b, a.shift_d), Lt);
-                    }
-                    if (k < matched) {
-                        s_xp[e.host] = s2.next; s_xg[e.host] = e.ex; s_xf[e.host] = s2.alive ? 1 : 2;
-                    } else if (gs >= 0) {
-                        if (s2.alive) { s_gp[gs] = s2.next; s_ggi[gs] = e.ex; s_gbf[gs] = t; }
+                    // ---- where the track lives from here on ----
+                    if (e.kind == 1) {
+                        const bool popped = k >= matched + gmatched;
+                        if (popped && s2.alive && t == a.n_flows - 1) {
+                            // born in the last frame on a popped lane: its owner never gets to adopt it, so the
+                            // "still active at the end" record (last valid time n_flows) is written here
+                            const int slot = atomicAdd(&s_rec_cnt, 1);
+                            psfm_put_record(a, slot, psfm_key(a.n_flows, t, e.ex, a.shift_b, a.shift_d), col);
+                        }
+                        if (k < matched) {
+                            s_xp[e.host] = s2.next; s_xg[e.host] = e.ex; s_xf[e.host] = s2.alive ? 1 : 2;
+                        } else if (gs >= 0) {
+                            if (s2.alive) { s_gp[gs] = s2.next; s_ggi[gs] = e.ex; s_gbf[gs] = t; }
+                        } else if (PP_CHK(col, a.cap_main, 8)) {
+                            unsigned long long* h = a.handoff + (size_t)col * 3;
+                            psfm_coh_st(h, (unsigned long long)__double_as_longlong(s2.next.x));
+                            psfm_coh_st(h + 1, (unsigned long long)__double_as_longlong(s2.next.y));
+                            psfm_coh_st(h + 2, (unsigned long long)(unsigned)e.ex |
+                                                   ((unsigned long long)(unsigned)(2 * t + (s2.alive ? 1 : 0)) << 32));
+                        }
+                    } else if (e.kind == 2) {
+                        if (s2.alive) s_xp[e.ex] = s2.next;
+                        s_xf[e.ex] = s2.alive ? 1 : 2;
                     } else {
-                        if (!PP_CHK(Lt, a.cap_main, 8)) continue;
-                        unsigned long long* h = a.handoff + (size_t)Lt * 3;
-                        psfm_coh_st(h, (unsigned long long)__double_as_longlong(s2.next.x));
-                        psfm_coh_st(h + 1, (unsigned long long)__double_as_longlong(s2.next.y));
-                        psfm_coh_st(h + 2, (unsigned long long)(unsigned)e.ex |
-                                               ((unsigned long long)(unsigned)(2 * t + (s2.alive ? 1 : 0)) << 32));
+                        if (s2.alive) s_gp[e.ex] = s2.next;
+                        else s_gbf[e.ex] = -1;   // free from the next frame on (this frame's free list is already fixed)
                     }
                 } else {
                     atomicOr(&a.ctr->overflow, 4);   // more tracks than resident lanes: the per-frame path takes over
-                }
-            } else if (e.kind == 2) {
-                const double2 q = s_xp[e.ex];
-                const PsfmStep s2 = psfm_step_finish(v, q, l2);
-                const int Lo = blockIdx.x * PP_BLOCK + e.ex;
-                if (s2.alive) {
-                    if (PP_CHK(Lo, a.cap, 4)) dlog_t[Lo] = s2.flow;
-                    psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
-                    any_alive = true;
-                    ++npts;
-                    s_xp[e.ex] = s2.next; s_xf[e.ex] = 1;
-                } else {
-                    const int slot = atomicAdd(&s_rec_cnt, 1);
-                    psfm_put_record(a, slot, psfm_key(t, t - 1, s_xg[e.ex], a.shift_b, a.shift_d), Lo);
-                    s_xf[e.ex] = 2;
-                }
-            } else if (e.kind == 3) {
-                const double2 q = s_gp[e.ex];
-                const PsfmStep s2 = psfm_step_finish(v, q, l2);
-                const int Lg = a.cap_main + blockIdx.x * PP_GUESTS + e.ex;
-                if (s2.alive) {
-                    if (PP_CHK(Lg, a.cap, 5)) dlog_t[Lg] = s2.flow;
-                    psfm_block_grid<R, PP_COH_MARKS>(v, (int)s2.next.x, (int)s2.next.y);
-                    any_alive = true;
-                    ++npts;
-                    s_gp[e.ex] = s2.next;
-                } else {
-                    const int slot = atomicAdd(&s_rec_cnt, 1);
-                    psfm_put_record(a, slot, psfm_key(t, s_gbf[e.ex], s_ggi[e.ex], a.shift_b, a.shift_d), Lg);
-                    s_gbf[e.ex] = -1;   // free from the next frame on (this frame's free list is already fixed)
                 }
             }
         }
         PP_TL(5);
         if (npts) s_npts[tid] += npts;
         const unsigned long long alm = __ballot(any_alive);
-        if (lane == 0 && alm != 0ull) s_alive_any = 1;   // benign race: every writer stores 1
+        if (lane == 0 && alm != 0ull) s_alive_any[t & 1] = 1;   // benign race: every writer stores 1
         __syncthreads();
         // ---- owners pick up what the phase-2 threads computed for them ----
         {
@@ -618,7 +612,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                 }
             }
         }
-        if (tid == 0 && s_alive_any) { psfm_coh_st(a.survsh + (cur * PSFM_NSHARD + shard) * 32, (unsigned)(t + 1)); s_alive_any = 0; }
+        if (tid == 0 && s_alive_any[t & 1]) { psfm_coh_st(a.survsh + (cur * PSFM_NSHARD + shard) * 32, (unsigned)(t + 1)); s_alive_any[t & 1] = 0; }
         // ---- F: everything this block wrote is acknowledged -> arrive ----
         // (a step samples the occlusion map of its frame as early as right after the previous arrival, when only the
         // barrier before that one is known to be complete: maps up to t+2 must be finished before arriving at #t+1)
@@ -626,13 +620,20 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
             const int need = t + 3 < a.n_flows ? t + 3 : a.n_flows;
             for (; fc_next < need; ++fc_next) psfm_fc_slice(a, fc_next, tid);
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        // ---- F: arrive.  No block barrier in front of it: a wave whose stores are acknowledged counts itself in (LDS) and
+        //      goes on to the next frame; the wave that comes last arrives for the block ----
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         PP_TL(6);
-        __syncthreads();
-        PP_TL(7);
-        // (the LAST wave arrives: wave 0 carries the phase-2 work and the barrier poll of the next frame and should not sit
-        // out the round trip of the arrival atomic)
-        if (wave == PP_NW - 1) psfm_bar_arrive(a, shard, t + 1, lane);
+        {
+            int last_wave = 0;
+            if (lane == 0) last_wave = atomicAdd(&s_done, 1) == PP_NW - 1 ? 1 : 0;
+            last_wave = __builtin_amdgcn_readfirstlane(last_wave);
+            if (last_wave) {
+                if (lane == 0) s_done = 0;
+                PP_TL(7);
+                psfm_bar_arrive(a, shard, t + 1, lane);
+            }
+        }
 #ifndef PP_NO_SETPRIO
         __builtin_amdgcn_s_setprio(0);   // ... its next step ahead of the barrier is not
 #endif
