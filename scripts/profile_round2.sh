@@ -15,10 +15,12 @@ timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o $TAG -- $B1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o f -- $B2 > $OUT/pmc_fetch.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -f csv -d $OUT/pmc_write -o w -- $B2 > $OUT/pmc_write.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM -f csv -d $OUT/pmc_sq -o s -- $B2 > $OUT/pmc_sq.log 2>&1 < /dev/null
+if [ -z "$PSFM_PROFILE_HEADLINE_ONLY" ]; then
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/opt_stats -o ${TAG}_opt -- $O1 > $OUT/opt_under_rocprof.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/opt_pmc_fetch -o f -- $O1 > $OUT/opt_pmc_fetch.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -f csv -d $OUT/opt_pmc_write -o w -- $O1 > $OUT/opt_pmc_write.log 2>&1 < /dev/null
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM -f csv -d $OUT/opt_pmc_sq -o s -- $O1 > $OUT/opt_pmc_sq.log 2>&1 < /dev/null
+fi   # PSFM_PROFILE_HEADLINE_ONLY=1: only the headline step (the track_optimize kernels did not change)
 timeout 500 python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err < /dev/null
 
 
