@@ -407,7 +407,7 @@ def main():
     if not args.no_extras or world > 1:
         if world > 1:
             dist.barrier()
-        single, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, args.single_seq_frames), 600)
+        single, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, args.single_seq_frames), 240)
 
     if rank == 0:
         # ---- roofline of the flow-chaining kernel (K2): algorithmic bytes per launch / avg duration ----
