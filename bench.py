@@ -454,6 +454,8 @@ def main():
             "unit": "trajectory-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 sampling + f64 positions", "data": "synthetic",
+            # finished trajectories per second (rank 0's count x ranks: every rank runs the same shape)
+            "trajectories_per_s": int(info.n_traj) * world * args.steps / dt_max,
             "config": {"workload": "configs[1]: synthetic %dx(1920x1080) flow pairs, sample_ratio=2, "
                                    "flow_check + chaining + occlusion + id assignment, 1 sequence per GPU" % n_flows,
                        "frames": n_frames, "height": H, "width": W, "sample_ratio": RATIO,
