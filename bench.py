@@ -236,6 +236,29 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
     return out
 
 
+def stream_ceilings(dev):
+    """Empirical streaming rates of THIS device (context for the roofline fractions, which are quoted against the
+    8 TB/s spec): device-to-device copy (read + write bytes), read-only reduction, fill; 1 GiB fp32 buffers, torch kernels."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+
+    def timed(fn, reps=10):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    out = {"copy_GBs": 2 * n * 4 / timed(lambda: b.copy_(a)) / 1e9, "read_GBs": n * 4 / timed(lambda: a.sum()) / 1e9,
+           "fill_GBs": n * 4 / timed(lambda: b.fill_(1.0)) / 1e9, "buffers": "2 x 1 GiB fp32, torch kernels, HIP events"}
+    del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="configs[2] shape"):
     """track_optimize (chaining + Ceres-compatible path-consistency solve) on a synthetic sequence -- by default a
     stand-in of configs[2] (Sintel alley_1 shape: 436x1024, 50 frames, sample_ratio 2): GPU time per sequence and the
@@ -503,6 +526,7 @@ def main():
                 del Rg
             # secondary figure (outside the timed region): the path-consistency path on configs[2]'s shape
             if not args.no_extras:
+                out["stream_ceilings"] = stream_ceilings(dev)
                 out["secondary"] = secondary_track_optimize(ctx)
                 del flows_b
                 # north_star's target workload for the path-consistency path: the headline shape with the solver on
