@@ -328,6 +328,8 @@ class TrajectorySet:
 
     def __getstate__(self):
         import os
+        if self.__dict__.get("_state_override") is not None:     # (the streaming writer's template instance, see reference_pickle.py)
+            return self._state_override
         layout = self.pickle_layout or os.environ.get("PSFM_TRACK_LAYOUT", "reference")
         if layout == "csr" and self._csr is not None and self._map is None:
             ids, birth, length, off, xy, labels = self._csr
@@ -341,5 +343,39 @@ class TrajectorySet:
             self._csr = (state["ids"], state["birth"], state["length"], state["off"], state["xy"], state["labels"])
             self._map = None
             return
+        csr = self._csr_from_reference_state(state)
+        if csr is not None:        # (array-speed consumers; `trajs` is materialised from it on demand)
+            self._csr, self._map = csr, None
+            return
         self._csr = None
         self._map = {int(k): (v if isinstance(v, Trajectory) else Trajectory(v)) for k, v in sorted(state.items())}
+
+    @staticmethod
+    def _csr_from_reference_state(state):
+        """The reference's `{id: {"frame_ids", "locations", "labels"}}` state as CSR arrays, when it is what the builder writes:
+        consecutive frame ids, no label set, (n, 2) locations.  None otherwise (the generic map takes over).  At 1e6+
+        trajectories this is what makes loading a reference-layout file array-speed on this side (no Trajectory objects)."""
+        if not isinstance(state, dict) or len(state) < 1024:
+            return None
+        try:
+            keys = sorted(state)
+            n = len(keys)
+            ids = np.fromiter(keys, np.int64, n)
+            birth, length, locs = np.empty(n, np.int32), np.empty(n, np.int32), []
+            for j, k in enumerate(keys):
+                v = state[k]
+                f, loc = v["frame_ids"], v["locations"]
+                m = len(f)
+                if m == 0 or any(v["labels"]) or len(v["labels"]) != m or f != list(range(f[0], f[0] + m)):
+                    return None
+                if not isinstance(loc, np.ndarray):
+                    loc = np.asarray(loc, np.float64)
+                if loc.shape != (m, 2) or loc.dtype != np.float64:
+                    return None
+                birth[j], length[j] = f[0], m
+                locs.append(loc)
+            off = np.zeros(n + 1, np.int64)
+            np.cumsum(length, out=off[1:])
+            return (ids, birth, length, off, np.concatenate(locs), None)
+        except (KeyError, TypeError, ValueError, IndexError):
+            return None

@@ -1,0 +1,108 @@
+"""track.npy in the REFERENCE's pickle state, streamed from the CSR arrays ("emit the identical pickle object
+graph straight from SoA arrays").
+
+The reference's `TrajectorySet` pickles as `{id: {"frame_ids": [int], "locations": [V2D], "labels": [bool]}}`
+(optimize/src/bindings.cc:64-71 over Trajectory::as_dict, trajectory_base.cpp:47-53).  Built as Python objects that is 1.9 M dicts
+and 5e7 list elements for BASELINE configs[1] (45 s to write, 50 s to read back in the build container).  Here the pickle
+OPCODES are written directly, one fixed-size record per trajectory, filled in with NumPy:
+
+    J id  }  (  "frame_ids"  list(range(b, b + n))
+                "locations"  getitem(XY, slice(s, e))        XY = the (n_points, 2) f64 array, pickled ONCE in front
+                "labels"     mul([False], n)
+             u
+
+`list`, `range`, `slice`, `operator.getitem`, `operator.mul`, the three keys, `[False]` and XY are memoised once and fetched with
+BINGET; the outer dict takes all records in one SETITEMS.  What a consumer unpickles is the same mapping with the same values:
+`frame_ids` a list of ints, `labels` a list of bools, `locations` an (n, 2) float64 array (a view of XY -- pybind's
+`std::vector<V2D>` caster and `np.array()` take it row by row, exactly like the list of 2-vectors the reference's own dump holds).
+The container around it (the .npy header, the 0-d object array, the class reference) is taken from a real `pickle.dumps` of a
+template instance, so it is whatever this NumPy / this class produce.
+"""
+import pickle
+import struct
+
+import numpy as np
+
+_SENTINEL = b"@@PSFM-TRAJECTORY-SET-STATE@@"
+# memo slots of the preamble (the template uses single-digit slots)
+_M_XY, _M_LIST, _M_RANGE, _M_SLICE, _M_GETITEM, _M_MUL, _M_FALSE, _M_KF, _M_KL, _M_KB = range(200, 210)
+
+
+def _global(module, name, slot):
+    return b"c" + module + b"\n" + name + b"\n" + b"q" + bytes([slot]) + b"0"        # GLOBAL, BINPUT slot, POP
+
+
+def _key(text, slot):
+    return b"X" + struct.pack("<I", len(text)) + text + b"q" + bytes([slot]) + b"0"   # BINUNICODE, BINPUT slot, POP
+
+
+def _record_template():
+    """One trajectory's opcodes with zeroed integer fields; returns (bytes, offsets of the 4-byte fields id, b, b+n, s, e, n)."""
+    g = lambda slot: b"h" + bytes([slot])                                             # BINGET
+    J = b"J\x00\x00\x00\x00"                                                          # BININT (4-byte signed)
+    parts, at = [], {}
+
+    def put(x, name=None):
+        if name:
+            at[name] = sum(len(q) for q in parts) + 1
+        parts.append(x)
+    put(J, "id"); put(b"}("); put(g(_M_KF))
+    put(g(_M_LIST)); put(g(_M_RANGE)); put(J, "b"); put(J, "bn"); put(b"\x86R\x85R")       # list(range(b, b + n))
+    put(g(_M_KL))
+    put(g(_M_GETITEM)); put(g(_M_XY)); put(g(_M_SLICE)); put(J, "s"); put(J, "e"); put(b"\x86R\x86R")   # getitem(XY, slice(s, e))
+    put(g(_M_KB))
+    put(g(_M_MUL)); put(g(_M_FALSE)); put(J, "n"); put(b"\x86R")                          # mul([False], n)
+    put(b"u")
+    return b"".join(parts), at
+
+
+def can_stream(ts):
+    """The streaming form covers what the builder produces: a CSR-backed set without labels, fewer than 2^31 points."""
+    csr = getattr(ts, "_csr", None)
+    return (csr is not None and getattr(ts, "_map", 1) is None and csr[5] is None and int(csr[3][-1]) < (1 << 31)
+            and (len(csr[0]) == 0 or (int(np.max(csr[0])) < (1 << 31) and int(np.min(csr[0])) >= 0)))
+
+
+def dump(fp, ts):
+    """Write the object array holding `ts` (what np.save(path, ts) writes behind the .npy header) to the open binary file."""
+    ids, birth, length, off, xy, _ = ts._csr
+    n = len(ids)
+    # the container: pickle a template instance whose state is a sentinel, cut the stream at the sentinel
+    tmpl = type(ts).__new__(type(ts))
+    tmpl.__dict__["_state_override"] = _SENTINEL
+    arr = np.empty((), dtype=object)
+    arr[()] = tmpl
+    stream = pickle.dumps(arr, protocol=3)
+    mark = b"C" + bytes([len(_SENTINEL)]) + _SENTINEL
+    i = stream.index(mark)
+    j = i + len(mark)
+    assert stream[j:j + 1] == b"q" and stream.count(mark) == 1, "unexpected pickle layout of the template"
+    prefix, suffix = stream[:i], stream[j + 2:]
+    fp.write(prefix)
+    # preamble: the shared objects, each memoised and popped again
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    # (the pickler streams the point array into the file without an intermediate bytes object; PROTO / FRAME opcodes inside a
+    # stream are legal, its closing STOP is stepped back over)
+    pickle.Pickler(fp, protocol=5).dump(xy)
+    fp.seek(-1, 1)
+    fp.write(b"q" + bytes([_M_XY]) + b"0")
+    fp.write(_global(b"builtins", b"list", _M_LIST) + _global(b"builtins", b"range", _M_RANGE) + _global(b"builtins", b"slice", _M_SLICE)
+             + _global(b"operator", b"getitem", _M_GETITEM) + _global(b"operator", b"mul", _M_MUL)
+             + b"]\x89a" + b"q" + bytes([_M_FALSE]) + b"0"                      # EMPTY_LIST NEWFALSE APPEND -> [False]
+             + _key(b"frame_ids", _M_KF) + _key(b"locations", _M_KL) + _key(b"labels", _M_KB))
+    # the state: one dict, all records under one MARK ... SETITEMS
+    fp.write(b"}(")
+    rec, at = _record_template()
+    R = len(rec)
+    step = 1 << 18
+    ids = np.asarray(ids, np.int64); birth = np.asarray(birth, np.int64); length = np.asarray(length, np.int64); off = np.asarray(off, np.int64)
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        buf = np.tile(np.frombuffer(rec, np.uint8), hi - lo).reshape(hi - lo, R)
+        fields = {"id": ids[lo:hi], "b": birth[lo:hi], "bn": birth[lo:hi] + length[lo:hi], "s": off[lo:hi], "e": off[lo + 1:hi + 1],
+                  "n": length[lo:hi]}
+        for name, v in fields.items():
+            buf[:, at[name]:at[name] + 4] = v.astype("<i4").view(np.uint8).reshape(-1, 4)
+        fp.write(buf.tobytes())
+    fp.write(b"u")
+    fp.write(suffix)

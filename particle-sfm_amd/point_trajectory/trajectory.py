@@ -13,6 +13,7 @@ import numpy as np
 
 from . import _hip
 from .optimize.build import particlesfm
+from . import reference_pickle
 
 
 def grid_sample(data, xy):
@@ -159,7 +160,10 @@ def save_track_npy(path, trajectories, layout="reference"):
     arr[()] = trajectories
     with open(path if str(path).endswith(".npy") else str(path) + ".npy", "wb") as fp:
         np.lib.format.write_array_header_1_0(fp, np.lib.format.header_data_from_array_1_0(arr))
-        pickle.dump(arr, fp, protocol=5)
+        if layout == "reference" and reference_pickle.can_stream(trajectories):
+            reference_pickle.dump(fp, trajectories)      # the reference's object graph as opcodes, straight from the CSR
+        else:
+            pickle.dump(arr, fp, protocol=5)
 
 
 def _as_device_stack(maps, dtype, trailing):

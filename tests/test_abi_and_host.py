@@ -332,6 +332,70 @@ def test_default_track_npy_loads_with_a_pybind_module_that_only_knows_the_refere
             assert np.array_equal(np.array(loc), xy[off[i]:off[i + 1]])
 
 
+@pytest.mark.parametrize("n", [0, 1, 37, 3000])
+def test_reference_layout_is_streamed_from_the_csr(tmp_path, n):
+    """save_track_npy writes the reference's pickle state (bindings.cc:64-71) as opcodes straight from the CSR arrays
+    (point_trajectory/reference_pickle.py).  What unpickles must be exactly what the generic pickler produces from the same set:
+    the plain-Python object graph {id: {"frame_ids": [int], "locations": (n,2) f64, "labels": [bool]}} -- read here with the
+    class replaced by a recorder, so nothing of this package's loading code is involved -- and the set itself on this side
+    (3000 entries: loaded back as CSR, array-speed; fewer: the generic map)."""
+    import pickle
+    from point_trajectory.optimize.build import particlesfm
+    from point_trajectory.trajectory import save_track_npy
+    from point_trajectory import reference_pickle
+    rng = np.random.default_rng(n)
+    length = rng.integers(1, 30, n).astype(np.int32)
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum(length)
+    birth = rng.integers(0, 400, n).astype(np.int32)
+    xy = rng.normal(size=(int(off[-1]), 2)) * 1e3
+    ids = np.sort(rng.choice(10 * n + 5, n, replace=False)).astype(np.int64)
+    ts = particlesfm.TrajectorySet._from_csr(ids, birth, length, off, xy)
+    assert reference_pickle.can_stream(ts)
+    save_track_npy(str(tmp_path / "fast.npy"), ts)
+    generic = pickle.loads(pickle.dumps(particlesfm.TrajectorySet._from_csr(ids, birth, length, off, xy)))._legacy_state()
+
+    class Recorder:                      # stands in for the class named in the stream: records the raw state
+        def __setstate__(self, state):
+            self.state = state
+    real = particlesfm.TrajectorySet
+    particlesfm.TrajectorySet = Recorder
+    try:
+        raw = np.load(str(tmp_path / "fast.npy"), allow_pickle=True).item().state
+    finally:
+        particlesfm.TrajectorySet = real
+    assert type(raw) is dict and list(raw.keys()) == ids.tolist() == list(generic.keys())
+    for j, k in enumerate(raw):
+        v = raw[k]
+        assert set(v) == {"frame_ids", "locations", "labels"}
+        assert type(v["frame_ids"]) is list and v["frame_ids"] == list(range(birth[j], birth[j] + length[j])) == generic[k]["frame_ids"]
+        assert type(v["labels"]) is list and v["labels"] == [False] * int(length[j]) == generic[k]["labels"]
+        assert all(type(x) is int for x in v["frame_ids"][:3]) and all(x is False for x in v["labels"][:3])
+        loc = np.asarray(v["locations"])
+        assert loc.dtype == np.float64 and loc.shape == (length[j], 2) and np.array_equal(loc, xy[off[j]:off[j + 1]])
+    if n:
+        raw[ids[0]]["labels"].append(True)            # the label lists are independent objects (not one shared list)
+        assert raw[ids[-1]]["labels"] == [False] * int(length[-1]) or n == 1
+    back = np.load(str(tmp_path / "fast.npy"), allow_pickle=True).item()
+    assert isinstance(back, real)
+    if n >= 1024:
+        assert back._csr is not None and back._map is None      # array-speed load of the reference layout
+        assert np.array_equal(back._csr[0], ids) and np.array_equal(back._csr[1], birth) and np.array_equal(back._csr[2], length)
+        assert np.array_equal(back._csr[4], xy)
+    assert len(back.trajs) == n
+    for j in (0, n // 2, n - 1) if n else ():
+        t = back.trajs[int(ids[j])]
+        assert t.length() == length[j] and np.array_equal(np.asarray(t.as_dict()["locations"]), xy[off[j]:off[j + 1]])
+    # a set with labels (after motion segmentation) is outside the streaming form: the generic pickler writes it
+    if n == 37:
+        lab = rng.uniform(size=int(off[-1])) < 0.5
+        tl = particlesfm.TrajectorySet._from_csr(ids, birth, length, off, xy, lab)
+        assert not reference_pickle.can_stream(tl)
+        save_track_npy(str(tmp_path / "lab.npy"), tl)
+        bl = np.load(str(tmp_path / "lab.npy"), allow_pickle=True).item()
+        assert bl.trajs[int(ids[3])].as_dict()["labels"] == lab[off[3]:off[4]].tolist()
+
+
 def test_package_imports_from_a_git_archive(tmp_path):
     """What `git archive HEAD` exports must be a working source tree: every module of the product package is tracked
     (an unanchored ignore pattern once hid point_trajectory/optimize/build/) and `import point_trajectory` works from it."""
