@@ -53,8 +53,11 @@ __global__ __launch_bounds__(PM_BLOCK) void pm_compact_kernel(const uint8_t* __r
     const int64_t q = q_of[p];
     const int t = pm_owner(off, k, p);
     const int f = birth[t] + (int)(p - off[t]);
-    if (f < 0 || f >= n_img) { *bad = 1; return; }
-    kfr[q] = (unsigned)f;
+    // a frame outside the image list is an argument error, reported by the host once this pass is over; the entry is still
+    // written (frame 0) -- the sort and the kernels behind it run before the host looks at the flag and must stay in bounds
+    const bool outside = f < 0 || f >= n_img;
+    if (outside) *bad = 1;
+    kfr[q] = outside ? 0u : (unsigned)f;
     kpt[q] = p;
     ktraj[q] = t;
     iota[q] = (unsigned)q;
