@@ -23,6 +23,12 @@ import struct
 
 import numpy as np
 
+# Behind the pickle's STOP the writer leaves a 64-byte footer (np.load / pickle.load stop reading at STOP and never see it): where
+# the point array's raw bytes and the records sit in the file.  `load()` uses it to read its own files back at array speed --
+# the reference layout itself can only be unpickled one Python object per frame id and label (22 s for 1.9 M trajectories).
+_FOOTER_MAGIC = b"PSFMTRK1"
+_FOOTER = struct.Struct("<8sqqqqqq8s")        # magic, xy offset, n_points, records offset, n, record size, file size before the footer, magic
+
 _SENTINEL = b"@@PSFM-TRAJECTORY-SET-STATE@@"
 # memo slots of the preamble (the template uses single-digit slots)
 _M_XY, _M_LIST, _M_RANGE, _M_SLICE, _M_GETITEM, _M_MUL, _M_FALSE, _M_KF, _M_KL, _M_KB = range(200, 210)
@@ -83,8 +89,10 @@ def dump(fp, ts):
     xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
     # (the pickler streams the point array into the file without an intermediate bytes object; PROTO / FRAME opcodes inside a
     # stream are legal, its closing STOP is stepped back over)
+    xy_start = fp.tell()
     pickle.Pickler(fp, protocol=5).dump(xy)
     fp.seek(-1, 1)
+    xy_end = fp.tell()
     fp.write(b"q" + bytes([_M_XY]) + b"0")
     fp.write(_global(b"builtins", b"list", _M_LIST) + _global(b"builtins", b"range", _M_RANGE) + _global(b"builtins", b"slice", _M_SLICE)
              + _global(b"operator", b"getitem", _M_GETITEM) + _global(b"operator", b"mul", _M_MUL)
@@ -94,6 +102,7 @@ def dump(fp, ts):
     fp.write(b"}(")
     rec, at = _record_template()
     R = len(rec)
+    rec_start = fp.tell()
     step = 1 << 18
     ids = np.asarray(ids, np.int64); birth = np.asarray(birth, np.int64); length = np.asarray(length, np.int64); off = np.asarray(off, np.int64)
     for lo in range(0, n, step):
@@ -106,3 +115,52 @@ def dump(fp, ts):
         fp.write(buf.tobytes())
     fp.write(b"u")
     fp.write(suffix)
+    # footer: where the raw point bytes are (an in-band buffer: BINBYTES8 / BYTEARRAY8 opcode + 8-byte length + data)
+    end = fp.tell()
+    xy_data = -1
+    if xy.nbytes > 0:
+        fp.seek(xy_start)
+        head = fp.read(min(4096, xy_end - xy_start))
+        for op in (b"\x8e", b"\x96"):
+            k = head.find(op + struct.pack("<Q", xy.nbytes))
+            if k >= 0:
+                xy_data = xy_start + k + 9
+        fp.seek(end)
+    if xy_data >= 0 or xy.nbytes == 0:
+        fp.write(_FOOTER.pack(_FOOTER_MAGIC, xy_data, xy.shape[0], rec_start, n, R, end, _FOOTER_MAGIC))
+
+
+def load(path):
+    """track.npy -> TrajectorySet.  Files written by dump() are read back through their footer (CSR arrays straight from the
+    file, nothing unpickled); anything else goes through np.load(path, allow_pickle=True).item()."""
+    import os
+    from .optimize.build import particlesfm
+    try:
+        size = os.path.getsize(path)
+        with open(path, "rb") as fp:
+            if size > _FOOTER.size:
+                fp.seek(size - _FOOTER.size)
+                m0, xy_data, n_pts, rec_start, n, R, end, m1 = _FOOTER.unpack(fp.read(_FOOTER.size))
+                rec, at = _record_template()
+                if (m0 == _FOOTER_MAGIC and m1 == _FOOTER_MAGIC and end == size - _FOOTER.size and R == len(rec) and n >= 0
+                        and rec_start + n * R < end and (n_pts == 0 or 0 < xy_data < rec_start)):
+                    fp.seek(rec_start)
+                    buf = np.frombuffer(fp.read(n * R), np.uint8).reshape(n, R)
+                    zero = np.frombuffer(rec, np.uint8).copy()
+                    field = lambda name: np.ascontiguousarray(buf[:, at[name]:at[name] + 4]).view("<i4").reshape(-1).astype(np.int64)
+                    ids, birth, bn, s0, e0, ln = (field(k) for k in ("id", "b", "bn", "s", "e", "n"))
+                    chk = buf.copy()
+                    for name in at:
+                        chk[:, at[name]:at[name] + 4] = 0
+                    off = np.zeros(n + 1, np.int64)
+                    np.cumsum(ln, out=off[1:])
+                    if (n == 0 or ((chk == zero).all() and np.array_equal(bn, birth + ln) and np.array_equal(s0, off[:-1])
+                                   and np.array_equal(e0, off[1:]))) and int(off[-1]) == n_pts:
+                        if n_pts:     # (mapped copy-on-write: pages come in as the consumer touches them)
+                            xy = np.memmap(path, dtype=np.float64, mode="c", offset=xy_data, shape=(n_pts, 2))
+                        else:
+                            xy = np.zeros((0, 2))
+                        return particlesfm.TrajectorySet._from_csr(ids, birth.astype(np.int32), ln.astype(np.int32), off, xy)
+    except (OSError, ValueError, struct.error):
+        pass
+    return np.load(path, allow_pickle=True).item()

@@ -127,7 +127,8 @@ def traj_to_matches(img_dir, traj_dir, match_list_file, remove_dynamic=True, sam
     """sfm/matches_from_flow.py:51-118, same arguments.  as_arrays=True keeps `.keypoints` / `.match_pairs[...]` as
     (n,2) ndarrays instead of nested lists -- the only consumer (sfm/import_feature_matches.py:82,96) wraps them in
     np.array() anyway, and building ~1e7 two-element lists is what dominates the list form."""
-    trajectories = np.load(os.path.join(traj_dir, "track.npy"), allow_pickle=True).item()
+    from point_trajectory.trajectory import load_track_npy
+    trajectories = load_track_npy(os.path.join(traj_dir, "track.npy"))      # (either layout; this package's files at array speed)
     image_names = sorted(os.listdir(img_dir))
     off, frames, xy, labels = _flatten(trajectories)
     tables = match_tables_host(off, frames, xy, labels, len(image_names), remove_dynamic, sample_k)

@@ -386,6 +386,19 @@ def test_reference_layout_is_streamed_from_the_csr(tmp_path, n):
     for j in (0, n // 2, n - 1) if n else ():
         t = back.trajs[int(ids[j])]
         assert t.length() == length[j] and np.array_equal(np.asarray(t.as_dict()["locations"]), xy[off[j]:off[j + 1]])
+    # this package's own reader takes the footer behind the pickle: the same set without unpickling anything
+    from point_trajectory.trajectory import load_track_npy
+    fast = load_track_npy(str(tmp_path / "fast.npy"))
+    assert isinstance(fast, real) and fast._csr is not None and fast._map is None
+    for got, want in zip(fast._csr[:5], (ids, birth, length, off, xy)):
+        assert np.array_equal(np.asarray(got), want)
+    assert fast._csr[5] is None
+    # ... and falls back to np.load for every other file (the compact layout, a file whose footer does not match)
+    save_track_npy(str(tmp_path / "csr.npy"), particlesfm.TrajectorySet._from_csr(ids, birth, length, off, xy), layout="csr")
+    assert len(load_track_npy(str(tmp_path / "csr.npy")).trajs) == n
+    blob = open(str(tmp_path / "fast.npy"), "rb").read()
+    open(str(tmp_path / "cut.npy"), "wb").write(blob[:-8] + b"XXXXXXXX")
+    assert len(load_track_npy(str(tmp_path / "cut.npy")).trajs) == n
     # a set with labels (after motion segmentation) is outside the streaming form: the generic pickler writes it
     if n == 37:
         lab = rng.uniform(size=int(off[-1])) < 0.5
