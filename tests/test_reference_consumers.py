@@ -143,3 +143,47 @@ def test_launcher_resolves_point_trajectory_here_and_the_other_stages_in_the_che
     assert os.path.abspath(out["motion_seg"]).startswith(os.path.abspath(REF))
     assert os.path.abspath(out["sfm"]).startswith(os.path.abspath(REF))
     assert out["entry"] == "point_trajectory.main_connect_point_trajectories" and out["argv"] == ["--flag", "x"]
+
+
+def test_reference_traj_to_matches_consumes_the_streamed_reference_layout(tmp_path):
+    """The DEFAULT writer (point_trajectory/reference_pickle.py: the reference's pickle state as opcodes straight from the CSR
+    arrays) read by the reference's own, unmodified traj_to_matches: same keypoints, matches and pair file as from the file the
+    generic pickler writes from the same trajectories, and as this package's vectorised consumer returns."""
+    import pickle
+    from oracle import oracle as orc
+    from point_trajectory.optimize.build import particlesfm
+    from point_trajectory.trajectory import save_track_npy, TrajectoryList
+    from point_trajectory import reference_pickle
+    from psfm_sfm import matches_from_flow as ours
+    T, H, W, r = 9, 48, 64, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=78, sigma=0.2, n_occluders=2, stride2=False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    O = orc.track(d["flows_f"], occ, r)
+    ts = TrajectoryList(O.birth, O.length, O.off, O.xy).to_trajectory_set(3)      # CSR-backed, as the stage entry produces it
+    assert reference_pickle.can_stream(ts)
+    ref = _load_reference_consumer()
+    out = {}
+    for tag in ("streamed", "generic"):
+        traj_dir, img_dir = tmp_path / tag / "trajectories", tmp_path / tag / "images"
+        traj_dir.mkdir(parents=True); img_dir.mkdir(parents=True)
+        for i in range(T):
+            (img_dir / ("%05d.png" % i)).write_bytes(b"")
+        if tag == "streamed":
+            save_track_npy(str(traj_dir / "track.npy"), ts)
+        else:
+            arr = np.empty((), dtype=object)
+            arr[()] = ts
+            with open(str(traj_dir / "track.npy"), "wb") as fp:
+                np.lib.format.write_array_header_1_0(fp, np.lib.format.header_data_from_array_1_0(arr))
+                pickle.dump(arr, fp, protocol=3)
+        out[tag] = ref.traj_to_matches(str(img_dir), str(traj_dir), str(tmp_path / (tag + ".txt")), remove_dynamic=True)
+        if tag == "streamed":
+            out["ours"] = ours.traj_to_matches(str(img_dir), str(traj_dir), str(tmp_path / "ours.txt"), remove_dynamic=True)
+    A, B, C = out["streamed"], out["generic"], out["ours"]
+    assert list(A) == list(B) == list(C) and sum(len(v.keypoints) for v in A.values()) == int(O.length[O.length >= 3].sum())
+    for name in A:
+        assert A[name].keypoints == B[name].keypoints == C[name].keypoints
+        assert list(A[name].match_pairs) == list(B[name].match_pairs) == list(C[name].match_pairs)
+        for k in A[name].match_pairs:
+            assert A[name].match_pairs[k] == B[name].match_pairs[k] == C[name].match_pairs[k]
+    assert open(str(tmp_path / "streamed.txt")).read() == open(str(tmp_path / "generic.txt")).read() == open(str(tmp_path / "ours.txt")).read()
