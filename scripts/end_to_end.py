@@ -34,19 +34,23 @@ for rep in range(2):     # second pass = warm page cache / warm workspaces
     t1 = time.perf_counter()
     info = run_connect(ff, fb, None, None, 1.0, r, return_device=True); sync()
     t2 = time.perf_counter()
-    from point_trajectory.trajectory import result_to_trajectory_set, save_track_npy
+    from point_trajectory.trajectory import result_to_trajectory_set, save_track_npy, load_track_npy
     ts = result_to_trajectory_set(ctx, info, 3, reuse_pinned=True)      # min-length filter on the device, pinned staging
     t3 = time.perf_counter()
-    save_track_npy(os.path.join(work, "track.npy"), ts)
+    save_track_npy(os.path.join(work, "track.npy"), ts)                 # the default: the reference's pickle state, streamed
     t4 = time.perf_counter()
-    back = np.load(os.path.join(work, "track.npy"), allow_pickle=True).item()
+    back = load_track_npy(os.path.join(work, "track.npy"))              # this package's reader (footer); np.load of this layout: ~20 s
     t5 = time.perf_counter()
+    save_track_npy(os.path.join(work, "track_csr.npy"), ts, layout="csr")
+    t6 = time.perf_counter()
+    back2 = np.load(os.path.join(work, "track_csr.npy"), allow_pickle=True).item()
+    t7 = time.perf_counter()
     nk = len(ts._csr[0])
     print("pass %d: ingest %.0f ms (%.2f GB of .flo, %.1f GB/s) | compute %.2f ms | filter + D2H %.0f ms (%d of %d trajectories kept) | "
-          "save track.npy %.0f ms | np.load %.0f ms | points %d" % (
+          "save track.npy (reference layout) %.0f ms, load_track_npy %.0f ms | save (csr layout) %.0f ms, np.load %.0f ms | points %d" % (
               rep, (t1 - t0) * 1e3, gb, gb / (t1 - t0), (t2 - t1) * 1e3, (t3 - t2) * 1e3, nk, info.n_traj, (t4 - t3) * 1e3,
-              (t5 - t4) * 1e3, info.n_points))
-    del ff, fb, ts, back
+              (t5 - t4) * 1e3, (t6 - t5) * 1e3, (t7 - t6) * 1e3, info.n_points))
+    del ff, fb, ts, back, back2
 t0 = time.perf_counter()
 main_connect_point_trajectories(os.path.join(work, "flows"), os.path.join(work, "traj"), sample_ratio=r, skip_path_consistency=True)
 print("main_connect_point_trajectories (the stage entry, warm): %.2f s" % (time.perf_counter() - t0))
