@@ -1,5 +1,5 @@
-"""Whole-sequence parity of the path-consistency path (flow_check x2 + track_optimize + id order) at BASELINE.json's
-full sizes, against the CPU oracle on the same tensors:
+"""Whole-sequence parity at BASELINE.json's full sizes, against the CPU oracle on the same tensors: configs[0]'s shape in
+track mode (last test), and the path-consistency path (flow_check x2 + track_optimize + id order) on
 
     configs[2] shape   436 x 1024 x   50 frames, sample_ratio 2            (Sintel alley_1 stand-in)
     configs[3] shape  1080 x 1920 x  401 frames, sample_ratio 2            (the 8-GPU config, here on ONE GPU)
@@ -81,3 +81,32 @@ def test_whole_sequence_track_optimize_vs_oracle(H, W, T, r, thres, seed):
                                  "ids_lengths_equal": True, "max_abs_dxy_px": err, "solves": T - 2,
                                  "trust_region_iterations": int(sum(s["iterations"] for s in O.solves)),
                                  "iterations_and_terminations_equal": True, "solver_counters": cnt}) + "\n")
+
+
+def test_whole_sequence_track_configs0_vs_oracle():
+    """BASELINE configs[0] shape (DAVIS 'snowboard' stand-in: 480 x 854 x 50 frames, sample_ratio 4, `track` only): the whole
+    sequence through flow_check + track on the device -- in every way of running the recurrence (persistent loop, one launch
+    per frame, psfm_connect with flow_check fused / on the side stream) -- against the CPU oracle: occlusion maps bit-equal,
+    ids / lengths / positions bit-equal."""
+    import torch
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    from point_trajectory.trajectory import run_connect, run_track
+    from point_trajectory.utils import flow_check_device
+    T, H, W, r = 50, 480, 854, 4
+    d = psfm_synth.synth_sequence_torch(T, H, W, seed=2, sigma=0.05, n_occluders=2, stride2=False, device="cuda")
+    ff, fb = d["flows_f"].cpu().numpy(), d["flows_b"].cpu().numpy()
+    _, occ_o = orc.flow_check(list(ff), list(fb), 1.0)
+    O = orc.track(list(ff), occ_o, r)
+    _, occ = flow_check_device(d["flows_f"], d["flows_b"], 1.0)
+    assert np.array_equal(occ.cpu().numpy().astype(bool), np.stack(occ_o))
+    ctx = _hip.context()
+    try:
+        for mode in (1, 2):
+            ctx.set_chain_mode(mode)
+            for R in (run_track(d["flows_f"], occ, None, None, r), run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, r)):
+                assert R.info["chain_mode"] == mode
+                assert len(R) == O.n_traj and R.n_points == O.n_points
+                assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and np.array_equal(R.xy, O.xy)
+    finally:
+        ctx.set_chain_mode(0)
