@@ -409,6 +409,24 @@ def test_reference_layout_is_streamed_from_the_csr(tmp_path, n):
         assert bl.trajs[int(ids[3])].as_dict()["labels"] == lab[off[3]:off[4]].tolist()
 
 
+def test_streaming_writer_declines_what_its_records_cannot_hold():
+    """4-byte fields: a set with 2^31 or more points, or an id outside [0, 2^31), goes through the generic pickler."""
+    from point_trajectory.optimize.build import particlesfm
+    from point_trajectory import reference_pickle
+    mk = lambda ids, off_last: particlesfm.TrajectorySet._from_csr(np.asarray(ids, np.int64), np.zeros(len(ids), np.int32),
+                                                                  np.ones(len(ids), np.int32),
+                                                                  np.concatenate([np.arange(len(ids)), [off_last]]).astype(np.int64),
+                                                                  np.zeros((0, 2)))
+    assert reference_pickle.can_stream(mk([0, 1, 2], 3))
+    assert not reference_pickle.can_stream(mk([0, 1, 2], 1 << 31))
+    assert not reference_pickle.can_stream(mk([0, 1, 1 << 31], 3))
+    assert not reference_pickle.can_stream(mk([-1, 1, 2], 3))
+    ts = mk([0, 1, 2], 3)
+    _ = ts.trajs                                   # the map was materialised (and may have been edited): generic path
+    assert not reference_pickle.can_stream(ts)
+    assert not reference_pickle.can_stream({0: {}})
+
+
 def test_package_imports_from_a_git_archive(tmp_path):
     """What `git archive HEAD` exports must be a working source tree: every module of the product package is tracked
     (an unanchored ignore pattern once hid point_trajectory/optimize/build/) and `import point_trajectory` works from it."""
