@@ -120,3 +120,21 @@ def test_connect_sharded_two_processes_one_gpu():
         birth, length, xy, its, n_local = ret[rank]
         assert np.array_equal(birth, O.birth) and np.array_equal(length, O.length) and float(np.abs(xy - O.xy).max()) <= 1e-4
         assert its == [s["iterations"] for s in O.solves] and 0 < n_local < O.n_traj
+
+
+@pytest.mark.gpu
+def test_rccl_operations_of_the_sharded_mode_on_a_one_rank_group():
+    """The collectives psfm_dist.TorchComm issues under backend "nccl" (= RCCL): all_reduce(MAX) on the uint8 blocked map,
+    all_gather_into_tensor on the f64 solver sums and on the bit-packed occlusion maps, all_gather_object, barrier -- on a
+    1-rank group in a child process (dtype / op support of the installed RCCL; what several ranks add is covered by the gloo
+    and thread-rank tests)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(29700 + os.getpid() % 200)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_rccl_ops.py")], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0 and "rccl ops ok: nccl" in r.stdout, (r.stdout + r.stderr)[-2000:]
