@@ -352,6 +352,9 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // flow_check); any other way of running the recurrence first fills them with the stand-alone kernel.
     if (occ_pitch == 0) occ_pitch = (int64_t)h * w;
     PSFM_CHECK_CTX(c);
+    // a psfm_shard_begin run that was never finished: this call overwrites its lane tables, so it ends here (a later
+    // psfm_shard_* call on the context reports "no sharded run in progress" instead of stepping foreign state)
+    psfm_shard_abandon(c);
     const bool optimize = flows_f2 != nullptr;
     if (n_flows < 1 || h < 2 || w < 2 || ratio < 1 || !flows || !occ || (optimize && !occ_s2 && n_flows > 1)) {
         psfm_set_error("psfm_track: bad argument (n_flows=%d h=%d w=%d ratio=%d)", n_flows, h, w, ratio);
@@ -367,6 +370,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
 
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;
+    c->res_n_flows = n_flows;
 
     // ---- track mode: the whole recurrence as ONE persistent launch when every lane can be resident at once ----
     if (!optimize && c->chain_mode != 1) {

@@ -134,6 +134,7 @@ struct psfm_ctx {
     PsfmBuf sort_keys, sort_lanes, sort_tmp, scan_tmp;
     PsfmBuf res_birth, res_len, res_off, res_xy;
     int64_t res_n_traj = 0, res_n_points = 0;
+    int res_n_flows = 0;           // flows of the sequence the result came from (psfm_result_keys checks its packed key)
     // solver workspace
     PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats, sol_fused;
     int solve_K = 4;        // fused solve: trust-region iterations speculated per launch (adapted at checkpoints)

@@ -38,9 +38,15 @@ extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, 
         psfm_set_error("psfm_shard_begin: bad argument (n_flows=%d h=%d w=%d ratio=%d)", n_flows, h, w, ratio);
         return PSFM_ERR_ARG;
     }
+    // the ids over ranks come from the key last << 51 | birth << 40 | grid index (psfm_result_keys): 11 bits per time field
+    if (n_flows + 2 >= (1 << 11)) {
+        psfm_set_error("psfm_shard_begin: %d flows: the (last, birth, grid) key of a sharded run holds times below 2046", n_flows);
+        return PSFM_ERR_ARG;
+    }
     PsfmTrackDims d;
     psfm_status st;
     const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
+    if (G >= ((int64_t)1 << 40)) { psfm_set_error("psfm_shard_begin: %lld grid points", (long long)G); return PSFM_ERR_ARG; }
     if (g0 < 0 || g1 < g0 || g1 > G || map_pitch < G + 1) {
         psfm_set_error("psfm_shard_begin: band [%lld, %lld) of %lld grid points, map pitch %lld", (long long)g0, (long long)g1,
                        (long long)G, (long long)map_pitch);
@@ -52,6 +58,7 @@ extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, 
     if (optimize && (st = psfm_solve_prepare(c, d)) != PSFM_OK) return st;
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;
+    c->res_n_flows = n_flows;
     delete c->shard_dims;
     c->shard_dims = new PsfmTrackDims(d);
     c->shard_optimize = optimize != 0;
@@ -161,6 +168,10 @@ extern "C" psfm_status psfm_result_keys(psfm_ctx* c, int ratio, int w, int64_t* 
     PSFM_HIP(hipSetDevice(c->device));
     PsfmGate gate(c->device, 0);
     const int64_t n = c->res_n_traj;
+    if (c->res_n_flows + 2 >= (1 << 11)) {     // (the result of a plain psfm_track of a longer sequence)
+        psfm_set_error("psfm_result_keys: the result spans %d flows: the packed key holds times below 2046", c->res_n_flows);
+        return PSFM_ERR_ARG;
+    }
     if (n > 0) {
         hipLaunchKernelGGL(psfm_shard_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            c->res_birth.as<int>(), c->res_len.as<int>(), c->res_off.as<int64_t>(), c->res_xy.as<double2>(), n, ratio,

@@ -19,6 +19,7 @@ The container around it (the .npy header, the 0-d object array, the class refere
 template instance, so it is whatever this NumPy / this class produce.
 """
 import pickle
+import pickletools
 import struct
 
 import numpy as np
@@ -87,12 +88,18 @@ def dump(fp, ts):
     fp.write(prefix)
     # preamble: the shared objects, each memoised and popped again
     xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
-    # (the pickler streams the point array into the file without an intermediate bytes object; PROTO / FRAME opcodes inside a
-    # stream are legal, its closing STOP is stepped back over)
-    xy_start = fp.tell()
-    pickle.Pickler(fp, protocol=5).dump(xy)
-    fp.seek(-1, 1)
-    xy_end = fp.tell()
+    # XY as hand-written opcodes, no PROTO / FRAME inside the stream (a protocol-5 sub-pickle would leave its last FRAME open across
+    # the opcodes that follow: the C unpickler tolerates that, `pickle._Unpickler` -- PyPy's only one -- does not):
+    #     <what ndarray.__reduce_ex__(5) names, e.g. numpy._core.numeric._frombuffer>(BYTEARRAY8 raw, dtype('<f8'), (n, 2), 'C')
+    # The raw bytes go from the array to the file without an intermediate copy; BYTEARRAY8 keeps the array writable.
+    rebuild = np.zeros((1, 2)).__reduce_ex__(5)[0]
+    item = lambda o: pickletools.optimize(pickle.dumps(o, protocol=3))[2:-1]     # protocol 3: no framing; optimize: no memo slots
+    fp.write(b"c" + rebuild.__module__.encode() + b"\n" + rebuild.__name__.encode() + b"\n(")      # GLOBAL, MARK
+    fp.write(b"\x96" + struct.pack("<Q", xy.nbytes))                                                 # BYTEARRAY8
+    xy_data = fp.tell() if xy.nbytes > 0 else -1
+    if xy.nbytes > 0:
+        fp.write(xy.reshape(-1).view(np.uint8).data)
+    fp.write(item(xy.dtype) + item(tuple(int(x) for x in xy.shape)) + item("C") + b"tR")             # ... TUPLE, REDUCE
     fp.write(b"q" + bytes([_M_XY]) + b"0")
     fp.write(_global(b"builtins", b"list", _M_LIST) + _global(b"builtins", b"range", _M_RANGE) + _global(b"builtins", b"slice", _M_SLICE)
              + _global(b"operator", b"getitem", _M_GETITEM) + _global(b"operator", b"mul", _M_MUL)
@@ -115,17 +122,8 @@ def dump(fp, ts):
         fp.write(buf.tobytes())
     fp.write(b"u")
     fp.write(suffix)
-    # footer: where the raw point bytes are (an in-band buffer: BINBYTES8 / BYTEARRAY8 opcode + 8-byte length + data)
+    # footer: where the raw point bytes are
     end = fp.tell()
-    xy_data = -1
-    if xy.nbytes > 0:
-        fp.seek(xy_start)
-        head = fp.read(min(4096, xy_end - xy_start))
-        for op in (b"\x8e", b"\x96"):
-            k = head.find(op + struct.pack("<Q", xy.nbytes))
-            if k >= 0:
-                xy_data = xy_start + k + 9
-        fp.seek(end)
     if xy_data >= 0 or xy.nbytes == 0:
         fp.write(_FOOTER.pack(_FOOTER_MAGIC, xy_data, xy.shape[0], rec_start, n, R, end, _FOOTER_MAGIC))
 

@@ -158,12 +158,22 @@ def save_track_npy(path, trajectories, layout="reference"):
         trajectories.pickle_layout = layout
     arr = np.empty((), dtype=object)
     arr[()] = trajectories
-    with open(path if str(path).endswith(".npy") else str(path) + ".npy", "w+b") as fp:
-        np.lib.format.write_array_header_1_0(fp, np.lib.format.header_data_from_array_1_0(arr))
-        if layout == "reference" and reference_pickle.can_stream(trajectories):
-            reference_pickle.dump(fp, trajectories)      # the reference's object graph as opcodes, straight from the CSR
-        else:
-            pickle.dump(arr, fp, protocol=5)
+    # written beside the target and moved over it: a TrajectorySet loaded from the SAME path maps its points from the old file
+    # (reference_pickle.load), and truncating that file in place would take the pages away under it (SIGBUS)
+    target = path if str(path).endswith(".npy") else str(path) + ".npy"
+    tmp = "%s.tmp-%d" % (target, os.getpid())
+    try:
+        with open(tmp, "w+b") as fp:
+            np.lib.format.write_array_header_1_0(fp, np.lib.format.header_data_from_array_1_0(arr))
+            if layout == "reference" and reference_pickle.can_stream(trajectories):
+                reference_pickle.dump(fp, trajectories)      # the reference's object graph as opcodes, straight from the CSR
+            else:
+                pickle.dump(arr, fp, protocol=5)
+        os.replace(tmp, target)
+    except BaseException:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise
 
 
 def load_track_npy(path):

@@ -6,7 +6,7 @@ Two producers feed ONE assembler:
   * `traj_to_matches(img_dir, traj_dir, match_list_file, remove_dynamic=True)` -- the reference's signature; reads
     track.npy and does the index arithmetic in NumPy on the host;
   * `traj_to_matches_device(ctx, image_names, match_list_file)` -- the same tables computed by
-    psfm_traj_to_matches (csrc/psfm_window.hip) straight from the saved set that psfm_result_filter left in HBM; only
+    psfm_traj_to_matches (csrc/psfm_matches.hip) straight from the saved set that psfm_result_filter left in HBM; only
     the finished tables cross PCIe.
 Both return what the reference returns: {image name: object with .keypoints and .match_pairs} in image order, and write
 the pair list file.  Element for element equal to the reference's own function (tests/test_reference_consumers.py,
@@ -67,6 +67,9 @@ def match_tables_host(off, frames, xy, labels, n_img, remove_dynamic=True, sampl
     kp_off (n_img+1), kp_xy (n_kept,2), pair_key (n_pairs) = src_image * n_img + tgt_image in ascending key order,
     pair_off (n_pairs+1), pair_first (n_pairs) = position of the pair's first match in the loop order, rows (n_matches,2)."""
     n_traj = len(off) - 1
+    if len(frames) and (int(np.min(frames)) < 0 or int(np.max(frames)) >= n_img):
+        # the reference indexes image_names[frame] (matches_from_flow.py:79) and raises; the device path returns PSFM_ERR_ARG
+        raise IndexError("traj_to_matches: frame ids span [%d, %d], %d images" % (int(np.min(frames)), int(np.max(frames)), n_img))
     owner = np.repeat(np.arange(n_traj), np.diff(off))
     keep = ~labels if remove_dynamic else np.ones(len(frames), bool)     # :71-74
     frames, xy, owner = frames[keep], xy[keep], owner[keep]

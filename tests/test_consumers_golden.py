@@ -54,6 +54,19 @@ def test_host_match_tables_equal_reference_fixture(name, tmp_path):
     _check_against_fixture(mff.assemble(names, tables, str(tmp_path / "pairs.txt")), names, g)
 
 
+def test_host_match_tables_reject_frames_outside_the_image_list():
+    """The reference indexes image_names[frame] (sfm/matches_from_flow.py:79) and raises IndexError on a frame beyond the image
+    list; the device path returns PSFM_ERR_ARG.  The host tables must not silently drop or misfile such points."""
+    from psfm_sfm import matches_from_flow as mff
+    off = np.array([0, 3], np.int64)
+    xy = np.zeros((3, 2))
+    labels = np.zeros(3, bool)
+    for frames in (np.array([0, 1, 4], np.int64), np.array([-1, 0, 1], np.int64)):
+        with pytest.raises(IndexError):
+            mff.match_tables_host(off, frames, xy, labels, 4, remove_dynamic=True)
+    mff.match_tables_host(off, np.array([1, 2, 3], np.int64), xy, labels, 4, remove_dynamic=True)
+
+
 @pytest.fixture(scope="module")
 def pt():
     import torch
