@@ -27,14 +27,49 @@ for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
 
 H, W, N_FRAMES, RATIO, THRES = 1080, 1920, 101, 2, 1.0
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# f64 VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 f64 instruction per 4 cycles of its SIMD (MI355X_MICROARCH.md: SIMD-32,
+# v_fma_f32 2 cycles; the 78.6 TFLOP/s vector f64 peak = half the f32 rate) -> 614.4 G wave-instructions/s
+VALU_PEAK_GWIPS = 256 * 4 * 2.4 / 4.0
+
+
+REFERENCE_SOLVER_THREADS = 8     # solver_options.num_threads at trajectory_optimize.cpp:79 (what BASELINE.md specifies)
+
+
+def reference_python_on_this_box(flows_f, flows_b, frames=4):
+    """The reference's OWN Python (point_trajectory/utils.py flow_check + track.py track, unmodified, through oracle/ref_shim.py)
+    timed on THIS box's host cores on the first `frames` frame pairs of the same tensors -- only where a reference tree is
+    reachable (PSFM_REFERENCE_ROOT, default /root/reference: present in the build container, absent on the driver's GPU box;
+    the sources are never copied into this repo).  Returns None when it is not."""
+    from oracle import ref_shim
+    if not ref_shim.available():
+        return None
+    import torch
+    ref = ref_shim.load()
+    ff = [f for f in flows_f[:frames].cpu().numpy()]
+    fb = [f for f in flows_b[:frames].cpu().numpy()]
+    t0 = time.perf_counter()
+    _, occ = ref.flow_check(ff, fb, THRES)
+    t1 = time.perf_counter()
+    tr = ref.track(ff, occ, RATIO)
+    t2 = time.perf_counter()
+    pts = sum(t.length() for t in tr)
+    return {"value": pts / (t2 - t0), "unit": "trajectory-points/s", "kind": "reference",
+            "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+            "track_points_per_s": pts / (t2 - t1), "flow_check_s_per_pair": (t1 - t0) / frames,
+            "sample": "first %d of %d frame pairs at 1080p, sample_ratio=2: the reference's flow_check + track (Python, torch-CPU "
+                      "grid_sample with %d threads, SciPy EDT; per-track pybind-style objects): %d points in %.1f s"
+                      % (frames, N_FRAMES - 1, torch.get_num_threads(), pts, t2 - t0)}
 
 
 def cpu_baseline(flows_f, flows_b, n_pairs):
-    """The CPU oracle ("port": C restatement of the reference path, OpenMP over independent tracks / pixels with
-    OMP_NUM_THREADS or all host cores) on the first n_pairs frame pairs of the same tensors."""
+    """The CPU oracle ("port": C restatement of the reference path, OpenMP over independent tracks / pixels) on the first
+    n_pairs frame pairs of the same tensors.  Threads: PSFM_CPU_THREADS, else min(32, host cores) -- the restatement stops
+    scaling there (the per-track list bookkeeping of extend_all is serial); the reference itself runs its solver on 8 threads
+    (trajectory_optimize.cpp:79) and everything else of the chain-only path on torch's intra-op pool."""
     import numpy as np
     from oracle import oracle as orc
-    orc.set_num_threads(min(32, os.cpu_count() or 1))
+    want = int(os.environ.get("PSFM_CPU_THREADS", "0")) or min(32, os.cpu_count() or 1)
+    orc.set_num_threads(want)
     ff = [f for f in flows_f[:n_pairs].cpu().numpy()]
     fb = [f for f in flows_b[:n_pairs].cpu().numpy()]
     t0 = time.perf_counter()
@@ -42,10 +77,16 @@ def cpu_baseline(flows_f, flows_b, n_pairs):
     R = orc.track(ff, occ, RATIO)
     dt = time.perf_counter() - t0
     out = {"value": R.n_points / dt, "unit": "trajectory-points/s", "cores": orc.num_threads(), "host_cores": os.cpu_count(),
-           "kind": "port",
+           "kind": "port", "reference_solver_threads": REFERENCE_SOLVER_THREADS,
            "sample": "first %d of %d frame pairs at 1080p, sample_ratio=2: flow_check + track + id order; %d points in %.1f s "
                      "(C restatement, OpenMP over tracks / pixels; the per-track list bookkeeping of extend_all is serial)"
                      % (n_pairs, N_FRAMES - 1, R.n_points, dt)}
+    try:
+        here = reference_python_on_this_box(flows_f, flows_b)
+    except Exception as e:     # noqa: BLE001
+        here = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if here is not None:
+        out["reference_python_this_box"] = here
     ref = os.path.join(ROOT, "BASELINE_MEASURED.json")
     if os.path.exists(ref):     # the reference's own Python, timed in the build container (scripts/measure_reference_baseline.py)
         try:
@@ -53,6 +94,7 @@ def cpu_baseline(flows_f, flows_b, n_pairs):
             out["reference_python_build_container"] = {
                 "track_points_per_s": m["track"]["points_per_s"], "track_optimize_points_per_s": m["track_optimize"]["points_per_s"],
                 "flow_check_s_per_pair": m["flow_check_s_per_pair"], "host": m["host"], "frames": m["workload"]["frames"],
+                "source": "BASELINE_MEASURED.json (replayed, not measured in this run)",
                 "note": "unmodified reference Python through oracle/ref_shim.py, not this box: see BASELINE_MEASURED.json"}
         except Exception:
             pass
@@ -216,14 +258,36 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
         fused = cnt["fused"] + cnt["fused_redone"] > cnt["chain"]
         name = ("psfm_seq_kernel = the frame kernel, device-paced (ONE launch per frame: chain step + fused solve)" if merged else
                 "psfm_pc_fused_kernel (one launch per solve)") if fused else "pc_init + pc_iter chain (one span per solve)"
-        out["frame_kernel" if merged else "solver"] = {
-            "kernel": name, "bound": "hbm", "bytes_per_launch": per_solve,
-            "bytes_breakdown": {"pc_prepare + pc_solve (SURVEY 8d)": tot / len(frames), "chain_step": cb if merged else 0.0},
-            "avg_launch_us": us, "launches_timed": int(prof["solver"]["launches"]),
-            "achieved": per_solve / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": per_solve / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_iterations": float(np.mean(its)),
-            "note": "f64 issue-bound, not bandwidth-bound: ~940 VALU instructions per track and trust-region iteration; the "
-                    "timed launches include the few that overlap a flow_check chunk of the side stream (2x) and the retries"}
+        # What bounds these launches is f64 VALU issue, not bandwidth: wave-instructions per launch from the
+        # PMC pass of the same kernel (SQ_INSTS_VALU, profiles/solver_valu.json: replayed, scaled by this run's track-iterations)
+        # against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 instruction; the SURVEY 8(d) byte MODEL and the PMC traffic ride along.
+        entry = {
+            "kernel": name, "bound": "valu-issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GWIPS,
+            "avg_launch_us": us, "launches_timed": int(prof["solver"]["launches"]), "avg_iterations": float(np.mean(its)),
+            "track_iterations_per_launch": float(np.mean([k * float(tb[f - 1] - tl[f]) for f, k in zip(frames, its)])),
+            "hbm_model": {"bytes_per_launch": per_solve,
+                          "bytes_breakdown": {"pc_prepare + pc_solve (SURVEY 8d)": tot / len(frames), "chain_step": cb if merged else 0.0},
+                          "model_GBs": per_solve / (us * 1e-6) / 1e9, "model_frac_of_hbm_peak": per_solve / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "note": "SURVEY 8(d) prices one re-read of the state per trust-region iteration; the fused kernel keeps the "
+                                  "iterate in registers, so this is NOT its HBM utilisation (see traffic)"},
+            "note": "the timed launches include the few that overlap a flow_check chunk of the side stream and the retries"}
+        vfile = os.path.join(ROOT, "profiles", "solver_valu.json")
+        if fused and os.path.exists(vfile):
+            try:
+                v = json.load(open(vfile))
+                wi = (v["valu_per_wave_per_iteration"] * entry["avg_iterations"] + v["valu_per_wave_fixed"]) * \
+                     (entry["track_iterations_per_launch"] / max(entry["avg_iterations"], 1e-9)) / 64.0
+                entry.update({"achieved": wi / (us * 1e-6) / 1e9, "frac": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS,
+                              "valu_wave_instructions_per_launch": wi,
+                              "valu_source": "profiles/solver_valu.json (PMC SQ_INSTS_VALU of an earlier run of this binary, replayed; "
+                                             "scaled by this run's tracks x iterations)",
+                              "traffic": v.get("hbm_bytes_per_launch"),
+                              "traffic_source": v.get("traffic_source", "profiles/solver_valu.json (replayed)")})
+            except Exception:
+                pass
+        if "frac" not in entry:
+            entry.update({"achieved": None, "frac": None})
+        out["frame_kernel" if merged else "solver"] = entry
     if ch["launches"] > 0 and not merged:
         us = 1e3 * ch["total_ms"] / ch["launches"]
         out["chain_step"] = {"kernel": "psfm_chain_step_kernel<R, OPT>", "bound": "hbm", "bytes_per_launch": cb, "avg_launch_us": us,
@@ -259,7 +323,7 @@ def stream_ceilings(dev):
     return out
 
 
-def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="configs[2] shape"):
+def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="configs[2] shape", dist=None):
     """track_optimize (chaining + Ceres-compatible path-consistency solve) on a synthetic sequence -- by default a
     stand-in of configs[2] (Sintel alley_1 shape: 436x1024, 50 frames, sample_ratio 2): GPU time per sequence and the
     CPU oracle on the first k flows of the same tensors, with the parity of those flows checked on the spot."""
@@ -269,7 +333,8 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     from oracle import oracle as orc
     from point_trajectory.utils import flow_check_device
     from point_trajectory.trajectory import run_track, _result_to_host
-    d = psfm_synth.synth_sequence_torch(t, h, w, seed=seed, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
+    dist = dist or dict(sigma=0.05, n_occluders=2)
+    d = psfm_synth.synth_sequence_torch(t, h, w, seed=seed, stride2=True, device="cuda", **dist)
     ctx.set_profiling(0)
 
     from point_trajectory.trajectory import run_connect
@@ -295,6 +360,7 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     cnt = ctx.solver_counters()
     Rh = _result_to_host(ctx, info)
     roof = solver_roofline(Rh, pr, cnt, h, w, t - 1)
+    info_stats = list(Rh.solve_stats)
     del Rh
     _, occ = flow_check_device(d["flows_f"], d["flows_b"], THRES)
     _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], THRES)
@@ -305,7 +371,9 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     cpu_s = time.perf_counter() - t0
     Rg = _result_to_host(ctx, run_track(d["flows_f"][:k], occ[:k], d["flows_f2"][:k - 1], occ2[:k - 1], r, return_device=True))
     same = bool(np.array_equal(Rg.birth, Rc.birth) and np.array_equal(Rg.length, Rc.length))
+    rej = int(sum(s_["iterations"] - s_["successful_steps"] for s_ in info_stats)) if info_stats else None
     return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check x2 + track_optimize" % (label, h, w, t, r),
+            "flows": dict(dist), "rejected_steps": rej,
             "ms_per_sequence": ms, "trajectory_points_per_s": info.n_points / (ms * 1e-3), "points": int(info.n_points),
             "solves": int(info.n_solves), "trust_region_iterations": int(info.solver_iterations),
             "solver_counters": cnt, "roofline": roof,
@@ -330,6 +398,20 @@ def main():
                          "measured outside the timed region (overlapped psfm_connect, track_optimize, concurrent sequences)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched bare (`python bench.py --gpus N`): become the launcher -- one rank per GPU under torch.distributed.run,
+        # exactly the command line the driver uses -- and hand its exit code back.  Never print a line for fewer GPUs than asked.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -337,6 +419,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the job has %d rank(s) (WORLD_SIZE): refusing to report a line for another size"
+                 % (args.gpus, world))
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: rank %d needs cuda:%d, %d device(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -489,7 +576,10 @@ def main():
                          if persistent else "psfm_chain_step_kernel",
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_launch": chain_bytes, "avg_launch_us": chain_us,
+                         "traffic": traffic,
+                         "traffic_source": ("profiles/%s (PMC passes of an earlier run of this binary, replayed: counters cannot be "
+                                            "collected inside the timed run)" % os.path.basename(tfile)) if traffic is not None else None,
+                         "bytes_per_launch": chain_bytes, "avg_launch_us": chain_us,
                          "steps_per_launch": n_flows if persistent else 1,
                          "us_per_step": chain_us / (n_flows if persistent else 1),
                          "bytes_per_step": frame_bytes,
@@ -532,6 +622,10 @@ def main():
                 # north_star's target workload for the path-consistency path: the headline shape with the solver on
                 out["secondary_1080p"] = secondary_track_optimize(ctx, H, W, n_frames, RATIO, seed=5, k=10,
                                                                   label="headline shape with path consistency")
+                # SURVEY 8(d)'s second distribution on the same shape (sigma 0.3, 5 % occluder area): every solve rejects steps and
+                # takes interpolated dogleg steps, i.e. the launch chain instead of the speculated fused solve
+                out["secondary_hard"] = secondary_track_optimize(ctx, H, W, n_frames, RATIO, seed=6, k=6, dist=psfm_synth.HARD,
+                                                                 label="headline shape with path consistency, hard flows")
                 out["concurrent"] = concurrent_sequences(3, n_frames)
         print(json.dumps(out), flush=True)
     if hung:            # a rank is stuck in a collective of the extra mode: the line is out, leave without the barrier

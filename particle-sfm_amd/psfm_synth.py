@@ -26,14 +26,35 @@ def _clean_np(xx, yy, H, W, amp, ph):
     return u, v
 
 
-def synth_sequence(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluders=0, stride2=True):
+def _clean_drift_np(xx, yy, H, W, amp, ph, drift):
+    u, v = _clean_np(xx, yy, H, W, amp, ph)
+    return u + drift[0], v + drift[1]
+
+
+def _backward_of(fwd, xx, yy):
+    """B(q) = -F(p) with p + F(p) = q, by three fixed-point steps p <- q - F(p) (the flows used here move a few percent per
+    pixel, so this is exact to far below the noise)."""
+    px, py = xx, yy
+    for _ in range(3):
+        u, v = fwd(px, py)
+        px, py = xx - u, yy - v
+    u, v = fwd(px, py)
+    return -u, -v
+
+
+def synth_sequence(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluders=0, stride2=True, drift=(0.0, 0.0), warp_b=False):
     """Returns dict(flows_f, flows_b[, flows_f2, flows_b2]) of lists of (H,W,2) float32 arrays.
 
-    n_frames images -> n_frames-1 stride-1 pairs and n_frames-2 stride-2 pairs."""
+    n_frames images -> n_frames-1 stride-1 pairs and n_frames-2 stride-2 pairs.
+    drift: a constant (dx, dy) added to every clean forward flow (large motion: tracks cross the image and leave it, stride-2
+    flows reach the reference's 20 px gate, trajectory.py:179).  warp_b: the backward flow is the true inverse of the clean
+    forward flow (B(p + F(p)) = -F(p)) instead of -F at the same pixel -- what keeps large flows forward/backward consistent.
+    The defaults reproduce the generator the committed fixtures were made with."""
     rng = np.random.default_rng(seed)
     yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
     n_pairs = n_frames - 1
     phases = rng.uniform(0, 2 * np.pi, size=(n_pairs + 1, 4))
+    plain = (float(drift[0]) == 0.0 and float(drift[1]) == 0.0 and not warp_b)
 
     def noisy(u, v):
         out = np.stack([u, v], -1)
@@ -49,25 +70,46 @@ def synth_sequence(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluders=0, s
             fb[y0:y0 + bh, x0:x0 + bw, :] = ff_clean[y0:y0 + bh, x0:x0 + bw, :]
         return fb
 
+    def fwd1(t):
+        return lambda px, py: _clean_drift_np(px, py, H, W, amp, phases[t], drift)
+
+    def fwd2(t):
+        def f(px, py):
+            u, v = fwd1(t)(px, py)
+            u2, v2 = fwd1(t + 1)(px + u, py + v)
+            return u + u2, v + v2
+        return f
+
     out = {"flows_f": [], "flows_b": []}
     for t in range(n_pairs):
-        u, v = _clean_np(xx, yy, H, W, amp, phases[t])
+        if plain:
+            u, v = _clean_np(xx, yy, H, W, amp, phases[t])
+            bu, bv = -u, -v
+        else:
+            u, v = fwd1(t)(xx, yy)
+            bu, bv = _backward_of(fwd1(t), xx, yy) if warp_b else (-u, -v)
         out["flows_f"].append(noisy(u, v))
-        fb = noisy(-u, -v)
+        fb = noisy(bu, bv)
         out["flows_b"].append(occlude(fb, np.stack([u, v], -1).astype(np.float32)))
     if stride2:
         out["flows_f2"], out["flows_b2"] = [], []
         for t in range(n_pairs - 1):
-            u, v = _clean_np(xx, yy, H, W, amp, phases[t])
-            u2, v2 = _clean_np(xx + u, yy + v, H, W, amp, phases[t + 1])
-            out["flows_f2"].append(noisy(u + u2, v + v2))
-            fb = noisy(-(u + u2), -(v + v2))
-            out["flows_b2"].append(occlude(fb, np.stack([u + u2, v + v2], -1).astype(np.float32)))
+            if plain:
+                u, v = _clean_np(xx, yy, H, W, amp, phases[t])
+                u2, v2 = _clean_np(xx + u, yy + v, H, W, amp, phases[t + 1])
+                su, sv = u + u2, v + v2
+                bu, bv = -su, -sv
+            else:
+                su, sv = fwd2(t)(xx, yy)
+                bu, bv = _backward_of(fwd2(t), xx, yy) if warp_b else (-su, -sv)
+            out["flows_f2"].append(noisy(su, sv))
+            fb = noisy(bu, bv)
+            out["flows_b2"].append(occlude(fb, np.stack([su, sv], -1).astype(np.float32)))
     return out
 
 
 def synth_sequence_torch(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluders=0, stride2=False,
-                         device="cuda"):
+                         device="cuda", drift=(0.0, 0.0), warp_b=False):
     """Same formula evaluated with torch on `device`.  Returns dict of (n,H,W,2) float32 tensors."""
     import torch
 
@@ -78,11 +120,23 @@ def synth_sequence_torch(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluder
     phases = host_rng.uniform(0, 2 * np.pi, size=(n_pairs + 1, 4))
     ys = torch.arange(H, device=device, dtype=torch.float32)[:, None]
     xs = torch.arange(W, device=device, dtype=torch.float32)[None, :]
+    dx, dy = float(drift[0]), float(drift[1])
 
     def clean(xx, yy, ph):
-        u = amp * torch.sin(2 * math.pi * 1.5 * xx / W + ph[0]) * torch.cos(2 * math.pi * yy / H + ph[1])
-        v = amp * torch.cos(2 * math.pi * xx / W + ph[2]) * torch.sin(2 * math.pi * 1.5 * yy / H + ph[3])
+        u = amp * torch.sin(2 * math.pi * 1.5 * xx / W + ph[0]) * torch.cos(2 * math.pi * yy / H + ph[1]) + dx
+        v = amp * torch.cos(2 * math.pi * xx / W + ph[2]) * torch.sin(2 * math.pi * 1.5 * yy / H + ph[3]) + dy
         return u, v
+
+    def clean2(xx, yy, t):
+        u, v = clean(xx, yy, phases[t])
+        u2, v2 = clean(xx + u, yy + v, phases[t + 1])
+        return u + u2, v + v2
+
+    def backward(fwd):
+        if not warp_b:
+            u, v = fwd(xs, ys)
+            return -u, -v
+        return _backward_of(fwd, xs, ys)
 
     def noisy(dst, u, v):
         dst[..., 0] = u
@@ -106,14 +160,21 @@ def synth_sequence_torch(n_frames, H, W, seed=0, amp=3.0, sigma=0.05, n_occluder
         u, v = clean(xs, ys, phases[t])
         u, v = u.expand(H, W), v.expand(H, W)
         noisy(out["flows_f"][t], u, v)
-        noisy(out["flows_b"][t], -u, -v)
+        bu, bv = backward(lambda xx, yy: clean(xx, yy, phases[t]))
+        noisy(out["flows_b"][t], bu.expand(H, W), bv.expand(H, W))
         occlude(out["flows_b"][t], torch.stack([u, v], -1))
         if stride2 and t < n_pairs - 1:
-            u2, v2 = clean(xs + u, ys + v, phases[t + 1])
-            noisy(out["flows_f2"][t], u + u2, v + v2)
-            noisy(out["flows_b2"][t], -(u + u2), -(v + v2))
-            occlude(out["flows_b2"][t], torch.stack([u + u2, v + v2], -1))
+            su, sv = clean2(xs, ys, t)
+            noisy(out["flows_f2"][t], su, sv)
+            bu, bv = backward(lambda xx, yy: clean2(xx, yy, t))
+            noisy(out["flows_b2"][t], bu, bv)
+            occlude(out["flows_b2"][t], torch.stack([su, sv], -1))
     return out
+
+
+# SURVEY 8(d)'s second distribution ("sigma = 0.3 and 5 % rectangular occluder regions, to exercise deaths / respawn / kinks"):
+# three boxes of H/8 x W/8 = 4.7 % of the image per backward field.
+HARD = dict(sigma=0.3, n_occluders=3)
 
 
 NONFINITE_VALUES = (float("nan"), float("inf"), float("-inf"), 1e30, -1e30, 3e38, 1e10, -1e10, 2147483648.0, -2147483904.0)

@@ -27,7 +27,9 @@ def regen_inputs(g, stride2):
                                   amp=float(g["amp"]) if "amp" in g else 3.0,
                                   sigma=float(g["sigma"]) if "sigma" in g else 0.05,
                                   n_occluders=int(g["n_occluders"]) if "n_occluders" in g else 0,
-                                  stride2=stride2)
+                                  stride2=stride2,
+                                  drift=tuple(float(x) for x in g["drift"]) if "drift" in g else (0.0, 0.0),
+                                  warp_b=bool(int(g["warp_b"])) if "warp_b" in g else False)
     assert input_hash(d) == str(g["input_hash"]), "psfm_synth no longer reproduces this fixture's inputs"
     return d
 
@@ -58,6 +60,10 @@ def solver_batch(H, W, n, seed, sigma, kink=False):
     scale[rng.uniform(size=n) < 0.2] = 0.0
     return uv, ref1, ref2, scale, flow12
 
+
+# reference-python fixtures with ~10 px of drift per frame: stride-2 flows on both sides of the 20 px gate of trajectory.py:179,
+# fractional occ02 weights, tracks leaving the image (tests/golden/make_golden.py::make_large_motion)
+LARGE_MOTION = ["opt_largemotion_96x128_r2", "opt_largemotion_90x140_r3"]
 
 # the batches every solver test runs (GPU vs oracle, oracle vs the second restatement, real Ceres when available)
 SOLVER_BATCHES = [

@@ -67,11 +67,75 @@ def make_nonfinite(ref):
           int((~np.isfinite(np.concatenate([np.ravel(a) for a in d["flows_f"]]))).sum()), "non-finite forward components")
 
 
+LARGE_MOTION_CASES = [
+    # name, T, H, W, ratio, seed, amp, sigma, occluders, drift
+    ("opt_largemotion_96x128_r2", 9, 96, 128, 2, 61, 1.5, 0.05, 3, (9.6, 1.5)),
+    ("opt_largemotion_90x140_r3", 8, 90, 140, 3, 62, 2.0, 0.25, 2, (-8.8, 4.0)),
+]
+
+
+def make_large_motion(ref):
+    """`loss02_scale = (1 - occ02) * (|flow02| < 20)` (trajectory.py:179) on BOTH sides of the gate, with
+    continuous occ02 weights at occluder borders, and tracks whose solver parameters / chain taps leave the image (a drift of
+    ~10 px per frame).  The reference's own optimize_buffer is watched from outside (its `optimize_location` argument
+    `ref2_scale` and the samples its `grid_sample` returns) so that the fixture records what it actually exercised."""
+    seen = {"scale_zero": 0, "scale_one": 0, "scale_frac": 0, "norm_ge20": 0, "norm_lt20_s2": 0, "solves": 0}
+    real_opt = ref.particlesfm.optimize_location
+    real_gs = ref.trajectory.grid_sample
+    state = {"in_opt": 0, "calls": []}
+
+    def gs(tensor, xy):
+        out = real_gs(tensor, xy)
+        state["calls"].append(np.asarray(out))
+        return out
+
+    def opt(uv12, ref1, ref2, scale, *a, **k):
+        sc = np.asarray(scale, np.float64).reshape(-1)
+        seen["solves"] += 1
+        seen["scale_zero"] += int((sc == 0).sum())
+        seen["scale_one"] += int((sc == 1).sum())
+        seen["scale_frac"] += int(((sc > 0) & (sc < 1)).sum())
+        # optimize_buffer samples flow01, flow02, occ02 in this order right before the call (trajectory.py:172-178)
+        flow02 = state["calls"][-2]
+        nrm = np.sqrt((flow02.astype(np.float32) ** 2).sum(-1))
+        assert flow02.shape == (len(sc), 2)
+        seen["norm_ge20"] += int((nrm >= 20).sum())
+        seen["norm_lt20_s2"] += int((nrm < 20).sum())
+        state["calls"].clear()
+        return real_opt(uv12, ref1, ref2, scale, *a, **k)
+
+    ref.trajectory.grid_sample = gs
+    ref.particlesfm.optimize_location = opt
+    try:
+        for name, T, H, W, r, seed, amp, sigma, nocc, drift in LARGE_MOTION_CASES:
+            for k in seen:
+                seen[k] = 0
+            d = psfm_synth.synth_sequence(T, H, W, seed=seed, amp=amp, sigma=sigma, n_occluders=nocc, stride2=True, drift=drift,
+                                          warp_b=True)
+            _, occ = ref.flow_check(d["flows_f"], d["flows_b"], 1.0)
+            _, occ2 = ref.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+            tr = ref.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+            b, l, off, xy = ref_shim.trajs_to_csr(tr)
+            outside = int(((xy[:, 0] < 0) | (xy[:, 0] > W - 1) | (xy[:, 1] < 0) | (xy[:, 1] > H - 1)).sum())
+            assert seen["norm_ge20"] > 100 and seen["norm_lt20_s2"] > 100 and seen["scale_frac"] > 100, seen
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), T=T, H=H, W=W, ratio=r, seed=seed, amp=amp, sigma=sigma,
+                                n_occluders=nocc, drift=np.asarray(drift, np.float64), warp_b=1, input_hash=input_hash(d),
+                                birth=b, length=l, xy=xy, occ=np.packbits(np.stack(occ)), occ2=np.packbits(np.stack(occ2)),
+                                gate_closed=seen["norm_ge20"], gate_open=seen["norm_lt20_s2"], scale_fractional=seen["scale_frac"],
+                                scale_zero=seen["scale_zero"], scale_one=seen["scale_one"], points_outside_image=outside)
+            print(name, len(tr), "tracks,", int(l.sum()), "points;", dict(seen), "points outside the image:", outside)
+    finally:
+        ref.trajectory.grid_sample = real_gs
+        ref.particlesfm.optimize_location = real_opt
+
+
 def main():
     import torch
     ref = ref_shim.load()
     if sys.argv[1:] == ["nonfinite"]:
         return make_nonfinite(ref)
+    if sys.argv[1:] == ["largemotion"]:
+        return make_large_motion(ref)
     out = {}
 
     # ---- 1. sampler known answers (trajectory.py:25-37) -------------------
@@ -153,6 +217,7 @@ def main():
     print("EDT == integer-disc rule verified for r=1..5")
 
     make_nonfinite(ref)
+    make_large_motion(ref)
 
 
 if __name__ == "__main__":

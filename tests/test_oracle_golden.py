@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from _common import solver_batch, SOLVER_BATCHES, golden, regen_inputs, assert_csr_equal
+from _common import solver_batch, SOLVER_BATCHES, LARGE_MOTION, golden, regen_inputs, assert_csr_equal
 import psfm_synth
 
 
@@ -102,6 +102,21 @@ def test_track_optimize_orchestration(name):
     d = regen_inputs(g, stride2=True)
     _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
     _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    R = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+    assert len(R.solves) == int(g["T"]) - 2
+
+
+@pytest.mark.parametrize("name", LARGE_MOTION)
+def test_track_optimize_large_motion(name):
+    """The 20 px gate of `loss02_scale` (trajectory.py:179) from both sides and fractional occ02 weights: the fixture is the
+    reference's own Python on flows drifting ~10 px per frame, and records how often each branch was taken."""
+    g = golden(name)
+    assert int(g["gate_closed"]) > 1000 and int(g["gate_open"]) > 1000 and int(g["scale_fractional"]) > 100
+    d = regen_inputs(g, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    assert np.array_equal(np.packbits(np.stack(occ)), g["occ"]) and np.array_equal(np.packbits(np.stack(occ2)), g["occ2"])
     R = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
     assert_csr_equal(R.birth, R.length, R.xy, g)
     assert len(R.solves) == int(g["T"]) - 2
