@@ -16,24 +16,27 @@
 //             x 13 sums are reduced wave -> block -> group -> grid and the last block REPLAYS the control flow below over
 //             them.  The first decision that is not "Gauss-Newton step accepted" ends the belief: termination = done, anything
 //             else = the solve is redone by the launch chain from the values it started with.
-//   pc_init   (launch chain) per track: refs/scale (fp32 sampler, trajectory.py:173-183), Jacobi scaling, and -- in the same
-//             launch -- trust-region iteration 1 (below)
-//   pc_iter   ONE launch per trust-region iteration, one pass per track: r, J at x (f64 bilinear gather), the
-//             4x4 block of the normal equations solved by a register-resident Cholesky, the step, the model decrease,
-//             the candidate x+ and its cost.  The dogleg case depends on GLOBAL norms that only exist after the
-//             launch, so the kernel speculates the overwhelmingly common case (pure Gauss-Newton step inside the trust
-//             region); when the reduced norms say otherwise the control step re-issues the iteration with the
-//             interpolation coefficients fixed.  x ping-pongs between iterate buffers 1 and 2; buffer 0 (the caller's
-//             values / the log slabs) is only written by the write-back.
-//   control   pc_control_step: Ceres' scalar logic for one iteration from its 13 global sums -- accept / reject / radius /
-//             mu / the three tolerances.  Consecutive rejections whose shrunken radius still contains the Gauss-Newton step
-//             reproduce the same candidate, so they are replayed without relaunching (bit-identical to Ceres, which
-//             recomputes the same step each time).  Run by the last block of each launch (ticket after write-through
-//             partials), or -- track-sharded runs -- by psfm_pc_control_kernel on the totals over all ranks.
-//             Nothing returns to the host inside the loop.
+//   pc_init   (launch chain) per track: refs/scale (fp32 sampler, trajectory.py:173-183), Jacobi scaling, cost and the
+//             Gauss-Newton system at the start values; its control step runs Ceres' iteration 0 and fixes the first step
+//   pc_iter   ONE launch per trust-region iteration, one pass per track: the candidate x + a u + b d of the dogleg step the
+//             control step chose, its cost, and -- evaluated AHEAD, as if the step were accepted -- the Gauss-Newton system
+//             and its sums at the candidate.  The sums at an iterate (|ghat|^2, |gn|^2, ghat.gn, |J u|^2, (J u).(J d),
+//             |J d|^2) price EVERY dogleg step of that iterate -- norm and model decrease -- in the control step, so a
+//             rejection (radius halves, same system, new coefficients) and an acceptance (the system at the new iterate is
+//             already reduced) both go on with the next launch: launches = iterations, no re-issued launches.  (Round 2
+//             speculated the Gauss-Newton step per launch and re-issued the launch whenever the reduced norms prescribed
+//             another dogleg case: iterations + non-Gauss-Newton steps launches.)  An invalid step (model decrease <= 0)
+//             raises mu, which changes the system at the same x: one "refresh" launch.  x ping-pongs between iterate
+//             buffers 1 and 2; buffer 0 (the caller's values / the log slabs) is only written by the write-back.
+//   control   pc_chain_control (launch chain) / pc_control_step (replay of a fused launch): Ceres' scalar logic for one
+//             iteration from the global sums -- accept / reject / radius / mu / the three tolerances.  Consecutive rejections
+//             whose shrunken radius still contains the Gauss-Newton step reproduce the same candidate, so they are replayed
+//             without relaunching (bit-identical to Ceres, which recomputes the same step each time).  Run by the last block
+//             of each launch (ticket after write-through partials), or -- track-sharded runs -- by psfm_pc_control_kernel on
+//             the totals over all ranks.  Nothing returns to the host inside the loop.
 //
-// All arithmetic f64 without contraction; reductions have a fixed order (bitwise reproducible for a
-// given lane assignment).
+// All arithmetic f64 (psfm_pc_core.h: explicit fma); reductions have a fixed order (bitwise reproducible for a given
+// lane assignment).
 #include <string.h>
 #include <stdlib.h>
 #include <hip/hip_ext.h>
@@ -41,18 +44,24 @@
 #include "psfm_device.h"
 #include "psfm_internal.h"
 #include "psfm_chain_step.h"
+#include "psfm_pc_core.h"
 
 #define PC_BLOCK 256
 #ifndef PC_RED_ROWS
 #define PC_RED_ROWS 32        // partial rows a thread of the last block keeps in flight
 #endif
 #ifndef PC_MAX_BLOCKS
-#define PC_MAX_BLOCKS 512    // 152 VGPRs = 3 waves/SIMD; 512 blocks measured best on the 401-frame 1080p run (66 ms; 768: 67.6,
-                             // 384: 70.9, 430: 69.2, 537: 71 -- an equal number of blocks on every CU matters more than an equal number of
-                             // tracks per thread; capped to 128 VGPRs / 4 waves with 14 spills: 78 ms)
+#define PC_MAX_BLOCKS 1024   // rows of the launch chain's partial sums
 #endif
-#define PC_NSUM 13
+#ifndef PC_CHAIN_BLOCKS
+#define PC_CHAIN_BLOCKS 512  // blocks of a launch-chain kernel: 512 measured best on the 401-frame 1080p run in round 2 (152 VGPRs, 3
+                             // waves/SIMD: 66 ms; 768: 67.6, 384: 70.9, 430: 69.2, 537: 71 -- an equal number of blocks on every CU
+                             // matters more than an equal number of tracks per thread)
+#endif
 #define PC_KMAX 8            // fused solve: most trust-region iterations speculated in one launch
+#ifndef PSFM_SEQ_WAVES_DEFAULT
+#define PSFM_SEQ_WAVES_DEFAULT 3
+#endif
 #define PC_GROUP 32          // fused solve: blocks per first-level reduction group
 
 
@@ -67,6 +76,11 @@ struct PsfmSolveCtrl {
     int n_tracks, failed, dl_case, launches;
     int fresh_x, k_first;            // x was accepted by the previous control step: gradient test pending; iterations of the
                                      // solve's first fused launch (fixes where its iterates live)
+    // launch chain: the two more sums at x that price any dogleg step (psfm_pc_core.h), the model cost change of the step the
+    // next launch evaluates, and what that launch is: 0 = the candidate of (dl_a, dl_b) + the system at it, 1 = the system
+    // at x again (mu was raised by an invalid step)
+    double qud, qdd, mcc;
+    int kind_next, pad_;
 };
 
 struct PcParams {
@@ -116,195 +130,15 @@ __device__ __forceinline__ double2* pc_buf2(const PcParams& P, int m) { return m
 // the launch chain's candidate buffer while the iterate sits in buffer `cur`
 __device__ __forceinline__ int pc_other(int cur) { return cur == 1 ? 2 : 1; }
 
-// ---- f64 clamp-to-edge bilinear interpolation (linear_interpolation.h:97-123 over ceres::Grid2D) ----
-__device__ __forceinline__ void pc_bilerp(const float2* __restrict__ flow, int H, int W, double r, double c,
-                                          double f[2], double dr[2], double dc[2])
+// The per-track arithmetic (evaluation, normal equations through the 2x2 Schur complement, dogleg step, the terms of the 13
+// sums) lives in psfm_pc_core.h; it is shared by the launch chain and the fused solve, so the two give the same bits.
+// P.jscale holds (S0^2, S1^2): the squared Jacobi scaling of columns 0, 1.
+__device__ __forceinline__ PcConst pc_const_load(double s, double2 js)
 {
-    double fr = floor(r), fc = floor(c);
-    fr = fr > -1.0e9 ? fr : -1.0e9; fr = fr < 1.0e9 ? fr : 1.0e9;   // also maps NaN to -1e9
-    fc = fc > -1.0e9 ? fc : -1.0e9; fc = fc < 1.0e9 ? fc : 1.0e9;
-    const int row = (int)fr, col = (int)fc;
-    const int r0 = min(max(row, 0), H - 1), r1 = min(max(row + 1, 0), H - 1);
-    const int c0 = min(max(col, 0), W - 1), c1 = min(max(col + 1, 0), W - 1);
-    const float2 p00 = flow[(int64_t)r0 * W + c0], p01 = flow[(int64_t)r0 * W + c1];
-    const float2 p10 = flow[(int64_t)r1 * W + c0], p11 = flow[(int64_t)r1 * W + c1];
-    const double tc = c - (double)col, tr = r - (double)row;
-    {
-        const double a00 = p00.x, a01 = p01.x, a10 = p10.x, a11 = p11.x;
-        const double f0 = (1.0 - tc) * a00 + tc * a01, f1 = (1.0 - tc) * a10 + tc * a11;
-        f[0] = (1.0 - tr) * f0 + tr * f1;
-        dr[0] = f1 - f0;
-        dc[0] = (1.0 - tr) * (a01 - a00) + tr * (a11 - a10);
-    }
-    {
-        const double a00 = p00.y, a01 = p01.y, a10 = p10.y, a11 = p11.y;
-        const double f0 = (1.0 - tc) * a00 + tc * a01, f1 = (1.0 - tc) * a10 + tc * a11;
-        f[1] = (1.0 - tr) * f0 + tr * f1;
-        dr[1] = f1 - f0;
-        dc[1] = (1.0 - tr) * (a01 - a00) + tr * (a11 - a10);
-    }
+    PcConst c;
+    c.s = s; c.S0q = js.x; c.S1q = js.y; c.H22 = fma(s, s, 1.0);
+    return c;
 }
-
-// residuals and the four non-trivial Jacobian entries (rows 4,5 wrt x1,y1), path_consistency_cost.h:50-57
-__device__ __forceinline__ void pc_eval(const float2* __restrict__ flow, int H, int W, const double x[4],
-                                        double2 ref1, double2 ref2, double s, double r[6], double jac[4])
-{
-    double f[2], dr[2], dc[2];
-    pc_bilerp(flow, H, W, x[1], x[0], f, dr, dc);
-    r[0] = x[0] - ref1.x;
-    r[1] = x[1] - ref1.y;
-    r[2] = (x[2] - ref2.x) * s;
-    r[3] = (x[3] - ref2.y) * s;
-    r[4] = (x[2] - x[0]) - f[0];
-    r[5] = (x[3] - x[1]) - f[1];
-    jac[0] = -1.0 - dc[0];
-    jac[1] = 0.0 - dr[0];
-    jac[2] = 0.0 - dc[1];
-    jac[3] = -1.0 - dr[1];
-}
-
-// The scaled sparse 6x4 Jacobian Js = J diag(S):  rows 0..3 = diag(a0,a1,a2,a3),
-// row 4 = (b0,b1,b2,0), row 5 = (c0,c1,0,c3).
-struct PcJac { double a0, a1, a2, a3, b0, b1, b2, c0, c1, c3; };
-
-__device__ __forceinline__ PcJac pc_scaled_jac(const double jac[4], double s, const double S[4])
-{
-    PcJac J;
-    J.a0 = 1.0 * S[0]; J.a1 = 1.0 * S[1]; J.a2 = s * S[2]; J.a3 = s * S[3];
-    J.b0 = jac[0] * S[0]; J.b1 = jac[1] * S[1]; J.b2 = 1.0 * S[2];
-    J.c0 = jac[2] * S[0]; J.c1 = jac[3] * S[1]; J.c3 = 1.0 * S[3];
-    return J;
-}
-
-// IEEE division a / b given y = 1.0 / b (itself a true division): q = RN(a y) is within 1.5 ulp of a/b, the residual
-// a - b q is exact in an fma, and RN(q + r y) is the correctly rounded quotient (Markstein's correction step; exact
-// for every one of 4e8 random and special-significand pairs against `/` on the host, and bit-identical trajectories
-// against the true-division CPU restatement on the whole-sequence parity runs).  Three full-rate instructions instead
-// of the ~11 of the IEEE expansion with its quarter-rate v_rcp_f64 -- each pivot divides several numerators.
-// (b == 0 / non-finite operands only occur in solves that are flagged as failed anyway.)
-__device__ __forceinline__ double pc_div(double a, double b, double y)
-{
-    const double q = a * y;
-    const double r = fma(-b, q, a);
-    return fma(r, y, q);
-}
-
-// Gauss-Newton system of one track: diag (and its reciprocals), scaled gradient ghat, scaled GN step gn; returns false
-// when the Cholesky factorisation of (Js^T Js + mu diag^2) breaks down.  Also the Cauchy-point term |Js (ghat/diag)|^2.
-// PRE: columns 2 and 3 of the scaled Jacobian are per-track constants (a2 = a3 = s S2, b2 = c3 = S2), hence so are
-// their squared norm, its clamped root, the reciprocal and -- at a fixed mu -- the diagonal entries of the normal
-// equations: pre = {n2, d2, 1/d2, A22}, computed once per solve by the same expressions (pc_gn_pre), bit for bit.
-struct PcGnPre { double n2, d2, yd2, A22; };
-__device__ __forceinline__ PcGnPre pc_gn_pre(double s, double S2, double mu)
-{
-    PcGnPre q;
-    const double a2 = s * S2, b2 = 1.0 * S2;
-    q.n2 = a2 * a2 + b2 * b2;
-    const double cn = fmin(fmax(q.n2, 1e-6), 1e32);
-    q.d2 = sqrt(cn);
-    q.yd2 = 1.0 / q.d2;
-    const double D = q.d2 * sqrt(mu);
-    q.A22 = q.n2 + D * D;
-    return q;
-}
-
-template <bool PRE>
-__device__ __forceinline__ bool pc_gn_system_t(const PcJac& J, const double r[6], double mu, double d[4], double yd[4],
-                                               double gh[4], double gn[4], double* jg2, const PcGnPre& pre)
-{
-    const double n0 = (J.a0 * J.a0 + J.b0 * J.b0) + J.c0 * J.c0;
-    const double n1 = (J.a1 * J.a1 + J.b1 * J.b1) + J.c1 * J.c1;
-    const double n2 = PRE ? pre.n2 : J.a2 * J.a2 + J.b2 * J.b2;
-    const double n3 = PRE ? pre.n2 : J.a3 * J.a3 + J.c3 * J.c3;
-    const double q[4] = {(J.a0 * r[0] + J.b0 * r[4]) + J.c0 * r[5], (J.a1 * r[1] + J.b1 * r[4]) + J.c1 * r[5],
-                         J.a2 * r[2] + J.b2 * r[4], J.a3 * r[3] + J.c3 * r[5]};
-    const double nn[4] = {n0, n1, n2, n3};
-    double sg[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (PRE && c >= 2) { d[c] = pre.d2; yd[c] = pre.yd2; }
-        else {
-            const double cn = fmin(fmax(nn[c], 1e-6), 1e32);   // min/max_lm_diagonal
-            d[c] = sqrt(cn);
-            yd[c] = 1.0 / d[c];
-        }
-        gh[c] = pc_div(q[c], d[c], yd[c]);
-        sg[c] = pc_div(gh[c], d[c], yd[c]);
-    }
-    {
-        const double m0 = J.a0 * sg[0], m1 = J.a1 * sg[1], m2 = J.a2 * sg[2], m3 = J.a3 * sg[3];
-        const double m4 = (J.b0 * sg[0] + J.b1 * sg[1]) + J.b2 * sg[2];
-        const double m5 = (J.c0 * sg[0] + J.c1 * sg[1]) + J.c3 * sg[3];
-        *jg2 = ((((m0 * m0 + m1 * m1) + m2 * m2) + m3 * m3) + m4 * m4) + m5 * m5;
-    }
-    // normal equations (lower triangle) + mu * diag^2, dense 4x4 Cholesky
-    const double smu = sqrt(mu);
-    double A[4][4];
-    double D;
-    D = d[0] * smu; A[0][0] = n0 + D * D;
-    D = d[1] * smu; A[1][1] = n1 + D * D;
-    if (PRE) { A[2][2] = pre.A22; A[3][3] = pre.A22; }
-    else {
-        D = d[2] * smu; A[2][2] = n2 + D * D;
-        D = d[3] * smu; A[3][3] = n3 + D * D;
-    }
-    A[1][0] = J.b0 * J.b1 + J.c0 * J.c1;
-    A[2][0] = J.b0 * J.b2;
-    A[2][1] = J.b1 * J.b2;
-    A[3][0] = J.c0 * J.c3;
-    A[3][1] = J.c1 * J.c3;
-    A[3][2] = 0.0;
-    double L[4][4], yL[4];
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double sum = A[i][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) sum -= L[i][k] * L[j][k];
-            if (i == j) {
-                ok = ok && (sum > 0.0);
-                L[i][i] = sqrt(sum);
-                yL[i] = 1.0 / L[i][i];
-            } else {
-                L[i][j] = pc_div(sum, L[j][j], yL[j]);
-            }
-        }
-    }
-    double z[4], y[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        double sum = q[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) sum -= L[i][k] * z[k];
-        z[i] = pc_div(sum, L[i][i], yL[i]);
-    }
-#pragma unroll
-    for (int i = 3; i >= 0; --i) {
-        double sum = z[i];
-#pragma unroll
-        for (int k = i + 1; k < 4; ++k) sum -= L[k][i] * y[k];
-        y[i] = pc_div(sum, L[i][i], yL[i]);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        ok = ok && (y[c] == y[c]) && (fabs(y[c]) <= 1.7e308);
-        gn[c] = y[c] * (-d[c]);   // gauss_newton_step *= -diagonal
-    }
-    return ok;
-}
-
-__device__ __forceinline__ bool pc_gn_system(const PcJac& J, const double r[6], double mu, double d[4], double yd[4],
-                                             double gh[4], double gn[4], double* jg2)
-{
-    const PcGnPre none = {0.0, 0.0, 0.0, 0.0};
-    return pc_gn_system_t<false>(J, r, mu, d, yd, gh, gn, jg2, none);
-}
-
-// sums slots
-enum { SUM_MCC = 0, SUM_COST = 1, SUM_STEP2 = 2, SUM_DL2 = 3, SUM_XN2 = 4, SUM_GMAX = 5, SUM_G2 = 6, SUM_JG2 = 7,
-       SUM_GN2 = 8, SUM_DOT = 9, SUM_FAIL = 10, SUM_CNT = 11, SUM_COST0 = 12 };
 
 __device__ __forceinline__ double pc_wave_sum(double v)
 {
@@ -359,72 +193,11 @@ __device__ __forceinline__ bool pc_participates(const PcParams& P, int i, int n)
     return bf >= 0 && bf <= P.max_birth;
 }
 
-// One trust-region iteration for one track at its current iterate x: everything Ceres evaluates at x (cost terms,
-// gradient max-norm, |x|^2, the Gauss-Newton system and its global sums) plus the step (a * ghat + b * gn) / diag,
-// the model decrease, the candidate and the candidate's cost.  Writes the candidate; returns nothing else.
-__device__ __forceinline__ void pc_track_iteration(const PcParams& P, const double x[4], double2 r1, double2 r2, double s,
-                                                   const double S[4], double mu, double a, double b, double2* xn1,
-                                                   double2* xn2, int i, double acc[PC_NSUM], double* cost_at_x)
-{
-    double r[6], jac[4];
-    pc_eval(P.flow12, P.H, P.W, x, r1, r2, s, r, jac);
-    if (cost_at_x) {
-        double ss = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ss += r[k] * r[k];
-        *cost_at_x = 0.5 * ss;
-    }
-    // |x - Plus(x,-g)|_inf with g = J^T r unscaled (trust_region_minimizer.cc EvaluateGradientAndJacobian)
-    const double g[4] = {(r[0] + jac[0] * r[4]) + jac[2] * r[5], (r[1] + jac[1] * r[4]) + jac[3] * r[5],
-                         s * r[2] + r[4], s * r[3] + r[5]};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        acc[SUM_GMAX] = fmax(acc[SUM_GMAX], fabs(x[k] - (x[k] + (-g[k]))));
-        acc[SUM_XN2] += x[k] * x[k];
-    }
-    const PcJac J = pc_scaled_jac(jac, s, S);
-    double d[4], yd[4], gh[4], gn[4], jg2;
-    const bool ok = pc_gn_system(J, r, mu, d, yd, gh, gn, &jg2);
-    acc[SUM_JG2] += jg2;
-    if (!ok) acc[SUM_FAIL] += 1.0;
-    // dogleg step in the scaled space, then /diag (ComputeTraditionalDoglegStep)
-    double st[4], xp[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        acc[SUM_G2] += gh[k] * gh[k];
-        acc[SUM_GN2] += gn[k] * gn[k];
-        acc[SUM_DOT] += gh[k] * gn[k];
-        const double v = a * gh[k] + b * gn[k];
-        acc[SUM_DL2] += v * v;
-        st[k] = pc_div(v, d[k], yd[k]);
-    }
-    // model_cost_change = -(J step)'(r + J step / 2)
-    {
-        const double m0 = J.a0 * st[0], m1 = J.a1 * st[1], m2 = J.a2 * st[2], m3 = J.a3 * st[3];
-        const double m4 = (J.b0 * st[0] + J.b1 * st[1]) + J.b2 * st[2];
-        const double m5 = (J.c0 * st[0] + J.c1 * st[1]) + J.c3 * st[3];
-        acc[SUM_MCC] += ((((m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0)) + m2 * (r[2] + m2 / 2.0)) +
-                          m3 * (r[3] + m3 / 2.0)) + m4 * (r[4] + m4 / 2.0)) + m5 * (r[5] + m5 / 2.0);
-    }
-    // candidate = x + step .* jacobi_scaling
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        xp[k] = x[k] + st[k] * S[k];
-        const double dd = x[k] - xp[k];
-        acc[SUM_STEP2] += dd * dd;
-    }
-    xn1[i] = make_double2(xp[0], xp[1]);
-    xn2[i] = make_double2(xp[2], xp[3]);
-    // cost at the candidate (residuals only)
-    {
-        double f[2], dr[2], dc[2];
-        pc_bilerp(P.flow12, P.H, P.W, xp[1], xp[0], f, dr, dc);
-        const double q0 = xp[0] - r1.x, q1 = xp[1] - r1.y;
-        const double q2 = (xp[2] - r2.x) * s, q3 = (xp[3] - r2.y) * s;
-        const double q4 = (xp[2] - xp[0]) - f[0], q5 = (xp[3] - xp[1]) - f[1];
-        acc[SUM_COST] += 0.5 * (((((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3) + q4 * q4) + q5 * q5);
-    }
-}
+// Rows of the launch chain's sums (13 per launch, like the fused solve's, so that the track-sharded exchange is the same):
+// the sums AT an iterate keep their fused-solve slots (SUM_XN2, SUM_GMAX, SUM_G2, SUM_JG2, SUM_GN2, SUM_DOT, SUM_FAIL); the
+// slots of the per-track step sums carry (J u).(J d) and |J d|^2 instead; SUM_COST / SUM_STEP2 belong to the candidate;
+// SUM_CNT / SUM_COST0 to pc_init.
+enum { CH_QUD = SUM_MCC, CH_QDD = SUM_DL2 };
 
 // (force-inlined: as a called function it dragged the call ABI's register budget into the kernels -- 248 VGPRs,
 // 2 waves/SIMD -- although the per-track code needs 152)
@@ -485,19 +258,14 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
         const double2 p1 = P.x1a[i], p2 = P.x2a[i];
         const double x[4] = {p1.x, p1.y, p2.x, p2.y};
         // Jacobi scaling 1/(1+sqrt(colnorm^2)) from the Jacobian at x0, computed once (trust_region_minimizer.cc)
-        double f[2], dr[2], dc[2];
-        pc_bilerp(P.flow12, P.H, P.W, x[1], x[0], f, dr, dc);
-        const double j0 = -1.0 - dc[0], j1 = 0.0 - dr[0], j2 = 0.0 - dc[1], j3 = -1.0 - dr[1];
-        const double c0 = (1.0 + j0 * j0) + j2 * j2;
-        const double c1 = (1.0 + j1 * j1) + j3 * j3;
-        const double c2 = s * s + 1.0;
-        const double S2 = 1.0 / (1.0 + sqrt(c2));
-        const double S[4] = {1.0 / (1.0 + sqrt(c0)), 1.0 / (1.0 + sqrt(c1)), S2, S2};
-        P.jscale[i] = make_double2(S[0], S[1]);
+        double r0[6], j0[4];
+        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r0, j0);
+        const PcConst c = pc_core_const(s, j0);
+        P.jscale[i] = make_double2(c.S0q, c.S1q);
         acc[SUM_CNT] += 1.0;
-        double c_at_x;
-        pc_track_iteration(P, x, r1, r2, s, S, mu, 0.0, 1.0, pc_buf1(P, 1), pc_buf2(P, 1), i, acc, &c_at_x);   // iteration 1, speculated
-        acc[SUM_COST0] += c_at_x;
+        acc[SUM_COST0] += pc_core_cost(r0);
+        PcSys y;
+        pc_core_system<true>(x, r0, j0, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
     }
     pc_block_reduce(acc, P.partials);
     if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1, P.export_sums);
@@ -534,7 +302,9 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
     const double2* xc2 = pc_buf2(P, C.cur);
     double2* xn1 = pc_buf1(P, pc_other(C.cur));
     double2* xn2 = pc_buf2(P, pc_other(C.cur));
-    const double a = C.dl_fixed ? C.dl_a : 0.0, b = C.dl_fixed ? C.dl_b : 1.0;
+    const double a = C.dl_a, b = C.dl_b;
+    const bool refresh = C.kind_next != 0;
+    const double mu_next = fmax(1e-8, 2.0 * C.mu / 10.0);      // DoglegStrategy::StepAccepted: the mu of the system at the candidate
     double acc[PC_NSUM];
 #pragma unroll
     for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
@@ -542,12 +312,27 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
         if (!pc_participates(P, i, n)) continue;
         const double2 r1 = P.ref1[i], r2 = P.ref2[i];
         const double s = P.scale[i];
-        const double2 js = P.jscale[i];
-        const double S2 = 1.0 / (1.0 + sqrt(s * s + 1.0));
-        const double S[4] = {js.x, js.y, S2, S2};
+        const PcConst c = pc_const_load(s, P.jscale[i]);
         const double2 p1 = xc1[i], p2 = xc2[i];
         const double x[4] = {p1.x, p1.y, p2.x, p2.y};
-        pc_track_iteration(P, x, r1, r2, s, S, C.mu, a, b, xn1, xn2, i, acc, nullptr);
+        double r[6], jac[4];
+        PcSys y;
+        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
+        if (refresh) {      // the system at x for the mu an invalid step has raised
+            pc_core_system<true>(x, r, jac, c, C.mu, pc_core_iA22(c, C.mu), acc, y, CH_QUD, CH_QDD);
+            continue;
+        }
+        double unused[PC_NSUM], xp[4];      // (the sums at x are in the control block already)
+#pragma unroll
+        for (int k = 0; k < PC_NSUM; ++k) unused[k] = 0.0;
+        pc_core_system<false>(x, r, jac, c, C.mu, pc_core_iA22(c, C.mu), unused, y, 0, 0);
+        pc_core_step<false, false>(x, r, jac, c, y, a, b, acc, xp);
+        xn1[i] = make_double2(xp[0], xp[1]);
+        xn2[i] = make_double2(xp[2], xp[3]);
+        // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
+        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, xp, r1.x, r1.y, r2.x, r2.y, s, r, jac);
+        acc[SUM_COST] += pc_core_cost(r);
+        pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
     }
     PC_TL(1);
     pc_block_reduce(acc, P.partials);
@@ -680,6 +465,127 @@ __device__ __forceinline__ void pc_control_step(PsfmSolveCtrl& C, const double* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The launch chain's control step.  Same decisions, in the same order, as pc_control_step (which replays the fused
+// solve's rows); what differs is where the numbers come from: the sums AT the current iterate sit in the control block
+// (adopted when that iterate was accepted -- the launch that evaluated it as a candidate reduced them ahead of the
+// decision), every dogleg step of the iterate is priced from them, and a launch only contributes the candidate's cost
+// and step length.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pc_chain_adopt(PsfmSolveCtrl& C, const double* tot)
+{
+    C.x_norm = sqrt(tot[SUM_XN2]);
+    C.gmax = tot[SUM_GMAX];
+    C.g2 = tot[SUM_G2]; C.jg2 = tot[SUM_JG2]; C.gn2 = tot[SUM_GN2]; C.dot = tot[SUM_DOT];
+    C.qud = tot[CH_QUD]; C.qdd = tot[CH_QDD];
+}
+
+// The step pc_choose_dogleg has just fixed: its norm and model cost change from the sums at x; an invalid step
+// (TrustRegionMinimizer::HandleInvalidStep + DoglegStrategy::StepIsInvalid) is an iteration of its own that raises mu --
+// the system at x has to be reduced again before the next step can be chosen.
+__device__ __forceinline__ void pc_chain_price(PsfmSolveCtrl& C)
+{
+    const double min_radius = 1e-32, mu_increase = 10.0;
+    const int max_iter = 200, max_invalid = 5;
+    const double a = C.dl_a, b = C.dl_b;
+    if (C.dl_norm < 0.0) C.dl_norm = sqrt((a * a * C.g2 + 2.0 * a * b * C.dot) + b * b * C.gn2);
+    C.mcc = -((a * C.g2 + b * C.dot) + 0.5 * ((a * a * C.jg2 + 2.0 * a * b * C.qud) + b * b * C.qdd));
+    C.kind_next = 0;
+    if (!(C.mcc > 0.0)) {
+        C.iteration += 1;
+        if (C.dl_case != 1) C.nonGN += 1;
+        if (++C.n_invalid >= max_invalid) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; }
+        C.mu *= mu_increase;
+        C.kind_next = 1;
+        if (!C.done) {
+            if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
+            else if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
+        }
+    }
+}
+
+// kind 0: behind pc_init; 1: behind pc_iter (which did what C.kind_next said)
+__device__ __forceinline__ void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
+{
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    const double min_relative_decrease = 1e-3, min_radius = 1e-32;
+    const double min_mu = 1e-8, mu_increase = 10.0;
+    const int max_iter = 200;
+    if (kind == 0) {
+        memset(&C, 0, sizeof(C));
+        C.radius = 1e4; C.mu = min_mu;
+        C.n_tracks = (int)tot[SUM_CNT];
+        C.x_cost = tot[SUM_COST0]; C.initial_cost = C.x_cost;
+        C.termination = PSFM_TERM_MAX_ITER;
+        if (C.n_tracks == 0) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; return; }
+        if (tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; return; }
+        pc_chain_adopt(C, tot);
+        if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; return; }   // iteration 0
+        pc_choose_dogleg(C);
+        pc_chain_price(C);
+        return;
+    }
+    if (C.done) return;
+    if (C.kind_next != 0) {     // the system at x for the raised mu
+        if (tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; return; }
+        pc_chain_adopt(C, tot);
+        pc_choose_dogleg(C);
+        pc_chain_price(C);
+        return;
+    }
+    // ---- the candidate of (dl_a, dl_b) has been evaluated ----
+    bool rejected = false, accepted = false;
+    C.iteration += 1;
+    if (C.dl_case != 1) C.nonGN += 1;
+    C.n_invalid = 0;
+    const double cand = tot[SUM_COST];
+    const double step_norm = sqrt(tot[SUM_STEP2]);
+    if (step_norm <= parameter_tolerance * (C.x_norm + parameter_tolerance)) {
+        C.done = 1; C.termination = PSFM_TERM_PARAMETER_TOL;
+    } else if (fabs(C.x_cost - cand) <= function_tolerance * C.x_cost) {
+        C.done = 1; C.termination = PSFM_TERM_FUNCTION_TOL;
+    } else {
+        const double rho = (C.x_cost - cand) / C.mcc;
+        if (rho > min_relative_decrease) {
+            // HandleSuccessfulStep + DoglegStrategy::StepAccepted
+            C.cur = pc_other(C.cur);
+            C.x_cost = cand;
+            C.successful += 1;
+            if (rho < 0.25) C.radius *= 0.5;
+            if (rho > 0.75) C.radius = fmax(C.radius, 3.0 * C.dl_norm);
+            C.mu = fmax(min_mu, 2.0 * C.mu / mu_increase);
+            accepted = true;
+        } else {
+            rejected = true;
+        }
+    }
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (!C.done) {
+        if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
+        else if (!rejected && C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; }
+    }
+    if (accepted && !C.done) {
+        // the launch reduced the system at the candidate with the mu that is in force now: it is the current iterate's
+        if (tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; return; }
+        pc_chain_adopt(C, tot);
+        if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; return; }
+        pc_choose_dogleg(C);
+        pc_chain_price(C);
+        return;
+    }
+    // StepRejected: radius /= 2 and the SAME Gauss-Newton system.  While the shrunken region still contains the
+    // Gauss-Newton step the dogleg returns the same step, hence the same candidate and the same rejection: those
+    // iterations are counted here; the first radius that prescribes another step goes to the next launch.
+    while (rejected && !C.done) {
+        C.radius *= 0.5;
+        if (C.radius <= min_radius) { C.done = 1; C.termination = PSFM_TERM_MIN_RADIUS; break; }
+        pc_choose_dogleg(C);
+        if (C.dl_case != 1) { pc_chain_price(C); break; }
+        C.iteration += 1;   // identical step, identical rho: rejected again
+        if (C.iteration >= max_iter) { C.done = 1; C.termination = PSFM_TERM_MAX_ITER; }
+    }
+}
+
 // Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket after an agent-scope
 // release; the reading block acquires before touching the other blocks' partials -- cdna_hip_programming.md G16):
 // fixed-order reduction of the per-block partials, then the scalar control step on thread 0.
@@ -726,7 +632,7 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
     }
     if (threadIdx.x != 0) return;
     PsfmSolveCtrl C = *ctrl;
-    pc_control_step(C, s_tot, is_init, is_init ? 1 : pc_other(C.cur));   // (init: the candidate of iteration 1 is in buffer 1)
+    pc_chain_control(C, s_tot, is_init ? 0 : 1);
     C.launches += 1;
     *ctrl = C;
 }
@@ -799,62 +705,25 @@ __device__ __forceinline__ void pc_fused_replay(const PcParams& P, const double*
 struct PcTrack {            // one track's solve state in registers
     double x[4], r[6], jac[4];
     double2 r1, r2;
-    double s, S0, S1, S2;
-    PcGnPre pre;
+    PcConst c;
+    double iA22;            // 1 / (H22 (1 + mu)) at the mu the fused solve speculates
 };
 
 // sums of one trust-region iteration at T.x (already evaluated: T.r, T.jac) into v[]; the candidate goes to (xn1, xn2)[i]
-// and becomes T.x, evaluated.  Same arithmetic, operation for operation, as pc_track_iteration with (a, b) = (0, 1).
+// and becomes T.x, evaluated.  The same function as the launch chain's iteration, with (a, b) = (0, 1) at compile time.
 __device__ __forceinline__ void pc_fused_iteration(const PcParams& P, PcTrack& T, double mu, double2* xn1, double2* xn2, int i,
                                                    double v[PC_NSUM])
 {
-    const double* x = T.x; const double* r = T.r; const double* jac = T.jac;
-    const double s = T.s;
-    const double S[4] = {T.S0, T.S1, T.S2, T.S2};
-    const double g[4] = {(r[0] + jac[0] * r[4]) + jac[2] * r[5], (r[1] + jac[1] * r[4]) + jac[3] * r[5],
-                         s * r[2] + r[4], s * r[3] + r[5]};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        v[SUM_GMAX] = fmax(v[SUM_GMAX], fabs(x[k] - (x[k] + (-g[k]))));
-        v[SUM_XN2] += x[k] * x[k];
-    }
-    const PcJac J = pc_scaled_jac(jac, s, S);
-    double d[4], yd[4], gh[4], gn[4], jg2;
-    const bool ok = pc_gn_system_t<true>(J, r, mu, d, yd, gh, gn, &jg2, T.pre);
-    v[SUM_JG2] += jg2;
-    if (!ok) v[SUM_FAIL] += 1.0;
-    double st[4], xp[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        v[SUM_G2] += gh[k] * gh[k];
-        v[SUM_GN2] += gn[k] * gn[k];
-        v[SUM_DOT] += gh[k] * gn[k];
-        const double w = 0.0 * gh[k] + 1.0 * gn[k];
-        v[SUM_DL2] += w * w;
-        st[k] = pc_div(w, d[k], yd[k]);
-    }
-    {
-        const double m0 = J.a0 * st[0], m1 = J.a1 * st[1], m2 = J.a2 * st[2], m3 = J.a3 * st[3];
-        const double m4 = (J.b0 * st[0] + J.b1 * st[1]) + J.b2 * st[2];
-        const double m5 = (J.c0 * st[0] + J.c1 * st[1]) + J.c3 * st[3];
-        v[SUM_MCC] += ((((m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0)) + m2 * (r[2] + m2 / 2.0)) +
-                        m3 * (r[3] + m3 / 2.0)) + m4 * (r[4] + m4 / 2.0)) + m5 * (r[5] + m5 / 2.0);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        xp[k] = x[k] + st[k] * S[k];
-        const double dd = x[k] - xp[k];
-        v[SUM_STEP2] += dd * dd;
-    }
+    double xp[4];
+    pc_core_iteration<true>(T.x, T.r, T.jac, T.c, mu, T.iA22, 0.0, 1.0, v, xp);
     if (xn1) {
         xn1[i] = make_double2(xp[0], xp[1]);
         xn2[i] = make_double2(xp[2], xp[3]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) T.x[k] = xp[k];
-    pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, s, T.r, T.jac);
-    v[SUM_COST] += 0.5 * (((((T.r[0] * T.r[0] + T.r[1] * T.r[1]) + T.r[2] * T.r[2]) + T.r[3] * T.r[3]) + T.r[4] * T.r[4]) +
-                          T.r[5] * T.r[5]);
+    pc_core_eval((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
+    v[SUM_COST] += pc_core_cost(T.r);
 }
 
 // Sums of one iteration over the 64 tracks of a WAVE, through LDS, without a block barrier (the four waves of a block
@@ -876,21 +745,25 @@ __device__ __forceinline__ void pc_wave_reduce(PcWaveRed& R, const double v[PC_N
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (the max slot on its own branch: one select per addition otherwise -- 4 instructions per step instead of 1)
     const int k = lane >> 2, q = lane & 3;
-    if (k < PC_NSUM) {
+    if (k < PC_NSUM && k != SUM_GMAX) {
         double t = R.park[w][k][q];
 #pragma unroll
-        for (int j = 1; j < 16; ++j) t = (k == SUM_GMAX) ? fmax(t, R.park[w][k][4 * j + q]) : t + R.park[w][k][4 * j + q];
+        for (int j = 1; j < 16; ++j) t += R.park[w][k][4 * j + q];
         R.quarter[w][k][q] = t;
+    } else if (k == SUM_GMAX) {
+        double t = R.park[w][SUM_GMAX][q];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t = fmax(t, R.park[w][SUM_GMAX][4 * j + q]);
+        R.quarter[w][SUM_GMAX][q] = t;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < PC_NSUM) {
-        double t = R.quarter[w][lane][0];
-#pragma unroll
-        for (int j = 1; j < 4; ++j) t = (lane == SUM_GMAX) ? fmax(t, R.quarter[w][lane][j]) : t + R.quarter[w][lane][j];
-        R.wsum[w][iter][lane] = t;
+        const double q0 = R.quarter[w][lane][0], q1 = R.quarter[w][lane][1], q2 = R.quarter[w][lane][2], q3 = R.quarter[w][lane][3];
+        R.wsum[w][iter][lane] = (lane == SUM_GMAX) ? fmax(fmax(fmax(q0, q1), q2), q3) : ((q0 + q1) + q2) + q3;
     }
     // (the next iteration's park stores come behind these loads in the wave's LDS queue)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -931,21 +804,14 @@ __device__ __forceinline__ double pc_track_setup(const PcParams& P, PcTrack& T, 
     const float o02 = psfm_sample_mask(P.occ02, k, t);
     const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
     const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
-    T.s = (double)sf;
     T.r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
     T.r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
     T.x[0] = p1.x; T.x[1] = p1.y; T.x[2] = p2.x; T.x[3] = p2.y;
-    pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, T.s, T.r, T.jac);
-    // Jacobi scaling from the Jacobian at x0 (jac[] holds exactly the entries psfm_pc_init_kernel rebuilds)
-    const double q0 = (1.0 + T.jac[0] * T.jac[0]) + T.jac[2] * T.jac[2];
-    const double q1 = (1.0 + T.jac[1] * T.jac[1]) + T.jac[3] * T.jac[3];
-    const double q2 = T.s * T.s + 1.0;
-    T.S0 = 1.0 / (1.0 + sqrt(q0)); T.S1 = 1.0 / (1.0 + sqrt(q1)); T.S2 = 1.0 / (1.0 + sqrt(q2));
-    T.pre = pc_gn_pre(T.s, T.S2, mu);
-    double ss = 0.0;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) ss += T.r[q] * T.r[q];
-    return 0.5 * ss;
+    pc_core_eval((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, (double)sf, T.r, T.jac);
+    // Jacobi scaling from the Jacobian at x0 (what psfm_pc_init_kernel stores in P.jscale)
+    T.c = pc_core_const((double)sf, T.jac);
+    T.iA22 = pc_core_iA22(T.c, mu);
+    return pc_core_cost(T.r);
 }
 
 // The block's sums of n_it iterations (the waves' sums, in wave order) -> its partial row; then the two tickets: the
@@ -1090,7 +956,7 @@ __device__ __forceinline__ void pc_more_body(const PcParams& P, int n_active, Ps
         (void)pc_track_setup(P, T, p0, s1, s2, mu);
         const double2 c1 = pc_buf1(P, pc_phys(base, e))[i], c2 = pc_buf2(P, pc_phys(base, e))[i];  // the current iterate
         T.x[0] = c1.x; T.x[1] = c1.y; T.x[2] = c2.x; T.x[3] = c2.y;
-        pc_eval(P.flow12, P.H, P.W, T.x, T.r1, T.r2, T.s, T.r, T.jac);
+        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
     }
     for (int j = 0; j < n_it; ++j) {
         double v[PC_NSUM];
@@ -1163,8 +1029,8 @@ __host__ __device__ inline void pc_params_rebase(PcParams& P, const PsfmSeqStrid
 // launch_id: a block that is dispatched after the control thread has moved the counter on (only blocks beyond the lane
 // snapshot can be) sees pc_owner != launch_id and leaves.
 // ------------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+template <int R, int WAVES>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void psfm_seq_kernel(PsfmChainArgs a, PcParams P, PsfmSeqStride st, int64_t occ2_stride, int n_flows, int launch_id)
 {
     PsfmCounters* ctr = a.ctr;
@@ -1199,7 +1065,7 @@ __global__ void psfm_pc_control_kernel(PcParams P, const double* totals, int K, 
     }
     PsfmSolveCtrl C = *P.ctrl;
     if (mode == 2 && C.done) return;
-    pc_control_step(C, totals, mode == 1, mode == 1 ? 1 : pc_other(C.cur));
+    pc_chain_control(C, totals, mode == 1 ? 0 : 1);
     C.launches += 1;
     *P.ctrl = C;
 }
@@ -1281,8 +1147,11 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_load_rows_kernel(const doubl
 // ------------------------------------------------------------------------------------------------
 static int pc_blocks(int n_rows_upper)
 {
+    // grid of the launch chain's grid-stride kernels; PSFM_PC_BLOCKS (<= PC_MAX_BLOCKS) overrides for measurements
+    static const int limit_env = getenv("PSFM_PC_BLOCKS") ? atoi(getenv("PSFM_PC_BLOCKS")) : 0;
+    const int limit = limit_env >= 1 && limit_env <= PC_MAX_BLOCKS ? limit_env : PC_CHAIN_BLOCKS;
     int n_blocks = (n_rows_upper + PC_BLOCK - 1) / PC_BLOCK;
-    if (n_blocks > PC_MAX_BLOCKS) n_blocks = PC_MAX_BLOCKS;
+    if (n_blocks > limit) n_blocks = limit;
     return n_blocks < 1 ? 1 : n_blocks;
 }
 
@@ -1631,16 +1500,30 @@ psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* fl
         }
     }
     const dim3 grid((unsigned)n_blocks), block(PC_BLOCK);
+    // waves per SIMD of the frame kernel: 3 (<= 168 VGPRs; leaves the register file room for the background flow_check's
+    // block beside it) or 4 (<= 128 VGPRs: the solver core fits since round 3); PSFM_SEQ_WAVES overrides for measurements
+    static const int seq_waves = getenv("PSFM_SEQ_WAVES") ? atoi(getenv("PSFM_SEQ_WAVES")) : PSFM_SEQ_WAVES_DEFAULT;
     for (int k = 0; k < n_launches; ++k) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         c->prof.kernel_span(PSFM_PROF_SOLVER, &e0, &e1, true);
         const int id = launch_id0 + k;
-        switch (d.ratio) {
-            case 1: hipExtLaunchKernelGGL(psfm_seq_kernel<1>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
-            case 2: hipExtLaunchKernelGGL(psfm_seq_kernel<2>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
-            case 4: hipExtLaunchKernelGGL(psfm_seq_kernel<4>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
-            default: hipExtLaunchKernelGGL(psfm_seq_kernel<0>, grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id); break;
+#define PSFM_SEQ_LAUNCH(R_, W_) hipExtLaunchKernelGGL((psfm_seq_kernel<R_, W_>), grid, block, 0, s, e0, e1, 0, a, P, st, Pix, d.n_flows, id)
+        if (seq_waves == 4) {
+            switch (d.ratio) {
+                case 1: PSFM_SEQ_LAUNCH(1, 4); break;
+                case 2: PSFM_SEQ_LAUNCH(2, 4); break;
+                case 4: PSFM_SEQ_LAUNCH(4, 4); break;
+                default: PSFM_SEQ_LAUNCH(0, 4); break;
+            }
+        } else {
+            switch (d.ratio) {
+                case 1: PSFM_SEQ_LAUNCH(1, 3); break;
+                case 2: PSFM_SEQ_LAUNCH(2, 3); break;
+                case 4: PSFM_SEQ_LAUNCH(4, 3); break;
+                default: PSFM_SEQ_LAUNCH(0, 3); break;
+            }
         }
+#undef PSFM_SEQ_LAUNCH
     }
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;

@@ -17,9 +17,12 @@ from point_trajectory import _hip
 from point_trajectory.trajectory import run_connect
 
 H, W, T, r = (int(x) for x in sys.argv[1:5]) if len(sys.argv) >= 5 else (1080, 1920, 101, 2)
-d = psfm_synth.synth_sequence_torch(T, H, W, seed=5, sigma=0.05, n_occluders=2, stride2=True, device="cuda")
+# PSFM_PROBE_HARD=1: SURVEY 8(d)'s second distribution (sigma 0.3, 5 % occluder area) -- every solve goes through the launch chain
+dist = psfm_synth.HARD if os.environ.get("PSFM_PROBE_HARD") else dict(sigma=0.05, n_occluders=2)
+d = psfm_synth.synth_sequence_torch(T, H, W, seed=6 if os.environ.get("PSFM_PROBE_HARD") else 5, stride2=True, device="cuda", **dist)
 ctx = _hip.context()
-out = {"shape": [H, W, T, r], "fused_waves": os.environ.get("PSFM_FUSED_WAVES", "3")}
+out = {"shape": [H, W, T, r], "fused_waves": os.environ.get("PSFM_FUSED_WAVES", "3"), "seq_waves": os.environ.get("PSFM_SEQ_WAVES", "default"),
+       "pc_blocks": os.environ.get("PSFM_PC_BLOCKS", "default"), "flows": dict(dist)}
 MODES = {"chain": (1, 0), "fused": (2, 0), "adaptive": (0, 0), "fused_k4": (2, 4), "fused_k2": (2, 2), "fused_k5": (2, 5)}
 names = os.environ.get("PSFM_PROBE_MODES", "chain,fused,adaptive,fused_k4").split(",")
 for name, mode, k in [(n, *MODES[n]) for n in names]:
@@ -41,6 +44,7 @@ for name, mode, k in [(n, *MODES[n]) for n in names]:
     ctx.set_profiling(0)
     out[name] = {"ms_per_sequence": ms, "points": int(info.n_points), "iters": int(info.solver_iterations),
                  "solves": int(info.n_solves), "counters": ctx.solver_counters(),
-                 "solver_ms_per_seq": pr["solver"]["total_ms"] / n, "chain_ms_per_seq": pr["chain_step"]["total_ms"] / n}
+                 "solver_ms_per_seq": pr["solver"]["total_ms"] / n, "solver_launches_per_seq": pr["solver"]["launches"] / n,
+                 "chain_ms_per_seq": pr["chain_step"]["total_ms"] / n}
 ctx.set_solver(0, 0)
 print(json.dumps(out))

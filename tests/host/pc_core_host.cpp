@@ -1,0 +1,43 @@
+// Host build of particle-sfm_amd/csrc/psfm_pc_core.h for tests/test_pc_core_host.py: one trust-region iteration of a batch
+// of tracks, sums added in track order.  Test infrastructure (compiled by the test with g++ -O2 -mfma).
+#include "psfm_pc_core.h"
+
+extern "C" void pc_host_iteration(long n, const double* x0, const double* x, const double* ref1, const double* ref2,
+                                  const double* scale, const float* flow, int H, int W, double mu, double a, double b, int gn,
+                                  double* sums, double* xp_out, double* cost_at_x)
+{
+    for (int k = 0; k < PC_NSUM; ++k) sums[k] = 0.0;
+    const PcF2* F = (const PcF2*)flow;
+    for (long i = 0; i < n; ++i) {
+        double r[6], j[4], xp[4];
+        const double s = scale[i];
+        pc_core_eval(F, H, W, x0 + 4 * i, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+        const PcConst c = pc_core_const(s, j);
+        pc_core_eval(F, H, W, x + 4 * i, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+        cost_at_x[i] = pc_core_cost(r);
+        const double iA22 = pc_core_iA22(c, mu);
+        if (gn) pc_core_iteration<true>(x + 4 * i, r, j, c, mu, iA22, 0.0, 1.0, sums, xp);
+        else pc_core_iteration<false>(x + 4 * i, r, j, c, mu, iA22, a, b, sums, xp);
+        pc_core_eval(F, H, W, xp, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+        sums[SUM_COST] += pc_core_cost(r);
+        sums[SUM_CNT] += 1.0;
+        for (int k = 0; k < 4; ++k) xp_out[4 * i + k] = xp[k];
+    }
+}
+
+// the sums at x with the two extra ones (slots 0 and 3) the launch chain's control step prices dogleg steps with
+extern "C" void pc_host_system(long n, const double* x0, const double* x, const double* ref1, const double* ref2,
+                               const double* scale, const float* flow, int H, int W, double mu, double* sums)
+{
+    for (int k = 0; k < PC_NSUM; ++k) sums[k] = 0.0;
+    const PcF2* F = (const PcF2*)flow;
+    for (long i = 0; i < n; ++i) {
+        double r[6], j[4];
+        const double s = scale[i];
+        pc_core_eval(F, H, W, x0 + 4 * i, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+        const PcConst c = pc_core_const(s, j);
+        pc_core_eval(F, H, W, x + 4 * i, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+        PcSys y;
+        pc_core_system<true>(x + 4 * i, r, j, c, mu, pc_core_iA22(c, mu), sums, y, 0, 3);
+    }
+}

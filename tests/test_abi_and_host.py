@@ -522,3 +522,24 @@ def test_save_over_a_loaded_track_file_keeps_the_loaded_set_alive(tmp_path):
     assert np.array_equal(np.asarray(a._csr[4]), xy) and np.array_equal(np.asarray(b._csr[4]), xy)
     assert np.array_equal(np.asarray(load_track_npy(path)._csr[4]), xy2)
     assert not [f for f in os.listdir(str(tmp_path)) if ".tmp-" in f]
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus N` without a launcher must run N ranks (it re-executes itself under
+    torch.distributed.run) and never print a line for another size.  Without GPUs here every rank stops at its device check --
+    what is asserted is that BOTH ranks were started, that no JSON line came out, and that the exit code is not 0; and that a
+    job whose WORLD_SIZE differs from --gpus refuses to run."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+    assert "rank 0 needs cuda:0" in r.stdout and "rank 1 needs cuda:1" in r.stdout, r.stdout[-2000:]
+    env.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but the job has 1 rank" in r.stdout and '"metric"' not in r.stdout

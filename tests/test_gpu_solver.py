@@ -1,6 +1,6 @@
 """GPU parity of the path-consistency solver (psfm_optimize_location / track_optimize) against the CPU oracle.
 Tolerance: ids / lengths bit-exact, positions within 1e-4 px (north_star); in practice ~1e-10 because both
-sides run the same Ceres-compatible control flow in f64 and differ only in summation order."""
+sides run the same Ceres-compatible control flow in f64 and differ only in rounding (operation and summation order)."""
 import numpy as np
 import pytest
 
@@ -60,12 +60,10 @@ def test_optimize_location_vs_oracle(pt, H, W, n, seed, sigma, kink):
     assert st_g["successful_steps"] == st_o["successful_steps"] and st_g["termination"] == st_o["termination"]
     assert st_g["dogleg_nonGN"] == st_o["dogleg_nonGN"]
     assert abs(st_g["final_cost"] - st_o["final_cost"]) <= 1e-9 * max(1.0, st_o["final_cost"])
+    # far inside the 1e-4 px bar: the device solves the same normal equations in another order (psfm_pc_core.h: unscaled system,
+    # 2x2 Schur complement, contracted multiply-adds) than the C restatement (scaled system, dense Cholesky), so the iterates
+    # differ by rounding; every decision of the loop above is the same
     assert float(np.abs(out_g - out_o).max()) <= 1e-8
-    # stronger than the 1e-4 px bar: every per-track operation rounds like the C restatement (true IEEE divisions there,
-    # reciprocal + fma correction here), so pure Gauss-Newton solves give the same bits; an interpolated dogleg step
-    # takes its two coefficients from sums over all tracks, whose order differs (tree vs sequential) by design
-    if st_o["dogleg_nonGN"] == 0:
-        assert np.array_equal(out_g, out_o)
 
 
 def test_optimize_location_exercises_dogleg(pt):

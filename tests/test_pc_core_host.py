@@ -1,0 +1,188 @@
+"""The per-track arithmetic of the device solver (particle-sfm_amd/csrc/psfm_pc_core.h: unscaled system, 2x2 Schur
+complement, no square roots) against a NumPy restatement of what Ceres computes in the scaled space -- Jacobi scaling S,
+dogleg diagonal D, (Js^T Js + mu D^2) y = Js^T r by a dense solve, gn = -D y, step = (a ghat + b gn) / D, x+ = x + S step
+(trust_region_minimizer.cc / dogleg_strategy.cc as configured at trajectory_optimize.cpp:74-79; the same formulas as
+oracle/psfm_oracle.c).  The header is compiled for the host with g++; every one of the 13 sums of an iteration and every
+candidate must agree to rounding.  No GPU involved."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from _common import solver_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUM = dict(MCC=0, COST=1, STEP2=2, DL2=3, XN2=4, GMAX=5, G2=6, JG2=7, GN2=8, DOT=9, FAIL=10, CNT=11, COST0=12)
+
+
+@pytest.fixture(scope="module")
+def core(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("pc_core") / "libpc_core_host.so")
+    cmd = ["g++", "-O2", "-mfma", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off",
+           "-I", os.path.join(ROOT, "particle-sfm_amd", "csrc"), os.path.join(ROOT, "tests", "host", "pc_core_host.cpp"), "-o", out]
+    subprocess.run(cmd, check=True)
+    L = ctypes.CDLL(out)
+    dp, fp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)
+    L.pc_host_iteration.argtypes = [ctypes.c_long, dp, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                    ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp, dp]
+    L.pc_host_system.argtypes = [ctypes.c_long, dp, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp]
+    return L
+
+
+def _bilerp(flow, x):
+    """linear_interpolation.h:97-123 over Grid2D (clamp to edge): f, df/drow, df/dcol at (row = y1, col = x1)."""
+    H, W = flow.shape[:2]
+    r, c = x[:, 1], x[:, 0]
+    row, col = np.floor(r).astype(np.int64), np.floor(c).astype(np.int64)
+    cl = lambda v, hi: np.clip(v, 0, hi)
+    p00 = flow[cl(row, H - 1), cl(col, W - 1)].astype(np.float64)
+    p01 = flow[cl(row, H - 1), cl(col + 1, W - 1)].astype(np.float64)
+    p10 = flow[cl(row + 1, H - 1), cl(col, W - 1)].astype(np.float64)
+    p11 = flow[cl(row + 1, H - 1), cl(col + 1, W - 1)].astype(np.float64)
+    tc, tr = (c - col)[:, None], (r - row)[:, None]
+    f0 = (1 - tc) * p00 + tc * p01
+    f1 = (1 - tc) * p10 + tc * p11
+    return (1 - tr) * f0 + tr * f1, f1 - f0, (1 - tr) * (p01 - p00) + tr * (p11 - p10)
+
+
+def _res_jac(flow, x, ref1, ref2, s):
+    f, dr, dc = _bilerp(flow, x)
+    n = len(x)
+    r = np.stack([x[:, 0] - ref1[:, 0], x[:, 1] - ref1[:, 1], (x[:, 2] - ref2[:, 0]) * s, (x[:, 3] - ref2[:, 1]) * s,
+                  (x[:, 2] - x[:, 0]) - f[:, 0], (x[:, 3] - x[:, 1]) - f[:, 1]], 1)
+    J = np.zeros((n, 6, 4))
+    J[:, 0, 0] = 1; J[:, 1, 1] = 1; J[:, 2, 2] = s; J[:, 3, 3] = s
+    J[:, 4, 0] = -1 - dc[:, 0]; J[:, 4, 1] = -dr[:, 0]; J[:, 4, 2] = 1
+    J[:, 5, 0] = -dc[:, 1]; J[:, 5, 1] = -1 - dr[:, 1]; J[:, 5, 3] = 1
+    return r, J
+
+
+def _reference_iteration(flow, x0, x, ref1, ref2, s, mu, a, b):
+    _, J0 = _res_jac(flow, x0, ref1, ref2, s)
+    S = 1.0 / (1.0 + np.sqrt((J0 ** 2).sum(1)))                       # (n,4) Jacobi scaling, computed once at x0
+    r, J = _res_jac(flow, x, ref1, ref2, s)
+    Js = J * S[:, None, :]
+    q = np.einsum("nij,ni->nj", Js, r)
+    cn = np.clip((Js ** 2).sum(1), 1e-6, 1e32)
+    d = np.sqrt(cn)
+    gh = q / d
+    A = np.einsum("nij,nik->njk", Js, Js) + mu * np.einsum("nj,jk->njk", cn, np.eye(4))
+    y = np.linalg.solve(A, q[:, :, None])[:, :, 0]
+    gn = -d * y
+    g = np.einsum("nij,ni->nj", J, r)
+    sums = np.zeros(13)
+    sums[SUM["GMAX"]] = np.abs(x - (x - g)).max()
+    sums[SUM["XN2"]] = (x ** 2).sum()
+    sums[SUM["G2"]] = (gh ** 2).sum()
+    sums[SUM["JG2"]] = (np.einsum("nij,nj->ni", Js, gh / d) ** 2).sum()
+    sums[SUM["GN2"]] = (gn ** 2).sum()
+    sums[SUM["DOT"]] = (gh * gn).sum()
+    v = a * gh + b * gn
+    sums[SUM["DL2"]] = (v ** 2).sum()
+    st = v / d
+    m = np.einsum("nij,nj->ni", Js, st)
+    sums[SUM["MCC"]] = (m * (r + m / 2)).sum()
+    xp = x + st * S
+    sums[SUM["STEP2"]] = ((x - xp) ** 2).sum()
+    rp, _ = _res_jac(flow, xp, ref1, ref2, s)
+    sums[SUM["COST"]] = 0.5 * (rp ** 2).sum()
+    sums[SUM["CNT"]] = len(x)
+    return sums, xp, 0.5 * (r ** 2).sum(1)
+
+
+CASES = [
+    # H, W, n, seed, sigma, kink, mu, (a, b)
+    (60, 80, 3000, 1, 0.02, False, 1e-8, None),
+    (60, 80, 3000, 2, 0.5, False, 1e-8, None),
+    (45, 70, 5000, 3, 0.3, True, 1e-8, None),              # points outside the image: Grid2D clamping
+    (60, 80, 3000, 2, 0.5, False, 1e-8, (-0.37, 0.61)),    # an interpolated dogleg step
+    (60, 80, 3000, 4, 0.3, False, 1e-8, (-0.9, 0.0)),      # the scaled Cauchy step
+    (45, 70, 4000, 5, 0.3, True, 1e-3, (-0.2, 0.8)),       # mu raised by invalid steps
+    (33, 47, 1, 5, 0.1, False, 1e-8, None),
+]
+
+
+@pytest.mark.parametrize("H,W,n,seed,sigma,kink,mu,ab", CASES)
+def test_core_iteration_matches_the_scaled_space_formulas(core, H, W, n, seed, sigma, kink, mu, ab):
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, seed, sigma, kink)
+    rng = np.random.default_rng(seed + 100)
+    x0 = np.ascontiguousarray(uv)
+    x = np.ascontiguousarray(x0 + rng.normal(0, 0.3, x0.shape))        # an iterate away from the start values
+    s = np.ascontiguousarray(scale[:, 0])
+    a, b = ab if ab else (0.0, 1.0)
+    want, xp_want, cost_want = _reference_iteration(flow12, x0, x, ref1, ref2, s, mu, a, b)
+    sums = np.zeros(13)
+    xp = np.zeros_like(x)
+    cost = np.zeros(n)
+    P = lambda arr: np.ascontiguousarray(arr, np.float64).ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    flow = np.ascontiguousarray(flow12, np.float32)
+    core.pc_host_iteration(n, P(x0), P(x), P(ref1), P(ref2), P(s), flow.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), H, W,
+                           mu, a, b, 1 if ab is None else 0, P(sums), P(xp), P(cost))
+    assert sums[SUM["FAIL"]] == 0 and sums[SUM["CNT"]] == n
+    assert np.abs(xp - xp_want).max() <= 1e-11 * max(1.0, np.abs(xp_want).max())
+    assert np.allclose(cost, cost_want, rtol=1e-12, atol=1e-13)
+    for k, i in SUM.items():
+        if k in ("FAIL", "CNT", "COST0"):
+            continue
+        assert abs(sums[i] - want[i]) <= 1e-10 * max(abs(want[i]), 1e-12), (k, sums[i], want[i])
+
+
+def test_core_flags_what_a_cholesky_would_refuse(core):
+    """Non-finite residuals / Jacobians (a NaN flow under the track) must raise the FAIL count -- the solve then ends like Ceres'
+    FAILURE -- and a clamped diagonal (a column scaled up by > 1e3 against the start values) must still give a finite step."""
+    H, W, n = 40, 50, 64
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, 9, 0.05, False)
+    bad = flow12.copy()
+    bad[:, :, 0] = np.nan
+    x = np.ascontiguousarray(uv)
+    s = np.ascontiguousarray(scale[:, 0])
+    sums, xp, cost = np.zeros(13), np.zeros_like(x), np.zeros(n)
+    P = lambda arr: np.ascontiguousarray(arr, np.float64).ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    core.pc_host_iteration(n, P(x), P(x), P(ref1), P(ref2), P(s), bad.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), H, W,
+                           1e-8, 0.0, 1.0, 1, P(sums), P(xp), P(cost))
+    assert sums[SUM["FAIL"]] == n
+    # x0 on a flat part of the map (S0 = 1/2), x where the flow gradient is 1e17 px/px: S0^2 H_00 = 2.5e33 > max_lm_diagonal, so
+    # the dogleg diagonal of column 0 is the clamped 1e32 / S0^2 and not H_00; at mu = 1 that halves the damping term, i.e. the
+    # step is ~2x what an unclamped diagonal would give -- compared against the scaled-space restatement (itself only good
+    # to ~1e-6 on a system this badly conditioned)
+    steep = np.zeros((H, W, 2), np.float32)
+    steep[:, 25:, 0] = 1e17
+    x0 = np.tile(np.array([[5.5, 5.5, 6.5, 6.5]]), (n, 1))
+    xs = np.tile(np.array([[24.5, 5.5, 25.5, 6.5]]), (n, 1))
+    core.pc_host_iteration(n, P(x0), P(xs), P(ref1), P(ref2), P(s), steep.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), H, W,
+                           1.0, 0.0, 1.0, 1, P(sums), P(xp), P(cost))
+    want, xp_want, _ = _reference_iteration(steep, x0, xs, ref1, ref2, s, 1.0, 0.0, 1.0)
+    assert sums[SUM["FAIL"]] == 0 and np.isfinite(xp).all()
+    assert np.allclose(xp, xp_want, rtol=1e-5, atol=1e-9)
+    assert abs(sums[SUM["GN2"]] - want[SUM["GN2"]]) <= 1e-5 * want[SUM["GN2"]]
+
+
+@pytest.mark.parametrize("mu", [1e-8, 1e-2])
+def test_any_dogleg_step_is_priced_from_the_sums_at_x(core, mu):
+    """The launch chain's control step no longer needs a pass over the tracks to know a dogleg step's norm and model decrease:
+    |a ghat + b gn|^2 = a^2 G2 + 2ab DOT + b^2 GN2 and (J dl).(r + J dl/2) = a G2 + b DOT + (a^2 JG2 + 2ab QUD + b^2 QDD)/2 with
+    QUD = sum (J u).(J d), QDD = sum |J d|^2 reduced once per iterate.  Checked against the per-track sums of the same step."""
+    H, W, n = 60, 80, 3000
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, 2, 0.5, False)
+    rng = np.random.default_rng(7)
+    x0 = np.ascontiguousarray(uv)
+    x = np.ascontiguousarray(x0 + rng.normal(0, 0.3, x0.shape))
+    s = np.ascontiguousarray(scale[:, 0])
+    P = lambda arr: np.ascontiguousarray(arr, np.float64).ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    flow = np.ascontiguousarray(flow12, np.float32)
+    fptr = flow.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    at_x = np.zeros(13)
+    core.pc_host_system(n, P(x0), P(x), P(ref1), P(ref2), P(s), fptr, H, W, mu, P(at_x))
+    qud, qdd = at_x[0], at_x[3]
+    G2, JG2, GN2, DOT = at_x[SUM["G2"]], at_x[SUM["JG2"]], at_x[SUM["GN2"]], at_x[SUM["DOT"]]
+    for a, b in ((0.0, 1.0), (-0.37, 0.61), (-0.9, 0.0), (-1e-3, 0.999)):
+        sums, xp, cost = np.zeros(13), np.zeros_like(x), np.zeros(n)
+        core.pc_host_iteration(n, P(x0), P(x), P(ref1), P(ref2), P(s), fptr, H, W, mu, a, b, 0, P(sums), P(xp), P(cost))
+        dl2 = a * a * G2 + 2 * a * b * DOT + b * b * GN2
+        mcc = a * G2 + b * DOT + 0.5 * (a * a * JG2 + 2 * a * b * qud + b * b * qdd)
+        assert abs(dl2 - sums[SUM["DL2"]]) <= 1e-11 * abs(sums[SUM["DL2"]])
+        assert abs(mcc - sums[SUM["MCC"]]) <= 1e-10 * max(abs(sums[SUM["MCC"]]), abs(a * G2) + abs(b * DOT))
+        assert np.array_equal(sums[[SUM["G2"], SUM["JG2"], SUM["GN2"], SUM["DOT"], SUM["XN2"], SUM["GMAX"]]],
+                              at_x[[SUM["G2"], SUM["JG2"], SUM["GN2"], SUM["DOT"], SUM["XN2"], SUM["GMAX"]]])
