@@ -70,7 +70,7 @@ struct PsfmPersistArgs {
     const float2* flows; const uint8_t* occ;   // (n_flows,H,W,2) f32 / n_flows maps of H*W u8, `occ_pitch` bytes apart
     // fused flow_check (psfm_connect): the blocks compute the occlusion maps themselves, in the time they would spend
     // waiting at the frame barriers, always at least three frames ahead of the step that samples them
-    const float2* flows_b; uint8_t* occ_w; float thres, t2; int fc;
+    const float2* flows_b; uint8_t* occ_w; float thres, t2; int fc; int fc_xcd_per;
     int64_t occ_pitch; PsfmFastDiv wdiv;
     int H, W; float cw, ch, rcw, rch;
     int ratio, GW, GH, G;
@@ -185,8 +185,14 @@ __device__ __forceinline__ void psfm_fc_slice(const PsfmPersistArgs& a, int f, i
     const float2* __restrict__ F = a.flows + (size_t)f * P;
     const float2* __restrict__ B = a.flows_b + (size_t)f * P;
     uint8_t* O = a.occ_w + (size_t)f * a.occ_pitch;
-    for (int c0 = blockIdx.x * 1024; c0 < P; c0 += gridDim.x * 1024) {
-        const int p0 = c0 + tid;
+    // chunk -> block: XCD-aware when a.fc_xcd_per > 0 (block b runs on XCD b % 8 and takes chunk (b % 8) * per + b / 8 of every
+    // round: each XCD covers one band of rows, so a row of B is gathered through ONE private L2 instead of two -- psfm_track.hip)
+    const int nch = (P + 1023) / 1024;
+    const int per = a.fc_xcd_per;
+    for (int q0 = blockIdx.x; q0 < (per > 0 ? 8 * per : nch); q0 += gridDim.x) {
+        const int ci = per > 0 ? (q0 & 7) * per + (q0 >> 3) : q0;
+        if (ci >= nch) continue;
+        const int p0 = ci * 1024 + tid;
         float2 fv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -727,6 +733,11 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
     a.flows = (const float2*)flows; a.occ = occ;
     a.occ_pitch = occ_pitch;
     a.flows_b = (const float2*)flows_b; a.occ_w = const_cast<uint8_t*>(occ); a.thres = thres; a.t2 = psfm_sq_threshold(thres); a.fc = flows_b != nullptr;
+    {
+        static const int xcd_on = getenv("PSFM_FC_XCD") ? atoi(getenv("PSFM_FC_XCD")) : 1;
+        const int64_t nch = ((int64_t)d.H * d.W + 1023) / 1024;
+        a.fc_xcd_per = xcd_on && nch >= 64 ? (int)((nch + 7) / 8) : 0;
+    }
     a.wdiv = psfm_fastdiv_make((unsigned)d.W);
     a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch; a.rcw = psfm_rcp_host(d.cw); a.rch = psfm_rcp_host(d.ch);
     a.ratio = d.ratio; a.GW = d.GW; a.GH = d.GH; a.G = (int)d.G;

@@ -60,7 +60,7 @@
 #endif
 #define PC_KMAX 8            // fused solve: most trust-region iterations speculated in one launch
 #ifndef PSFM_SEQ_WAVES_DEFAULT
-#define PSFM_SEQ_WAVES_DEFAULT 3
+#define PSFM_SEQ_WAVES_DEFAULT 4
 #endif
 #define PC_GROUP 32          // fused solve: blocks per first-level reduction group
 

@@ -107,15 +107,30 @@ __device__ __forceinline__ uint8_t psfm_flow_check_px16(const float2* __restrict
     return (uint8_t)((s2 > q.t2) | oob);
 }
 
+// XCD-aware block -> pixel mapping (xcd_per > 0): workgroups go to the eight XCDs round-robin by linear id, and the XCDs'
+// L2s are private.  With blocks walking the map in id order, the rows y and y + 1 of pixels -- whose taps share a row of
+// B -- are handled by different XCDs, so every row of B crosses the fabric twice (rocprofv3 FETCH_SIZE: 1.6x the
+// algorithmic reads).  Here the launch has 8 * xcd_per blocks per pair and block x takes chunk (x % 8) * xcd_per + x / 8:
+// every XCD streams ONE contiguous band of H / 8 rows, top to bottom, and B's rows are re-read from its own L2.
+__device__ __forceinline__ int psfm_xcd_chunk(int bx, int xcd_per) { return xcd_per > 0 ? (bx & 7) * xcd_per + (bx >> 3) : bx; }
+static inline int psfm_xcd_per(int64_t chunks)
+{
+    static const int on = getenv("PSFM_FC_XCD") ? atoi(getenv("PSFM_FC_XCD")) : 1;
+    return on && chunks >= 64 ? (int)((chunks + 7) / 8) : 0;
+}
+
 template <bool NT>     // NT: non-temporal F loads / mask stores (streamed once: keep them out of the way of the B taps in L2)
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_kernel(
-    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q, uint8_t* __restrict__ occ_out, PsfmFastDiv wdiv)
+    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q, uint8_t* __restrict__ occ_out, PsfmFastDiv wdiv,
+    int xcd_per)
 {
     const int P = q.H * q.W;                      // (even: the launcher falls back to the x4 kernel otherwise)
     const int64_t base = (int64_t)blockIdx.y * P;
     const float2* __restrict__ F = flows_f + base;
     const float2* __restrict__ B = flows_b + base;
-    const int p0 = (blockIdx.x * (PSFM_BLOCK * PSFM_FC2_UNROLL) + threadIdx.x) * 2;
+    const int bx = psfm_xcd_chunk((int)blockIdx.x, xcd_per);
+    if ((int64_t)bx * (PSFM_BLOCK * PSFM_FC2_UNROLL * 2) >= P) return;
+    const int p0 = (bx * (PSFM_BLOCK * PSFM_FC2_UNROLL) + threadIdx.x) * 2;
     float4 f[PSFM_FC2_UNROLL];
 #pragma unroll
     for (int k = 0; k < PSFM_FC2_UNROLL; ++k) {
@@ -155,14 +170,15 @@ PsfmFcParams psfm_fc_params(int h, int w, float thres);
 #define PSFM_FC_BG_UNROLL 2   // (32 VGPRs: 3 x 160 of the frame kernel + 32 = 512 per SIMD lane)
 __global__ __launch_bounds__(PSFM_BLOCK) __attribute__((amdgpu_num_vgpr(32))) void psfm_flow_check_bg_kernel(
     const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q, uint8_t* __restrict__ occ_out,
-    PsfmFastDiv wdiv, int n_pairs)
+    PsfmFastDiv wdiv, int n_pairs, int xcd_per)
 {
     extern __shared__ char psfm_fc_bg_reserve[];      // (occupancy control only)
     const int P = q.H * q.W;
     const int chunks = (P + PSFM_BLOCK * PSFM_FC_BG_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_BG_UNROLL);
     // gridDim.y == 1: a few resident blocks walk over the whole chunk of pairs; gridDim.y == n_pairs: one short-lived
     // block per 512 pixels (the LDS reservation then caps how many of them a CU hosts beside the frame kernel's blocks)
-    const int64_t w0 = gridDim.y > 1 ? (int64_t)blockIdx.y * chunks + blockIdx.x : blockIdx.x;
+    if (gridDim.y > 1 && (int)psfm_xcd_chunk((int)blockIdx.x, xcd_per) >= chunks) return;
+    const int64_t w0 = gridDim.y > 1 ? (int64_t)blockIdx.y * chunks + psfm_xcd_chunk((int)blockIdx.x, xcd_per) : blockIdx.x;
     const int64_t wstep = gridDim.y > 1 ? (int64_t)chunks * n_pairs : gridDim.x;
     for (int64_t w = w0; w < (int64_t)chunks * n_pairs; w += wstep) {
         const int pair = (int)(w / chunks), ch = (int)(w - (int64_t)pair * chunks);
@@ -196,13 +212,16 @@ psfm_status psfm_launch_flow_check_bg(const float* ff, const float* fb, int n_pa
     if (n_pairs <= 0) return PSFM_OK;
     const PsfmFcParams q = psfm_fc_params(h, w, thres);
     dim3 grid((unsigned)n_blocks);
+    int xcd_per = 0;
     if (n_blocks <= 0) {      // one short-lived block per PSFM_BLOCK * PSFM_FC_BG_UNROLL pixels
         const int64_t P = (int64_t)h * w;
-        grid = dim3((unsigned)((P + PSFM_BLOCK * PSFM_FC_BG_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_BG_UNROLL)), (unsigned)n_pairs);
+        const int64_t chunks = (P + PSFM_BLOCK * PSFM_FC_BG_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_BG_UNROLL);
+        xcd_per = psfm_xcd_per(chunks);
+        grid = dim3((unsigned)(xcd_per > 0 ? 8 * xcd_per : chunks), (unsigned)n_pairs);
     }
     const int lds_kb = getenv("PSFM_FC_BG_LDS_KB") ? atoi(getenv("PSFM_FC_BG_LDS_KB")) : PSFM_FC_BG_LDS_KB_DEFAULT;
     hipLaunchKernelGGL(psfm_flow_check_bg_kernel, grid, dim3(PSFM_BLOCK), (size_t)(lds_kb > 0 ? lds_kb : 0) * 1024, s, (const float2*)ff,
-                       (const float2*)fb, q, occ, psfm_fastdiv_make((unsigned)w), n_pairs);
+                       (const float2*)fb, q, occ, psfm_fastdiv_make((unsigned)w), n_pairs, xcd_per);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
@@ -227,13 +246,15 @@ psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs
     if (!err && fc_kernel >= 2 && (P % 2) == 0 && P >= PSFM_BLOCK * PSFM_FC2_UNROLL * 2 && ((uintptr_t)ff % 16) == 0 &&
         ((uintptr_t)fb % 16) == 0 && ((uintptr_t)occ % 2) == 0) {
         const int64_t per_block = (int64_t)PSFM_BLOCK * PSFM_FC2_UNROLL * 2;
-        dim3 grid((unsigned)((P + per_block - 1) / per_block), (unsigned)n_pairs);
+        const int64_t chunks = (P + per_block - 1) / per_block;
+        const int xcd_per = psfm_xcd_per(chunks);
+        dim3 grid((unsigned)(xcd_per > 0 ? 8 * xcd_per : chunks), (unsigned)n_pairs);
         if (fc_kernel == 3)
             hipLaunchKernelGGL(psfm_flow_check_x2v_kernel<true>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb, q, occ,
-                               psfm_fastdiv_make((unsigned)w));
+                               psfm_fastdiv_make((unsigned)w), xcd_per);
         else
             hipLaunchKernelGGL(psfm_flow_check_x2v_kernel<false>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb, q, occ,
-                               psfm_fastdiv_make((unsigned)w));
+                               psfm_fastdiv_make((unsigned)w), xcd_per);
     } else if (P >= PSFM_BLOCK * PSFM_FC_UNROLL) {
         dim3 grid((unsigned)((P + PSFM_BLOCK * PSFM_FC_UNROLL - 1) / (PSFM_BLOCK * PSFM_FC_UNROLL)), (unsigned)n_pairs);
         if (err)

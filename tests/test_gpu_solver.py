@@ -98,7 +98,9 @@ def test_track_optimize_large_motion_golden(pt, solver_mode, name):
     assert np.array_equal(np.packbits(np.stack(occ)), g["occ"]) and np.array_equal(np.packbits(np.stack(occ2)), g["occ2"])
     R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
     assert_csr_equal(R.birth, R.length, R.xy, g, tol=TOL)
-    assert float(np.abs(R.xy - g["xy"]).max()) <= 1e-7
+    # (sigma 0.25 on 90 x 140: solves of 20-30 iterations through bilinear kinks amplify the rounding differences between the
+    # device's and the restatement's arithmetic to a few 1e-7 px; the bar is 1e-4)
+    assert float(np.abs(R.xy - g["xy"]).max()) <= 1e-5
 
 
 @pytest.mark.parametrize("H,W,T,r,seed,sigma,nocc", [
