@@ -58,6 +58,29 @@ __device__ __forceinline__ uint8_t psfm_flow_check_px(const float2* __restrict__
     return (uint8_t)((s2 > q.t2) | oob);
 }
 
+#ifndef PSFM_FC_INTERIOR_PAIRS
+#define PSFM_FC_INTERIOR_PAIRS 0   // 1: the two taps of a row as one 16-byte load (36 spilled VGPRs in the persistent loop's 64)
+#endif
+// The same verdict for a pixel whose four taps are known to lie inside the map (the caller tests that for the whole wave):
+// the two taps of a row are ONE 16-byte load, nothing is clamped or zero-padded.  Same blend, same bits.
+__device__ __forceinline__ uint8_t psfm_flow_check_px_interior(const float2* __restrict__ B, float X, float Y, float2 f, const PsfmTaps& t,
+                                                               const PsfmFcParams& q)
+{
+    const unsigned o = (unsigned)(t.y0 * q.W + t.x0) * 8u, o2 = o + (unsigned)q.W * 8u;
+#if PSFM_FC_INTERIOR_PAIRS
+    const float4 n4 = *(const float4*)((const char*)B + o);
+    const float4 s4 = *(const float4*)((const char*)B + o2);
+    const float bx = psfm_blend(n4.x, n4.z, s4.x, s4.z, t), by = psfm_blend(n4.y, n4.w, s4.y, s4.w, t);
+#else
+    const float2 nw = psfm_ld(B, o), ne = psfm_ld(B, o + 8u), sw = psfm_ld(B, o2), se = psfm_ld(B, o2 + 8u);
+    const float bx = psfm_blend(nw.x, ne.x, sw.x, se.x, t), by = psfm_blend(nw.y, ne.y, sw.y, se.y, t);
+#endif
+    const float eu = __fadd_rn(bx, f.x), ev = __fadd_rn(by, f.y);
+    const float s2 = __fmaf_rn(ev, ev, __fmul_rn(eu, eu));
+    const bool oob = (X < 0.0f) | (X > (float)(q.W - 1)) | (Y < 0.0f) | (Y > (float)(q.H - 1));
+    return (uint8_t)((s2 > q.t2) | oob);
+}
+
 struct PsfmStep { bool alive; double2 next; float2 flow; };   // flow: the sampled (fx, fy), next = p + (double)flow
 
 // One chain step split in two so that the caller can issue the gathers of several steps back to back and keep

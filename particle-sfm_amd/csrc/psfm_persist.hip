@@ -48,6 +48,9 @@
                          // 1080p sequence end to end: window 4 -> 2.80 ms, 3 -> 2.84, 8 -> 2.96, unbounded -> 3.19 (front-loads the
                          // memory system), slices also behind the barrier -> 3.12, always one slice per frame -> 2.86
 #endif
+#ifndef PP_FC_FAST
+#define PP_FC_FAST 0     // fused flow_check: wave-uniform "all taps interior" form (16-byte tap pairs, no padding selects)
+#endif
 #define PP_GUESTS 32   // extra lanes per block whose state lives in LDS (stepped as phase-2 entries)
 #define PP_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))
 
@@ -204,8 +207,19 @@ __device__ __forceinline__ void psfm_fc_slice(const PsfmPersistArgs& a, int f, i
         for (int k = 0; k < 4; ++k) {
             const int p = p0 + k * 256;
             if (p >= P) break;
+            uint8_t o;
+#if PP_FC_FAST
+            {   // wave-uniform short cut: every lane's taps inside the map (all but the border waves)
+                const float X = __fadd_rn((float)x, fv[k].x), Y = __fadd_rn((float)y, fv[k].y);
+                const PsfmTaps t = psfm_taps_t<true>(X, Y, q.cw, q.ch, q.rcw, q.rch, q.H, q.W);
+                const bool interior = (t.x0 >= 0) & (t.x0 + 1 < q.W) & (t.y0 >= 0) & (t.y0 + 1 < q.H);
+                if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) o = psfm_flow_check_px_interior(B, X, Y, fv[k], t, q);
+                else { float e; int xb = x, yb = y; asm volatile("" : "+v"(xb), "+v"(yb)); o = psfm_flow_check_px<false>(B, xb, yb, fv[k], q, &e); }
+            }
+#else
             float e;
-            const uint8_t o = psfm_flow_check_px<false>(B, x, y, fv[k], q, &e);
+            o = psfm_flow_check_px<false>(B, x, y, fv[k], q, &e);
+#endif
             psfm_coh_st(O + p, o);
             x += 256;
             while (x >= a.W) { x -= a.W; ++y; }

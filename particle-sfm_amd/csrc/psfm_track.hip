@@ -83,11 +83,39 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x4_kernel(
 // fastest at), the two horizontally adjacent taps of a row of B as one 16-byte load (2 loads per pixel instead of 4), the
 // mask leaves as one 2-byte store.  PSFM_FC2_UNROLL pairs per thread, block-strided like the x4 kernel.
 #define PSFM_FC2_UNROLL 2
-__device__ __forceinline__ uint8_t psfm_flow_check_px16(const float2* __restrict__ B, int x, int y, float2 f, const PsfmFcParams& q)
+struct PsfmFcGeom { PsfmTaps t; float X, Y; bool interior; };
+__device__ __forceinline__ PsfmFcGeom psfm_fc_geom(int x, int y, float2 f, const PsfmFcParams& q)
 {
-    const float X = __fadd_rn((float)x, f.x), Y = __fadd_rn((float)y, f.y);
-    const PsfmTaps t = psfm_taps_t<true>(X, Y, q.cw, q.ch, q.rcw, q.rch, q.H, q.W);
-    const int x0 = t.x0, y0 = t.y0;
+    PsfmFcGeom g;
+    g.X = __fadd_rn((float)x, f.x); g.Y = __fadd_rn((float)y, f.y);
+    g.t = psfm_taps_t<true>(g.X, g.Y, q.cw, q.ch, q.rcw, q.rch, q.H, q.W);
+    // all four taps inside the map: the pair load needs no clamping and no tap is zero-padded
+    g.interior = (g.t.x0 >= 0) & (g.t.x0 + 1 < q.W) & (g.t.y0 >= 0) & (g.t.y0 + 1 < q.H);
+    return g;
+}
+__device__ __forceinline__ uint8_t psfm_fc_verdict(float bx, float by, float2 f, const PsfmFcGeom& g, const PsfmFcParams& q)
+{
+    const float eu = __fadd_rn(bx, f.x), ev = __fadd_rn(by, f.y);
+    const float s2 = __fmaf_rn(ev, ev, __fmul_rn(eu, eu));
+    const bool oob = (g.X < 0.0f) | (g.X > (float)(q.W - 1)) | (g.Y < 0.0f) | (g.Y > (float)(q.H - 1));
+    return (uint8_t)((s2 > q.t2) | oob);
+}
+// INTERIOR (wave-uniform: every lane's taps lie inside the map -- all but the border waves): the west / east taps are the two
+// halves of the pair load, nothing is selected.  Same blend, same bits.
+template <bool INTERIOR>
+__device__ __forceinline__ uint8_t psfm_flow_check_px16(const float2* __restrict__ B, float2 f, const PsfmFcGeom& g, const PsfmFcParams& q)
+{
+    const PsfmTaps& t = g.t;
+    int x0 = t.x0, y0 = t.y0;
+    // (the border form's clamps and selects are pure arithmetic: without this fence the compiler computes them ahead of the
+    // wave-uniform branch, for every wave)
+    if (!INTERIOR) asm volatile("" : "+v"(x0), "+v"(y0));
+    if (INTERIOR) {
+        const unsigned o = (unsigned)(y0 * q.W + x0) * 8u;
+        const float4 n4 = *(const float4*)((const char*)B + o);
+        const float4 s4 = *(const float4*)((const char*)B + o + (unsigned)q.W * 8u);
+        return psfm_fc_verdict(psfm_blend(n4.x, n4.z, s4.x, s4.z, t), psfm_blend(n4.y, n4.w, s4.y, s4.w, t), f, g, q);
+    }
     const int xc = min(max(x0, 0), q.W - 2);                         // the pair (xc, xc + 1) lies inside the row
     const int rn = min(max(y0, 0), q.H - 1), rs = min(max(y0 + 1, 0), q.H - 1);
     const float4 n4 = *(const float4*)((const char*)B + ((unsigned)(rn * q.W + xc)) * 8u);
@@ -100,11 +128,7 @@ __device__ __forceinline__ uint8_t psfm_flow_check_px16(const float2* __restrict
     const float nex = (xe & yn) ? (elo ? n4.x : n4.z) : z, ney = (xe & yn) ? (elo ? n4.y : n4.w) : z;
     const float swx = (xw & ys) ? (wlo ? s4.x : s4.z) : z, swy = (xw & ys) ? (wlo ? s4.y : s4.w) : z;
     const float sex = (xe & ys) ? (elo ? s4.x : s4.z) : z, sey = (xe & ys) ? (elo ? s4.y : s4.w) : z;
-    const float bx = psfm_blend(nwx, nex, swx, sex, t), by = psfm_blend(nwy, ney, swy, sey, t);
-    const float eu = __fadd_rn(bx, f.x), ev = __fadd_rn(by, f.y);
-    const float s2 = __fmaf_rn(ev, ev, __fmul_rn(eu, eu));
-    const bool oob = (X < 0.0f) | (X > (float)(q.W - 1)) | (Y < 0.0f) | (Y > (float)(q.H - 1));
-    return (uint8_t)((s2 > q.t2) | oob);
+    return psfm_fc_verdict(psfm_blend(nwx, nex, swx, sex, t), psfm_blend(nwy, ney, swy, sey, t), f, g, q);
 }
 
 // XCD-aware block -> pixel mapping (xcd_per > 0): workgroups go to the eight XCDs round-robin by linear id, and the XCDs'
@@ -149,8 +173,15 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_kernel(
         int x1 = x + 1, y1 = y;
         if (x1 >= q.W) { x1 = 0; ++y1; }
         uchar2 o;
-        o.x = psfm_flow_check_px16(B, x, y, make_float2(f[k].x, f[k].y), q);
-        o.y = psfm_flow_check_px16(B, x1, y1, make_float2(f[k].z, f[k].w), q);
+        const float2 fa = make_float2(f[k].x, f[k].y), fb = make_float2(f[k].z, f[k].w);
+        const PsfmFcGeom ga = psfm_fc_geom(x, y, fa, q), gb = psfm_fc_geom(x1, y1, fb, q);
+        if (__builtin_amdgcn_ballot_w64(!(ga.interior & gb.interior)) == 0ull) {
+            o.x = psfm_flow_check_px16<true>(B, fa, ga, q);
+            o.y = psfm_flow_check_px16<true>(B, fb, gb, q);
+        } else {
+            o.x = psfm_flow_check_px16<false>(B, fa, ga, q);
+            o.y = psfm_flow_check_px16<false>(B, fb, gb, q);
+        }
         if (NT) __builtin_nontemporal_store(*(unsigned short*)&o, (unsigned short*)(occ_out + base + p));
         else *(uchar2*)(occ_out + base + p) = o;
     }
