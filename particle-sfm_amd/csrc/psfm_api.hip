@@ -24,7 +24,10 @@ std::shared_mutex& psfm_device_gate(int device) { return g_dev_gate[device & 15]
 //     ->  additionally >= 400 k grid points and at most 6 pixels per grid point.
 static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int ratio, bool fused)
 {
-    if (optimize || c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;
+    if (c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;
+    // track_optimize: no persistent frame loop, but solves that reject steps run their trust-region loop as one persistent
+    // launch (psfm_pc_persist_kernel) when the call has the device to itself -- take the gate if it is free
+    if (optimize) return 1;
     const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
     const int64_t P = (int64_t)h * w;
     const int maxb = psfm_persist_max_blocks(c);
@@ -153,7 +156,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
                        &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
-                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->sol_fused, &c->occ_own, &c->occ2_own,
+                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->sol_fused, &c->sol_bar, &c->occ_own, &c->occ2_own,
                        &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar, &c->win_ws, &c->flt_ids, &c->flt_birth, &c->flt_len, &c->flt_off, &c->flt_xy,
                        &c->mt_kp_off, &c->mt_q, &c->mt_pts, &c->mt_kp_ind, &c->mt_kp_xy, &c->mt_moff, &c->mt_keys, &c->mt_rows, &c->mt_gid, &c->mt_pairs};
     for (auto b : bufs) b->release();
@@ -260,7 +263,8 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
                                               double* out, psfm_solve_stats* stats_host, void* stream)
 {
     PSFM_CHECK_CTX(c);
-    PsfmGate gate(c->device, 0);
+    PsfmGate gate(c->device, 1);          // (exclusive if no other psfm call is in flight: the solve may then run as one persistent launch)
+    c->pc_persist_ok = gate.exclusive;
     if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
         psfm_set_error("psfm_optimize_location: bad argument (n=%lld h=%d w=%d)", (long long)n, h, w);
         return PSFM_ERR_ARG;
@@ -371,6 +375,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;
     c->res_n_flows = n_flows;
+    c->pc_persist_ok = device_is_ours;
 
     // ---- track mode: the whole recurrence as ONE persistent launch when every lane can be resident at once ----
     if (!optimize && c->chain_mode != 1) {

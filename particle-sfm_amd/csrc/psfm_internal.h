@@ -136,7 +136,9 @@ struct psfm_ctx {
     int64_t res_n_traj = 0, res_n_points = 0;
     int res_n_flows = 0;           // flows of the sequence the result came from (psfm_result_keys checks its packed key)
     // solver workspace
-    PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats, sol_fused;
+    PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats, sol_fused, sol_bar;
+    int pc_persist_blocks = -1;    // co-resident blocks of psfm_pc_persist_kernel on this device (-1: not queried yet)
+    bool pc_persist_ok = false;    // this call has the device to itself: the launch chain may run as one persistent launch
     int solve_K = 4;        // fused solve: trust-region iterations speculated per launch (adapted at checkpoints)
     int solve_mode = 0;     // 0 fused solve (one launch per frame), 1 launch chain (sequences whose solves reject steps)
     int solver_mode = 0, solver_K = 0;   // psfm_ctx_set_solver: 0 adaptive / 1 chain / 2 fused; K 0 = adaptive

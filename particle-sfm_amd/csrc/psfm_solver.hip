@@ -271,6 +271,48 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
     if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1, P.export_sums);
 }
 
+// What one launch of the chain does for this block's tracks (grid-stride): the refresh form (the system at x for a raised
+// mu) or the evaluate-ahead form (candidate of (a, b), its cost, the system there).  Sums into acc[].
+// (Two tracks per thread at a time, stage by stage, at 2 waves per SIMD / 227 VGPRs: 66 instead of 55 ms per hard 1080p
+// sequence -- the slot without a track in a thread's last pass costs more arithmetic than the overlap saves; EXPERIMENTS.md.)
+__device__ __forceinline__ void pc_iter_tracks(const PcParams& P, int cur, double mu, double a, double b, bool refresh, double acc[PC_NSUM])
+{
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    const double2* xc1 = pc_buf1(P, cur);
+    const double2* xc2 = pc_buf2(P, cur);
+    double2* xn1 = pc_buf1(P, pc_other(cur));
+    double2* xn2 = pc_buf2(P, pc_other(cur));
+    const double mu_next = fmax(1e-8, 2.0 * mu / 10.0);      // DoglegStrategy::StepAccepted: the mu of the system at the candidate
+#pragma unroll
+    for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
+    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
+        if (!pc_participates(P, i, n)) continue;
+        const double2 r1 = P.ref1[i], r2 = P.ref2[i];
+        const double s = P.scale[i];
+        const PcConst c = pc_const_load(s, P.jscale[i]);
+        const double2 p1 = xc1[i], p2 = xc2[i];
+        const double x[4] = {p1.x, p1.y, p2.x, p2.y};
+        double r[6], jac[4];
+        PcSys y;
+        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
+        if (refresh) {      // the system at x for the mu an invalid step has raised
+            pc_core_system<true>(x, r, jac, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
+            continue;
+        }
+        double unused[PC_NSUM], xp[4];      // (the sums at x are in the control block already)
+#pragma unroll
+        for (int k = 0; k < PC_NSUM; ++k) unused[k] = 0.0;
+        pc_core_system<false>(x, r, jac, c, mu, pc_core_iA22(c, mu), unused, y, 0, 0);
+        pc_core_step<false, false>(x, r, jac, c, y, a, b, acc, xp);
+        xn1[i] = make_double2(xp[0], xp[1]);
+        xn2[i] = make_double2(xp[2], xp[3]);
+        // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
+        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, xp, r1.x, r1.y, r2.x, r2.y, s, r, jac);
+        acc[SUM_COST] += pc_core_cost(r);
+        pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pc_iter: one trust-region iteration at the current iterate.
 // ------------------------------------------------------------------------------------------------
@@ -297,43 +339,8 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
     const int tl_slot = C.iteration == 1 && g_pc_tl_n < 64 ? g_pc_tl_n : -1;   // the first pc_iter launch of a solve
     PC_TL(0);
 #endif
-    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
-    const double2* xc1 = pc_buf1(P, C.cur);
-    const double2* xc2 = pc_buf2(P, C.cur);
-    double2* xn1 = pc_buf1(P, pc_other(C.cur));
-    double2* xn2 = pc_buf2(P, pc_other(C.cur));
-    const double a = C.dl_a, b = C.dl_b;
-    const bool refresh = C.kind_next != 0;
-    const double mu_next = fmax(1e-8, 2.0 * C.mu / 10.0);      // DoglegStrategy::StepAccepted: the mu of the system at the candidate
     double acc[PC_NSUM];
-#pragma unroll
-    for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
-    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
-        if (!pc_participates(P, i, n)) continue;
-        const double2 r1 = P.ref1[i], r2 = P.ref2[i];
-        const double s = P.scale[i];
-        const PcConst c = pc_const_load(s, P.jscale[i]);
-        const double2 p1 = xc1[i], p2 = xc2[i];
-        const double x[4] = {p1.x, p1.y, p2.x, p2.y};
-        double r[6], jac[4];
-        PcSys y;
-        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
-        if (refresh) {      // the system at x for the mu an invalid step has raised
-            pc_core_system<true>(x, r, jac, c, C.mu, pc_core_iA22(c, C.mu), acc, y, CH_QUD, CH_QDD);
-            continue;
-        }
-        double unused[PC_NSUM], xp[4];      // (the sums at x are in the control block already)
-#pragma unroll
-        for (int k = 0; k < PC_NSUM; ++k) unused[k] = 0.0;
-        pc_core_system<false>(x, r, jac, c, C.mu, pc_core_iA22(c, C.mu), unused, y, 0, 0);
-        pc_core_step<false, false>(x, r, jac, c, y, a, b, acc, xp);
-        xn1[i] = make_double2(xp[0], xp[1]);
-        xn2[i] = make_double2(xp[2], xp[3]);
-        // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
-        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, xp, r1.x, r1.y, r2.x, r2.y, s, r, jac);
-        acc[SUM_COST] += pc_core_cost(r);
-        pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
-    }
+    pc_iter_tracks(P, C.cur, C.mu, C.dl_a, C.dl_b, C.kind_next != 0, acc);
     PC_TL(1);
     pc_block_reduce(acc, P.partials);
     const bool last_block = pc_is_last_block(P.ticket);
@@ -589,43 +596,54 @@ __device__ __forceinline__ void pc_chain_control(PsfmSolveCtrl& C, const double*
 // Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket after an agent-scope
 // release; the reading block acquires before touching the other blocks' partials -- cdna_hip_programming.md G16):
 // fixed-order reduction of the per-block partials, then the scalar control step on thread 0.
-__device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
-                                                      int is_init, double* export_sums)
+// totals of the launch's partial rows, in LDS (pc_totals()), valid for every thread of the block after the call
+__device__ __forceinline__ double* pc_totals()
+{
+    __shared__ double s_tot[PC_NSUM];
+    return s_tot;
+}
+__device__ __forceinline__ void pc_reduce_totals(double* partials, int n_blocks)
 {
     // Fixed-order reduction of partials[n_blocks][PC_NSUM]: thread t owns slot (t % 16) of the block rows
     // t/16, t/16 + 16, ...; its loads are independent (issued back to back), summed in increasing row order; the 16
     // row groups are then combined in order by the first PC_NSUM threads.  (One pass, two barriers: a slot-by-slot tree
     // with a barrier per level cost ~40 us per launch when the loads bypass the caches.)
     __shared__ double s_part[16][16];
-    __shared__ double s_tot[PC_NSUM];
-    {
-        const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
-        double v = 0.0;
-        if (k < PC_NSUM) {
-            // all rows of this thread in flight at once (32 for 512 blocks): the loads bypass the caches, so every
-            // batch is a full round trip on the tail of the launch -- one batch instead of four (summed in the same order)
-            for (int b0 = g; b0 < n_blocks; b0 += 16 * PC_RED_ROWS) {
-                double p[PC_RED_ROWS];
+    double* s_tot = pc_totals();
+    const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+    double v = 0.0;
+    if (k < PC_NSUM) {
+        // all rows of this thread in flight at once (32 for 512 blocks): the loads bypass the caches, so every
+        // batch is a full round trip on the tail of the launch -- one batch instead of four (summed in the same order)
+        for (int b0 = g; b0 < n_blocks; b0 += 16 * PC_RED_ROWS) {
+            double p[PC_RED_ROWS];
 #pragma unroll
-                for (int u = 0; u < PC_RED_ROWS; ++u) {
-                    const int bb = b0 + 16 * u;
-                    p[u] = bb < n_blocks ? __hip_atomic_load(&partials[(int64_t)bb * PC_NSUM + k], __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_SYSTEM)
-                                         : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < PC_RED_ROWS; ++u) v = (k == SUM_GMAX) ? fmax(v, p[u]) : v + p[u];
+            for (int u = 0; u < PC_RED_ROWS; ++u) {
+                const int bb = b0 + 16 * u;
+                p[u] = bb < n_blocks ? __hip_atomic_load(&partials[(int64_t)bb * PC_NSUM + k], __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_SYSTEM)
+                                     : 0.0;
             }
+#pragma unroll
+            for (int u = 0; u < PC_RED_ROWS; ++u) v = (k == SUM_GMAX) ? fmax(v, p[u]) : v + p[u];
         }
-        s_part[g][k] = v;
-        __syncthreads();
-        if (threadIdx.x < PC_NSUM) {
-            double t = s_part[0][threadIdx.x];
-            for (int gg = 1; gg < 16; ++gg) t = (threadIdx.x == SUM_GMAX) ? fmax(t, s_part[gg][threadIdx.x]) : t + s_part[gg][threadIdx.x];
-            s_tot[threadIdx.x] = t;
-        }
-        __syncthreads();
     }
+    __syncthreads();       // (a previous round's totals have been consumed)
+    s_part[g][k] = v;
+    __syncthreads();
+    if (threadIdx.x < PC_NSUM) {
+        double t = s_part[0][threadIdx.x];
+        for (int gg = 1; gg < 16; ++gg) t = (threadIdx.x == SUM_GMAX) ? fmax(t, s_part[gg][threadIdx.x]) : t + s_part[gg][threadIdx.x];
+        s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict__ ctrl, double* partials, int n_blocks,
+                                                      int is_init, double* export_sums)
+{
+    pc_reduce_totals(partials, n_blocks);
+    const double* s_tot = pc_totals();
     if (export_sums) {
         if (threadIdx.x < PC_NSUM) export_sums[threadIdx.x] = s_tot[threadIdx.x];
         return;
@@ -637,6 +655,86 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
     *ctrl = C;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// pc_persist: the launch chain's loop inside ONE launch.  Solves that reject steps take 20-40 trust-region iterations;
+// as launches each of them costs a launch gap, a tail behind the last block and a round trip for the control block
+// (~21 us per iteration at 1080p, of which ~5 are arithmetic).  Here the grid stays resident (every block co-resident:
+// <= PC_CHAIN_BLOCKS blocks of 256 at 4 waves per SIMD, the device to ourselves like the persistent frame loop) and the
+// iterations are separated by a device-wide barrier: per-block partial sums written through -> arrival on one of
+// PC_BAR_SHARDS counters -> the last arriver of a shard bumps the top counter -> the last block overall reduces the
+// partials in the fixed order of the launch chain, runs pc_chain_control on its copy of the control block, writes it
+// through and releases the replicated flags the other blocks poll.  Every block keeps the control block in LDS.
+// Same kernels' arithmetic, same reduction order, same control step: the iterates are the launch chain's bit for bit.
+// A block that waits longer than the spin limit (the grid was not co-resident after all) leaves; the control block then
+// still says "not done" and the pc_iter launches the host keeps behind this kernel carry on from it.
+// ------------------------------------------------------------------------------------------------
+#define PC_BAR_SHARDS 32
+#define PC_BAR_WORDS ((2 * PC_BAR_SHARDS + 1) * 32)     // counters / flags 128 bytes apart
+static_assert(sizeof(PsfmSolveCtrl) % 8 == 0, "the control block is broadcast as 8-byte words");
+#define PC_CTRL_WORDS ((int)(sizeof(PsfmSolveCtrl) / 8))
+
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_persist_kernel(PcParams P, unsigned* bar, int spin_limit, int max_rounds)
+{
+    if (*P.stall) return;
+    __shared__ PsfmSolveCtrl s_C;
+    __shared__ int s_state;           // 0 go on, 1 this block is the last arriver, 2 give up
+    const int tid = threadIdx.x;
+    const int nblk = (int)gridDim.x;
+    const int nsh = nblk < PC_BAR_SHARDS ? nblk : PC_BAR_SHARDS;
+    const int sh = (int)blockIdx.x % nsh;
+    const unsigned members = (unsigned)((nblk - sh + nsh - 1) / nsh);
+    if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
+    __syncthreads();
+    for (unsigned it = 0; it < (unsigned)max_rounds; ++it) {
+        if (s_C.done) break;
+        double acc[PC_NSUM];
+        pc_iter_tracks(P, s_C.cur, s_C.mu, s_C.dl_a, s_C.dl_b, s_C.kind_next != 0, acc);
+        pc_block_reduce(acc, P.partials);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have been performed
+        __syncthreads();
+        if (tid == 0) {
+            int state = 0;
+            const unsigned t = __hip_atomic_fetch_add(bar + sh * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (it + 1u) * members - 1u) {
+                const unsigned t2 = __hip_atomic_fetch_add(bar + PC_BAR_SHARDS * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t2 == (it + 1u) * (unsigned)nsh - 1u) state = 1;
+            }
+            s_state = state;
+        }
+        __syncthreads();
+        if (s_state == 1) {
+            // ---- the last block of this round: totals in the launch chain's order, control step, broadcast ----
+            pc_reduce_totals(P.partials, nblk);
+            if (tid == 0) {
+                PsfmSolveCtrl C = s_C;
+                pc_chain_control(C, pc_totals(), 1);
+                C.launches += 1;
+                s_C = C;
+            }
+            __syncthreads();
+            if (tid < PC_CTRL_WORDS)
+                __hip_atomic_store((unsigned long long*)P.ctrl + tid, ((const unsigned long long*)&s_C)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < nsh) __hip_atomic_store(bar + (PC_BAR_SHARDS + 1 + tid) * 32, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            if (tid == 0) {
+                int spins = 0, state = 0;
+                while (__hip_atomic_load(bar + (PC_BAR_SHARDS + 1 + sh) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < it + 1u) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > spin_limit) { state = 2; break; }
+                }
+                s_state = state;
+            }
+            __syncthreads();
+            if (s_state == 2) return;
+            if (tid < PC_CTRL_WORDS)
+                ((unsigned long long*)&s_C)[tid] = __hip_atomic_load((const unsigned long long*)P.ctrl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // pc_fused: the WHOLE solve of a frame in one launch, speculating that every trust-region iteration takes the pure
@@ -1244,6 +1342,29 @@ static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const fl
     return pc_setup(c, P, s);
 }
 
+// The trust-region loop of the launch chain as ONE persistent launch behind pc_init (psfm_pc_persist_kernel), when this call
+// has the device to itself and the grid is co-resident; returns false when it is not used (the caller launches iterations).
+// PSFM_PC_PERSIST=0 keeps one launch per iteration (measurements, tests).
+static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, hipStream_t s)
+{
+    const char* env = getenv("PSFM_PC_PERSIST");          // (read per call: the tests switch it inside one process)
+    if ((env && atoi(env) == 0) || !c->pc_persist_ok || P.export_sums) return false;
+    if (c->pc_persist_blocks < 0) {
+        c->pc_persist_blocks = 0;
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, psfm_pc_persist_kernel, PC_BLOCK, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, c->device) == hipSuccess)
+            c->pc_persist_blocks = per_cu * prop.multiProcessorCount;
+    }
+    if (n_blocks > c->pc_persist_blocks) return false;
+    if (c->sol_bar.ensure(sizeof(unsigned) * PC_BAR_WORDS) != PSFM_OK) return false;
+    if (hipMemsetAsync(c->sol_bar.p, 0, sizeof(unsigned) * PC_BAR_WORDS, s) != hipSuccess) return false;
+    static const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 400000;   // x (s_sleep 2 + one uncached load) ~ 0.3 s
+    hipLaunchKernelGGL(psfm_pc_persist_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, c->sol_bar.as<unsigned>(), spin_limit, 2 * 200 + 64);
+    return true;
+}
+
 // Enqueue one frame's solve with `unroll` iterations and NO host synchronisation: if the solve needs more, its
 // write-back kernel raises the device-side stall flag, which turns everything enqueued behind it into no-ops.
 psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
@@ -1254,6 +1375,9 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
     if (rc != PSFM_OK) return rc;
     const int n_blocks = pc_blocks((int)d.cap);
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    // the whole loop in one launch when possible (two launches behind it for a loop that gave up on its barrier), else
+    // `unroll` launches of one iteration each
+    if (pc_persist_enqueue(c, P, n_blocks, s)) unroll = unroll < 2 ? unroll : 2;
     for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
     PSFM_HIP(hipGetLastError());
@@ -1291,7 +1415,8 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     }
     const int n_blocks = pc_blocks((int)d.cap);
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    if (!pc_persist_enqueue(c, P, n_blocks, s))
+        for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
     return pc_finish_sync(c, P, n_blocks, nullptr, st, s);
 }
@@ -1572,7 +1697,8 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     PSFM_HIP(hipMemcpyAsync(P.ref2, ref2, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
     PSFM_HIP(hipMemcpyAsync(P.scale, scale, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    if (!pc_persist_enqueue(c, P, n_blocks, s))
+        for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
     rc = pc_finish_sync(c, P, n_blocks, out, st, s);
     if (rc != PSFM_OK) return rc;

@@ -34,10 +34,17 @@ def connect_sequences(flow_dirs, traj_dirs, sample_ratio=2, flow_check_thres=1.0
     todo = list(mine)
     errors = []
 
+    n_threads = max(1, min(int(concurrency), len(mine)))
+
     def worker():
         torch.cuda.set_device(device)
         stream = torch.cuda.Stream(device=device)
         try:
+            if n_threads > 1:
+                # several sequences in flight on this GPU: launches only -- the persistent forms (the frame loop of track mode,
+                # the trust-region loop of a solve that rejects steps) need the device to themselves and would take the
+                # device gate, i.e. serialise the sequences
+                _hip.context().set_chain_mode(1)
             with torch.cuda.stream(stream):
                 while True:
                     with lock:
@@ -55,7 +62,7 @@ def connect_sequences(flow_dirs, traj_dirs, sample_ratio=2, flow_check_thres=1.0
         finally:
             _hip.release_thread_contexts()
 
-    threads = [threading.Thread(target=worker) for _ in range(max(1, min(int(concurrency), len(mine))))]
+    threads = [threading.Thread(target=worker) for _ in range(n_threads)]
     for t in threads:
         t.start()
     for t in threads:

@@ -278,3 +278,48 @@ def test_track_optimize_full_size_properties(pt):
         assert [s["iterations"] for s in Rk.solve_stats] == [s["iterations"] for s in O.solves]
         del d, R, R_seq
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("H,W,T,r,seed", [(120, 200, 9, 2, 61), (90, 140, 8, 3, 62), (436, 1024, 6, 2, 63)])
+def test_launch_chain_as_one_persistent_launch_is_the_same_solve(pt, monkeypatch, H, W, T, r, seed):
+    """Solves that reject steps run the launch chain; with the device to itself the chain's loop is ONE persistent launch
+    (psfm_pc_persist_kernel: a device-wide barrier per trust-region iteration) instead of one launch per iteration.  Both forms
+    run the same per-track code, the same reduction order and the same control step: identical bits -- and the oracle's
+    decisions.  Hard flows (sigma 0.3, 5 % occluders): every solve takes 20-40 iterations with rejections and dogleg steps."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    d = psfm_synth.synth_sequence(T, H, W, seed=seed, stride2=True, **psfm_synth.HARD)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    assert sum(s["iterations"] - s["successful_steps"] for s in O.solves) > T and sum(s["dogleg_nonGN"] for s in O.solves) > T
+    ctx = _hip.context()
+    ctx.set_solver(1, 0)            # the launch chain for every solve
+    try:
+        res = {}
+        for persist in ("1", "0"):
+            monkeypatch.setenv("PSFM_PC_PERSIST", persist)
+            res[persist] = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        A, B = res["1"], res["0"]
+        # (bit-equal where the lanes are placed deterministically; on larger grids births pop lanes from the shared stacks in
+        # atomic order, which permutes the partial sums of two runs of the SAME form as well)
+        assert np.array_equal(A.birth, B.birth) and np.array_equal(A.length, B.length)
+        assert float(np.abs(A.xy - B.xy).max()) <= 1e-9
+        if H * W < 100000:
+            assert np.array_equal(A.xy, B.xy)
+        keys = ("iterations", "successful_steps", "termination", "dogleg_nonGN")
+        assert [[s[k] for k in keys] for s in A.solve_stats] == [[s[k] for k in keys] for s in B.solve_stats]
+        assert np.array_equal(A.birth, O.birth) and np.array_equal(A.length, O.length)
+        assert float(np.abs(A.xy - O.xy).max()) <= TOL
+        assert [s["iterations"] for s in A.solve_stats] == [s["iterations"] for s in O.solves]
+        assert [s["termination"] for s in A.solve_stats] == [s["termination"] for s in O.solves]
+        # the batch entry point too
+        uv, ref1, ref2, scale, flow12 = _batch(60, 80, 3000, 2, 0.5)
+        outs = {}
+        for persist in ("1", "0"):
+            monkeypatch.setenv("PSFM_PC_PERSIST", persist)
+            outs[persist] = pt.particlesfm.optimize_location(uv, ref1, ref2, scale, flow12, uv.shape[0], 80, 60)
+            outs[persist + "s"] = dict(pt.particlesfm.optimize_location.last_stats)
+        assert np.array_equal(outs["1"], outs["0"]) and outs["1s"] == outs["0s"] and outs["1s"]["iterations"] > outs["1s"]["successful_steps"]
+    finally:
+        ctx.set_solver(0, 0)
