@@ -167,9 +167,21 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2):
     comm = psfm_dist.TorchComm()
     eng = HipShardEngine()
 
+    # The four stacks are OWNED by frame-pair slices (Stage A's shards): a rank keeps 1 / world of the sequence and
+    # receives Stage B's frames by broadcast from their owners, two frames ahead (psfm_dist.FrameWindow).  (The generator makes
+    # the whole sequence on every rank first -- synthetic data has no files to read a slice of; the rest is freed here.)
+    n_total = frames - 1
+    if world > 1:
+        lo, hi = psfm_dist.shard_range(n_total, rank, world)
+        lo2, hi2 = psfm_dist.shard_range(n_total - 1, rank, world)
+        d = {"flows_f": d["flows_f"][lo:hi].clone(), "flows_b": d["flows_b"][lo:hi].clone(),
+             "flows_f2": d["flows_f2"][lo2:hi2].clone(), "flows_b2": d["flows_b2"][lo2:hi2].clone()}
+        torch.cuda.empty_cache()
+
     def once():
         return psfm_dist.connect_sharded(eng, d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], THRES, RATIO,
-                                         flow_check_slice, comm=comm, keep_on_device=True)   # result left in HBM, like the headline step
+                                         flow_check_slice, comm=comm, keep_on_device=True,   # result left in HBM, like the headline step
+                                         n_flows_total=n_total if world > 1 else None)
 
     def sync():
         if world > 1:
@@ -193,7 +205,9 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2):
            "ms_per_sequence": 1e3 * dt, "trajectory_points_per_s": pts / dt, "points": int(pts), "trajectories": int(part["n_traj"]),
            "solves": part["n_solves"], "trust_region_iterations": part["solver_iterations"],
            "solver_counters": dict(eng.counters), "local_trajectories_rank0": int(part["ids"].numel())}
-    if rank == 0:   # the one-GPU product call on the same tensors: time and counts
+    out["flow_stacks_per_rank_GB"] = sum(int(v.numel()) * 4 for v in d.values()) / 1e9
+    out["flow_ownership"] = "frame-pair slices + per-frame broadcast (psfm_dist.FrameWindow)" if world > 1 else "whole sequence (one rank)"
+    if rank == 0 and world == 1:   # the one-GPU product call on the same tensors: time and counts
         info = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], THRES, RATIO, return_device=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

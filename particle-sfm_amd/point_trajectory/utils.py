@@ -36,7 +36,17 @@ def load_flows(dir):
     return [read_flo(name) for name in sorted(glob.glob(dir + "/*.flo"))]
 
 
-def load_flows_device(dir, device=None, n_staging=8, n_readers=4):
+def load_flows_device_slice(dir, rank, world, device=None, **kw):
+    """This rank's frame-pair slice of a stack (psfm_dist.shard_range over the sorted .flo names): what a rank of the
+    track-sharded mode owns (psfm_dist.connect_sharded(..., n_flows_total=n)).  Returns (tensor (k,H,W,2), n_total) --
+    1 / world of the ingest per rank instead of the whole stack on every rank."""
+    import psfm_dist
+    names = sorted(glob.glob(dir + "/*.flo"))
+    lo, hi = psfm_dist.shard_range(len(names), int(rank), int(world))
+    return load_flows_device(dir, device=device, _names=names[lo:hi], _probe=names[:1], **kw), len(names)
+
+
+def load_flows_device(dir, device=None, n_staging=8, n_readers=4, _names=None, _probe=None):
     """`load_flows` (utils.py:26-32) straight into HBM: the .flo files are read by a few reader threads into pinned
     host buffers (owned by the context, reused across calls) and copied to their slot of one (n,H,W,2) device tensor with
     asynchronous H2D copies on a side stream, so disk / page-cache reads and PCIe transfers overlap (at
@@ -44,10 +54,16 @@ def load_flows_device(dir, device=None, n_staging=8, n_readers=4):
     Returns a float32 device tensor (empty (0,0,0,2) if no files)."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
-    names = sorted(glob.glob(dir + "/*.flo"))
+    names = sorted(glob.glob(dir + "/*.flo")) if _names is None else list(_names)
     ctx = _hip.context(device)
     dev = torch.device("cuda", ctx.device)
     if not names:
+        if _probe:          # an empty slice of a non-empty stack keeps the frame shape
+            with open(_probe[0], 'rb') as f:
+                tag = np.fromfile(f, np.float32, count=1)[0]
+                assert tag == TAG_FLOAT, 'Flow number %r incorrect. Invalid .flo file %r' % (tag, _probe[0])
+                w = int(np.fromfile(f, np.int32, count=1)[0]); h = int(np.fromfile(f, np.int32, count=1)[0])
+            return torch.zeros((0, h, w, 2), dtype=torch.float32, device=dev)
         return torch.zeros((0, 0, 0, 2), dtype=torch.float32, device=dev)
 
     def header(f, name):

@@ -69,6 +69,26 @@ class TorchComm:
         dist.all_gather_object(out, obj, group=self.group)
         return out
 
+    def broadcast_(self, t, src, async_op=False):
+        """`t` of rank `src` (a rank of this group) into `t` on every rank.  Returns an object with .wait() (async_op: the
+        transfer is in flight -- RCCL runs it on its own stream; wait() orders the caller's stream behind it)."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return _Done()
+        gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
+        if self.cpu_only and t.is_cuda:           # gloo moves host memory: stage (synchronous; tests only)
+            h = t.cpu()
+            dist.broadcast(h, src=gsrc, group=self.group)
+            t.copy_(h)
+            return _Done()
+        w = dist.broadcast(t, src=gsrc, group=self.group, async_op=async_op)
+        return w if async_op else _Done()
+
+
+class _Done:
+    def wait(self):
+        return True
+
 
 def _comm(comm, group=None):
     return comm if comm is not None else TorchComm(group)
@@ -106,20 +126,28 @@ def unpack_bits(packed, H, W):
     return bits.reshape(packed.shape[0], -1)[:, :H * W].reshape(-1, H, W)
 
 
-def flow_check_sharded(flows_f, flows_b, thres, check_fn, group=None, comm=None):
+def flow_check_sharded(flows_f, flows_b, thres, check_fn, group=None, comm=None, n_total=None):
     """Frame-pair-sharded flow_check with an all-gather stitch.
 
-    flows_f / flows_b: (n,H,W,2) tensors present on every rank (or at least this rank's slice valid);
+    flows_f / flows_b: (n,H,W,2) tensors present on every rank -- or, with n_total, ONLY this rank's slice
+    [shard_range(n_total, rank, world)) of the n_total pairs (the stacks are owned by frame-pair shards);
     check_fn(f_slice, b_slice, thres) -> (k,H,W) uint8/bool tensor for a slice (on GPU:
     point_trajectory.utils.flow_check_device; in the CPU tests: the oracle).  Returns the full (n,H,W) uint8 stack
     on every rank."""
     import torch
     comm = _comm(comm, group)
     world, rank = comm.world, comm.rank
-    n, H, W = int(flows_f.shape[0]), int(flows_f.shape[1]), int(flows_f.shape[2])
-    lo, hi = shard_range(n, rank, world)
-    mine = check_fn(flows_f[lo:hi], flows_b[lo:hi], thres) if hi > lo else torch.zeros((0, H, W), dtype=torch.uint8,
-                                                                                       device=flows_f.device)
+    H, W = int(flows_f.shape[1]), int(flows_f.shape[2])
+    if n_total is None:
+        n = int(flows_f.shape[0])
+        lo, hi = shard_range(n, rank, world)
+        f_mine, b_mine = flows_f[lo:hi], flows_b[lo:hi]
+    else:
+        n = int(n_total)
+        lo, hi = shard_range(n, rank, world)
+        assert int(flows_f.shape[0]) == hi - lo == int(flows_b.shape[0]), "this rank's slice of the pairs expected"
+        f_mine, b_mine = flows_f, flows_b
+    mine = check_fn(f_mine, b_mine, thres) if hi > lo else torch.zeros((0, H, W), dtype=torch.uint8, device=flows_f.device)
     if world == 1:
         return mine.to(torch.uint8)
     per = (n + world - 1) // world                       # all_gather needs equal shapes: pad the short shards
@@ -219,8 +247,57 @@ def global_ids_device(keys, comm):
     return ids, int(sum(cnts))
 
 
+class FrameWindow:
+    """Stage B's view of a frame stack that is OWNED by frame-pair slices (Stage A's shards): frame k lives on
+    rank owner(k) only; every rank receives it by broadcast `ahead` frames before the recurrence needs it -- in flight
+    behind the frames being computed -- and drops it once the recurrence is past it.  Per rank: its slice of the stack
+    plus ahead + 2 frames, instead of the whole stack.  world == 1: the local stack itself.
+    `touched` records the frames this rank read from its OWN slice (tests: never a frame of another owner)."""
+
+    def __init__(self, local, n_total, comm, ahead=2):
+        self.local, self.n, self.comm, self.ahead = local, int(n_total), comm, int(ahead)
+        self.lo, self.hi = shard_range(self.n, comm.rank, comm.world)
+        assert int(local.shape[0]) == self.hi - self.lo, "this rank's slice of the frames expected"
+        self.bounds = [shard_range(self.n, r, comm.world) for r in range(comm.world)]
+        self.live, self.pool, self.touched = {}, [], []
+
+    def owner(self, k):
+        for r, (lo, hi) in enumerate(self.bounds):
+            if lo <= k < hi:
+                return r
+        raise IndexError(k)
+
+    def _request(self, k):
+        import torch
+        if k in self.live or not (0 <= k < self.n):
+            return
+        src = self.owner(k)
+        buf = self.pool.pop() if self.pool else torch.empty(tuple(self.local.shape[1:]), dtype=self.local.dtype,
+                                                            device=self.local.device)
+        if src == self.comm.rank:
+            buf.copy_(self.local[k - self.lo])
+            self.touched.append(k)
+        self.live[k] = (buf, self.comm.broadcast_(buf, src, async_op=True))
+
+    def get(self, k):
+        """frame k (requests k .. k + ahead on the way; every rank calls this with the same k in the same order)"""
+        if self.comm.world == 1:
+            return self.local[k]
+        for j in range(k, min(self.n, k + self.ahead + 1)):
+            self._request(j)
+        buf, work = self.live[k]
+        work.wait()
+        return buf
+
+    def release_below(self, k):
+        for j in [j for j in self.live if j < k]:
+            buf, work = self.live.pop(j)
+            work.wait()
+            self.pool.append(buf)
+
+
 def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, check_fn, group=None, comm=None,
-                    keep_on_device=False):
+                    keep_on_device=False, n_flows_total=None):
     """main_connect_point_trajectories.py:36-53 for ONE sequence on all ranks of `group`, exactly.
 
     flows_*: (n,H,W,2) float32 tensors on every rank (flows_f2 / flows_b2 None: track() instead of track_optimize());
@@ -230,37 +307,57 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
         begin(n_flows, H, W, ratio, g0, g1, optimize)
         step(t, flow_t, occ_t) -> uint8 tensor (G marks of this rank's survivors + 1 survivor byte), exchanged here
         after_exchange(t, x); solve(t, flow_{t-1}, flow_t, flow2_{t-1}, occ2_{t-1}, reduce); finish() -> CSR + stats
+    n_flows_total: the four stacks are OWNED by frame-pair slices -- every rank passes only its slice
+    [shard_range(n, rank, world)) of each stack (n = n_flows_total pairs, n - 1 stride-2 pairs; load_flows_device(dir,
+    rank=, world=) reads exactly that); Stage B's frames arrive by broadcast (FrameWindow).  Per-rank HBM for the
+    stacks: 1 / world of the sequence + a window of a few frames.
     Returns {"birth","length","off","xy": this rank's trajectories; "ids": their ids in the single-process order;
     "n_traj": trajectories over all ranks; "solve_stats"; "occ","occ2"}."""
     comm = _comm(comm, group)
     world, rank = comm.world, comm.rank
     optimize = flows_f2 is not None
-    n_flows, H, W = int(flows_f.shape[0]), int(flows_f.shape[1]), int(flows_f.shape[2])
+    owned = n_flows_total is not None
+    n_flows, H, W = int(n_flows_total if owned else flows_f.shape[0]), int(flows_f.shape[1]), int(flows_f.shape[2])
+    n2 = max(n_flows - 1, 0)
     r = int(sample_ratio)
     GW, GH = (W + r - 1) // r, (H + r - 1) // r
     # ---- Stage A: occlusion maps, frame-pair shards + one all-gather per stack ----
-    occ = flow_check_sharded(flows_f, flows_b, thres, check_fn, comm=comm)
-    occ2 = flow_check_sharded(flows_f2, flows_b2, thres, check_fn, comm=comm) if optimize and flows_f2.shape[0] > 0 else None
+    occ = flow_check_sharded(flows_f, flows_b, thres, check_fn, comm=comm, n_total=n_flows if owned else None)
+    occ2 = (flow_check_sharded(flows_f2, flows_b2, thres, check_fn, comm=comm, n_total=n2 if owned else None)
+            if optimize and n2 > 0 else None)
     # ---- Stage B: the recurrence, tracks split by birth row band ----
+    # n_flows_total given: the four stacks are owned by Stage A's frame-pair shards (every rank passed its slice only); the
+    # forward stacks reach the other ranks frame by frame, broadcast from their owner two frames ahead of the recurrence
+    wf = FrameWindow(flows_f, n_flows, comm) if owned else None
+    w2 = FrameWindow(flows_f2, n2, comm) if owned and optimize and n2 > 0 else None
     g0, g1 = band_range(GH, GW, rank, world)
     engine.begin(n_flows, H, W, r, g0, g1, optimize)
     reduce = make_reduce(comm=comm)
     for t in range(n_flows):
-        x = engine.step(t, flows_f[t], occ[t])                               # track.py:33-47 for the own tracks
+        f_t = wf.get(t) if owned else flows_f[t]
+        x = engine.step(t, f_t, occ[t])                                      # track.py:33-47 for the own tracks
         comm.all_reduce_max_(x)                                              # marks of every rank's survivors
         engine.after_exchange(t, x)
         if optimize and t + 1 >= 2:                                          # track_optimize.py:49-50
-            engine.solve(t, flows_f[t - 1], flows_f[t], flows_f2[t - 1], occ2[t - 1], reduce)
+            f_prev = wf.get(t - 1) if owned else flows_f[t - 1]
+            f2_prev = w2.get(t - 1) if owned else flows_f2[t - 1]
+            engine.solve(t, f_prev, f_t, f2_prev, occ2[t - 1], reduce)
+        if owned:
+            wf.release_below(t)              # (frame t is the next solve's flow01)
+            if w2 is not None:
+                w2.release_below(t)
     if keep_on_device:      # the trajectories stay in the engine's HBM (psfm_result_device); only their ids are formed
         info, keys = engine.finish_device(r, W)
         ids, n_traj = global_ids_device(keys, comm)
         return {"info": info, "ids": ids, "n_traj": n_traj, "n_points_local": int(info.n_points), "n_solves": int(info.n_solves),
-                "solver_iterations": int(info.solver_iterations), "occ": occ, "occ2": occ2, "band": (g0, g1)}
+                "solver_iterations": int(info.solver_iterations), "occ": occ, "occ2": occ2, "band": (g0, g1),
+                "frames_read_from_own_slice": (sorted(wf.touched) if owned else None)}
     birth, length, off, xy, stats = engine.finish()
     first = xy[off[:-1]] if len(birth) else np.zeros((0, 2))
     ids, n_traj = global_ids(birth, length, first, n_flows, r, GW, comm=comm)
     return {"birth": birth, "length": length, "off": off, "xy": xy, "ids": ids, "n_traj": n_traj, "solve_stats": stats,
-            "occ": occ, "occ2": occ2, "band": (g0, g1)}
+            "occ": occ, "occ2": occ2, "band": (g0, g1), "frames_read_from_own_slice": (sorted(wf.touched) if owned else None),
+            "stride2_frames_read_from_own_slice": (sorted(w2.touched) if w2 is not None else None)}
 
 
 def gather_result(part, group=None, comm=None):

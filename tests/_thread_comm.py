@@ -39,6 +39,16 @@ class ThreadComm:
     def all_gather_object(self, obj):
         return self._exchange(obj)
 
+    def broadcast_(self, t, src, async_op=False):
+        vals = self._exchange(t.clone() if self.rank == src else None)
+        if self.rank != src:
+            t.copy_(vals[src].to(t.device))
+
+        class Done:
+            def wait(self):
+                return True
+        return Done()
+
 
 def run_ranks(world, fn):
     """fn(comm) on `world` threads; returns the list of results (re-raises the first exception)."""

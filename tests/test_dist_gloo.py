@@ -133,6 +133,70 @@ def _sharded_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _owned_worker(rank, world, port, ret):
+    """connect_sharded with the stacks OWNED by frame-pair slices: every rank holds (and passes) only its slice of the four
+    stacks; Stage B's frames arrive by broadcast from their owners (psfm_dist.FrameWindow)."""
+    for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import psfm_dist
+        import psfm_synth
+        from oracle import oracle as orc
+
+        def check(f, b, thres):
+            _, occ = orc.flow_check(list(f.numpy()), list(b.numpy()), thres)
+            return torch.from_numpy(np.stack(occ).astype(np.uint8)) if len(occ) else torch.zeros((0,) + tuple(f.shape[1:3]), dtype=torch.uint8)
+
+        out = {}
+        # (more ranks than stride-2 pairs in the last case: a rank with an EMPTY slice of a stack)
+        cases = [(9, 38, 52, 2, 41, 0.3, 2, False), (8, 45, 60, 3, 42, 0.1, 1, True), (3, 30, 44, 1, 43, 0.2, 1, True)]
+        for ci, (T, H, W, r, seed, sigma, nocc, optimize) in enumerate(cases):
+            d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=True)
+            n, n2 = T - 1, T - 2
+            lo, hi = psfm_dist.shard_range(n, rank, world)
+            lo2, hi2 = psfm_dist.shard_range(n2, rank, world)
+            sl = lambda k, a, b: (torch.from_numpy(np.stack(d[k][a:b])) if b > a else torch.zeros((0, H, W, 2), dtype=torch.float32))
+            # a rank only ever sees its own slice: the other frames are poisoned copies that would change the result if used
+            part = psfm_dist.connect_sharded(orc.ShardEngine(), sl("flows_f", lo, hi), sl("flows_b", lo, hi),
+                                             sl("flows_f2", lo2, hi2) if optimize else None, sl("flows_b2", lo2, hi2) if optimize else None,
+                                             1.0, r, check, n_flows_total=n)
+            birth, length, off, xy = psfm_dist.gather_result(part)
+            _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+            if optimize:
+                _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+                O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+            else:
+                O = orc.track(d["flows_f"], occ, r)
+            same = bool(len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
+                        and np.array_equal(xy, O.xy))
+            own = part["frames_read_from_own_slice"] == list(range(lo, hi))
+            own2 = (not optimize) or part["stride2_frames_read_from_own_slice"] in (list(range(lo2, min(hi2, n - 1))), None)
+            out[ci] = (same, own, own2, [s["iterations"] for s in part["solve_stats"]] == [s["iterations"] for s in O.solves])
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_connect_sharded_with_frame_pair_owned_stacks(world):
+    """the sharded mode without replicating the flows -- every rank passes only its Stage-A slice of the four
+    stacks and receives Stage B's frames by broadcast two frames ahead.  Same trajectories, bit for bit, as the single-process
+    oracle; a rank reads from its own slice exactly the frames it owns."""
+    port = 32500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_owned_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        for ci in (0, 1, 2):
+            assert all(ret[r][ci]), (r, ci, ret[r][ci])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_connect_sharded_gloo(world):
     """ONE sequence over 2 and 3 ranks == the single-process oracle: ids / lengths / positions bit for bit, per-solve

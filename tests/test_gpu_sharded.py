@@ -72,6 +72,43 @@ def test_connect_sharded_hip_engine(world, T, H, W, r, seed, sigma, nocc, optimi
         assert res[0][2]["fused_redone"] >= len(O.solves) // 2  # noisy sequence: the chain protocol did the work
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_connect_sharded_hip_engine_frame_pair_owned_stacks(world):
+    """The sharded mode without replicated flows on the GPU engine: every thread-rank passes only its Stage-A slice of the four
+    stacks (device tensors); Stage B's frames come by broadcast (psfm_dist.FrameWindow).  Same result as the oracle."""
+    import torch
+    import psfm_dist
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    from point_trajectory.shard import HipShardEngine, flow_check_slice
+    T, H, W, r, seed = 10, 60, 84, 2, 22
+    d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=0.05, n_occluders=1, stride2=True)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n, n2 = T - 1, T - 2
+
+    def rank_fn(comm):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            try:
+                lo, hi = psfm_dist.shard_range(n, comm.rank, comm.world)
+                lo2, hi2 = psfm_dist.shard_range(n2, comm.rank, comm.world)
+                sl = lambda k, a, b: torch.from_numpy(np.stack(d[k][a:b])).to(dev)
+                part = psfm_dist.connect_sharded(HipShardEngine(), sl("flows_f", lo, hi), sl("flows_b", lo, hi), sl("flows_f2", lo2, hi2),
+                                                 sl("flows_b2", lo2, hi2), 1.0, r, flow_check_slice, comm=comm, n_flows_total=n)
+                assert part["frames_read_from_own_slice"] == list(range(lo, hi))
+                return psfm_dist.gather_result(part, comm=comm), [s["iterations"] for s in part["solve_stats"]]
+            finally:
+                _hip.release_thread_contexts()
+
+    res = run_ranks(world, rank_fn)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    for (birth, length, off, xy), its in res:
+        assert np.array_equal(birth, O.birth) and np.array_equal(length, O.length) and float(np.abs(xy - O.xy).max()) <= 1e-4
+        assert its == [s["iterations"] for s in O.solves]
+
+
 def _proc_worker(rank, world, port, ret):
     """one PROCESS per rank on the box's single GPU, torch.distributed over gloo (device tensors staged through the host by
     psfm_dist.TorchComm): the multi-process plumbing of connect_sharded with the HIP engine"""
