@@ -1,7 +1,9 @@
 """Random sequences through track_optimize on the device vs the CPU oracle: ids / lengths / per-solve iteration counts
-and terminations must be equal, positions within 1e-9 px (bit-equal whenever no solve left the Gauss-Newton path).
+and terminations must be equal, positions within 1e-5 px (the device's solver arithmetic differs from the restatement's by
+rounding since round 3; long noisy solves amplify that to ~1e-7).  A third of the cases drift ~10 px per frame (the 20 px gate
+of loss02_scale, tracks leaving the image).  Prints one JSON line at the end.
 Usage: python scripts/stress_optimize.py [n_cases] [seed]"""
-import os, sys, time
+import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "particle-sfm_amd"))
 import numpy as np
@@ -10,14 +12,18 @@ from point_trajectory.track_optimize import track_optimize
 from oracle import oracle as orc
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+orc.set_num_threads(min(8, os.cpu_count() or 1))    # (tiny maps: the OpenMP loops of the oracle crawl on all 256 cores of a GPU box)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = exact = 0
+bad = exact = iters = rejected = 0
+worst = 0.0
 t0 = time.time()
 for k in range(n_cases):
     H, W = int(rng.integers(40, 200)), int(rng.integers(40, 240))
     T, r = int(rng.integers(4, 14)), int(rng.integers(1, 5))
     sigma, nocc = float(rng.uniform(0.02, 0.6)), int(rng.integers(0, 4))
-    d = psfm_synth.synth_sequence(T, H, W, seed=int(rng.integers(1 << 30)), sigma=sigma, n_occluders=nocc, stride2=True)
+    drift = (float(rng.uniform(-11, 11)), float(rng.uniform(-4, 4))) if rng.uniform() < 0.33 else (0.0, 0.0)
+    d = psfm_synth.synth_sequence(T, H, W, seed=int(rng.integers(1 << 30)), sigma=sigma, n_occluders=nocc, stride2=True,
+                                  amp=float(rng.uniform(1.0, 3.0)), drift=drift, warp_b=drift != (0.0, 0.0))
     _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
     _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
     O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
@@ -27,8 +33,14 @@ for k in range(n_cases):
             and [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves])
     err = float(np.abs(R.xy - O.xy).max()) if same else float("inf")
     non_gn = sum(s["dogleg_nonGN"] for s in O.solves)
-    if not same or err > 1e-9 or (non_gn == 0 and err != 0.0):
+    worst = max(worst, err if same else 0.0)
+    iters += sum(s["iterations"] for s in O.solves); rejected += sum(s["iterations"] - s["successful_steps"] for s in O.solves)
+    if not same or err > 1e-5:
         bad += 1
         print("MISMATCH case %d: %dx%d T=%d r=%d sigma=%.3f occluders=%d: same=%s err=%.3e nonGN=%d" % (k, H, W, T, r, sigma, nocc, same, err, non_gn))
     exact += int(err == 0.0)
-print("%d cases, %d mismatches, %d bit-equal, %.1f s" % (n_cases, bad, exact, time.time() - t0))
+    if (k + 1) % 20 == 0:       # (progress: a run cut short by a timeout still reports what it checked)
+        print(json.dumps({"cases_so_far": k + 1, "mismatches": bad, "max_abs_dxy_px": worst, "trust_region_iterations": iters,
+                          "rejected_steps": rejected, "seconds": round(time.time() - t0, 1)}), flush=True)
+print(json.dumps({"cases": n_cases, "mismatches": bad, "bit_equal": exact, "max_abs_dxy_px": worst, "trust_region_iterations": iters,
+                  "rejected_steps": rejected, "seconds": round(time.time() - t0, 1)}))
