@@ -238,6 +238,16 @@ psfm_status psfm_shard_solve_export(psfm_ctx* ctx, const float* flow01, const fl
                                     const uint8_t* occ02, int frame, int kind, int k, double* sums_out, void* stream);
 psfm_status psfm_shard_solve_control(psfm_ctx* ctx, int frame, int kind, int k, const double* totals, int32_t* done_host,
                                      int32_t* redo_host, psfm_solve_stats* stats_host, void* stream);
+/* The fused path without a host round trip per solve: psfm_shard_solve_control_async runs the control step of a fused export
+ * (kind 0, k iterations) and returns; psfm_shard_window_state synchronises once for a whole window of frames -- the stalled
+ * frame (a solve that did not go as speculated; every later launch of the context has been a no-op since) or -1, and the
+ * statistics of the window's solves.  The caller then redoes the stalled solve (restore + the per-iteration protocol) and
+ * re-runs the frames behind it. */
+psfm_status psfm_shard_solve_control_async(psfm_ctx* ctx, int frame, int k, const double* totals, void* stream);
+psfm_status psfm_shard_window_state(psfm_ctx* ctx, int f_lo, int f_hi, psfm_solve_stats* stats_host, int32_t* stalled_frame,
+                                    void* stream);
+/* the stall flag as of the last control step the device has completed, without synchronising (-1: none) */
+psfm_status psfm_shard_peek_stall(psfm_ctx* ctx, int32_t* stalled_frame);
 psfm_status psfm_shard_solve_restore(psfm_ctx* ctx, int frame, void* stream);
 psfm_status psfm_shard_solve_writeback(psfm_ctx* ctx, int frame, const psfm_solve_stats* stats, void* stream);
 psfm_status psfm_shard_solve_record(psfm_ctx* ctx, const psfm_solve_stats* stats);

@@ -59,6 +59,7 @@ extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, 
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;
     c->res_n_flows = n_flows;
+    *(int32_t*)((char*)c->host_pinned + c->host_pinned_bytes - 64) = 0;
     delete c->shard_dims;
     c->shard_dims = new PsfmTrackDims(d);
     c->shard_optimize = optimize != 0;
@@ -101,10 +102,59 @@ extern "C" psfm_status psfm_shard_solve_control(psfm_ctx* c, int frame, int kind
     return PSFM_OK;
 }
 
+// The control step of a fused export WITHOUT reading anything back: the caller goes on enqueuing the next frames and looks at
+// a whole window of solves at once (psfm_shard_window_state).  A solve that did not go as speculated raises the device-side
+// stall flag, which turns every later launch of this context into a no-op until psfm_shard_solve_restore.
+extern "C" psfm_status psfm_shard_solve_control_async(psfm_ctx* c, int frame, int k, const double* totals, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    psfm_status st = psfm_solve_control(c, *c->shard_dims, frame, 0, k, totals, (hipStream_t)stream);
+    if (st != PSFM_OK) return st;
+    // the stall flag follows the control step into pinned memory: psfm_shard_peek_stall reads it without a synchronisation
+    int32_t* peek = (int32_t*)((char*)c->host_pinned + c->host_pinned_bytes - 64);
+    PSFM_HIP(hipMemcpyAsync(peek, &c->counters.as<PsfmCounters>()->stall, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PSFM_OK;
+}
+
+// The stall flag as of the last control step the device has COMPLETED (no synchronisation: the value lags the queue by the
+// frames in flight): frame whose solve stalled, or -1.
+extern "C" psfm_status psfm_shard_peek_stall(psfm_ctx* c, int32_t* stalled_frame)
+{
+    if (!c || !stalled_frame) { psfm_set_error("psfm_shard_peek_stall: NULL argument"); return PSFM_ERR_ARG; }
+    const volatile int32_t* peek = (const volatile int32_t*)((char*)c->host_pinned + c->host_pinned_bytes - 64);
+    const int32_t v = *peek;
+    *stalled_frame = v ? v - 1 : -1;
+    return PSFM_OK;
+}
+
+// Synchronises: the stalled frame (-1: none) and the statistics of the solves of frames [f_lo, f_hi] (those below the stalled
+// frame are final; a frame whose solve had no track reports termination -1).
+extern "C" psfm_status psfm_shard_window_state(psfm_ctx* c, int f_lo, int f_hi, psfm_solve_stats* stats_host, int32_t* stalled_frame,
+                                               void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    const PsfmTrackDims& d = *c->shard_dims;
+    if (f_lo < 1 || f_hi < f_lo || f_hi >= d.n_flows || !stats_host || !stalled_frame) {
+        psfm_set_error("psfm_shard_window_state: bad argument (frames %d..%d)", f_lo, f_hi);
+        return PSFM_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
+    PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipMemcpyAsync(stats_host, c->sol_stats.as<psfm_solve_stats>() + f_lo, sizeof(psfm_solve_stats) * (size_t)(f_hi - f_lo + 1),
+                            hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    *stalled_frame = hc->stall ? hc->stall - 1 : -1;
+    return PSFM_OK;
+}
+
 extern "C" psfm_status psfm_shard_solve_restore(psfm_ctx* c, int frame, void* stream)
 {
     PSFM_SHARD_CHECK(c);
     PsfmGate gate(c->device, 0);
+    *(int32_t*)((char*)c->host_pinned + c->host_pinned_bytes - 64) = 0;     // (the caller has synchronised: nothing is in flight)
     return psfm_solve_restore(c, *c->shard_dims, frame, (hipStream_t)stream);
 }
 

@@ -17,6 +17,8 @@ class HipShardEngine:
         self.ctx = ctx or _hip.context()
         self.k = int(k)                    # iterations speculated per fused solve; follows what the sequence needs
         self._need = []                    # ... = the most a clean solve of the last 16 frames needed
+        self._pending = []                 # solves enqueued since the last checkpoint: (frame, the tensors a redo needs)
+        self.check_every = 16              # frames between two checkpoints (earlier when stalled() says a solve has to be redone)
         self.counters = {"fused": 0, "fused_redone": 0}
 
     @property
@@ -54,34 +56,69 @@ class HipShardEngine:
         return bool(done.value), bool(redo.value), st
 
     def solve(self, t, flow_prev, flow_cur, flow2_prev, occ2_prev, reduce):
-        """track_optimize.py:49-50 for the own tracks: fused export -> sums over the ranks -> control; the launch chain
-        (one export / reduce / control per trust-region iteration) redoes a solve that did not go as speculated."""
+        """track_optimize.py:49-50 for the own tracks: fused export -> sums over the ranks -> control, all ENQUEUED -- nothing is
+        read back here.  A solve that does not go as speculated raises the device-side stall flag (every later launch of this
+        context is a no-op from then on); checkpoint() finds out, redoes it with the launch chain (one export / reduce / control
+        per trust-region iteration) and tells the driver where to resume."""
         L, h = _hip.lib(), self.ctx.handle
         p = (_hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ2_prev))
         k = max(1, min(K_MAX, self.k))
         mask = [(i % N_SUM) == SUM_GMAX for i in range(k * N_SUM)]
         _hip.check(L.psfm_shard_solve_export(h, *p, int(t), 0, k, _hip.ptr(self.sums), self._sp()))
         reduce(self.sums[:k * N_SUM], mask)
-        done, redo, st = self._control(t, 0, k)
-        if not redo:
-            assert done
+        _hip.check(L.psfm_shard_solve_control_async(h, int(t), k, _hip.ptr(self.sums), self._sp()))
+        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev)))    # (keeps the frames alive for a redo)
+
+    def stalled(self):
+        """True once the device has got to a solve that did not go as speculated (read from pinned memory, no synchronisation)."""
+        v = ctypes.c_int32(-1)
+        _hip.check(_hip.lib().psfm_shard_peek_stall(self.ctx.handle, ctypes.byref(v)))
+        return v.value >= 0
+
+    def checkpoint(self, reduce):
+        """One host synchronisation for all solves enqueued since the last call.  Returns None when every one of them went as
+        speculated, else the frame whose solve has been redone here: the frames behind it were no-ops and must be run again."""
+        if not self._pending:
+            return None
+        L, h = _hip.lib(), self.ctx.handle
+        f_lo, f_hi = self._pending[0][0], self._pending[-1][0]
+        stats = (_hip.SolveStats * (f_hi - f_lo + 1))()
+        stalled = ctypes.c_int32(-1)
+        _hip.check(L.psfm_shard_window_state(h, f_lo, f_hi, stats, ctypes.byref(stalled), self._sp()))
+        fs = int(stalled.value)
+        last_ok = f_hi if fs < 0 else fs - 1
+        for t, _ in self._pending:
+            if t > last_ok:
+                break
+            st = stats[t - f_lo]
             _hip.check(L.psfm_shard_solve_record(h, ctypes.byref(st)))
             self.counters["fused"] += 1
-        else:
+            self._adapt(st)
+        redo = None
+        if fs >= 0:
+            frames = dict(self._pending)
+            p = tuple(_hip.ptr(x) for x in frames[fs])
             self.counters["fused_redone"] += 1
-            _hip.check(L.psfm_shard_solve_restore(h, int(t), self._sp()))
+            _hip.check(L.psfm_shard_solve_restore(h, fs, self._sp()))
+            mask = [(i % N_SUM) == SUM_GMAX for i in range(N_SUM)]
             kind, n = 1, 0
             while True:
-                _hip.check(L.psfm_shard_solve_export(h, *p, int(t), kind, 1, _hip.ptr(self.sums), self._sp()))
-                reduce(self.sums[:N_SUM], mask[:N_SUM])
-                done, _, st = self._control(t, kind, 1)
+                _hip.check(L.psfm_shard_solve_export(h, *p, fs, kind, 1, _hip.ptr(self.sums), self._sp()))
+                reduce(self.sums[:N_SUM], mask)
+                done, _, st = self._control(fs, kind, 1)
                 if done:
                     break
                 kind, n = 2, n + 1
                 if n > 2 * 200 + 64:
                     raise RuntimeError("path-consistency solver did not terminate")
-            _hip.check(L.psfm_shard_solve_writeback(h, int(t), ctypes.byref(st), self._sp()))
-        # the next solve speculates what this one needed (same statistics, same choice on every rank)
+            _hip.check(L.psfm_shard_solve_writeback(h, fs, ctypes.byref(st), self._sp()))
+            self._adapt(st)
+            redo = fs
+        self._pending = []
+        return redo
+
+    def _adapt(self, st):
+        # the next solves speculate what the clean ones of the last 16 frames needed (same statistics, same choice on every rank)
         clean = st.dogleg_nonGN == 0 and st.termination != 5 and (st.iterations == st.successful_steps + 1 or
                                                                   (st.termination == 2 and st.iterations == st.successful_steps))
         if st.termination >= 0 and clean:
@@ -91,6 +128,7 @@ class HipShardEngine:
     def finish(self):
         """the own trajectories on the HOST: (birth, length, off, xy, solve statistics)"""
         from .trajectory import _result_to_host
+        assert not self._pending, "HipShardEngine.finish: solves enqueued since the last checkpoint()"
         info = _hip.TrackInfo()
         _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
         R = _result_to_host(self.ctx, info)
@@ -99,6 +137,7 @@ class HipShardEngine:
     def finish_device(self, ratio, width):
         """the own trajectories stay in HBM (psfm_result_device); returns (track info, their order keys as a device tensor)"""
         import torch
+        assert not self._pending, "HipShardEngine.finish_device: solves enqueued since the last checkpoint()"
         info = _hip.TrackInfo()
         _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
         keys = torch.empty(int(info.n_traj), dtype=torch.int64, device=self.device)

@@ -296,6 +296,13 @@ class FrameWindow:
             self.pool.append(buf)
 
 
+def _any_stalled(engine, comm):
+    """Has a solve enqueued since the last checkpoint stalled on this rank's device?  The ranks must agree on when to
+    checkpoint (it contains collectives), and the flag reaches their hosts at different times: world == 1 peeks, several ranks
+    keep the fixed cadence."""
+    return comm.world == 1 and hasattr(engine, "stalled") and engine.stalled()
+
+
 def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, check_fn, group=None, comm=None,
                     keep_on_device=False, n_flows_total=None):
     """main_connect_point_trajectories.py:36-53 for ONE sequence on all ranks of `group`, exactly.
@@ -333,7 +340,17 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     g0, g1 = band_range(GH, GW, rank, world)
     engine.begin(n_flows, H, W, r, g0, g1, optimize)
     reduce = make_reduce(comm=comm)
-    for t in range(n_flows):
+    # Engines that only ENQUEUE a frame's solve (the HIP engine: no host round trip per solve) are asked every CHECK frames whether
+    # one of them did not go as speculated; they redo it there and the frames behind it -- no-ops on the device since -- run again.
+    # Every rank sees the same stall (the control step is replicated on the same totals), so the ranks rewind together.
+    has_ck = optimize and hasattr(engine, "checkpoint")
+    if has_ck:
+        # one rank sees a stall early (_any_stalled); several ranks must agree without talking: a short fixed window
+        engine.check_every = 16 if world == 1 else 4
+    confirmed = 0                  # frames below this are final
+    since = 0                      # frames enqueued since the last checkpoint
+    t = 0
+    while t < n_flows:
         f_t = wf.get(t) if owned else flows_f[t]
         x = engine.step(t, f_t, occ[t])                                      # track.py:33-47 for the own tracks
         comm.all_reduce_max_(x)                                              # marks of every rank's survivors
@@ -342,10 +359,22 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
             f_prev = wf.get(t - 1) if owned else flows_f[t - 1]
             f2_prev = w2.get(t - 1) if owned else flows_f2[t - 1]
             engine.solve(t, f_prev, f_t, f2_prev, occ2[t - 1], reduce)
-        if owned:
-            wf.release_below(t)              # (frame t is the next solve's flow01)
+        since += 1
+        # (every 16 frames -- or as soon as the engine sees, without synchronising, that a solve of the window has stalled)
+        if has_ck and (since >= engine.check_every or t == n_flows - 1 or _any_stalled(engine, comm)):
+            redone = engine.checkpoint(reduce)
+            if redone is not None:
+                t = redone                   # frames redone + 1 .. are run again
+            confirmed = t + 1
+            since = 0
+        elif not has_ck:
+            confirmed = t + 1
+        if owned:                            # keep what a redo of an unconfirmed frame needs: its flow01 is frame - 1
+            keep = min(t, confirmed - 1)
+            wf.release_below(keep)           # (frame t is the next solve's flow01)
             if w2 is not None:
-                w2.release_below(t)
+                w2.release_below(keep)
+        t += 1
     if keep_on_device:      # the trajectories stay in the engine's HBM (psfm_result_device); only their ids are formed
         info, keys = engine.finish_device(r, W)
         ids, n_traj = global_ids_device(keys, comm)
