@@ -52,7 +52,10 @@
 #define PP_FC_FAST 0     // fused flow_check: wave-uniform "all taps interior" form (16-byte tap pairs, no padding selects)
 #endif
 #define PP_GUESTS 32   // extra lanes per block whose state lives in LDS (stepped as phase-2 entries)
-#define PP_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef PP_WAVES_N
+#define PP_WAVES_N 8     // waves per SIMD the loop is compiled for (8: 64 VGPRs, every lane of a 1080p / ratio-2 grid resident)
+#endif
+#define PP_WAVES __attribute__((amdgpu_waves_per_eu(PP_WAVES_N, PP_WAVES_N)))
 
 // lane states kept in the `bf` register: >= 0 birth frame of the live track; PP_POOLED: free, reachable through the
 // global stacks (or never used) -> polls its hand-off slot; PP_PEND: free, kept by the block for its own births
