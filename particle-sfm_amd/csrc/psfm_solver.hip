@@ -80,7 +80,7 @@ struct PsfmSolveCtrl {
     // next launch evaluates, and what that launch is: 0 = the candidate of (dl_a, dl_b) + the system at it, 1 = the system
     // at x again (mu was raised by an invalid step)
     double qud, qdd, mcc;
-    int kind_next, pad_;
+    int kind_next, written;          // written: the accepted iterate is in buffer 0 / the caller's rows and the statistics are out
 };
 
 struct PcParams {
@@ -223,14 +223,13 @@ __device__ __forceinline__ bool pc_is_last_block(unsigned* ticket)
 // ------------------------------------------------------------------------------------------------
 // pc_init: iteration 0.  Frame mode also prepares ref1/ref2/scale (trajectory.py:173-183).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
+// iteration 0 for this block's tracks (grid-stride): refs / scale (frame mode), Jacobi scaling, cost and system at the start values
+__device__ __forceinline__ void pc_init_tracks(const PcParams& P, double acc[PC_NSUM])
 {
-    if (*P.stall) return;
     // the chain step in front of this solve has consumed PsfmCounters::sel (positions of an earlier fused solve): the launch
     // chain works in buffer 0 from here on, whatever becomes of it
     if (P.sel && blockIdx.x == 0 && threadIdx.x == 0) *P.sel = 0;
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
-    double acc[PC_NSUM];
 #pragma unroll
     for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
     const double mu = 1e-8;
@@ -267,6 +266,13 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
         PcSys y;
         pc_core_system<true>(x, r0, j0, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
     }
+}
+
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
+{
+    if (*P.stall) return;
+    double acc[PC_NSUM];
+    pc_init_tracks(P, acc);
     pc_block_reduce(acc, P.partials);
     if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1, P.export_sums);
 }
@@ -670,12 +676,16 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
 // still says "not done" and the pc_iter launches the host keeps behind this kernel carry on from it.
 // ------------------------------------------------------------------------------------------------
 #define PC_BAR_SHARDS 32
+__device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const PsfmSolveCtrl& C, double* out_rows);
 #define PC_BAR_WORDS ((2 * PC_BAR_SHARDS + 1) * 32)     // counters / flags 128 bytes apart
 static_assert(sizeof(PsfmSolveCtrl) % 8 == 0, "the control block is broadcast as 8-byte words");
 #define PC_CTRL_WORDS ((int)(sizeof(PsfmSolveCtrl) / 8))
 
-__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_persist_kernel(PcParams P, unsigned* bar, int spin_limit, int max_rounds)
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_persist_kernel(PcParams P, unsigned* bar, int spin_limit, int max_rounds, double* out_rows)
 {
+    // Behind psfm_pc_init_kernel (iteration 0 inside this kernel as round 0 was measured: 181 VGPRs and 107 spilled SGPRs in the
+    // iteration loop, 56.7 instead of 54.8 ms per hard 1080p sequence).  When the loop ends with the solve done, every block
+    // writes its tracks back (what psfm_pc_writeback_kernel does) and the control block says so.
     if (*P.stall) return;
     __shared__ PsfmSolveCtrl s_C;
     __shared__ int s_state;           // 0 go on, 1 this block is the last arriver, 2 give up
@@ -734,6 +744,10 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_persist_kernel(PcParams P, u
             __syncthreads();
         }
     }
+    if (!s_C.done) return;            // (ran out of rounds: the launches behind this one carry on from the control block)
+    // ---- write-back: every block holds the final control block; a block copies the tracks it has been iterating on ----
+    pc_writeback_tracks(P, s_C, out_rows);
+    if (blockIdx.x == 0 && tid == 0) P.ctrl->written = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1184,17 +1198,9 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_flush_kernel(PcParams P)
 }
 __global__ void psfm_pc_clear_sel_kernel(int* sel, const int* stall) { if (!*stall) *sel = 0; }
 
-// final: if the accepted iterate lives in the scratch pair, copy it back (frame mode: into the log)
-__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P, double* out_rows)
+// final: if the accepted iterate lives in the scratch pair, copy it back (frame mode: into the log); C: the final control block
+__device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const PsfmSolveCtrl& C, double* out_rows)
 {
-    if (*P.stall) return;
-    const PsfmSolveCtrl C = *P.ctrl;
-    if (!C.done) {
-        // the unrolled iterations did not suffice: poison everything that was enqueued behind this solve; the
-        // host resumes it (psfm_track polls `stall` at its checkpoints) and re-enqueues the later frames
-        if (blockIdx.x == 0 && threadIdx.x == 0) *P.stall = P.frame + 1;
-        return;
-    }
     if (P.stats_dev && blockIdx.x == 0 && threadIdx.x == 0) {
         psfm_solve_stats st;
         st.iterations = C.iteration; st.successful_steps = C.successful;
@@ -1228,6 +1234,20 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P,
             P.x1a[i] = p1; P.x2a[i] = p2;
         }
     }
+}
+
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_writeback_kernel(PcParams P, double* out_rows)
+{
+    if (*P.stall) return;
+    const PsfmSolveCtrl C = *P.ctrl;
+    if (!C.done) {
+        // the unrolled iterations did not suffice: poison everything that was enqueued behind this solve; the
+        // host resumes it (psfm_track polls `stall` at its checkpoints) and re-enqueues the later frames
+        if (blockIdx.x == 0 && threadIdx.x == 0) *P.stall = P.frame + 1;
+        return;
+    }
+    if (C.written) return;       // (the persistent solve has written back itself)
+    pc_writeback_tracks(P, C, out_rows);
 }
 
 // batch mode: split (n,4) rows into the (x1, x2) pair and (n,2) refs into double2 arrays
@@ -1345,7 +1365,7 @@ static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const fl
 // The trust-region loop of the launch chain as ONE persistent launch behind pc_init (psfm_pc_persist_kernel), when this call
 // has the device to itself and the grid is co-resident; returns false when it is not used (the caller launches iterations).
 // PSFM_PC_PERSIST=0 keeps one launch per iteration (measurements, tests).
-static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, hipStream_t s)
+static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, hipStream_t s)
 {
     const char* env = getenv("PSFM_PC_PERSIST");          // (read per call: the tests switch it inside one process)
     if ((env && atoi(env) == 0) || !c->pc_persist_ok || P.export_sums) return false;
@@ -1361,7 +1381,8 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, hip
     if (c->sol_bar.ensure(sizeof(unsigned) * PC_BAR_WORDS) != PSFM_OK) return false;
     if (hipMemsetAsync(c->sol_bar.p, 0, sizeof(unsigned) * PC_BAR_WORDS, s) != hipSuccess) return false;
     static const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 400000;   // x (s_sleep 2 + one uncached load) ~ 0.3 s
-    hipLaunchKernelGGL(psfm_pc_persist_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, c->sol_bar.as<unsigned>(), spin_limit, 2 * 200 + 64);
+    // (the write-back is in the launch too)
+    hipLaunchKernelGGL(psfm_pc_persist_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, c->sol_bar.as<unsigned>(), spin_limit, 2 * 200 + 64, out_rows);
     return true;
 }
 
@@ -1374,11 +1395,12 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
     psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
     if (rc != PSFM_OK) return rc;
     const int n_blocks = pc_blocks((int)d.cap);
+    // iteration 0, then the loop and the write-back in one launch when possible (a loop that gave up on its barrier leaves the
+    // control block "not done": the write-back kernel behind it then raises the stall flag and the host redoes the solve at its
+    // checkpoint), else `unroll` launches of one iteration each + write-back
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    // the whole loop in one launch when possible (two launches behind it for a loop that gave up on its barrier), else
-    // `unroll` launches of one iteration each
-    if (pc_persist_enqueue(c, P, n_blocks, s)) unroll = unroll < 2 ? unroll : 2;
-    for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    if (!pc_persist_enqueue(c, P, n_blocks, nullptr, s))
+        for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
@@ -1415,7 +1437,7 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     }
     const int n_blocks = pc_blocks((int)d.cap);
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (!pc_persist_enqueue(c, P, n_blocks, s))
+    if (!pc_persist_enqueue(c, P, n_blocks, nullptr, s))
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
     return pc_finish_sync(c, P, n_blocks, nullptr, st, s);
@@ -1697,7 +1719,7 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     PSFM_HIP(hipMemcpyAsync(P.ref2, ref2, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
     PSFM_HIP(hipMemcpyAsync(P.scale, scale, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (!pc_persist_enqueue(c, P, n_blocks, s))
+    if (!pc_persist_enqueue(c, P, n_blocks, out, s))
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
     rc = pc_finish_sync(c, P, n_blocks, out, st, s);
