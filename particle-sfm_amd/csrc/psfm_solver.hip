@@ -1377,10 +1377,13 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
             hipGetDeviceProperties(&prop, c->device) == hipSuccess)
             c->pc_persist_blocks = per_cu * prop.multiProcessorCount;
     }
-    if (n_blocks > c->pc_persist_blocks) return false;
+    if (n_blocks > c->pc_persist_blocks * 2 / 3 + 1) return false;     // (see the spin limit below: never the full residency)
     if (c->sol_bar.ensure(sizeof(unsigned) * PC_BAR_WORDS) != PSFM_OK) return false;
     if (hipMemsetAsync(c->sol_bar.p, 0, sizeof(unsigned) * PC_BAR_WORDS, s) != hipSuccess) return false;
-    static const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 400000;   // x (s_sleep 2 + one uncached load) ~ 0.3 s
+    // x (s_sleep 2 + one uncached load): ~10 ms.  The grid (PC_CHAIN_BLOCKS = 2 blocks per CU) leaves a third of the kernel's
+    // residency unused on purpose: at the full 3 blocks per CU the background flow_check of the side stream takes slots the
+    // barrier is waiting for (768 blocks measured: 192 instead of 55 ms per hard 1080p sequence, all of it spin-limit fall-backs)
+    static const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 100000;
     // (the write-back is in the launch too)
     hipLaunchKernelGGL(psfm_pc_persist_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, c->sol_bar.as<unsigned>(), spin_limit, 2 * 200 + 64, out_rows);
     return true;
