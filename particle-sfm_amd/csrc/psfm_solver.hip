@@ -1383,7 +1383,7 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
     // x (s_sleep 2 + one uncached load): ~10 ms.  The grid (PC_CHAIN_BLOCKS = 2 blocks per CU) leaves a third of the kernel's
     // residency unused on purpose: at the full 3 blocks per CU the background flow_check of the side stream takes slots the
     // barrier is waiting for (768 blocks measured: 192 instead of 55 ms per hard 1080p sequence, all of it spin-limit fall-backs)
-    static const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 100000;
+    const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 100000;      // (read per call: a test forces the give-up with 0)
     // (the write-back is in the launch too)
     hipLaunchKernelGGL(psfm_pc_persist_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, c->sol_bar.as<unsigned>(), spin_limit, 2 * 200 + 64, out_rows);
     return true;

@@ -323,3 +323,31 @@ def test_launch_chain_as_one_persistent_launch_is_the_same_solve(pt, monkeypatch
         assert np.array_equal(outs["1"], outs["0"]) and outs["1s"] == outs["0s"] and outs["1s"]["iterations"] > outs["1s"]["successful_steps"]
     finally:
         ctx.set_solver(0, 0)
+
+
+def test_persistent_solve_that_gives_up_is_redone_with_launches(pt, monkeypatch):
+    """A persistent solve whose barrier times out (PSFM_PC_SPIN=0: every block but the last arriver of round 1 leaves at once -- what
+    happens when the grid is not co-resident) leaves the control block "not done"; the write-back kernel behind it raises the stall
+    flag, the host's checkpoint redoes the solve (the batch entry point: its polling loop carries on with launches).  Same result."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    T, H, W, r = 7, 120, 200, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=71, stride2=True, **psfm_synth.HARD)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    ctx = _hip.context()
+    ctx.set_solver(1, 0)
+    try:
+        monkeypatch.setenv("PSFM_PC_SPIN", "0")
+        R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and float(np.abs(R.xy - O.xy).max()) <= TOL
+        assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+        uv, ref1, ref2, scale, flow12 = _batch(60, 80, 3000, 2, 0.5)
+        out_o, st_o = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+        out_g = pt.particlesfm.optimize_location(uv, ref1, ref2, scale, flow12, uv.shape[0], 80, 60)
+        st_g = pt.particlesfm.optimize_location.last_stats
+        assert st_g["iterations"] == st_o["iterations"] and st_g["termination"] == st_o["termination"]
+        assert float(np.abs(out_g - out_o).max()) <= 1e-8
+    finally:
+        ctx.set_solver(0, 0)
