@@ -708,11 +708,16 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
     PSFM_HIP(hipEventRecord(e_in, s));
     PSFM_HIP(hipStreamWaitEvent(side, e_in, 0));
     PsfmOccPipeline pipe;
-    pipe.chunk = getenv("PSFM_FC_CHUNK") && atoi(getenv("PSFM_FC_CHUNK")) > 0 ? atoi(getenv("PSFM_FC_CHUNK")) : 10;
+    // pairs per side-stream launch: 10 beside the chain step of track mode; 5 beside track_optimize's frame kernel (round 3:
+    // 8.25 ms per 1080p sequence against 8.28-8.40 with 10 and 8.31-8.44 with 20)
+    pipe.chunk = getenv("PSFM_FC_CHUNK") && atoi(getenv("PSFM_FC_CHUNK")) > 0 ? atoi(getenv("PSFM_FC_CHUNK")) : (optimize ? 5 : 10);
     c->prof.begin(PSFM_PROF_FLOW_CHECK, side);
-    // track_optimize: the first chunk at full occupancy (the frame loop waits for it), the others as the background form
-    // that shares the CUs with the frame kernel (PSFM_FC_BG=0: every chunk at full occupancy)
-    const bool bg = optimize && !(getenv("PSFM_FC_BG") && atoi(getenv("PSFM_FC_BG")) == 0);
+    // track_optimize: every chunk as a full-occupancy launch of the stand-alone kernel.  (Round 2 ran all but the first chunk as a
+    // BACKGROUND kernel shaped to fit beside the frame kernel's three 160-VGPR waves per SIMD -- psfm_flow_check_bg_kernel, still
+    // there behind PSFM_FC_BG=1.  Since round 3 the frame kernel runs four 128-VGPR waves per SIMD, which leaves that kernel no
+    // registers to live in, and the stand-alone kernel got 15 % faster: 8.58-8.64 ms per 1080p sequence with the background form,
+    // 8.28-8.40 without.)
+    const bool bg = optimize && getenv("PSFM_FC_BG") && atoi(getenv("PSFM_FC_BG")) == 1;
     int cus = 256;
     if (bg) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
