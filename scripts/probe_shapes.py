@@ -14,7 +14,7 @@ for (H, W, r) in shapes:
     d = psfm_synth.synth_sequence_torch(T if H < 2000 else 31, H, W, seed=1, sigma=0.05, n_occluders=2, stride2=False)
     nf = d["flows_f"].shape[0]
     out = {}
-    for mode in (1, 2):
+    for mode in (1, 2, 0):
         ctx.set_chain_mode(mode)
         try:
             ts = []
@@ -22,9 +22,9 @@ for (H, W, r) in shapes:
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 info = run_connect(d["flows_f"], d["flows_b"], None, None, 1.0, r, return_device=True)
                 torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-            out[mode] = (1e3 * float(np.median(ts[2:])), info.n_points)
+            out[mode] = (1e3 * float(np.median(ts[2:])), info.n_points, int(info.chain_mode))
         except Exception as e:
-            out[mode] = (float("nan"), 0)
+            out[mode] = (float("nan"), 0, -1)
     _, occ = flow_check_device(d["flows_f"], d["flows_b"], 1.0)
     tr = {}
     for mode in (1, 2):
@@ -41,6 +41,7 @@ for (H, W, r) in shapes:
     G = ((H + r - 1) // r) * ((W + r - 1) // r)
     print("%4dx%4d r=%d frames %3d  G=%7d P=%8d | per-frame %7.3f ms (%5.1f us/frame)  persistent %7.3f ms (%5.1f us/frame)  ratio %.2f" % (
         H, W, r, nf, G, H * W, out[1][0], 1e3 * out[1][0] / nf, out[2][0], 1e3 * out[2][0] / nf, out[2][0] / out[1][0]))
+    print("        psfm_connect in the DEFAULT mode: %7.3f ms (ran the %s)" % (out[0][0], "persistent loop" if out[0][2] == 2 else "per-frame launches"))
     print("        psfm_track on ready maps: per-frame %7.3f ms  persistent %7.3f ms  ratio %.2f" % (tr[1], tr[2], tr[2] / tr[1]))
     del d
 ctx.set_chain_mode(0)
