@@ -74,6 +74,27 @@ LARGE_MOTION_CASES = [
 ]
 
 
+TRACK_LARGE_MOTION = [
+    # name, T, H, W, ratio, seed, amp, sigma, occluders, drift: track() with tracks crossing the image in ~10 frames and leaving it
+    ("track_largemotion_80x120_r2", 9, 80, 120, 2, 63, 1.5, 0.1, 2, (10.4, -2.2)),
+    ("track_largemotion_75x110_r1", 7, 75, 110, 1, 64, 2.5, 0.2, 1, (-7.6, 6.1)),
+]
+
+
+def make_track_large_motion(ref):
+    for name, T, H, W, r, seed, amp, sigma, nocc, drift in TRACK_LARGE_MOTION:
+        d = psfm_synth.synth_sequence(T, H, W, seed=seed, amp=amp, sigma=sigma, n_occluders=nocc, stride2=False, drift=drift, warp_b=True)
+        _, occ = ref.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        tr = ref.track(d["flows_f"], occ, r)
+        b, l, off, xy = ref_shim.trajs_to_csr(tr)
+        left = int((l[b + l - 1 < T - 1]).shape[0])          # trajectories that ended before the last frame
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), T=T, H=H, W=W, ratio=r, seed=seed, amp=amp, sigma=sigma,
+                            n_occluders=nocc, drift=np.asarray(drift, np.float64), warp_b=1, input_hash=input_hash(d),
+                            birth=b, length=l, xy=xy, occ=np.packbits(np.stack(occ)), ended_early=left)
+        print(name, len(tr), "tracks,", int(l.sum()), "points,", left, "ended before the last frame, occluded fraction",
+              round(float(np.stack(occ).mean()), 3))
+
+
 def make_large_motion(ref):
     """`loss02_scale = (1 - occ02) * (|flow02| < 20)` (trajectory.py:179) on BOTH sides of the gate, with
     continuous occ02 weights at occluder borders, and tracks whose solver parameters / chain taps leave the image (a drift of
@@ -135,6 +156,7 @@ def main():
     if sys.argv[1:] == ["nonfinite"]:
         return make_nonfinite(ref)
     if sys.argv[1:] == ["largemotion"]:
+        make_track_large_motion(ref)
         return make_large_motion(ref)
     out = {}
 
@@ -217,6 +239,7 @@ def main():
     print("EDT == integer-disc rule verified for r=1..5")
 
     make_nonfinite(ref)
+    make_track_large_motion(ref)
     make_large_motion(ref)
 
 
