@@ -101,7 +101,7 @@ struct PcParams {
     // per-track constants
     double2 *ref1, *ref2;
     double* scale;
-    double2* jscale;          // (S0, S1); S2 = S3 = 1/(1+sqrt(s^2+1))
+    double2* jscale;          // (S0^2, S1^2): squared Jacobi scaling of columns 0, 1 (columns 2, 3 need none: psfm_pc_core.h)
     const float2* flow12;
     // init-only inputs (frame mode)
     const float2* flow01;
@@ -1316,7 +1316,7 @@ static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double
     hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, out_rows);
     PSFM_HIP(hipGetLastError());
     if (st) pc_fill_stats(hctrl, st);
-    // (a failed solve -- invalid steps / Cholesky breakdown / non-finite residuals -- is not an error: like the reference,
+    // (a failed solve -- invalid steps / a system that is not positive definite / non-finite residuals -- is not an error: like the reference,
     // which ignores Ceres' FAILURE at trajectory_optimize.cpp:81-82, the parameters stay as they came in; stats say 5)
     return PSFM_OK;
 }
