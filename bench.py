@@ -299,6 +299,16 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
                               "traffic_source": v.get("traffic_source", "profiles/solver_valu.json (replayed)")})
             except Exception:
                 pass
+        if not fused and os.path.exists(vfile):
+            try:
+                v = json.load(open(vfile))["chain"]
+                wi = v["valu_per_track_iteration"] * entry["track_iterations_per_launch"] / 64.0 + \
+                     v["valu_per_wave_per_iteration_fixed"] * v["waves"] * entry["avg_iterations"]
+                entry.update({"achieved": wi / (us * 1e-6) / 1e9, "frac": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS,
+                              "valu_wave_instructions_per_launch": wi,
+                              "valu_source": "profiles/solver_valu.json 'chain': " + v["source"]})
+            except Exception:
+                pass
         if "frac" not in entry:
             entry.update({"achieved": None, "frac": None})
         out["frame_kernel" if merged else "solver"] = entry

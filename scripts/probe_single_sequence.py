@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""bench.py's single_sequence figure alone (ONE sequence through psfm_dist.connect_sharded at world size 1, beside the
+one-GPU call): for A/B runs of the sharded engine under environment knobs (PSFM_FUSED_WAVES=3|4 ...).
+
+    python scripts/probe_single_sequence.py [frames=201]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
+    sys.path.insert(0, p)
+import torch
+import bench
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 201
+out = bench.single_sequence_sharded(torch.device("cuda", 0), 0, 1, frames, reps=3)
+print(json.dumps({k: out[k] for k in ("ms_per_sequence", "one_gpu_psfm_connect_ms_per_sequence", "counts_equal_one_gpu",
+                                      "solver_counters", "trust_region_iterations", "solves")} |
+                 {"frames": frames, "fused_waves": os.environ.get("PSFM_FUSED_WAVES", "3")}))
