@@ -32,6 +32,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define PC_HD __host__ __device__ __forceinline__
@@ -99,30 +100,73 @@ PC_HD double pc_core_iA22(const PcConst& c, double mu) { return pc_rcp(fma(mu, c
 // ceres::Grid2D, path_consistency_cost.h:48), residuals and the four non-trivial Jacobian entries.
 // f0 = a00 + tc (a01 - a00) etc.: the differences of two f32 values are exact in f64, so this is Ceres' (1-tc) a00 + tc a01
 // with one rounding less.
-PC_HD void pc_core_eval(const PcF2* flow, int H, int W, const double x[4], double r1x, double r1y, double r2x, double r2y,
-                        double s, double r[6], double j[4])
+// In two halves, so that a caller can have the four taps of one track in flight while it computes on another:
+// pc_core_taps issues the loads, pc_core_eval_taps is everything behind them (it re-derives row / column from x: a
+// dozen instructions against six registers held across the wait).
+struct PcTaps { PcF2 p00, p01, p10, p11; };
+
+PC_HD void pc_core_cell(const double x[4], int& row, int& col)
 {
     double fr = floor(x[1]), fc = floor(x[0]);
     fr = fr > -1.0e9 ? fr : -1.0e9; fr = fr < 1.0e9 ? fr : 1.0e9;   // also maps NaN to -1e9
     fc = fc > -1.0e9 ? fc : -1.0e9; fc = fc < 1.0e9 ? fc : 1.0e9;
-    const int row = (int)fr, col = (int)fc;
+    row = (int)fr; col = (int)fc;
+}
+
+struct PcF4 { float x0, y0, x1, y1; };     // two flow vectors next to each other in a row
+PC_HD PcF4 pc_load_pair(const char* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const PcF4*)p;               // one 16-byte load (8-byte aligned: fine for global memory)
+#else
+    PcF4 v;
+    memcpy(&v, p, sizeof(v));
+    return v;
+#endif
+}
+
+// The two taps of a row are the halves of ONE 16-byte load of the columns (cb, cb + 1), cb = min(c0, W - 2): with the
+// clamping at the borders c0 and c1 are each cb or cb + 1, whatever the position.  Half as many gather instructions per
+// evaluation -- on scattered tracks every one of them is 64 separate cache-line look-ups.
+template <bool PAIR>
+PC_HD PcTaps pc_core_taps(const PcF2* flow, int H, int W, const double x[4])
+{
+    int row, col;
+    pc_core_cell(x, row, col);
     const int r0 = row < 0 ? 0 : (row > H - 1 ? H - 1 : row), r1 = row + 1 < 0 ? 0 : (row + 1 > H - 1 ? H - 1 : row + 1);
     const int c0 = col < 0 ? 0 : (col > W - 1 ? W - 1 : col), c1 = col + 1 < 0 ? 0 : (col + 1 > W - 1 ? W - 1 : col + 1);
     const unsigned o0 = (unsigned)r0 * (unsigned)W, o1 = (unsigned)r1 * (unsigned)W;
     const char* base = (const char*)flow;
-    const PcF2 p00 = *(const PcF2*)(base + (o0 + (unsigned)c0) * 8u), p01 = *(const PcF2*)(base + (o0 + (unsigned)c1) * 8u);
-    const PcF2 p10 = *(const PcF2*)(base + (o1 + (unsigned)c0) * 8u), p11 = *(const PcF2*)(base + (o1 + (unsigned)c1) * 8u);
+    PcTaps t;
+    if (PAIR && W >= 2) {
+        const int cb = c0 < W - 1 ? c0 : W - 2;
+        const PcF4 a = pc_load_pair(base + (o0 + (unsigned)cb) * 8u), b = pc_load_pair(base + (o1 + (unsigned)cb) * 8u);
+        const bool l0 = c0 == cb, l1 = c1 == cb;
+        t.p00.x = l0 ? a.x0 : a.x1; t.p00.y = l0 ? a.y0 : a.y1; t.p01.x = l1 ? a.x0 : a.x1; t.p01.y = l1 ? a.y0 : a.y1;
+        t.p10.x = l0 ? b.x0 : b.x1; t.p10.y = l0 ? b.y0 : b.y1; t.p11.x = l1 ? b.x0 : b.x1; t.p11.y = l1 ? b.y0 : b.y1;
+        return t;
+    }
+    t.p00 = *(const PcF2*)(base + (o0 + (unsigned)c0) * 8u); t.p01 = *(const PcF2*)(base + (o0 + (unsigned)c1) * 8u);
+    t.p10 = *(const PcF2*)(base + (o1 + (unsigned)c0) * 8u); t.p11 = *(const PcF2*)(base + (o1 + (unsigned)c1) * 8u);
+    return t;
+}
+
+PC_HD void pc_core_eval_taps(const PcTaps& t, const double x[4], double r1x, double r1y, double r2x, double r2y,
+                             double s, double r[6], double j[4])
+{
+    int row, col;
+    pc_core_cell(x, row, col);
     const double tc = x[0] - (double)col, tr = x[1] - (double)row;
     double f[2], dr[2], dc[2];
     {
-        const double a00 = p00.x, a10 = p10.x, d0 = (double)p01.x - a00, d1 = (double)p11.x - a10;
+        const double a00 = t.p00.x, a10 = t.p10.x, d0 = (double)t.p01.x - a00, d1 = (double)t.p11.x - a10;
         const double f0 = fma(tc, d0, a00), f1 = fma(tc, d1, a10);
         dr[0] = f1 - f0;
         f[0] = fma(tr, dr[0], f0);
         dc[0] = fma(tr, d1 - d0, d0);
     }
     {
-        const double a00 = p00.y, a10 = p10.y, d0 = (double)p01.y - a00, d1 = (double)p11.y - a10;
+        const double a00 = t.p00.y, a10 = t.p10.y, d0 = (double)t.p01.y - a00, d1 = (double)t.p11.y - a10;
         const double f0 = fma(tc, d0, a00), f1 = fma(tc, d1, a10);
         dr[1] = f1 - f0;
         f[1] = fma(tr, dr[1], f0);
@@ -138,6 +182,16 @@ PC_HD void pc_core_eval(const PcF2* flow, int H, int W, const double x[4], doubl
     j[1] = -dr[0];
     j[2] = -dc[1];
     j[3] = -1.0 - dr[1];
+}
+
+// PAIR: the taps as two 16-byte loads (the launch chain, whose tracks are scattered); the fused solve keeps four 8-byte
+// loads -- its lanes are neighbours in the image, and the frame kernel has no registers to spare for aligned quads.
+template <bool PAIR = false>
+PC_HD void pc_core_eval(const PcF2* flow, int H, int W, const double x[4], double r1x, double r1y, double r2x, double r2y,
+                        double s, double r[6], double j[4])
+{
+    const PcTaps t = pc_core_taps<PAIR>(flow, H, W, x);
+    pc_core_eval_taps(t, x, r1x, r1y, r2x, r2y, s, r, j);
 }
 
 PC_HD double pc_core_cost(const double r[6])

@@ -279,8 +279,37 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
 
 // What one launch of the chain does for this block's tracks (grid-stride): the refresh form (the system at x for a raised
 // mu) or the evaluate-ahead form (candidate of (a, b), its cost, the system there).  Sums into acc[].
+//
+// PC_ITER_PIPE selects how early the evaluate-ahead form requests its loads.  Written plainly (0, the default) a track is four
+// dependent round trips -- birth frame -> state -> taps at x -> taps at the candidate.  3 is the software-pipelined loop: the
+// state of track j + 1 (loaded together with its birth frame, whatever that says) is requested before the arithmetic of track j
+// and its taps at x are issued right behind track j's taps at the candidate, one basic block, same operations per track in the
+// same order, same order of the sums (the GPU tests pass with every setting).  It is SLOWER (see the macro): the loop is bound by
+// the bytes of per-track state it streams and by f64 issue, not by the round trips.
 // (Two tracks per thread at a time, stage by stage, at 2 waves per SIMD / 227 VGPRs: 66 instead of 55 ms per hard 1080p
 // sequence -- the slot without a track in a thread's last pass costs more arithmetic than the overlap saves; EXPERIMENTS.md.)
+#ifndef PC_ITER_PAIR
+#define PC_ITER_PAIR true   // the launch chain's taps as 16-byte pairs (psfm_pc_core.h)
+#endif
+#ifndef PC_ITER_PIPE
+#define PC_ITER_PIPE 0   // how early the iteration loop requests its loads (0 plain ... 3 software-pipelined over the thread's tracks).
+                         // Measured on the hard 1080p sequence (scripts/r03_t.sh, ms per sequence, persistent solve): 0 -> 56.2,
+                         // 1 -> 55.6, 2 -> 56.2, 3 -> 65.0 (168 VGPRs, 8 spilled; 62.2 at 184 VGPRs) -- the loop is not waiting for
+                         // round trips: a per-block timeline (scripts/r03_u.sh) puts it at 14-16 us of a 26 us launch, i.e. ~46 MB of
+                         // per-track state streamed per iteration (3-4 TB/s, cyclic, larger than the L2s) under ~8 us of f64 issue
+                         // at two waves per SIMD.  profiles/EXPERIMENTS.md 5.2.
+#endif
+struct PcIn { int bf; double2 r1, r2, js, p1, p2; double s; };
+
+__device__ __forceinline__ PcIn pc_load_in(const PcParams& P, const int* bfp, const double2* xc1, const double2* xc2, int i)
+{
+    PcIn in;
+    in.bf = bfp[i];
+    in.r1 = P.ref1[i]; in.r2 = P.ref2[i]; in.s = P.scale[i]; in.js = P.jscale[i];
+    in.p1 = xc1[i]; in.p2 = xc2[i];
+    return in;
+}
+
 __device__ __forceinline__ void pc_iter_tracks(const PcParams& P, int cur, double mu, double a, double b, bool refresh, double acc[PC_NSUM])
 {
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
@@ -291,32 +320,111 @@ __device__ __forceinline__ void pc_iter_tracks(const PcParams& P, int cur, doubl
     const double mu_next = fmax(1e-8, 2.0 * mu / 10.0);      // DoglegStrategy::StepAccepted: the mu of the system at the candidate
 #pragma unroll
     for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
-    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
-        if (!pc_participates(P, i, n)) continue;
-        const double2 r1 = P.ref1[i], r2 = P.ref2[i];
-        const double s = P.scale[i];
-        const PcConst c = pc_const_load(s, P.jscale[i]);
-        const double2 p1 = xc1[i], p2 = xc2[i];
-        const double x[4] = {p1.x, p1.y, p2.x, p2.y};
-        double r[6], jac[4];
-        PcSys y;
-        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
-        if (refresh) {      // the system at x for the mu an invalid step has raised
+    const int stride = (int)gridDim.x * PC_BLOCK;
+    int i = blockIdx.x * PC_BLOCK + threadIdx.x;
+    if (refresh) {      // the system at x for the mu an invalid step has raised (rare: plain loop)
+        for (; i < n; i += stride) {
+            if (!pc_participates(P, i, n)) continue;
+            const double2 r1 = P.ref1[i], r2 = P.ref2[i];
+            const double s = P.scale[i];
+            const PcConst c = pc_const_load(s, P.jscale[i]);
+            const double2 p1 = xc1[i], p2 = xc2[i];
+            const double x[4] = {p1.x, p1.y, p2.x, p2.y};
+            double r[6], jac[4];
+            PcSys y;
+            pc_core_eval<PC_ITER_PAIR>((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
             pc_core_system<true>(x, r, jac, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
-            continue;
         }
-        double unused[PC_NSUM], xp[4];      // (the sums at x are in the control block already)
-#pragma unroll
-        for (int k = 0; k < PC_NSUM; ++k) unused[k] = 0.0;
-        pc_core_system<false>(x, r, jac, c, mu, pc_core_iA22(c, mu), unused, y, 0, 0);
-        pc_core_step<false, false>(x, r, jac, c, y, a, b, acc, xp);
-        xn1[i] = make_double2(xp[0], xp[1]);
-        xn2[i] = make_double2(xp[2], xp[3]);
-        // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
-        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, xp, r1.x, r1.y, r2.x, r2.y, s, r, jac);
-        acc[SUM_COST] += pc_core_cost(r);
-        pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
+        return;
     }
+    if (i >= n) return;
+    const PcF2* F12 = (const PcF2*)P.flow12;
+    // (every load of the pipeline is unconditional -- the last track of a thread requests itself again, a solve without birth
+    // frames reads some word instead: the wait counts behind a skipped load would have to assume it was skipped, i.e. drain)
+    const int* bfp = P.birth_frame ? P.birth_frame : (const int*)P.scale;
+#if PC_ITER_PIPE <= 2
+    // 0: the plain loop (birth frame -> state -> taps at x -> taps at the candidate, four dependent round trips per track);
+    // 1: the state is requested together with the birth frame;  2: ... and the NEXT track's state under this track's arithmetic
+    PcIn in;
+    if (PC_ITER_PIPE == 2) in = pc_load_in(P, bfp, xc1, xc2, i);
+    for (;;) {
+        const int i_next = i + stride;
+        const bool more = i_next < n;
+        PcIn nin;
+        if (PC_ITER_PIPE == 2) nin = pc_load_in(P, bfp, xc1, xc2, more ? i_next : i);
+        bool part;
+        if (PC_ITER_PIPE == 0) {
+            part = pc_participates(P, i, n);
+            if (part) in = pc_load_in(P, bfp, xc1, xc2, i);
+        } else {
+            if (PC_ITER_PIPE == 1) in = pc_load_in(P, bfp, xc1, xc2, i);
+            part = !P.birth_frame || (in.bf >= 0 && in.bf <= P.max_birth);
+        }
+        if (part) {
+            const double x[4] = {in.p1.x, in.p1.y, in.p2.x, in.p2.y};
+            const PcConst c = pc_const_load(in.s, in.js);
+            double r[6], jac[4], xp[4], unused[PC_NSUM];      // (unused: the sums at x are in the control block already)
+            PcSys y;
+#pragma unroll
+            for (int k = 0; k < PC_NSUM; ++k) unused[k] = 0.0;
+            pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, x, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
+            pc_core_system<false>(x, r, jac, c, mu, pc_core_iA22(c, mu), unused, y, 0, 0);
+            pc_core_step<false, false>(x, r, jac, c, y, a, b, acc, xp);
+            xn1[i] = make_double2(xp[0], xp[1]);
+            xn2[i] = make_double2(xp[2], xp[3]);
+            // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
+            pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, xp, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
+            acc[SUM_COST] += pc_core_cost(r);
+            pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
+        }
+        if (!more) break;
+        if (PC_ITER_PIPE == 2) in = nin;
+        i = i_next;
+    }
+#else
+    PcIn in = pc_load_in(P, bfp, xc1, xc2, i);
+    PcTaps tx;
+    {
+        const double x0[4] = {in.p1.x, in.p1.y, in.p2.x, in.p2.y};
+        tx = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, x0);
+    }
+    for (;;) {
+        const int i_next = i + stride;
+        const bool more = i_next < n;
+        const PcIn nin = pc_load_in(P, bfp, xc1, xc2, more ? i_next : i);   // (requested now, used behind this track's step)
+        const bool part = !P.birth_frame || (in.bf >= 0 && in.bf <= P.max_birth);      // (pc_participates)
+        // No branch around the arithmetic: a lane without a track computes on whatever its row holds and contributes nothing
+        // (t[] is added as zeros, nothing is stored) -- one basic block, so every wait below counts exactly what is in flight.
+        // Each slot of t[] receives ONE term per track, so acc += (0 + term) is the sum the plain loop forms, bit for bit.
+        const double x[4] = {in.p1.x, in.p1.y, in.p2.x, in.p2.y};
+        const PcConst c = pc_const_load(in.s, in.js);
+        double r[6], jac[4], xp[4], t[PC_NSUM], unused[PC_NSUM];      // (unused: the sums at x are in the control block already)
+        PcSys y;
+#pragma unroll
+        for (int k = 0; k < PC_NSUM; ++k) { t[k] = 0.0; unused[k] = 0.0; }
+        pc_core_eval_taps(tx, x, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
+        pc_core_system<false>(x, r, jac, c, mu, pc_core_iA22(c, mu), unused, y, 0, 0);
+        pc_core_step<false, false>(x, r, jac, c, y, a, b, t, xp);
+        const PcTaps tc = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, xp);
+        const double xq[4] = {nin.p1.x, nin.p1.y, nin.p2.x, nin.p2.y};
+        const PcTaps ntx = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, xq);                // (the next track's taps at x ride behind tc)
+        if (part) {
+            xn1[i] = make_double2(xp[0], xp[1]);
+            xn2[i] = make_double2(xp[2], xp[3]);
+        }
+        // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
+        pc_core_eval_taps(tc, xp, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
+        t[SUM_COST] = pc_core_cost(r);
+        pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), t, y, CH_QUD, CH_QDD);
+#pragma unroll
+        for (int k = 0; k < PC_NSUM; ++k) {
+            if (k == SUM_GMAX) acc[k] = fmax(acc[k], part ? t[k] : 0.0);
+            else if (k != SUM_CNT && k != SUM_COST0) acc[k] += part ? t[k] : 0.0;
+        }
+        if (!more) break;
+        in = nin; tx = ntx; i = i_next;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,88 +774,145 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
 // pc_persist: the launch chain's loop inside ONE launch.  Solves that reject steps take 20-40 trust-region iterations;
 // as launches each of them costs a launch gap, a tail behind the last block and a round trip for the control block
 // (~21 us per iteration at 1080p, of which ~5 are arithmetic).  Here the grid stays resident (every block co-resident:
-// <= PC_CHAIN_BLOCKS blocks of 256 at 4 waves per SIMD, the device to ourselves like the persistent frame loop) and the
-// iterations are separated by a device-wide barrier: per-block partial sums written through -> arrival on one of
-// PC_BAR_SHARDS counters -> the last arriver of a shard bumps the top counter -> the last block overall reduces the
-// partials in the fixed order of the launch chain, runs pc_chain_control on its copy of the control block, writes it
-// through and releases the replicated flags the other blocks poll.  Every block keeps the control block in LDS.
+// <= PC_CHAIN_BLOCKS blocks of 256, the device to ourselves like the persistent frame loop) and the iterations are
+// separated by a device-wide hand-off with as few dependent memory operations as it takes:
+//   every block   per-block partial sums written through -> (acknowledged) -> one NON-RETURNING add on its shard's arrival
+//                 counter -> polls its shard's packet
+//   block 0       THE reducer, every round: polls the PC_BAR_SHARDS counters (one wave, one load per poll) -> reads the
+//                 partials in the fixed order of the launch chain -> runs pc_chain_control on the control block it keeps in
+//                 LDS -> publishes what the other blocks need for the next round (done, cur, kind_next, mu, dl_a, dl_b) as
+//                 seven data-tagged 8-byte granules per shard {round : 32 | half of the payload : 32} -- a granule is
+//                 valid by itself, so nothing orders the stores and the poll IS the read (MI355X_MICROARCH.md, form R2)
+// i.e. partial store ack -> counter visible -> partial loads -> packet visible: four hops.  (The first version elected
+// the last arriver through a second counter level and broadcast the whole control block behind a flag: two returning
+// atomics, a store acknowledgement between control block and flag, and a second load behind the poll -- seven hops,
+// EXPERIMENTS.md 5.2.)  The control block in memory is refreshed every round too (write-through, nobody waits for it):
+// it is what the launches behind a loop that gave up carry on from.
 // Same kernels' arithmetic, same reduction order, same control step: the iterates are the launch chain's bit for bit.
 // A block that waits longer than the spin limit (the grid was not co-resident after all) leaves; the control block then
 // still says "not done" and the pc_iter launches the host keeps behind this kernel carry on from it.
 // ------------------------------------------------------------------------------------------------
 #define PC_BAR_SHARDS 32
+#ifndef PC_PERSIST_WAVES
+#define PC_PERSIST_WAVES 3   // register target of the persistent solve: 3 waves per SIMD keeps the kernel's residency at 3 blocks per
+                             // CU, of which the grid uses 2 (see pc_persist_enqueue)
+#endif
 __device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const PsfmSolveCtrl& C, double* out_rows);
-#define PC_BAR_WORDS ((2 * PC_BAR_SHARDS + 1) * 32)     // counters / flags 128 bytes apart
-static_assert(sizeof(PsfmSolveCtrl) % 8 == 0, "the control block is broadcast as 8-byte words");
+#define PC_BAR_WORDS ((2 * PC_BAR_SHARDS + 1) * 32)     // counters / packets 128 bytes apart
+static_assert(sizeof(PsfmSolveCtrl) % 8 == 0, "the control block is copied as 8-byte words");
 #define PC_CTRL_WORDS ((int)(sizeof(PsfmSolveCtrl) / 8))
+#define PC_PKT_GRANULES 7      // flags, mu, dl_a, dl_b (two halves each)
 
-__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_persist_kernel(PcParams P, unsigned* bar, int spin_limit, int max_rounds, double* out_rows)
+struct PcRound { int done, cur, kind; double mu, a, b; };   // what a round of the loop needs from the control block
+
+__device__ __forceinline__ unsigned pc_pkt_half(const PsfmSolveCtrl& C, int g)
+{
+    if (g == 0) return (unsigned)(C.done ? 1 : 0) | ((unsigned)C.cur << 1) | ((unsigned)(C.kind_next != 0 ? 1 : 0) << 8);
+    const double v = g <= 2 ? C.mu : (g <= 4 ? C.dl_a : C.dl_b);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    return (g & 1) ? (unsigned)bits : (unsigned)(bits >> 32);      // odd granule: low half, even: high half
+}
+
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(PC_PERSIST_WAVES, PC_PERSIST_WAVES))) void psfm_pc_persist_kernel(PcParams P, unsigned* bar, int spin_limit, int max_rounds, double* out_rows)
 {
     // Behind psfm_pc_init_kernel (iteration 0 inside this kernel as round 0 was measured: 181 VGPRs and 107 spilled SGPRs in the
     // iteration loop, 56.7 instead of 54.8 ms per hard 1080p sequence).  When the loop ends with the solve done, every block
     // writes its tracks back (what psfm_pc_writeback_kernel does) and the control block says so.
     if (*P.stall) return;
-    __shared__ PsfmSolveCtrl s_C;
-    __shared__ int s_state;           // 0 go on, 1 this block is the last arriver, 2 give up
+    __shared__ PsfmSolveCtrl s_C;     // block 0: THE control block of the loop; others: the copy they started with
+    __shared__ PcRound s_R;
+    __shared__ unsigned s_pk[PC_PKT_GRANULES];
+    __shared__ int s_state;           // 0 go on, 2 give up
     const int tid = threadIdx.x;
     const int nblk = (int)gridDim.x;
     const int nsh = nblk < PC_BAR_SHARDS ? nblk : PC_BAR_SHARDS;
     const int sh = (int)blockIdx.x % nsh;
-    const unsigned members = (unsigned)((nblk - sh + nsh - 1) / nsh);
+    const bool reducer = blockIdx.x == 0;
     if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
     __syncthreads();
+    if (tid == 0) { s_R.done = s_C.done; s_R.cur = s_C.cur; s_R.kind = s_C.kind_next; s_R.mu = s_C.mu; s_R.a = s_C.dl_a; s_R.b = s_C.dl_b; }
+    __syncthreads();
     for (unsigned it = 0; it < (unsigned)max_rounds; ++it) {
-        if (s_C.done) break;
+        if (s_R.done) break;
         double acc[PC_NSUM];
-        pc_iter_tracks(P, s_C.cur, s_C.mu, s_C.dl_a, s_C.dl_b, s_C.kind_next != 0, acc);
+        pc_iter_tracks(P, s_R.cur, s_R.mu, s_R.a, s_R.b, s_R.kind != 0, acc);
         pc_block_reduce(acc, P.partials);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have been performed
         __syncthreads();
         if (tid == 0) {
-            int state = 0;
-            const unsigned t = __hip_atomic_fetch_add(bar + sh * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == (it + 1u) * members - 1u) {
-                const unsigned t2 = __hip_atomic_fetch_add(bar + PC_BAR_SHARDS * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t2 == (it + 1u) * (unsigned)nsh - 1u) state = 1;
-            }
-            s_state = state;
+            (void)__hip_atomic_fetch_add(bar + sh * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (result unused: no return trip)
+            s_state = 0;
         }
-        __syncthreads();
-        if (s_state == 1) {
-            // ---- the last block of this round: totals in the launch chain's order, control step, broadcast ----
-            pc_reduce_totals(P.partials, nblk);
+        if (reducer) {
+            // ---- every block's partials are in memory once each shard counter has reached members x rounds ----
+            if (tid < PSFM_WAVE) {
+                const unsigned members = tid < nsh ? (unsigned)((nblk - tid + nsh - 1) / nsh) : 0u;
+                const unsigned long long want = nsh >= 64 ? ~0ull : ((1ull << nsh) - 1ull);
+                int spins = 0;
+                for (;;) {
+                    unsigned v = 0;
+                    if (tid < nsh) v = __hip_atomic_load(bar + tid * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((__ballot(tid < nsh && v >= (it + 1u) * members) & want) == want) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > spin_limit) { if (tid == 0) s_state = 2; break; }
+                }
+            }
+            __syncthreads();
+            if (s_state == 2) return;
+            pc_reduce_totals(P.partials, nblk);            // totals in the launch chain's order
             if (tid == 0) {
                 PsfmSolveCtrl C = s_C;
                 pc_chain_control(C, pc_totals(), 1);
                 C.launches += 1;
                 s_C = C;
+                s_R.done = C.done; s_R.cur = C.cur; s_R.kind = C.kind_next; s_R.mu = C.mu; s_R.a = C.dl_a; s_R.b = C.dl_b;
             }
             __syncthreads();
+            if (tid < nsh * PC_PKT_GRANULES) {             // the packets: one tagged granule per lane, no order among them
+                const int s2 = tid / PC_PKT_GRANULES, g = tid - s2 * PC_PKT_GRANULES;
+                const unsigned long long w = ((unsigned long long)(it + 1u) << 32) | (unsigned long long)pc_pkt_half(s_C, g);
+                __hip_atomic_store((unsigned long long*)(bar + (PC_BAR_SHARDS + 1 + s2) * 32) + g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            // the control block in memory (for the launches behind a loop that gives up, and for the end of this one)
             if (tid < PC_CTRL_WORDS)
                 __hip_atomic_store((unsigned long long*)P.ctrl + tid, ((const unsigned long long*)&s_C)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid < nsh) __hip_atomic_store(bar + (PC_BAR_SHARDS + 1 + tid) * 32, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
-            if (tid == 0) {
-                int spins = 0, state = 0;
-                while (__hip_atomic_load(bar + (PC_BAR_SHARDS + 1 + sh) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < it + 1u) {
+            if (tid < PSFM_WAVE) {
+                const unsigned long long* pk = (const unsigned long long*)(bar + (PC_BAR_SHARDS + 1 + sh) * 32);
+                int spins = 0;
+                for (;;) {
+                    unsigned long long w = 0;
+                    if (tid < PC_PKT_GRANULES) w = __hip_atomic_load(pk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long ok = __ballot(tid < PC_PKT_GRANULES && (unsigned)(w >> 32) == it + 1u);
+                    if ((ok & ((1ull << PC_PKT_GRANULES) - 1ull)) == ((1ull << PC_PKT_GRANULES) - 1ull)) {
+                        if (tid < PC_PKT_GRANULES) s_pk[tid] = (unsigned)w;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > spin_limit) { state = 2; break; }
+                    if (++spins > spin_limit) { if (tid == 0) s_state = 2; break; }
                 }
-                s_state = state;
             }
             __syncthreads();
             if (s_state == 2) return;
-            if (tid < PC_CTRL_WORDS)
-                ((unsigned long long*)&s_C)[tid] = __hip_atomic_load((const unsigned long long*)P.ctrl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) {
+                const unsigned f = s_pk[0];
+                s_R.done = (int)(f & 1u); s_R.cur = (int)((f >> 1) & 0x7fu); s_R.kind = (int)((f >> 8) & 1u);
+                s_R.mu = __longlong_as_double((long long)(((unsigned long long)s_pk[2] << 32) | s_pk[1]));
+                s_R.a = __longlong_as_double((long long)(((unsigned long long)s_pk[4] << 32) | s_pk[3]));
+                s_R.b = __longlong_as_double((long long)(((unsigned long long)s_pk[6] << 32) | s_pk[5]));
+            }
             __syncthreads();
         }
     }
-    if (!s_C.done) return;            // (ran out of rounds: the launches behind this one carry on from the control block)
-    // ---- write-back: every block holds the final control block; a block copies the tracks it has been iterating on ----
+    if (!s_R.done) return;            // (ran out of rounds: the launches behind this one carry on from the control block)
+    // ---- write-back: a block copies the tracks it has been iterating on (block 0 holds the final control block: statistics) ----
+    if (!reducer && tid == 0) s_C.cur = s_R.cur;
+    __syncthreads();
     pc_writeback_tracks(P, s_C, out_rows);
-    if (blockIdx.x == 0 && tid == 0) P.ctrl->written = 1;
+    if (reducer && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the round's copy of the control block first)
+        P.ctrl->written = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1377,7 +1542,11 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
             hipGetDeviceProperties(&prop, c->device) == hipSuccess)
             c->pc_persist_blocks = per_cu * prop.multiProcessorCount;
     }
-    if (n_blocks > c->pc_persist_blocks * 2 / 3 + 1) return false;     // (see the spin limit below: never the full residency)
+#if PC_PERSIST_WAVES >= 3
+    if (n_blocks > c->pc_persist_blocks * 2 / 3 + 1 && !getenv("PSFM_PC_PERSIST_FULL")) return false;     // (see the spin limit below: never the full residency; the override is for measurements)
+#else
+    if (n_blocks > c->pc_persist_blocks) return false;                 // (measurement builds: 2 blocks per CU ARE the residency)
+#endif
     if (c->sol_bar.ensure(sizeof(unsigned) * PC_BAR_WORDS) != PSFM_OK) return false;
     if (hipMemsetAsync(c->sol_bar.p, 0, sizeof(unsigned) * PC_BAR_WORDS, s) != hipSuccess) return false;
     // x (s_sleep 2 + one uncached load): ~10 ms.  The grid (PC_CHAIN_BLOCKS = 2 blocks per CU) leaves a third of the kernel's
