@@ -41,3 +41,15 @@ extern "C" void pc_host_system(long n, const double* x0, const double* x, const 
         pc_core_system<true>(x + 4 * i, r, j, c, mu, pc_core_iA22(c, mu), sums, y, 0, 3);
     }
 }
+
+// the four taps of an evaluation, as 8-byte loads (PAIR = false) and as the halves of two 16-byte loads (PAIR = true)
+extern "C" void pc_host_taps(long n, const double* x, const float* flow, int H, int W, int pair, float* out)
+{
+    const PcF2* F = (const PcF2*)flow;
+    for (long i = 0; i < n; ++i) {
+        const PcTaps t = pair ? pc_core_taps<true>(F, H, W, x + 4 * i) : pc_core_taps<false>(F, H, W, x + 4 * i);
+        float* o = out + 8 * i;
+        o[0] = t.p00.x; o[1] = t.p00.y; o[2] = t.p01.x; o[3] = t.p01.y;
+        o[4] = t.p10.x; o[5] = t.p10.y; o[6] = t.p11.x; o[7] = t.p11.y;
+    }
+}

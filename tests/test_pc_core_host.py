@@ -28,6 +28,7 @@ def core(tmp_path_factory):
     L.pc_host_iteration.argtypes = [ctypes.c_long, dp, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_int, dp, dp, dp]
     L.pc_host_system.argtypes = [ctypes.c_long, dp, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp]
+    L.pc_host_taps.argtypes = [ctypes.c_long, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp]
     return L
 
 
@@ -186,3 +187,34 @@ def test_any_dogleg_step_is_priced_from_the_sums_at_x(core, mu):
         assert abs(mcc - sums[SUM["MCC"]]) <= 1e-10 * max(abs(sums[SUM["MCC"]]), abs(a * G2) + abs(b * DOT))
         assert np.array_equal(sums[[SUM["G2"], SUM["JG2"], SUM["GN2"], SUM["DOT"], SUM["XN2"], SUM["GMAX"]]],
                               at_x[[SUM["G2"], SUM["JG2"], SUM["GN2"], SUM["DOT"], SUM["XN2"], SUM["GMAX"]]])
+
+
+@pytest.mark.parametrize("H,W", [(7, 9), (5, 2), (3, 1), (1, 6), (2, 2)])
+def test_paired_tap_loads_equal_the_single_ones_everywhere(core, H, W):
+    """psfm_pc_core.h pc_core_taps<true> (the launch chain: two 16-byte loads of the columns cb, cb + 1) must return the taps
+    of Grid2D's clamp-to-edge rule (linear_interpolation.h:97-123) at every position -- inside, on every border, far outside,
+    non-finite -- exactly as the four 8-byte loads do, for any image width (W == 1 has no pair to load)."""
+    rng = np.random.default_rng(H * 100 + W)
+    flow = rng.normal(size=(H, W, 2)).astype(np.float32)
+    xs = [rng.uniform(-3, W + 3, 400), np.arange(-2, W + 2, dtype=np.float64), np.array([-1e12, 1e12, np.nan, np.inf, -np.inf, -0.0, W - 1.0, W - 1 - 1e-9])]
+    ys = [rng.uniform(-3, H + 3, 400), np.arange(-2, H + 2, dtype=np.float64), np.array([-1e12, 1e12, np.nan, np.inf, -np.inf, -0.0, H - 1.0, H - 1 - 1e-9])]
+    cx, cy = np.concatenate(xs), np.concatenate(ys)
+    gx, gy = np.meshgrid(np.concatenate(xs[1:]), np.concatenate(ys[1:]))
+    px = np.concatenate([cx[:400], gx.ravel()]); py = np.concatenate([cy[:400], gy.ravel()])
+    x = np.ascontiguousarray(np.stack([px, py, px, py], 1))
+    n = len(x)
+    out = [np.full((n, 8), -7.0, np.float32) for _ in range(2)]
+    dp, fp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)
+    # one guard row behind the map: the pair load of the last row must not depend on it (and must not read past it when W >= 2)
+    padded = np.concatenate([flow.reshape(-1), np.full(2, np.nan, np.float32)])
+    for pair in (0, 1):
+        core.pc_host_taps(n, x.ctypes.data_as(dp), padded.ctypes.data_as(fp), H, W, pair, out[pair].ctypes.data_as(fp))
+    assert np.array_equal(out[0], out[1], equal_nan=True)
+    # and both are the clamp-to-edge taps
+    with np.errstate(invalid="ignore"):
+        fr = np.clip(np.nan_to_num(np.floor(py), nan=-1e9, posinf=1e9, neginf=-1e9), -1e9, 1e9).astype(np.int64)
+        fc = np.clip(np.nan_to_num(np.floor(px), nan=-1e9, posinf=1e9, neginf=-1e9), -1e9, 1e9).astype(np.int64)
+    cl = lambda v, hi: np.clip(v, 0, hi)
+    want = np.concatenate([flow[cl(fr, H - 1), cl(fc, W - 1)], flow[cl(fr, H - 1), cl(fc + 1, W - 1)],
+                           flow[cl(fr + 1, H - 1), cl(fc, W - 1)], flow[cl(fr + 1, H - 1), cl(fc + 1, W - 1)]], 1)
+    assert np.array_equal(out[1], want)
