@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PSFM_VERSION 130   /* round 3: psfm_shard_solve_control_async, psfm_shard_window_state, psfm_shard_peek_stall */
+#define PSFM_VERSION 131   /* round 3: psfm_shard_solve_control_async, psfm_shard_window_state, psfm_shard_peek_stall */
 
 typedef enum psfm_status {
     PSFM_OK = 0,
@@ -236,6 +236,11 @@ psfm_status psfm_shard_begin(psfm_ctx* ctx, int n_flows, int h, int w, int sampl
 psfm_status psfm_shard_step(psfm_ctx* ctx, const float* flow, const uint8_t* occ, int frame, void* stream);
 psfm_status psfm_shard_solve_export(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02,
                                     const uint8_t* occ02, int frame, int kind, int k, double* sums_out, void* stream);
+/* psfm_shard_step(frame) + psfm_shard_solve_export(frame, kind 0, k) as ONE launch (track_optimize.py:31-50 for the own tracks:
+ * the chain step of the frame and the fused solve of its tracks, sums exported); frame >= 1, flow12 = the frame's own forward
+ * flow, occ = its occlusion map.  The frame's marks are exchanged behind it like psfm_shard_step's. */
+psfm_status psfm_shard_frame(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02, const uint8_t* occ,
+                             const uint8_t* occ02, int frame, int k, double* sums_out, void* stream);
 psfm_status psfm_shard_solve_control(psfm_ctx* ctx, int frame, int kind, int k, const double* totals, int32_t* done_host,
                                      int32_t* redo_host, psfm_solve_stats* stats_host, void* stream);
 /* The fused path without a host round trip per solve: psfm_shard_solve_control_async runs the control step of a fused export

@@ -213,7 +213,7 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
 psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                    const float* flow02, const uint8_t* occ02, int frame, int K, hipStream_t s);
 psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
-                              const uint8_t* occ, const uint8_t* occ02, int frame, int K, hipStream_t s);
+                              const uint8_t* occ, const uint8_t* occ02, int frame, int K, hipStream_t s, double* export_sums = nullptr);
 psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
                             const float* flows_f2, const uint8_t* occ_s2, int n_launches, int launch_id0, hipStream_t s);
 psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);

@@ -8,6 +8,7 @@
 //                              stamped grid-resolution `blocked` map of the frame (+ the survivor byte at offset G) sits in
 //                              a caller-owned buffer: the ranks all-reduce(max) its G + 1 bytes before the next step reads it
 //   psfm_shard_solve_export    the solve of the frame for the own tracks, sums only (fused: K x 13; chain: 13)
+//   psfm_shard_frame           the two above (fused export) as one launch
 //   psfm_shard_solve_control   Ceres' control step on the totals over all ranks (replicated: same numbers on every rank)
 //   psfm_shard_finish          write-backs pending, finalize: the own trajectories as the usual CSR result, sorted by the
 //                              key (last valid time, birth frame, birth grid index) -- global ids follow from the keys
@@ -82,6 +83,23 @@ extern "C" psfm_status psfm_shard_solve_export(psfm_ctx* c, const float* flow01,
     PsfmGate gate(c->device, 0);
     if (kind < 0 || kind > 2 || !sums_out || frame < 1) { psfm_set_error("psfm_shard_solve_export: bad argument"); return PSFM_ERR_ARG; }
     return psfm_solve_export(c, *c->shard_dims, flow01, flow12, flow02, occ02, frame, kind, k, sums_out, (hipStream_t)stream);
+}
+
+// Chain step of `frame` AND the fused export of its solve as ONE launch (psfm_frame_kernel with the sums exported): what
+// psfm_shard_step + psfm_shard_solve_export(kind 0) do in two, without the round trip of the tracks' tails through the log
+// in between.  The solve of frame t only needs this process's own tracks, so it does not wait for the exchange of the
+// frame's marks; the caller all-reduces the map and combines the sums behind the launch, then runs the control step.
+extern "C" psfm_status psfm_shard_frame(psfm_ctx* c, const float* flow01, const float* flow12, const float* flow02, const uint8_t* occ,
+                                        const uint8_t* occ02, int frame, int k, double* sums_out, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    const PsfmTrackDims& d = *c->shard_dims;
+    if (!flow01 || !flow12 || !flow02 || !occ || !occ02 || !sums_out || frame < 1 || frame >= d.n_flows || !c->shard_optimize) {
+        psfm_set_error("psfm_shard_frame: bad argument (frame %d)", frame);
+        return PSFM_ERR_ARG;
+    }
+    return psfm_launch_frame(c, d, flow01, flow12, flow02, occ, occ02, frame, k, (hipStream_t)stream, sums_out);
 }
 
 extern "C" psfm_status psfm_shard_solve_control(psfm_ctx* c, int frame, int kind, int k, const double* totals, int32_t* done_host,

@@ -47,6 +47,9 @@
 #include "psfm_pc_core.h"
 
 #define PC_BLOCK 256
+#ifndef PC_FUSED_PAIR
+#define PC_FUSED_PAIR false  // ... and the fused solve's: its lanes are neighbours in the image, and the frame kernel spills 7 VGPRs with them
+#endif
 #ifndef PC_RED_ROWS
 #define PC_RED_ROWS 32        // partial rows a thread of the last block keeps in flight
 #endif
@@ -59,6 +62,9 @@
                              // matters more than an equal number of tracks per thread)
 #endif
 #define PC_KMAX 8            // fused solve: most trust-region iterations speculated in one launch
+#ifndef PSFM_FRAME_WAVES
+#define PSFM_FRAME_WAVES 4    // psfm_frame_kernel (host-paced merged frames, the sharded engine's frames)
+#endif
 #ifndef PSFM_SEQ_WAVES_DEFAULT
 #define PSFM_SEQ_WAVES_DEFAULT 4
 #endif
@@ -999,7 +1005,7 @@ __device__ __forceinline__ void pc_fused_iteration(const PcParams& P, PcTrack& T
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) T.x[k] = xp[k];
-    pc_core_eval((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
+    pc_core_eval<PC_FUSED_PAIR>((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
     v[SUM_COST] += pc_core_cost(T.r);
 }
 
@@ -1084,7 +1090,7 @@ __device__ __forceinline__ double pc_track_setup(const PcParams& P, PcTrack& T, 
     T.r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
     T.r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
     T.x[0] = p1.x; T.x[1] = p1.y; T.x[2] = p2.x; T.x[3] = p2.y;
-    pc_core_eval((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, (double)sf, T.r, T.jac);
+    pc_core_eval<PC_FUSED_PAIR>((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, (double)sf, T.r, T.jac);
     // Jacobi scaling from the Jacobian at x0 (what psfm_pc_init_kernel stores in P.jscale)
     T.c = pc_core_const((double)sf, T.jac);
     T.iA22 = pc_core_iA22(T.c, mu);
@@ -1205,6 +1211,7 @@ __device__ __forceinline__ void pc_fused_body(const PcParams& P, bool part, doub
     if (!tot) return;
     if (P.export_sums) {      // track-sharded: the totals of THIS process; the control step follows the ranks' exchange
         if (tid < K * PC_NSUM) P.export_sums[tid] = tot[tid];
+        if (tid == 0 && snap_next) *snap_next = *n_lanes_live;   // (merged frame launch: every block is past its chain step)
         return;
     }
     if (tid != 0) return;
@@ -1233,7 +1240,7 @@ __device__ __forceinline__ void pc_more_body(const PcParams& P, int n_active, Ps
         (void)pc_track_setup(P, T, p0, s1, s2, mu);
         const double2 c1 = pc_buf1(P, pc_phys(base, e))[i], c2 = pc_buf2(P, pc_phys(base, e))[i];  // the current iterate
         T.x[0] = c1.x; T.x[1] = c1.y; T.x[2] = c2.x; T.x[3] = c2.y;
-        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
+        pc_core_eval<PC_FUSED_PAIR>((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
     }
     for (int j = 0; j < n_it; ++j) {
         double v[PC_NSUM];
@@ -1256,6 +1263,8 @@ __global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 void psfm_pc_fused_kernel(PcParams P)
 {
     if (*P.stall) return;
+    P.K = P.K < 1 ? 1 : (P.K > PC_KMAX ? PC_KMAX : P.K);      // (the host clamps it too: stated here, the range spares the iteration
+                                                             // loop 37 spilled VGPRs at 4 waves per SIMD)
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
     const int n_active = (n + PC_BLOCK - 1) / PC_BLOCK;        // blocks with a lane below the high-water mark
     if ((int)blockIdx.x >= n_active) return;
@@ -1274,9 +1283,10 @@ void psfm_pc_fused_kernel(PcParams P)
 // the lane state disappear.  Every block below the lane snapshot / the grid takes part in the solve's tickets.
 // ------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(PSFM_FRAME_WAVES, PSFM_FRAME_WAVES)))
 void psfm_frame_kernel(PsfmChainArgs a, PcParams P)
 {
+    P.K = P.K < 1 ? 1 : (P.K > PC_KMAX ? PC_KMAX : P.K);      // (clamped by the host already: the stated range keeps the loop from spilling)
     PsfmChainOut o;
     if (!psfm_chain_step_body<R, true, true>(a, o)) return;
     const int n_active = (max(a.ctr->n_lanes_snap[a.frame & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
@@ -1647,7 +1657,7 @@ psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const fl
     P.gticket = c->sol_fused.as<unsigned>();
     P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
     P.K = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
-    static const int waves = getenv("PSFM_FUSED_WAVES") ? atoi(getenv("PSFM_FUSED_WAVES")) : 3;   // (measured: 11.0 vs 11.7 ms per 1080p sequence)
+    static const int waves = getenv("PSFM_FUSED_WAVES") ? atoi(getenv("PSFM_FUSED_WAVES")) : 4;   // (round 3: 124 VGPRs, nothing spilled, once the kernel states the range of K)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     c->prof.kernel_span(PSFM_PROF_SOLVER, &e0, &e1, true);   // (profiling on: exact begin / end of every fused launch)
     if (waves == 3) hipExtLaunchKernelGGL(psfm_pc_fused_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, e0, e1, 0, P);
@@ -1678,7 +1688,7 @@ psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* 
         P.gticket = c->sol_fused.as<unsigned>();
         P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
         P.K = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
-        hipLaunchKernelGGL(psfm_pc_fused_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+        hipLaunchKernelGGL(psfm_pc_fused_kernel<4>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     } else {
         const int n_blocks = pc_blocks((int)d.cap);
         if (kind == 1) hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
@@ -1740,11 +1750,12 @@ psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame,
 // One loop iteration of track_optimize as ONE launch: chain step of `frame` + the fused solve of its tracks
 // (psfm_frame_kernel).  flow12 = the frame's own forward flow, occ = its occlusion map.
 psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
-                              const uint8_t* occ, const uint8_t* occ02, int frame, int K, hipStream_t s)
+                              const uint8_t* occ, const uint8_t* occ02, int frame, int K, hipStream_t s, double* export_sums)
 {
     PcParams P;
     psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
     if (rc != PSFM_OK) return rc;
+    P.export_sums = export_sums;      // track-sharded runs: the K x 13 sums of this process instead of the control step
     const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
     const int n_groups = (n_blocks + PC_GROUP - 1) / PC_GROUP;
     if ((rc = c->sol_partials.ensure(sizeof(double) * (size_t)n_blocks * PC_KMAX * PC_NSUM)) != PSFM_OK) return rc;

@@ -21,7 +21,7 @@ EXPORTS = [
     "psfm_ctx_set_solver", "psfm_solver_counters", "psfm_traj_to_matches", "psfm_matches_copy",
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
-    "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall",
+    "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
     L.psfm_shard_begin.argtypes = [vp, i32, i32, i32, i32, i64, i64, i32, vp, i64, vp]
     L.psfm_shard_step.argtypes = [vp, vp, vp, i32, vp]
     L.psfm_shard_solve_export.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.psfm_shard_frame.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.psfm_shard_solve_control.argtypes = [vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                            ctypes.POINTER(SolveStats), vp]
     L.psfm_shard_solve_control_async.argtypes = [vp, i32, i32, vp, vp]

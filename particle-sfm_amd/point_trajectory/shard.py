@@ -69,6 +69,23 @@ class HipShardEngine:
         _hip.check(L.psfm_shard_solve_control_async(h, int(t), k, _hip.ptr(self.sums), self._sp()))
         self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev)))    # (keeps the frames alive for a redo)
 
+    def frame(self, t, flow_prev, flow_cur, occ, flow2_prev, occ2_prev, reduce_first, reduce):
+        """step(t) and the fused export of solve(t) as ONE launch (psfm_shard_frame): the solve of frame t needs this rank's own
+        tracks only, so it does not wait for the exchange of the frame's marks.  reduce_first(x): the exchange of the marks (the
+        driver's all-reduce(max)), issued right behind the launch; then the sums over the ranks and the control step, enqueued
+        like solve()'s."""
+        L, h = _hip.lib(), self.ctx.handle
+        assert flow_cur.is_cuda and flow_cur.is_contiguous() and occ.is_contiguous()
+        k = max(1, min(K_MAX, self.k))
+        mask = [(i % N_SUM) == SUM_GMAX for i in range(k * N_SUM)]
+        _hip.check(L.psfm_shard_frame(h, _hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ),
+                                      _hip.ptr(occ2_prev), int(t), k, _hip.ptr(self.sums), self._sp()))
+        o = (int(t) & 1) * self.pitch
+        reduce_first(self.maps[o:o + self.G + 1])
+        reduce(self.sums[:k * N_SUM], mask)
+        _hip.check(L.psfm_shard_solve_control_async(h, int(t), k, _hip.ptr(self.sums), self._sp()))
+        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev)))
+
     def stalled(self):
         """True once the device has got to a solve that did not go as speculated (read from pinned memory, no synchronisation)."""
         v = ctypes.c_int32(-1)

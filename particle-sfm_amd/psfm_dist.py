@@ -18,6 +18,8 @@ What shards exactly:
     lengths and positions as one process; every message is latency-bound (<= 0.5 MB), so for chain-only runs this is
     slower than one GPU -- it is the exact single-sequence mode north_star asks for, measured as such by bench.py.
 """
+import os
+
 import numpy as np
 
 
@@ -344,6 +346,7 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     # one of them did not go as speculated; they redo it there and the frames behind it -- no-ops on the device since -- run again.
     # Every rank sees the same stall (the control step is replicated on the same totals), so the ranks rewind together.
     has_ck = optimize and hasattr(engine, "checkpoint")
+    merged = has_ck and hasattr(engine, "frame") and os.environ.get("PSFM_SHARD_MERGED", "1") != "0"
     if has_ck:
         # one rank sees a stall early (_any_stalled); several ranks must agree without talking: a short fixed window
         engine.check_every = 16 if world == 1 else 4
@@ -352,13 +355,20 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     t = 0
     while t < n_flows:
         f_t = wf.get(t) if owned else flows_f[t]
-        x = engine.step(t, f_t, occ[t])                                      # track.py:33-47 for the own tracks
-        comm.all_reduce_max_(x)                                              # marks of every rank's survivors
-        engine.after_exchange(t, x)
-        if optimize and t + 1 >= 2:                                          # track_optimize.py:49-50
+        if merged and t + 1 >= 2:
+            # step(t) + the fused export of solve(t) as one launch (the solve of frame t needs the own tracks only: it does not
+            # wait for the marks of step t), the two exchanges behind it
             f_prev = wf.get(t - 1) if owned else flows_f[t - 1]
             f2_prev = w2.get(t - 1) if owned else flows_f2[t - 1]
-            engine.solve(t, f_prev, f_t, f2_prev, occ2[t - 1], reduce)
+            engine.frame(t, f_prev, f_t, occ[t], f2_prev, occ2[t - 1], comm.all_reduce_max_, reduce)
+        else:
+            x = engine.step(t, f_t, occ[t])                                      # track.py:33-47 for the own tracks
+            comm.all_reduce_max_(x)                                              # marks of every rank's survivors
+            engine.after_exchange(t, x)
+            if optimize and t + 1 >= 2:                                          # track_optimize.py:49-50
+                f_prev = wf.get(t - 1) if owned else flows_f[t - 1]
+                f2_prev = w2.get(t - 1) if owned else flows_f2[t - 1]
+                engine.solve(t, f_prev, f_t, f2_prev, occ2[t - 1], reduce)
         since += 1
         # (every 16 frames -- or as soon as the engine sees, without synchronising, that a solve of the window has stalled)
         if has_ck and (since >= engine.check_every or t == n_flows - 1 or _any_stalled(engine, comm)):
