@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PSFM_VERSION 131   /* round 3: psfm_shard_solve_control_async, psfm_shard_window_state, psfm_shard_peek_stall */
+#define PSFM_VERSION 131   /* round 3: psfm_shard_solve_control_async, psfm_shard_window_state, psfm_shard_peek_stall, psfm_shard_frame */
 
 typedef enum psfm_status {
     PSFM_OK = 0,
