@@ -72,6 +72,14 @@ def test_connect_sharded_hip_engine(world, T, H, W, r, seed, sigma, nocc, optimi
         assert res[0][2]["fused_redone"] >= len(O.solves) // 2  # noisy sequence: the chain protocol did the work
 
 
+@pytest.mark.parametrize("case", [1, 2])
+def test_connect_sharded_hip_engine_two_launches_per_frame(case, monkeypatch):
+    """The default is one launch per frame (psfm_shard_frame = chain step + fused export); PSFM_SHARD_MERGED=0 keeps the
+    two-launch form (psfm_shard_step, psfm_shard_solve_export) that other engines and callers of the C ABI use: same result."""
+    monkeypatch.setenv("PSFM_SHARD_MERGED", "0")
+    test_connect_sharded_hip_engine(2, *CASES[case])
+
+
 @pytest.mark.parametrize("sigma", [0.05, 0.4])
 @pytest.mark.parametrize("world", [2, 3])
 def test_connect_sharded_hip_engine_frame_pair_owned_stacks(world, sigma):
