@@ -111,13 +111,13 @@ def shard_sequences(n_sequences, rank, world):
 def pack_bits(occ):
     """(n,H,W) bool/u8 torch tensor -> (n, ceil(H*W/8)) uint8, little-endian bit order, on the tensor's device."""
     import torch
-    n = occ.shape[0]
-    flat = (occ.reshape(n, -1) != 0).to(torch.uint8)
-    pad = (-flat.shape[1]) % 8
+    n, px = int(occ.shape[0]), int(occ.shape[1]) * int(occ.shape[2])
+    flat = (occ.reshape(n, px) != 0).to(torch.uint8)       # (explicit sizes: an empty slice -- n == 0 -- has no "-1")
+    pad = (-px) % 8
     if pad:
         flat = torch.nn.functional.pad(flat, (0, pad))
     w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=flat.device)
-    return (flat.reshape(n, -1, 8) * w).sum(-1, dtype=torch.int32).to(torch.uint8)
+    return (flat.reshape(n, (px + pad) // 8, 8) * w).sum(-1, dtype=torch.int32).to(torch.uint8)
 
 
 def unpack_bits(packed, H, W):
@@ -125,7 +125,8 @@ def unpack_bits(packed, H, W):
     import torch
     w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=packed.device)
     bits = ((packed.unsqueeze(-1) & w) != 0).to(torch.uint8)
-    return bits.reshape(packed.shape[0], -1)[:, :H * W].reshape(-1, H, W)
+    n = int(packed.shape[0])
+    return bits.reshape(n, int(packed.shape[1]) * 8)[:, :H * W].reshape(n, H, W)
 
 
 def flow_check_sharded(flows_f, flows_b, thres, check_fn, group=None, comm=None, n_total=None):
