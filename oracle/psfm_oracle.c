@@ -430,8 +430,15 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
     int iteration = 0;
     int step_successful = 1;       /* iteration 0 counts as successful */
     st.termination = 3;
+    /* IterationZero(): EvaluateGradientAndJacobian fails when a residual (or Jacobian entry) of ANY block is not finite
+     * (residual_block.cc ResidualBlock::Evaluate -> IsEvaluationValid / IsArrayValid) -- "Residual and Jacobian evaluation
+     * failed.", termination FAILURE before the first iteration.  The cost is finite iff every residual is (a Jacobian entry
+     * here is a difference of the taps the residual was blended from).  Evaluations of CANDIDATES that fail are steps of
+     * infinite cost instead (ComputeCandidatePointAndEvaluateCost): rejected below by the NaN comparisons. */
+    const int eval0_failed = !isfinite(x_cost);
+    if (eval0_failed) st.termination = 5;
 
-    for (;;) {
+    while (!eval0_failed) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue */
         if (step_successful && x_cost < minimum_cost) { /* trust_region_minimizer.cc: `if (x_cost_ < minimum_cost_)` -- strictly */
             minimum_cost = x_cost;

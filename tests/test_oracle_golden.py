@@ -175,6 +175,7 @@ def test_second_restatement_agrees_on_failure_and_trivial_cases():
     out_c, st_c = orc.optimize_location(uv, ref1, ref2, scale, bad, return_stats=True)
     out_n, st_n = ct.optimize_location(uv, ref1, ref2, scale, bad, uv.shape[0], 80, 60)
     assert st_c["termination"] == 5 and st_n["termination"] == 5          # FAILURE: parameters come back untouched
+    assert st_c["iterations"] == st_n["iterations"] == 0                   # in IterationZero: residual_block.cc IsEvaluationValid
     assert np.array_equal(out_c, uv) and np.array_equal(out_n, uv)
     # constant flow = linear least squares; already-optimal input
     H, W, n = 30, 40, 200
