@@ -1,0 +1,138 @@
+"""The DEVICE's arithmetic against the reference's golden vectors, without a GPU: particle-sfm_amd/csrc/psfm_device.h and
+psfm_chain.h -- the fp32 sampler (trajectory.py:25-37), the flow_check verdict of a pixel in its three forms (utils.py:58-105),
+a chain step (trajectory.py:45-62) and the EDT respawn rule folded into grid-resolution marks (trajectory.py:129-152) -- are
+compiled for the host through a stand-in for <hip/hip_runtime.h> (tests/host/shim: every *_rn intrinsic is the IEEE operation it
+names) and driven by tests/host/device_arith_host.cpp, which keeps plain lists where the kernels have lanes, ballots and
+atomics.  The vectors are the ones the reference's own Python produced (tests/golden/make_golden.py): bit-exact, like the GPU
+tests of the same kernels."""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import psfm_synth
+from _common import golden, regen_inputs, assert_csr_equal, input_hash
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("dev_arith") / "libdev_arith_host.so")
+    cmd = ["g++", "-O2", "-mfma", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "host", "shim"),
+           "-I", os.path.join(ROOT, "particle-sfm_amd", "csrc"), os.path.join(ROOT, "tests", "host", "device_arith_host.cpp"), "-o", out]
+    subprocess.run(cmd, check=True)
+    L = ctypes.CDLL(out)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+    L.psfm_host_grid_sample.argtypes = [vp, i32, i32, vp, i64, vp]
+    L.psfm_host_grid_sample1.argtypes = [vp, i32, i32, vp, i64, vp]
+    L.psfm_host_flow_check.argtypes = [vp, vp, i32, i32, ctypes.c_float, i32, vp, vp]
+    L.psfm_host_track.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i64, ctypes.POINTER(i64)]
+    L.psfm_host_track.restype = i64
+    return L
+
+
+def _sample(L, m, pts):
+    m = np.ascontiguousarray(m, np.float32)
+    pts = np.ascontiguousarray(pts, np.float32)
+    if m.ndim == 3:
+        out = np.empty((len(pts), 2), np.float32)
+        L.psfm_host_grid_sample(m.ctypes.data, m.shape[0], m.shape[1], pts.ctypes.data, len(pts), out.ctypes.data)
+    else:
+        out = np.empty(len(pts), np.float32)
+        L.psfm_host_grid_sample1(m.ctypes.data, m.shape[0], m.shape[1], pts.ctypes.data, len(pts), out.ctypes.data)
+    return out
+
+
+def _flow_check(L, f, b, thres, form):
+    f, b = np.ascontiguousarray(f, np.float32), np.ascontiguousarray(b, np.float32)
+    H, W = f.shape[:2]
+    occ, err = np.empty((H, W), np.uint8), np.empty((H, W), np.float32)
+    L.psfm_host_flow_check(f.ctypes.data, b.ctypes.data, H, W, thres, form, occ.ctypes.data, err.ctypes.data)
+    return err, occ.astype(bool)
+
+
+def _track(L, flows, occ, ratio):
+    fl = [np.ascontiguousarray(f, np.float32) for f in flows]
+    oc = [np.ascontiguousarray(o, np.uint8) for o in occ]
+    n = len(fl)
+    H, W = fl[0].shape[:2]
+    PA = ctypes.c_void_p * n
+    G = ((H + ratio - 1) // ratio) * ((W + ratio - 1) // ratio)
+    cap_t, cap_p = G * (n + 1), G * (n + 1) * 2
+    birth, length, xy = np.empty(cap_t, np.int32), np.empty(cap_t, np.int32), np.empty((cap_p, 2), np.float64)
+    npts = ctypes.c_long(0)
+    nt = L.psfm_host_track(PA(*[f.ctypes.data for f in fl]), PA(*[o.ctypes.data for o in oc]), n, H, W, ratio, birth.ctypes.data,
+                           length.ctypes.data, xy.ctypes.data, cap_t, cap_p, ctypes.byref(npts))
+    assert nt >= 0, nt
+    return birth[:nt].copy(), length[:nt].copy(), xy[:npts.value].copy()
+
+
+def test_device_sampler_bit_exact(dev):
+    g = golden("sampler")
+    rng = np.random.default_rng(int(g["seed"]))
+    H, W = int(g["H"]), int(g["W"])
+    m2 = rng.standard_normal((H, W, 2)).astype(np.float32)
+    m1 = (rng.uniform(size=(H, W)) < 0.3)
+    assert np.array_equal(_sample(dev, m2, g["pts"]).view(np.uint32), g["s2"].view(np.uint32))
+    assert np.array_equal(_sample(dev, m1.astype(np.float32), g["pts"]).view(np.uint32), g["s1"].reshape(-1).view(np.uint32))
+    rng.uniform([-3, -3], [W + 2, H + 2], size=(4000, 2))        # (the generator's point draws between the maps)
+    mb = rng.standard_normal((int(g["Hb"]), int(g["Wb"]), 2)).astype(np.float32)
+    assert hashlib.sha256(m2.tobytes() + m1.tobytes() + mb.tobytes()).hexdigest() == str(g["map_hash"])
+    assert np.array_equal(_sample(dev, mb, g["pb"]).view(np.uint32), g["sb"].view(np.uint32))       # 1080p coordinates
+
+
+def test_device_flow_check_bit_exact_in_its_three_forms(dev):
+    g = golden("flow_check")
+    d = psfm_synth.synth_sequence(4, 64, 96, seed=21, sigma=0.4, n_occluders=2, stride2=False)
+    for thres in (1.0, 3.0):
+        res = [[_flow_check(dev, f, b, thres, form) for f, b in zip(d["flows_f"], d["flows_b"])] for form in (0, 1, 2)]
+        assert np.array_equal(np.stack([e for e, _ in res[0]]).view(np.uint32), g["fc_err_%g" % thres].view(np.uint32))
+        for form in (0, 1, 2):       # the mask-only forms never take the root or the true division: same masks
+            assert np.array_equal(np.packbits(np.stack([o for _, o in res[form]])), g["fc_occ_%g" % thres]), form
+    dd = psfm_synth.synth_sequence(3, 40, 56, seed=22, amp=9.0, sigma=0.0, stride2=False)
+    for form in (0, 1, 2):
+        res = [_flow_check(dev, f, b, 1.0, form) for f, b in zip(dd["flows_f"], dd["flows_b"])]
+        if form == 0:
+            assert np.array_equal(np.stack([e for e, _ in res]).view(np.uint32), g["big_err"].view(np.uint32))
+        assert np.array_equal(np.packbits(np.stack([o for _, o in res])), g["big_occ"])
+
+
+@pytest.mark.parametrize("name", ["track_48x64_r2", "track_45x70_r1", "track_50x66_r3", "track_52x61_r4",
+                                  "track_largemotion_80x120_r2", "track_largemotion_75x110_r1"])
+def test_device_chain_arithmetic_reproduces_the_reference_track(dev, name):
+    """Births on the stride-r grid, the step, deaths, the respawn rule as grid-resolution marks, ids by the key: every trajectory
+    of the reference's own track() -- ids, lengths, f64 positions -- bit for bit."""
+    g = golden(name)
+    d = regen_inputs(g, stride2=False)
+    occ = [_flow_check(dev, f, b, 1.0, 1)[1] for f, b in zip(d["flows_f"], d["flows_b"])]
+    birth, length, xy = _track(dev, d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(birth, length, xy, g)
+
+
+def test_device_chain_arithmetic_all_tracks_die(dev):
+    g = golden("track_alldie_24x30_r2")
+    d = regen_inputs(g, stride2=False)
+    occ = [_flow_check(dev, f, b, 1.0, 2)[1] for f, b in zip(d["flows_f"], d["flows_b"])]
+    occ[1][:] = True
+    birth, length, xy = _track(dev, d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(birth, length, xy, g)
+
+
+def test_device_arithmetic_on_nonfinite_flows(dev):
+    g = golden("nonfinite_40x56_r2")
+    d = psfm_synth.poison_nonfinite(psfm_synth.synth_sequence(int(g["T"]), int(g["H"]), int(g["W"]), seed=int(g["seed"]),
+                                                              sigma=float(g["sigma"]), n_occluders=int(g["n_occluders"]),
+                                                              stride2=False), seed=int(g["seed"]) + 1)
+    assert input_hash(d) == str(g["input_hash"])
+    res = [_flow_check(dev, f, b, 1.0, 0) for f, b in zip(d["flows_f"], d["flows_b"])]
+    assert np.array_equal(np.stack([e for e, _ in res]).view(np.uint32), g["fc_err"].view(np.uint32))
+    occ = [o for _, o in res]
+    assert np.array_equal(np.packbits(np.stack(occ)), g["fc_occ"])
+    for form in (1, 2):
+        assert np.array_equal(np.packbits(np.stack([_flow_check(dev, f, b, 1.0, form)[1] for f, b in zip(d["flows_f"], d["flows_b"])])), g["fc_occ"])
+    birth, length, xy = _track(dev, d["flows_f"], occ, int(g["ratio"]))
+    assert_csr_equal(birth, length, xy, g)
