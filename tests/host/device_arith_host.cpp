@@ -7,6 +7,11 @@
 #include <vector>
 
 #include "psfm_chain.h"
+#include "psfm_pc_control.h"
+
+// tests/host/pc_chain_host.cpp (linked into the same library): the device's launch chain for a batch of tracks
+extern "C" int pc_host_chain_solve(long n, const double* x0, const double* ref1, const double* ref2, const double* scale,
+                                   const float* flow, int H, int W, int pair, double* x_out, int* stats, double* costs);
 
 extern "C" void psfm_host_grid_sample(const float* map, int H, int W, const float* xy, long n, float* out)
 {
@@ -62,8 +67,13 @@ struct HostTrack { int birth, gidx; std::vector<double2> pts; int last; };
 
 // track.py:24-50 with the device's arithmetic.  Returns the number of trajectories (ids = order of the key (last valid
 // time, birth frame, birth grid index), psfm_key); points into xy (cap_points x 2).
+// flows2 / occs2 != NULL: track_optimize.py:24-53 -- behind the step of frame t >= 1 the tracks with three buffered points
+// (times t-1, t, t+1) are optimised together (trajectory.py:161-194): references and weight from the fp32 sampler at p0
+// (restating pc_init_tracks of psfm_solver.hip with the device's sampler), the solve by the device's launch chain.
+// iters_out (n_flows - 1 entries, may be NULL): iterations of every solve.
 extern "C" long psfm_host_track(const float* const* flows, const uint8_t* const* occs, int n_flows, int H, int W, int ratio,
-                                int* birth_out, int* len_out, double* xy_out, long cap_tracks, long cap_points, long* n_points_out)
+                                int* birth_out, int* len_out, double* xy_out, long cap_tracks, long cap_points, long* n_points_out,
+                                const float* const* flows2, const uint8_t* const* occs2, int* iters_out, int* terms_out)
 {
     HostFrame a;
     a.H = H; a.W = W; a.cw = (float)((W - 1) / 2.0); a.ch = (float)((H - 1) / 2.0);
@@ -108,6 +118,40 @@ extern "C" long psfm_host_track(const float* const* flows, const uint8_t* const*
         active.swap(next);
         marks_prev.swap(marks_cur);
         any_prev = any;
+        if (flows2 && t + 1 >= 2) {      // track_optimize.py:49-50
+            const float2* flow01 = (const float2*)flows[t - 1];
+            const float2* flow02 = (const float2*)flows2[t - 1];
+            const uint8_t* occ02 = occs2[t - 1];
+            std::vector<HostTrack*> sel;
+            for (auto& k : active) if (k.birth <= t - 1) sel.push_back(&k);
+            const long n = (long)sel.size();
+            std::vector<double> x0(4 * n), r1(2 * n), r2(2 * n), sc(n), xo(4 * n);
+            for (long i = 0; i < n; ++i) {
+                const std::vector<double2>& q = sel[i]->pts;
+                const double2 p0 = q[q.size() - 3], p1 = q[q.size() - 2], p2 = q[q.size() - 1];
+                const PsfmTaps tp = psfm_taps((float)p0.x, (float)p0.y, a.cw, a.ch, H, W);
+                const PsfmTapIdx ki = psfm_tap_idx(H, W, tp);
+                const float2 f01 = psfm_sample_flow(flow01, ki, tp);
+                const float2 f02 = psfm_sample_flow(flow02, ki, tp);
+                const float o02 = psfm_sample_mask(occ02, ki, tp);
+                const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
+                const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);      // trajectory.py:179
+                sc[i] = (double)sf;
+                r1[2 * i] = p0.x + (double)f01.x; r1[2 * i + 1] = p0.y + (double)f01.y;
+                r2[2 * i] = p0.x + (double)f02.x; r2[2 * i + 1] = p0.y + (double)f02.y;
+                x0[4 * i] = p1.x; x0[4 * i + 1] = p1.y; x0[4 * i + 2] = p2.x; x0[4 * i + 3] = p2.y;
+            }
+            int st[7] = {0, 0, -1, 0, 0, 0, 0};
+            double costs[2];
+            if (n > 0) pc_host_chain_solve(n, x0.data(), r1.data(), r2.data(), sc.data(), flows[t], H, W, 1, xo.data(), st, costs);
+            if (iters_out) iters_out[t - 1] = n > 0 ? st[0] : -1;
+            if (terms_out) terms_out[t - 1] = n > 0 ? st[2] : -1;
+            for (long i = 0; i < n; ++i) {
+                std::vector<double2>& q = sel[i]->pts;
+                q[q.size() - 2] = make_double2(xo[4 * i], xo[4 * i + 1]);
+                q[q.size() - 1] = make_double2(xo[4 * i + 2], xo[4 * i + 3]);
+            }
+        }
     }
     for (auto& k : active) { k.last = n_flows; done.push_back(std::move(k)); }   // clear_active (trajectory.py:154-158)
     // ---- ids: rank under the device's key ----

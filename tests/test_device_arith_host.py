@@ -23,14 +23,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def dev(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("dev_arith") / "libdev_arith_host.so")
     cmd = ["g++", "-O2", "-mfma", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "host", "shim"),
-           "-I", os.path.join(ROOT, "particle-sfm_amd", "csrc"), os.path.join(ROOT, "tests", "host", "device_arith_host.cpp"), "-o", out]
+           "-I", os.path.join(ROOT, "particle-sfm_amd", "csrc"), os.path.join(ROOT, "tests", "host", "device_arith_host.cpp"),
+           os.path.join(ROOT, "tests", "host", "pc_chain_host.cpp"), "-o", out]
     subprocess.run(cmd, check=True)
     L = ctypes.CDLL(out)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
     L.psfm_host_grid_sample.argtypes = [vp, i32, i32, vp, i64, vp]
     L.psfm_host_grid_sample1.argtypes = [vp, i32, i32, vp, i64, vp]
     L.psfm_host_flow_check.argtypes = [vp, vp, i32, i32, ctypes.c_float, i32, vp, vp]
-    L.psfm_host_track.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i64, ctypes.POINTER(i64)]
+    L.psfm_host_track.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i64, i64, ctypes.POINTER(i64), vp, vp, vp, vp]
     L.psfm_host_track.restype = i64
     return L
 
@@ -55,20 +56,28 @@ def _flow_check(L, f, b, thres, form):
     return err, occ.astype(bool)
 
 
-def _track(L, flows, occ, ratio):
+def _track(L, flows, occ, ratio, flows2=None, occ2=None):
     fl = [np.ascontiguousarray(f, np.float32) for f in flows]
     oc = [np.ascontiguousarray(o, np.uint8) for o in occ]
     n = len(fl)
     H, W = fl[0].shape[:2]
-    PA = ctypes.c_void_p * n
     G = ((H + ratio - 1) // ratio) * ((W + ratio - 1) // ratio)
     cap_t, cap_p = G * (n + 1), G * (n + 1) * 2
     birth, length, xy = np.empty(cap_t, np.int32), np.empty(cap_t, np.int32), np.empty((cap_p, 2), np.float64)
     npts = ctypes.c_long(0)
-    nt = L.psfm_host_track(PA(*[f.ctypes.data for f in fl]), PA(*[o.ctypes.data for o in oc]), n, H, W, ratio, birth.ctypes.data,
-                           length.ctypes.data, xy.ctypes.data, cap_t, cap_p, ctypes.byref(npts))
+    ptrs = lambda arrs: (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    f2 = o2 = its = terms = None
+    if flows2 is not None:
+        f2l = [np.ascontiguousarray(f, np.float32) for f in flows2]
+        o2l = [np.ascontiguousarray(o, np.uint8) for o in occ2]
+        f2, o2 = ptrs(f2l), ptrs(o2l)
+        its, terms = np.full(n - 1, -2, np.int32), np.full(n - 1, -2, np.int32)
+    nt = L.psfm_host_track(ptrs(fl), ptrs(oc), n, H, W, ratio, birth.ctypes.data, length.ctypes.data, xy.ctypes.data, cap_t, cap_p,
+                           ctypes.byref(npts), f2, o2, its.ctypes.data if its is not None else None,
+                           terms.ctypes.data if terms is not None else None)
     assert nt >= 0, nt
-    return birth[:nt].copy(), length[:nt].copy(), xy[:npts.value].copy()
+    out = (birth[:nt].copy(), length[:nt].copy(), xy[:npts.value].copy())
+    return out + (its, terms) if flows2 is not None else out
 
 
 def test_device_sampler_bit_exact(dev):
@@ -136,3 +145,21 @@ def test_device_arithmetic_on_nonfinite_flows(dev):
         assert np.array_equal(np.packbits(np.stack([_flow_check(dev, f, b, 1.0, form)[1] for f, b in zip(d["flows_f"], d["flows_b"])])), g["fc_occ"])
     birth, length, xy = _track(dev, d["flows_f"], occ, int(g["ratio"]))
     assert_csr_equal(birth, length, xy, g)
+
+
+@pytest.mark.parametrize("name", ["opt_48x64_r2", "opt_45x70_r3", "opt_largemotion_96x128_r2", "opt_largemotion_90x140_r3"])
+def test_device_arithmetic_reproduces_the_reference_track_optimize(dev, name):
+    """track_optimize.py:24-53 with the device's arithmetic end to end: chain step, references / weight of optimize_buffer from
+    the fp32 sampler (both sides of the 20 px gate of trajectory.py:179 in the large-motion fixtures), every frame's solve by the
+    device's launch chain -- against the fixtures the reference's own Python produced (with the C restatement in the solver's
+    seat): ids and lengths exact, positions to 1e-5 px, and every solve's iteration count and termination equal to the oracle's."""
+    from oracle import oracle as orc
+    g = golden(name)
+    d = regen_inputs(g, stride2=True)
+    occ = [_flow_check(dev, f, b, 1.0, 1)[1] for f, b in zip(d["flows_f"], d["flows_b"])]
+    occ2 = [_flow_check(dev, f, b, 1.0, 1)[1] for f, b in zip(d["flows_f2"], d["flows_b2"])]
+    birth, length, xy, its, terms = _track(dev, d["flows_f"], occ, int(g["ratio"]), d["flows_f2"], occ2)
+    assert_csr_equal(birth, length, xy, g, tol=1e-5)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
+    assert [int(v) for v in its] == [s["iterations"] for s in O.solves]
+    assert [int(v) for v in terms] == [s["termination"] for s in O.solves]
