@@ -81,3 +81,75 @@ extern "C" int pc_host_chain_solve(long n, const double* x0, const double* ref1,
     costs[0] = C.initial_cost; costs[1] = C.x_cost;
     return C.done ? 0 : 1;
 }
+
+// ---- the FUSED solve (psfm_pc_fused_kernel / the frame kernels: pc_fused_body + pc_fused_replay of psfm_solver.hip) ----
+// K trust-region iterations per track speculated as accepted Gauss-Newton steps at mu = min_mu, the K x 13 sums replayed by
+// pc_control_step; when all K were accepted without ending the solve, continuation launches of up to two more iterations from
+// the last iterate (pc_more_body); the first decision that is not "Gauss-Newton step accepted" ends the belief.
+// Returns 0: solved as speculated (x_out = the accepted iterate; a failed solve hands the start values back);
+//         1: not as speculated -- the product redoes the solve with the launch chain from the start values (x_out untouched).
+#define PC_HOST_KMAX 8
+extern "C" int pc_host_fused_solve(long n, const double* x0, const double* ref1, const double* ref2, const double* scale,
+                                   const float* flow, int H, int W, int K, double* x_out, int* stats, double* costs)
+{
+    const PcF2* F = (const PcF2*)flow;
+    const double mu = 1e-8;
+    if (K < 1) K = 1;
+    if (K > PC_HOST_KMAX) K = PC_HOST_KMAX;
+    std::vector<std::vector<double>> it(PC_HOST_KMAX + 1);          // iterate m = the positions after m accepted steps
+    it[0].assign(x0, x0 + 4 * n);
+    std::vector<PcConst> cs(n);
+    std::vector<double> c0(n);
+    for (long i = 0; i < n; ++i) {                                    // pc_track_setup: Jacobi scaling at the start values
+        double r[6], j[4];
+        pc_core_eval<false>(F, H, W, x0 + 4 * i, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], scale[i], r, j);
+        cs[i] = pc_core_const(scale[i], j);
+        c0[i] = pc_core_cost(r);
+    }
+    auto rows_from = [&](int base, int n_it, bool first, double* tot) {   // n_it speculated iterations behind iterate `base`
+        for (int q = 0; q < n_it * PC_NSUM; ++q) tot[q] = 0.0;
+        for (int j = 0; j < n_it; ++j) it[base + j + 1].assign(4 * n, 0.0);
+        for (long i = 0; i < n; ++i) {
+            double x[4], r[6], jac[4];
+            for (int k = 0; k < 4; ++k) x[k] = it[base][4 * i + k];
+            pc_core_eval<false>(F, H, W, x, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], scale[i], r, jac);
+            const double iA22 = pc_core_iA22(cs[i], mu);
+            for (int j = 0; j < n_it; ++j) {
+                double v[PC_NSUM], xp[4];
+                for (int k = 0; k < PC_NSUM; ++k) v[k] = 0.0;
+                pc_core_iteration<true>(x, r, jac, cs[i], mu, iA22, 0.0, 1.0, v, xp);           // pc_fused_iteration
+                for (int k = 0; k < 4; ++k) { x[k] = xp[k]; it[base + j + 1][4 * i + k] = xp[k]; }
+                pc_core_eval<false>(F, H, W, x, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], scale[i], r, jac);
+                v[SUM_COST] += pc_core_cost(r);
+                if (first && j == 0) { v[SUM_CNT] = 1.0; v[SUM_COST0] = c0[i]; }
+                double* row = tot + j * PC_NSUM;
+                for (int k = 0; k < PC_NSUM; ++k) row[k] = k == SUM_GMAX ? fmax(row[k], v[k]) : row[k] + v[k];
+            }
+        }
+    };
+    PsfmSolveCtrl C;
+    memset(&C, 0, sizeof(C));
+    double tot[PC_HOST_KMAX * PC_NSUM];
+    int base = 0, n_it = K;
+    bool first = true;
+    for (;;) {
+        rows_from(base, n_it, first, tot);
+        for (int j = 1; j <= n_it; ++j) {                             // pc_fused_replay
+            pc_control_step(C, tot + (j - 1) * PC_NSUM, first && j == 1, base + j);
+            if (C.done) break;
+            if (!(C.fresh_x && C.cur == base + j && C.dl_fixed == 0 && C.mu == 1e-8)) break;
+        }
+        C.launches += 1;
+        if (C.done) break;
+        const bool all_accepted = C.fresh_x && C.cur == base + n_it && C.dl_fixed == 0 && C.mu == 1e-8;
+        if (!(all_accepted && C.cur + 1 <= PC_HOST_KMAX)) return 1;   // the launch chain takes over from the start values
+        base = C.cur; n_it = PC_HOST_KMAX - base < 2 ? PC_HOST_KMAX - base : 2; first = false;      // pc_more_body
+    }
+    const std::vector<double>& xf = it[C.failed ? 0 : C.cur];
+    for (long i = 0; i < 4 * n; ++i) x_out[i] = xf[i];
+    stats[0] = C.iteration; stats[1] = C.successful; stats[2] = C.n_tracks == 0 ? -1 : C.termination; stats[3] = C.nonGN;
+    stats[4] = C.launches; stats[5] = C.done; stats[6] = C.failed;
+    if (C.failed) stats[2] = PSFM_TERM_FAILURE;
+    costs[0] = C.initial_cost; costs[1] = C.x_cost;
+    return 0;
+}

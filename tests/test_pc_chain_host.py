@@ -28,10 +28,12 @@ def chain(tmp_path_factory):
     dp, fp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
     L.pc_host_chain_solve.argtypes = [ctypes.c_long, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp]
     L.pc_host_chain_solve.restype = ctypes.c_int
+    L.pc_host_fused_solve.argtypes = [ctypes.c_long, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp]
+    L.pc_host_fused_solve.restype = ctypes.c_int
     return L
 
 
-def _solve(L, uv, ref1, ref2, scale, flow12, pair=1):
+def _solve(L, uv, ref1, ref2, scale, flow12, pair=1, fused_k=0):
     dp, fp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
     uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 4)
     n = len(uv)
@@ -40,8 +42,9 @@ def _solve(L, uv, ref1, ref2, scale, flow12, pair=1):
     fl = np.ascontiguousarray(flow12, np.float32)
     H, W = fl.shape[:2]
     out = np.empty((n, 4)); stats = np.zeros(7, np.int32); costs = np.zeros(2)
-    rc = L.pc_host_chain_solve(n, uv.ctypes.data_as(dp), r1.ctypes.data_as(dp), r2.ctypes.data_as(dp), sc.ctypes.data_as(dp),
-                               fl.ctypes.data_as(fp), H, W, pair, out.ctypes.data_as(dp), stats.ctypes.data_as(ip), costs.ctypes.data_as(dp))
+    fn = L.pc_host_fused_solve if fused_k else L.pc_host_chain_solve
+    rc = fn(n, uv.ctypes.data_as(dp), r1.ctypes.data_as(dp), r2.ctypes.data_as(dp), sc.ctypes.data_as(dp), fl.ctypes.data_as(fp), H, W,
+            fused_k if fused_k else pair, out.ctypes.data_as(dp), stats.ctypes.data_as(ip), costs.ctypes.data_as(dp))
     return out, {"iterations": int(stats[0]), "successful_steps": int(stats[1]), "termination": int(stats[2]),
                  "dogleg_nonGN": int(stats[3]), "launches": int(stats[4]), "done": int(stats[5]), "failed": int(stats[6]),
                  "initial_cost": float(costs[0]), "final_cost": float(costs[1])}, rc
@@ -124,3 +127,54 @@ def test_device_launch_chain_on_the_host_random_batches(chain, seed, n, sigma, k
     got, st, rc = _solve(chain, uv, ref1, ref2, scale, flow12)
     assert rc == 0
     _same_solve(got, st, want, st_o, 1e-6)
+
+
+@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 300), sigma=st.sampled_from([0.0, 0.01, 0.03, 0.06, 0.1, 0.3]),
+       k=st.integers(1, 8), hw=st.sampled_from([(24, 31), (40, 56), (64, 64)]), spread=st.sampled_from([0.02, 0.1, 0.5]))
+def test_device_fused_solve_on_the_host_is_the_chain_or_hands_over(chain, seed, n, sigma, k, hw, spread):
+    """The speculated form (what the frame kernels run: K Gauss-Newton iterations per launch, the sums replayed by the control
+    step, continuation launches while every step is accepted).  Whenever it finishes, the solve is the oracle's, decision for
+    decision, and bit-identical to the launch chain's on the same tracks; otherwise it hands over (return 1: the product then runs
+    the chain from the start values) and has not written anything.  Clean flows with nearby start values finish this way."""
+    from oracle import oracle as orc
+    H, W = hw
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, seed, sigma, False)
+    rng = np.random.default_rng(seed)
+    uv = np.concatenate([ref1, ref2], 1) + rng.normal(0, spread, (len(uv), 4))       # start values near the references
+    got, sg, rc = _solve(chain, uv, ref1, ref2, scale, flow12, fused_k=k)
+    want, so = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+    ch, sc, _ = _solve(chain, uv, ref1, ref2, scale, flow12, pair=0)
+    if rc == 0:
+        _same_solve(got, sg, want, so, 1e-6)
+        assert np.array_equal(got, ch) and all(sg[q] == sc[q] for q in ("iterations", "successful_steps", "termination", "dogleg_nonGN"))
+        assert sg["final_cost"] == sc["final_cost"]
+    else:
+        assert rc == 1
+    if so["iterations"] <= 7:        # (8 iterates per solve are buffered: longer clean solves hand over too)
+        assert (rc == 0) == _clean(so), so
+    _same_solve(ch, sc, want, so, 1e-6)
+
+
+def _clean(so):
+    """what the fused solve speculates: every iteration an accepted Gauss-Newton step at min_mu, but the one that ends the solve"""
+    extra = so["iterations"] - so["successful_steps"]
+    return so["dogleg_nonGN"] == 0 and (extra == 1 or (extra == 0 and so["termination"] in (2, 5)))
+
+
+def test_device_fused_solve_on_the_host_finishes_exactly_the_clean_solves(chain):
+    """K = 3 like the bench's sequences: solves of 4-5 clean iterations are finished by continuation launches, solves with a
+    rejected or interpolated step hand over -- the split is exactly the oracle's statistics."""
+    from oracle import oracle as orc
+    done = 0
+    for seed in range(12):
+        uv, ref1, ref2, scale, flow12 = solver_batch(60, 80, 2000, 100 + seed, 0.02, False)
+        uv = np.concatenate([ref1, ref2], 1) + np.random.default_rng(seed).normal(0, 0.05, (len(uv), 4))
+        got, sg, rc = _solve(chain, uv, ref1, ref2, scale, flow12, fused_k=3)
+        want, so = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+        assert (rc == 0) == _clean(so), so
+        if rc == 0:
+            done += 1
+            assert so["iterations"] > 3          # more than one launch's worth: the continuation ran
+            _same_solve(got, sg, want, so, 1e-6)
+    assert 3 <= done <= 9
