@@ -163,3 +163,22 @@ def test_device_arithmetic_reproduces_the_reference_track_optimize(dev, name):
     O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
     assert [int(v) for v in its] == [s["iterations"] for s in O.solves]
     assert [int(v) for v in terms] == [s["termination"] for s in O.solves]
+
+
+@pytest.mark.parametrize("T,H,W,r,seed,sigma,nocc,drift", [(12, 120, 214, 2, 31, 0.3, 3, (0.0, 0.0)), (10, 97, 131, 1, 32, 0.15, 2, (6.0, -4.0)),
+                                                          (14, 160, 200, 4, 33, 0.5, 4, (0.0, 0.0)), (9, 75, 203, 3, 34, 0.05, 1, (-9.0, 2.0))])
+def test_device_chain_arithmetic_equals_the_oracle_on_larger_sequences(dev, T, H, W, r, seed, sigma, nocc, drift):
+    """Beyond the committed fixtures: noisy / drifting sequences with thousands of deaths and respawns, against the oracle (itself
+    pinned bit-exact to the reference's Python): masks, ids, lengths and f64 positions bit for bit."""
+    from oracle import oracle as orc
+    d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=False, drift=drift)
+    err_o, occ_o = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    res = [_flow_check(dev, f, b, 1.0, 0) for f, b in zip(d["flows_f"], d["flows_b"])]
+    assert np.array_equal(np.stack([e for e, _ in res]).view(np.uint32), np.stack(err_o).view(np.uint32))
+    occ = [o for _, o in res]
+    assert np.array_equal(np.stack(occ), np.stack(occ_o))
+    O = orc.track(d["flows_f"], occ_o, r)
+    birth, length, xy = _track(dev, d["flows_f"], occ, r)
+    assert len(birth) == O.n_traj > 2000 and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
+    assert np.array_equal(xy, O.xy)
+    assert int((O.length < T).sum()) > 500          # plenty of tracks that died or were respawned
