@@ -152,7 +152,58 @@ def _owned_worker(rank, world, port, ret):
             _, occ = orc.flow_check(list(f.numpy()), list(b.numpy()), thres)
             return torch.from_numpy(np.stack(occ).astype(np.uint8)) if len(occ) else torch.zeros((0,) + tuple(f.shape[1:3]), dtype=torch.uint8)
 
+        class DeferredEngine(orc.ShardEngine):
+            """The shape of the HIP engine on top of the oracle's: a frame (step + solve) is only ENQUEUED -- with the tensors the
+            driver handed over, like kernels that read them later -- and a checkpoint runs the queue.  At the frames in `stall_at`
+            it behaves like a solve that did not go as speculated: that frame is completed, everything enqueued behind it is
+            dropped (on the device those launches were no-ops) and the driver is told to run the frames behind it again.  If the
+            driver's frame window recycled a buffer too early, or rewound to the wrong frame, the trajectories change."""
+
+            def __init__(self, stall_at):
+                super().__init__()
+                self.queue, self.stall_at, self.check_every, self.reruns = [], set(stall_at), 16, 0
+
+            def frame(self, t, flow_prev, flow_cur, occ, flow2_prev, occ2_prev, reduce_first, reduce):
+                self.queue.append((t, flow_prev, flow_cur, occ, flow2_prev, occ2_prev, reduce_first))
+
+            def stalled(self):
+                return False
+
+            def checkpoint(self, reduce):
+                redo = None
+                for k, (t, fp, fc, oc, f2, o2, reduce_first) in enumerate(self.queue):
+                    x = orc.ShardEngine.step(self, t, fc, oc)
+                    reduce_first(x)
+                    orc.ShardEngine.after_exchange(self, t, x)
+                    orc.ShardEngine.solve(self, t, fp, fc, f2, o2, reduce)
+                    if t in self.stall_at:
+                        self.stall_at.discard(t)
+                        self.reruns += len(self.queue) - k - 1
+                        redo = t
+                        break
+                self.queue = []
+                return redo
+
         out = {}
+        # the same sequence through an engine that only enqueues its frames and rewinds the driver twice (frames 3 and 9; the
+        # checkpoints fall every 4 frames with several ranks): owned stacks, so the frame window has to keep what a redo needs
+        T, H, W, r = 14, 36, 50, 2
+        d = psfm_synth.synth_sequence(T, H, W, seed=44, sigma=0.25, n_occluders=2, stride2=True)
+        n, n2 = T - 1, T - 2
+        lo, hi = psfm_dist.shard_range(n, rank, world)
+        lo2, hi2 = psfm_dist.shard_range(n2, rank, world)
+        sl = lambda k, a, b: (torch.from_numpy(np.stack(d[k][a:b])) if b > a else torch.zeros((0, H, W, 2), dtype=torch.float32))
+        eng = DeferredEngine([3, 9])
+        part = psfm_dist.connect_sharded(eng, sl("flows_f", lo, hi), sl("flows_b", lo, hi), sl("flows_f2", lo2, hi2),
+                                         sl("flows_b2", lo2, hi2), 1.0, r, check, n_flows_total=n)
+        birth, length, off, xy = psfm_dist.gather_result(part)
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+        O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        out["deferred"] = (bool(len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
+                                and np.array_equal(xy, O.xy)),
+                           [s["iterations"] for s in part["solve_stats"]] == [s["iterations"] for s in O.solves],
+                           eng.reruns > 0 and not eng.stall_at and not eng.queue)
         # (more ranks than stride-2 pairs in the last case: a rank with an EMPTY slice of a stack)
         cases = [(9, 38, 52, 2, 41, 0.3, 2, False), (8, 45, 60, 3, 42, 0.1, 1, True), (3, 30, 44, 1, 43, 0.2, 1, True)]
         for ci, (T, H, W, r, seed, sigma, nocc, optimize) in enumerate(cases):
@@ -193,7 +244,7 @@ def test_connect_sharded_with_frame_pair_owned_stacks(world):
     mp.spawn(_owned_worker, args=(world, port, ret), nprocs=world, join=True)
     assert len(ret) == world
     for r in range(world):
-        for ci in (0, 1, 2):
+        for ci in (0, 1, 2, "deferred"):
             assert all(ret[r][ci]), (r, ci, ret[r][ci])
 
 
