@@ -7,9 +7,11 @@ for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
         sys.path.insert(0, p)
 
 
-# The oracle's OpenMP team idles between the thousands of short solves the property tests make: let the threads sleep instead of
-# spinning (on a shared box the spin competes with the test itself; results do not depend on it).
-os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+# The oracle's OpenMP team idles between the thousands of short solves the property tests make: on a small shared box let the
+# threads sleep instead of spinning (the spin competes with the test itself; results do not depend on it).  The many-core GPU
+# boxes keep the default: there the oracle walks whole sequences through thousands of back-to-back parallel regions.
+if (os.cpu_count() or 1) <= 32:
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 
 def pytest_configure(config):
