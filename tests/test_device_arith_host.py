@@ -12,6 +12,7 @@ import subprocess
 
 import numpy as np
 import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
 
 import psfm_synth
 from _common import golden, regen_inputs, assert_csr_equal, input_hash
@@ -182,3 +183,49 @@ def test_device_chain_arithmetic_equals_the_oracle_on_larger_sequences(dev, T, H
     assert len(birth) == O.n_traj > 2000 and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
     assert np.array_equal(xy, O.xy)
     assert int((O.length < T).sum()) > 500          # plenty of tracks that died or were respawned
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2**31 - 1), h=st.integers(2, 19), w=st.integers(2, 23), thres=st.sampled_from([0.0, 0.5, 1.0, 3.0, 1e-30, 1e30]))
+def test_device_flow_check_forms_agree_with_the_oracle_on_absurd_fields(dev, seed, h, w, thres):
+    """Flow components of every magnitude -- subnormal, ordinary, 1e10, 1e30, 3e38, +-Inf, NaN, -0 -- in both fields: the error map of
+    the device's code is the oracle's bit for bit (NaN where the oracle has NaN), and the two mask-only forms (reciprocal division,
+    threshold under the root, 16-byte interior taps) return the same mask wherever they promise to: the fast division is exact
+    for |x| < 1e30 and +0 only, beyond that all four taps are out of bounds for both quotients."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    mags = np.array([0.0, -0.0, 1e-42, 1e-38, 1e-3, 1.0, 7.5, 1e3, 1e10, 1e30, 3e38, np.inf, -np.inf, np.nan], np.float32)
+
+    def field():
+        base = rng.normal(0, 2.0, (h, w, 2)).astype(np.float32)
+        pick = rng.random((h, w, 2)) < 0.25
+        sel = mags[rng.integers(0, len(mags), (h, w, 2))] * np.where(rng.random((h, w, 2)) < 0.5, 1.0, -1.0).astype(np.float32)
+        return np.where(pick, sel, base).astype(np.float32)
+
+    f, b = field(), field()
+    with np.errstate(all="ignore"):
+        err_o, occ_o = orc.flow_check([f], [b], thres)
+    e0, o0 = _flow_check(dev, f, b, thres, 0)
+    nan = np.isnan(err_o[0])              # (which NaN a host build produces -- sign, payload -- says nothing about the GPU's)
+    assert np.array_equal(np.isnan(e0), nan) and np.array_equal(e0[~nan].view(np.uint32), err_o[0][~nan].view(np.uint32))
+    assert np.array_equal(o0, occ_o[0])
+    for form in (1, 2):
+        assert np.array_equal(_flow_check(dev, f, b, thres, form)[1], occ_o[0]), form
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2**20), r=st.integers(1, 4), per_field=st.integers(1, 12), sigma=st.sampled_from([0.05, 0.3]))
+def test_device_chain_arithmetic_on_random_poisoned_sequences(dev, seed, r, per_field, sigma):
+    """NaN / +-Inf / 1e30 components sprinkled over every flow field: masks, ids, lengths and positions of the device's arithmetic
+    equal the oracle's (a track stepping to a non-finite position ends there; NaN errors compare false)."""
+    from oracle import oracle as orc
+    T, H, W = 6, 34, 45
+    d = psfm_synth.poison_nonfinite(psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=1, stride2=False),
+                                    seed=seed + 1, per_field=per_field)
+    with np.errstate(all="ignore"):
+        _, occ_o = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        O = orc.track(d["flows_f"], occ_o, r)
+    occ = [_flow_check(dev, f, b, 1.0, 2)[1] for f, b in zip(d["flows_f"], d["flows_b"])]
+    assert np.array_equal(np.stack(occ), np.stack(occ_o))
+    birth, length, xy = _track(dev, d["flows_f"], occ, r)
+    assert len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length) and np.array_equal(xy, O.xy)
