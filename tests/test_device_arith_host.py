@@ -229,3 +229,24 @@ def test_device_chain_arithmetic_on_random_poisoned_sequences(dev, seed, r, per_
     assert np.array_equal(np.stack(occ), np.stack(occ_o))
     birth, length, xy = _track(dev, d["flows_f"], occ, r)
     assert len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length) and np.array_equal(xy, O.xy)
+
+
+@pytest.mark.parametrize("seed,per_field", [(77, 6), (5, 3), (19, 10)])
+def test_device_arithmetic_track_optimize_carries_on_after_failed_solves(dev, seed, per_field):
+    """Non-finite flow components in all four stacks: a frame whose solve fails (FAILURE in IterationZero) keeps its chained
+    positions and the sequence goes on -- ids, lengths, per-solve iterations and terminations as in the oracle, positions to 1e-6 px
+    where finite and non-finite in the same places."""
+    from oracle import oracle as orc
+    T, H, W, r = 9, 60, 84, 2
+    d = psfm_synth.poison_nonfinite(psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=0.1, n_occluders=1, stride2=True),
+                                    seed=seed + 1, per_field=per_field)
+    with np.errstate(all="ignore"):
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+        O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    birth, length, xy, its, terms = _track(dev, d["flows_f"], occ, r, d["flows_f2"], occ2)
+    assert [int(v) for v in terms] == [s["termination"] for s in O.solves]
+    assert [int(v) for v in its] == [s["iterations"] for s in O.solves]
+    assert np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
+    both = np.isfinite(O.xy)
+    assert np.array_equal(np.isfinite(xy), both) and float(np.abs(xy[both] - O.xy[both]).max()) <= 1e-6
