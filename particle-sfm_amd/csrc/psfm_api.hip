@@ -156,7 +156,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
                        &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
-                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->sol_fused, &c->sol_bar, &c->occ_own, &c->occ2_own,
+                       &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->sol_fused, &c->sol_bar, &c->sol_list, &c->occ_own, &c->occ2_own,
                        &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar, &c->win_ws, &c->flt_ids, &c->flt_birth, &c->flt_len, &c->flt_off, &c->flt_xy,
                        &c->mt_kp_off, &c->mt_q, &c->mt_pts, &c->mt_kp_ind, &c->mt_kp_xy, &c->mt_moff, &c->mt_keys, &c->mt_rows, &c->mt_gid, &c->mt_pairs};
     for (auto b : bufs) b->release();
@@ -265,6 +265,7 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
     PSFM_CHECK_CTX(c);
     PsfmGate gate(c->device, 1);          // (exclusive if no other psfm call is in flight: the solve may then run as one persistent launch)
     c->pc_persist_ok = gate.exclusive;
+    c->pc_giveups = 0;
     if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
         psfm_set_error("psfm_optimize_location: bad argument (n=%lld h=%d w=%d)", (long long)n, h, w);
         return PSFM_ERR_ARG;
@@ -376,6 +377,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     c->res_n_traj = c->res_n_points = 0;
     c->res_n_flows = n_flows;
     c->pc_persist_ok = device_is_ours;
+    c->pc_giveups = 0;
 
     // ---- track mode: the whole recurrence as ONE persistent launch when every lane can be resident at once ----
     if (!optimize && c->chain_mode != 1) {
@@ -511,7 +513,8 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
             psfm_status st2 = psfm_solve_frame_resume(c, d, flows + (size_t)(fs - 1) * P * 2, flows + (size_t)fs * P * 2,
                                                       flows_f2 + (size_t)(fs - 1) * P * 2, occ_s2 + (size_t)(fs - 1) * P, fs, &ss,
                                                       (fused_now && !seq && c->solver_K == 0 && k_used < psfm_solve_kmax())
-                                                          ? (k_used + 2 < psfm_solve_kmax() ? k_used + 2 : psfm_solve_kmax()) : 0, s);
+                                                          ? (k_used + 2 < psfm_solve_kmax() ? k_used + 2 : psfm_solve_kmax()) : 0,
+                                                      !fused_now, s);
             if (st2 != PSFM_OK) return st2;
             hstats[fs] = ss;
             last_ok = fs;

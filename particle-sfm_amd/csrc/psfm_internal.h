@@ -137,8 +137,11 @@ struct psfm_ctx {
     int res_n_flows = 0;           // flows of the sequence the result came from (psfm_result_keys checks its packed key)
     // solver workspace
     PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats, sol_fused, sol_bar;
-    int pc_persist_blocks = -1;    // co-resident blocks of psfm_pc_persist_kernel on this device (-1: not queried yet)
+    PsfmBuf sol_list;              // launch chain / resident solve: per block, the lanes that take part in the solve (pc_build_list)
+    int pc_persist_blocks[4] = {-1, -1, -1, -1};   // co-resident blocks of psfm_pc_resident_kernel<NS> on this device (-1: not queried yet)
     bool pc_persist_ok = false;    // this call has the device to itself: the launch chain may run as one persistent launch
+    unsigned pc_epoch = 0;         // resident solve: launch counter, part of every granule's tag (stale granules never match)
+    int pc_giveups = 0;            // resident solves of this call whose hand-off timed out (two of them: launches from there on)
     int solve_K = 4;        // fused solve: trust-region iterations speculated per launch (adapted at checkpoints)
     int solve_mode = 0;     // 0 fused solve (one launch per frame), 1 launch chain (sequences whose solves reject steps)
     int solver_mode = 0, solver_K = 0;   // psfm_ctx_set_solver: 0 adaptive / 1 chain / 2 fused; K 0 = adaptive
@@ -209,7 +212,7 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
                                      const float* flow02, const uint8_t* occ02, int frame, int unroll, hipStream_t s);
 psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                     const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
-                                    int try_fused_k, hipStream_t s);
+                                    int try_fused_k, bool chain_stalled, hipStream_t s);
 psfm_status psfm_solve_frame_fused(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                    const float* flow02, const uint8_t* occ02, int frame, int K, hipStream_t s);
 psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,

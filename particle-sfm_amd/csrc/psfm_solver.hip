@@ -39,6 +39,7 @@
 // lane assignment).
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <hip/hip_ext.h>
 
 #include "psfm_device.h"
@@ -98,6 +99,9 @@ struct PcParams {
     const float2* flow02;
     const uint8_t* occ02;
     double* partials;         // [PC_MAX_BLOCKS][PC_NSUM]
+    // launch chain / resident solve: the lanes that take part in this solve, compacted per block by pc_init (pc_build_list):
+    // block b's entries are list[b * list_pitch + 0 .. list_n[b]), thread t walks entries t, t + PC_BLOCK, ...
+    int* list; int* list_n; int list_pitch;
     PsfmSolveCtrl* ctrl;
     int* stall;               // != 0: an earlier solve of this sequence ran out of unrolled iterations -> do nothing
     unsigned* ticket;         // last-block detection
@@ -142,35 +146,70 @@ __device__ __forceinline__ double pc_wave_max(double v)
     return v;
 }
 
-// block reduction of acc[PC_NSUM] (slot SUM_GMAX by max, others by sum) -> partials[blockIdx], in a fixed order:
-// through LDS (every thread parks its 13 accumulators; 13 x 16 threads add 16 values each in thread order; 13 threads
-// add the 16 group sums).  The wave-shuffle form (13 sums x 6 steps x 2 ds_bpermute per wave) took ~4 us of every
-// launch's tail.
+// Block reduction of acc[NS_] (slot SUM_GMAX by max, the others by sum) in a fixed order, in registers: inside a wave four
+// exchange steps on the DPP lanes (xor 1, xor 2, half-row mirror, row mirror: both partners of an exchange form the same
+// IEEE sum, so afterwards every lane of a 16-lane row holds the row's total), the four rows in order through v_readlane, the
+// block's four waves in order through 13 words of LDS each.  (Round 3 parked every thread's accumulators in LDS -- 27 KB, which
+// the resident solve needs for its tracks; a ds_bpermute tree -- 13 sums x 6 steps x 2 -- took ~4 us of every launch's tail.)
+// The block's sums are left in out[0 .. NS_) (LDS, valid for every thread after the call).  The launch chain reduces all
+// PC_NSUM slots, a round of the resident solve the first PC_RES_SUMS of them -- the slots are independent: same bits.
+template <int CTRL>
+__device__ __forceinline__ double pc_dpp(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double pc_readlane(double v, int lane)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+template <bool MAX>
+__device__ __forceinline__ double pc_wave_total(double v)
+{
+#define PC_OP(a_, b_) (MAX ? fmax((a_), (b_)) : (a_) + (b_))
+    v = PC_OP(v, pc_dpp<0xB1>(v));       // quad_perm [1,0,3,2]
+    v = PC_OP(v, pc_dpp<0x4E>(v));       // quad_perm [2,3,0,1]
+    v = PC_OP(v, pc_dpp<0x141>(v));      // row_half_mirror
+    v = PC_OP(v, pc_dpp<0x140>(v));      // row_mirror
+    const double r0 = pc_readlane(v, 0), r1 = pc_readlane(v, 16), r2 = pc_readlane(v, 32), r3 = pc_readlane(v, 48);
+    return PC_OP(PC_OP(PC_OP(r0, r1), r2), r3);
+#undef PC_OP
+}
+template <int NS_>
+__device__ __forceinline__ void pc_block_sums(const double* acc, double* out)
+{
+    __shared__ double s_w[PC_BLOCK / PSFM_WAVE][NS_];
+    const int tid = threadIdx.x, w = tid / PSFM_WAVE, lane = tid & (PSFM_WAVE - 1);
+#pragma unroll
+    for (int k = 0; k < NS_; ++k) {
+        const double t = (k == SUM_GMAX) ? pc_wave_total<true>(acc[k]) : pc_wave_total<false>(acc[k]);
+        if (lane == 0) s_w[w][k] = t;
+    }
+    __syncthreads();
+    if (tid < NS_) {
+        double v = s_w[0][tid];
+#pragma unroll
+        for (int q = 1; q < PC_BLOCK / PSFM_WAVE; ++q) v = (tid == SUM_GMAX) ? fmax(v, s_w[q][tid]) : v + s_w[q][tid];
+        out[tid] = v;
+    }
+    __syncthreads();
+}
+
+// ... -> partials[blockIdx] (launch chain)
 __device__ __forceinline__ void pc_block_reduce(double acc[PC_NSUM], double* __restrict__ partials)
 {
-    __shared__ double s_acc[PC_NSUM][PC_BLOCK + 1];
-    __shared__ double s_grp[PC_NSUM][16];
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < PC_NSUM; ++k) s_acc[k][tid] = acc[k];
-    __syncthreads();
-    if (tid < PC_NSUM * 16) {
-        const int k = tid >> 4, g = tid & 15;
-        double v = s_acc[k][g * 16];
-#pragma unroll
-        for (int j = 1; j < 16; ++j) v = (k == SUM_GMAX) ? fmax(v, s_acc[k][g * 16 + j]) : v + s_acc[k][g * 16 + j];
-        s_grp[k][g] = v;
-    }
-    __syncthreads();
-    if (tid < PC_NSUM) {
-        const int k = tid;
-        double v = s_grp[k][0];
-#pragma unroll
-        for (int g = 1; g < 16; ++g) v = (k == SUM_GMAX) ? fmax(v, s_grp[k][g]) : v + s_grp[k][g];
-        // write-through (sc0 sc1) store: the last block of the launch reads these with matching loads, so no
-        // agent-scope release (an L2 write-back per block) is needed -- MI355X_MICROARCH.md, valid hand-off forms
-        __hip_atomic_store(&partials[(int64_t)blockIdx.x * PC_NSUM + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    __shared__ double s_blk[PC_NSUM];
+    pc_block_sums<PC_NSUM>(acc, s_blk);
+    // write-through (sc0 sc1) store: the last block of the launch reads these with matching loads, so no
+    // agent-scope release (an L2 write-back per block) is needed -- MI355X_MICROARCH.md, valid hand-off forms
+    if (threadIdx.x < PC_NSUM)
+        __hip_atomic_store(&partials[(int64_t)blockIdx.x * PC_NSUM + threadIdx.x], s_blk[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 
@@ -180,6 +219,34 @@ __device__ __forceinline__ bool pc_participates(const PcParams& P, int i, int n)
     if (!P.birth_frame) return true;
     const int bf = P.birth_frame[i];
     return bf >= 0 && bf <= P.max_birth;
+}
+
+// The tracks of a solve, dealt to the blocks of the launch chain: block b looks at the lane chunks b, b + gridDim.x, ... (PC_BLOCK
+// lanes each) and compacts the lanes that take part (ballot -> wave offsets through LDS) into ITS list, in lane order.  Every
+// later launch of the solve -- pc_iter, the resident solve -- walks that list: thread t takes entries t, t + PC_BLOCK, ...; no
+// launch after pc_init reads a birth frame or skips a lane, the resident solve knows how many tracks a thread will ever hold,
+// and all forms add the tracks' terms in the same order.  Returns the block's count (also left in list_n[b]).
+__device__ __forceinline__ int pc_build_list(const PcParams& P, int n)
+{
+    __shared__ int s_wc[PC_BLOCK / PSFM_WAVE];
+    int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
+    const int lane = threadIdx.x & (PSFM_WAVE - 1), w = threadIdx.x / PSFM_WAVE;
+    int base = 0;
+    for (int c0 = blockIdx.x * PC_BLOCK; c0 < n; c0 += gridDim.x * PC_BLOCK) {
+        const int i = c0 + threadIdx.x;
+        const bool part = pc_participates(P, i, n);
+        const unsigned long long m = __ballot(part);
+        if (lane == 0) s_wc[w] = __popcll(m);
+        __syncthreads();
+        int off = base, tot = 0;
+#pragma unroll
+        for (int q = 0; q < PC_BLOCK / PSFM_WAVE; ++q) { if (q < w) off += s_wc[q]; tot += s_wc[q]; }
+        if (part) lst[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        base += tot;
+        __syncthreads();      // (s_wc is rewritten by the next chunk; the list entries are visible to the block behind it)
+    }
+    if (threadIdx.x == 0) P.list_n[blockIdx.x] = base;
+    return base;
 }
 
 
@@ -207,7 +274,24 @@ __device__ __forceinline__ bool pc_is_last_block(unsigned* ticket)
 // ------------------------------------------------------------------------------------------------
 // pc_init: iteration 0.  Frame mode also prepares ref1/ref2/scale (trajectory.py:173-183).
 // ------------------------------------------------------------------------------------------------
-// iteration 0 for this block's tracks (grid-stride): refs / scale (frame mode), Jacobi scaling, cost and system at the start values
+// refs / scale of a track from its p0 (trajectory.py:173-183): the fp32 sampler on flow01, flow02, occ02
+__device__ __forceinline__ void pc_refs(const PcParams& P, double2 p0, double2& r1, double2& r2, double& s)
+{
+    const PsfmTaps t = psfm_taps((float)p0.x, (float)p0.y, P.cw, P.ch, P.H, P.W);
+    const PsfmTapIdx k = psfm_tap_idx(P.H, P.W, t);
+    const float2 f01 = psfm_sample_flow(P.flow01, k, t);
+    const float2 f02 = psfm_sample_flow(P.flow02, k, t);
+    const float o02 = psfm_sample_mask(P.occ02, k, t);
+    // (1.0 - occ02) * (|flow02| < 20) in fp32; numpy's norm = sqrt(u*u + v*v) without fma (trajectory.py:179)
+    const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
+    const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
+    s = (double)sf;
+    r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
+    r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
+}
+
+// iteration 0 for this block's tracks: the block's list, then per entry refs / scale (frame mode), Jacobi scaling, cost and
+// system at the start values
 __device__ __forceinline__ void pc_init_tracks(const PcParams& P, double acc[PC_NSUM])
 {
     // the chain step in front of this solve has consumed PsfmCounters::sel (positions of an earlier fused solve): the launch
@@ -216,24 +300,15 @@ __device__ __forceinline__ void pc_init_tracks(const PcParams& P, double acc[PC_
     const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
 #pragma unroll
     for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
+    const int cnt = pc_build_list(P, n);
+    const int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
     const double mu = 1e-8;
-    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
-        if (!pc_participates(P, i, n)) continue;
+    for (int p = threadIdx.x; p < cnt; p += PC_BLOCK) {
+        const int i = lst[p];
         double2 r1, r2;
         double s;
         if (P.p0) {
-            const double2 p0 = P.p0[i];
-            const PsfmTaps t = psfm_taps((float)p0.x, (float)p0.y, P.cw, P.ch, P.H, P.W);
-            const PsfmTapIdx k = psfm_tap_idx(P.H, P.W, t);
-            const float2 f01 = psfm_sample_flow(P.flow01, k, t);
-            const float2 f02 = psfm_sample_flow(P.flow02, k, t);
-            const float o02 = psfm_sample_mask(P.occ02, k, t);
-            // (1.0 - occ02) * (|flow02| < 20) in fp32; numpy's norm = sqrt(u*u + v*v) without fma (trajectory.py:179)
-            const float nrm = sqrtf(__fadd_rn(__fmul_rn(f02.x, f02.x), __fmul_rn(f02.y, f02.y)));
-            const float sf = __fmul_rn(__fsub_rn(1.0f, o02), nrm < 20.0f ? 1.0f : 0.0f);
-            s = (double)sf;
-            r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
-            r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
+            pc_refs(P, P.p0[i], r1, r2, s);
             P.ref1[i] = r1; P.ref2[i] = r2; P.scale[i] = s;
         } else {
             r1 = P.ref1[i]; r2 = P.ref2[i]; s = P.scale[i];
@@ -261,154 +336,70 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_init_kernel(PcParams P)
     if (pc_is_last_block(P.ticket)) pc_reduce_and_control(P.ctrl, P.partials, (int)gridDim.x, 1, P.export_sums);
 }
 
-// What one launch of the chain does for this block's tracks (grid-stride): the refresh form (the system at x for a raised
-// mu) or the evaluate-ahead form (candidate of (a, b), its cost, the system there).  Sums into acc[].
-//
-// PC_ITER_PIPE selects how early the evaluate-ahead form requests its loads.  Written plainly (0, the default) a track is four
-// dependent round trips -- birth frame -> state -> taps at x -> taps at the candidate.  3 is the software-pipelined loop: the
-// state of track j + 1 (loaded together with its birth frame, whatever that says) is requested before the arithmetic of track j
-// and its taps at x are issued right behind track j's taps at the candidate, one basic block, same operations per track in the
-// same order, same order of the sums (the GPU tests pass with every setting).  It is SLOWER (see the macro): the loop is bound by
-// the bytes of per-track state it streams and by f64 issue, not by the round trips.
-// (Two tracks per thread at a time, stage by stage, at 2 waves per SIMD / 227 VGPRs: 66 instead of 55 ms per hard 1080p
-// sequence -- the slot without a track in a thread's last pass costs more arithmetic than the overlap saves; EXPERIMENTS.md.)
+// What one launch of the chain does for ONE track whose state is in memory (lane i): the refresh form (the system at x for a
+// raised mu) or the evaluate-ahead form (candidate of (a, b), its cost, the system there).  Sums into acc[].
+// (Round 3 measured how early these loads can be requested -- the state with the birth frame, the next track's state under this
+// track's arithmetic, a fully software-pipelined loop, two tracks per thread at a time: level or slower, profiles/EXPERIMENTS.md
+// 5.2.  What helped is not streaming the state at all: psfm_pc_resident_kernel below.)
 #ifndef PC_ITER_PAIR
 #define PC_ITER_PAIR true   // the launch chain's taps as 16-byte pairs (psfm_pc_core.h)
 #endif
-#ifndef PC_ITER_PIPE
-#define PC_ITER_PIPE 0   // how early the iteration loop requests its loads (0 plain ... 3 software-pipelined over the thread's tracks).
-                         // Measured on the hard 1080p sequence (scripts/r03_t.sh, ms per sequence, persistent solve): 0 -> 56.2,
-                         // 1 -> 55.6, 2 -> 56.2, 3 -> 65.0 (168 VGPRs, 8 spilled; 62.2 at 184 VGPRs) -- the loop is not waiting for
-                         // round trips: a per-block timeline (scripts/r03_u.sh) puts it at 14-16 us of a 26 us launch, i.e. ~46 MB of
-                         // per-track state streamed per iteration (3-4 TB/s, cyclic, larger than the L2s) under ~8 us of f64 issue
-                         // at two waves per SIMD.  profiles/EXPERIMENTS.md 5.2.
-#endif
-struct PcIn { int bf; double2 r1, r2, js, p1, p2; double s; };
-
-__device__ __forceinline__ PcIn pc_load_in(const PcParams& P, const int* bfp, const double2* xc1, const double2* xc2, int i)
+__device__ __forceinline__ void pc_refresh_entry(const PcParams& P, int i, const double2* xc1, const double2* xc2, double mu, double acc[PC_NSUM])
 {
-    PcIn in;
-    in.bf = bfp[i];
-    in.r1 = P.ref1[i]; in.r2 = P.ref2[i]; in.s = P.scale[i]; in.js = P.jscale[i];
-    in.p1 = xc1[i]; in.p2 = xc2[i];
-    return in;
+    const double2 r1 = P.ref1[i], r2 = P.ref2[i];
+    const double s = P.scale[i];
+    const PcConst c = pc_const_load(s, P.jscale[i]);
+    const double2 p1 = xc1[i], p2 = xc2[i];
+    const double x[4] = {p1.x, p1.y, p2.x, p2.y};
+    double r[6], jac[4];
+    PcSys y;
+    pc_core_eval<PC_ITER_PAIR>((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
+    pc_core_system<true>(x, r, jac, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
 }
 
-__device__ __forceinline__ void pc_iter_tracks(const PcParams& P, int cur, double mu, double a, double b, bool refresh, double acc[PC_NSUM])
+__device__ __forceinline__ void pc_ahead_entry(const PcParams& P, int i, const double2* xc1, const double2* xc2, double2* xn1, double2* xn2,
+                                               double mu, double mu_next, double a, double b, double acc[PC_NSUM])
 {
-    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    const PcF2* F12 = (const PcF2*)P.flow12;
+    const double2 r1 = P.ref1[i], r2 = P.ref2[i];
+    const double s = P.scale[i];
+    const PcConst c = pc_const_load(s, P.jscale[i]);
+    const double2 p1 = xc1[i], p2 = xc2[i];
+    const double x[4] = {p1.x, p1.y, p2.x, p2.y};
+    double r[6], jac[4], xp[4], unused[PC_NSUM];      // (unused: the sums at x are in the control block already)
+    PcSys y;
+#pragma unroll
+    for (int k = 0; k < PC_NSUM; ++k) unused[k] = 0.0;
+    pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
+    pc_core_system<false>(x, r, jac, c, mu, pc_core_iA22(c, mu), unused, y, 0, 0);
+    pc_core_step<false, false>(x, r, jac, c, y, a, b, acc, xp);
+    xn1[i] = make_double2(xp[0], xp[1]);
+    xn2[i] = make_double2(xp[2], xp[3]);
+    // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
+    pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, xp, r1.x, r1.y, r2.x, r2.y, s, r, jac);
+    acc[SUM_COST] += pc_core_cost(r);
+    pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
+}
+
+// DoglegStrategy::StepAccepted: the mu of the system at a candidate that is accepted
+__device__ __forceinline__ double pc_mu_next(double mu) { return fmax(1e-8, 2.0 * mu / 10.0); }
+
+// ... for the entries p0, p0 + PC_BLOCK, ... of this block's list (the launch chain: all of them; the resident solve: the ones
+// beyond the slots it keeps on chip)
+__device__ __forceinline__ void pc_iter_tracks(const PcParams& P, int p0, int cur, double mu, double a, double b, bool refresh, double acc[PC_NSUM])
+{
     const double2* xc1 = pc_buf1(P, cur);
     const double2* xc2 = pc_buf2(P, cur);
     double2* xn1 = pc_buf1(P, pc_other(cur));
     double2* xn2 = pc_buf2(P, pc_other(cur));
-    const double mu_next = fmax(1e-8, 2.0 * mu / 10.0);      // DoglegStrategy::StepAccepted: the mu of the system at the candidate
-#pragma unroll
-    for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
-    const int stride = (int)gridDim.x * PC_BLOCK;
-    int i = blockIdx.x * PC_BLOCK + threadIdx.x;
-    if (refresh) {      // the system at x for the mu an invalid step has raised (rare: plain loop)
-        for (; i < n; i += stride) {
-            if (!pc_participates(P, i, n)) continue;
-            const double2 r1 = P.ref1[i], r2 = P.ref2[i];
-            const double s = P.scale[i];
-            const PcConst c = pc_const_load(s, P.jscale[i]);
-            const double2 p1 = xc1[i], p2 = xc2[i];
-            const double x[4] = {p1.x, p1.y, p2.x, p2.y};
-            double r[6], jac[4];
-            PcSys y;
-            pc_core_eval<PC_ITER_PAIR>((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r, jac);
-            pc_core_system<true>(x, r, jac, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
-        }
+    const double mu_next = pc_mu_next(mu);
+    const int cnt = P.list_n[blockIdx.x];
+    const int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
+    if (refresh) {      // the system at x for the mu an invalid step has raised (rare)
+        for (int p = p0; p < cnt; p += PC_BLOCK) pc_refresh_entry(P, lst[p], xc1, xc2, mu, acc);
         return;
     }
-    if (i >= n) return;
-    const PcF2* F12 = (const PcF2*)P.flow12;
-    // (every load of the pipeline is unconditional -- the last track of a thread requests itself again, a solve without birth
-    // frames reads some word instead: the wait counts behind a skipped load would have to assume it was skipped, i.e. drain)
-    const int* bfp = P.birth_frame ? P.birth_frame : (const int*)P.scale;
-#if PC_ITER_PIPE <= 2
-    // 0: the plain loop (birth frame -> state -> taps at x -> taps at the candidate, four dependent round trips per track);
-    // 1: the state is requested together with the birth frame;  2: ... and the NEXT track's state under this track's arithmetic
-    PcIn in;
-    if (PC_ITER_PIPE == 2) in = pc_load_in(P, bfp, xc1, xc2, i);
-    for (;;) {
-        const int i_next = i + stride;
-        const bool more = i_next < n;
-        PcIn nin;
-        if (PC_ITER_PIPE == 2) nin = pc_load_in(P, bfp, xc1, xc2, more ? i_next : i);
-        bool part;
-        if (PC_ITER_PIPE == 0) {
-            part = pc_participates(P, i, n);
-            if (part) in = pc_load_in(P, bfp, xc1, xc2, i);
-        } else {
-            if (PC_ITER_PIPE == 1) in = pc_load_in(P, bfp, xc1, xc2, i);
-            part = !P.birth_frame || (in.bf >= 0 && in.bf <= P.max_birth);
-        }
-        if (part) {
-            const double x[4] = {in.p1.x, in.p1.y, in.p2.x, in.p2.y};
-            const PcConst c = pc_const_load(in.s, in.js);
-            double r[6], jac[4], xp[4], unused[PC_NSUM];      // (unused: the sums at x are in the control block already)
-            PcSys y;
-#pragma unroll
-            for (int k = 0; k < PC_NSUM; ++k) unused[k] = 0.0;
-            pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, x, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
-            pc_core_system<false>(x, r, jac, c, mu, pc_core_iA22(c, mu), unused, y, 0, 0);
-            pc_core_step<false, false>(x, r, jac, c, y, a, b, acc, xp);
-            xn1[i] = make_double2(xp[0], xp[1]);
-            xn2[i] = make_double2(xp[2], xp[3]);
-            // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
-            pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, xp, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
-            acc[SUM_COST] += pc_core_cost(r);
-            pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
-        }
-        if (!more) break;
-        if (PC_ITER_PIPE == 2) in = nin;
-        i = i_next;
-    }
-#else
-    PcIn in = pc_load_in(P, bfp, xc1, xc2, i);
-    PcTaps tx;
-    {
-        const double x0[4] = {in.p1.x, in.p1.y, in.p2.x, in.p2.y};
-        tx = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, x0);
-    }
-    for (;;) {
-        const int i_next = i + stride;
-        const bool more = i_next < n;
-        const PcIn nin = pc_load_in(P, bfp, xc1, xc2, more ? i_next : i);   // (requested now, used behind this track's step)
-        const bool part = !P.birth_frame || (in.bf >= 0 && in.bf <= P.max_birth);      // (pc_participates)
-        // No branch around the arithmetic: a lane without a track computes on whatever its row holds and contributes nothing
-        // (t[] is added as zeros, nothing is stored) -- one basic block, so every wait below counts exactly what is in flight.
-        // Each slot of t[] receives ONE term per track, so acc += (0 + term) is the sum the plain loop forms, bit for bit.
-        const double x[4] = {in.p1.x, in.p1.y, in.p2.x, in.p2.y};
-        const PcConst c = pc_const_load(in.s, in.js);
-        double r[6], jac[4], xp[4], t[PC_NSUM], unused[PC_NSUM];      // (unused: the sums at x are in the control block already)
-        PcSys y;
-#pragma unroll
-        for (int k = 0; k < PC_NSUM; ++k) { t[k] = 0.0; unused[k] = 0.0; }
-        pc_core_eval_taps(tx, x, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
-        pc_core_system<false>(x, r, jac, c, mu, pc_core_iA22(c, mu), unused, y, 0, 0);
-        pc_core_step<false, false>(x, r, jac, c, y, a, b, t, xp);
-        const PcTaps tc = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, xp);
-        const double xq[4] = {nin.p1.x, nin.p1.y, nin.p2.x, nin.p2.y};
-        const PcTaps ntx = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, xq);                // (the next track's taps at x ride behind tc)
-        if (part) {
-            xn1[i] = make_double2(xp[0], xp[1]);
-            xn2[i] = make_double2(xp[2], xp[3]);
-        }
-        // the candidate's cost and, ahead of the decision, the system there (what the next iteration needs if it is accepted)
-        pc_core_eval_taps(tc, xp, in.r1.x, in.r1.y, in.r2.x, in.r2.y, in.s, r, jac);
-        t[SUM_COST] = pc_core_cost(r);
-        pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), t, y, CH_QUD, CH_QDD);
-#pragma unroll
-        for (int k = 0; k < PC_NSUM; ++k) {
-            if (k == SUM_GMAX) acc[k] = fmax(acc[k], part ? t[k] : 0.0);
-            else if (k != SUM_CNT && k != SUM_COST0) acc[k] += part ? t[k] : 0.0;
-        }
-        if (!more) break;
-        in = nin; tx = ntx; i = i_next;
-    }
-#endif
+    for (int p = p0; p < cnt; p += PC_BLOCK) pc_ahead_entry(P, lst[p], xc1, xc2, xn1, xn2, mu, mu_next, a, b, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,7 +429,9 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
     PC_TL(0);
 #endif
     double acc[PC_NSUM];
-    pc_iter_tracks(P, C.cur, C.mu, C.dl_a, C.dl_b, C.kind_next != 0, acc);
+#pragma unroll
+    for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
+    pc_iter_tracks(P, (int)threadIdx.x, C.cur, C.mu, C.dl_a, C.dl_b, C.kind_next != 0, acc);
     PC_TL(1);
     pc_block_reduce(acc, P.partials);
     const bool last_block = pc_is_last_block(P.ticket);
@@ -452,9 +445,19 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
     }
 }
 
-// Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket after an agent-scope
-// release; the reading block acquires before touching the other blocks' partials -- cdna_hip_programming.md G16):
-// fixed-order reduction of the per-block partials, then the scalar control step on thread 0.
+// ------------------------------------------------------------------------------------------------
+// The order in which the blocks' sums are added (every form of the chain: launches, the resident solve, the sharded export),
+// with L = min(PC_LEADERS, n_blocks) and Q = ceil(ceil(n_blocks / PC_LEADERS) / 4):
+//     total = ((t_0 + t_1) + t_2) + t_3,      t_j  = S_{8j} + S_{8j+1} + ... + S_{8j+7}  (those below L, in order)
+//     S_x   = ((s_x0 + s_x1) + s_x2) + s_x3,  s_xj = the sums of blocks x + PC_LEADERS m, m in [j Q, (j + 1) Q), in order
+// -- S_x is what ONE block of the resident solve (the "leader" x) adds up from its members' granules, the rest is what every
+// block adds up from the leaders' (pc_res_allreduce): two hops, a few loads per lane in each.  SUM_GMAX by max.
+// ------------------------------------------------------------------------------------------------
+#define PC_LEADERS 32
+__host__ __device__ inline int pc_tree_q(int n_blocks) { return ((n_blocks + PC_LEADERS - 1) / PC_LEADERS + 3) / 4; }
+
+// Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket behind write-through partials; the loads
+// here bypass the caches -- cdna_hip_programming.md G16): the reduction above, then the scalar control step on thread 0.
 // totals of the launch's partial rows, in LDS (pc_totals()), valid for every thread of the block after the call
 __device__ __forceinline__ double* pc_totals()
 {
@@ -463,37 +466,48 @@ __device__ __forceinline__ double* pc_totals()
 }
 __device__ __forceinline__ void pc_reduce_totals(double* partials, int n_blocks)
 {
-    // Fixed-order reduction of partials[n_blocks][PC_NSUM]: thread t owns slot (t % 16) of the block rows
-    // t/16, t/16 + 16, ...; its loads are independent (issued back to back), summed in increasing row order; the 16
-    // row groups are then combined in order by the first PC_NSUM threads.  (One pass, two barriers: a slot-by-slot tree
-    // with a barrier per level cost ~40 us per launch when the loads bypass the caches.)
-    __shared__ double s_part[16][16];
+    __shared__ double s_sub[PC_LEADERS][4][PC_NSUM + 1];
+    __shared__ double s_S[PC_LEADERS][PC_NSUM + 1];
     double* s_tot = pc_totals();
-    const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
-    double v = 0.0;
-    if (k < PC_NSUM) {
-        // all rows of this thread in flight at once (32 for 512 blocks): the loads bypass the caches, so every
-        // batch is a full round trip on the tail of the launch -- one batch instead of four (summed in the same order)
-        for (int b0 = g; b0 < n_blocks; b0 += 16 * PC_RED_ROWS) {
-            double p[PC_RED_ROWS];
+    const int L = n_blocks < PC_LEADERS ? n_blocks : PC_LEADERS;
+    const int Q = pc_tree_q(n_blocks);
+    // work item (x, j, k): PC_LEADERS x 4 x 16 of them, its loads independent (issued back to back), added in member order
+    for (int w = threadIdx.x; w < PC_LEADERS * 4 * 16; w += PC_BLOCK) {
+        const int k = w & 15, j = (w >> 4) & 3, x = w >> 6;
+        if (k >= PC_NSUM || x >= L) continue;
+        const int cnt = (n_blocks - x + PC_LEADERS - 1) / PC_LEADERS;
+        double v = 0.0;
+        for (int u0 = 0; u0 < Q; u0 += 8) {
+            double pv[8];
 #pragma unroll
-            for (int u = 0; u < PC_RED_ROWS; ++u) {
-                const int bb = b0 + 16 * u;
-                p[u] = bb < n_blocks ? __hip_atomic_load(&partials[(int64_t)bb * PC_NSUM + k], __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_SYSTEM)
-                                     : 0.0;
+            for (int u = 0; u < 8; ++u) {
+                const int m = j * Q + u0 + u;
+                pv[u] = (u0 + u < Q && m < cnt) ? __hip_atomic_load(&partials[(int64_t)(x + PC_LEADERS * m) * PC_NSUM + k], __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_SYSTEM)
+                                                : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < PC_RED_ROWS; ++u) v = (k == SUM_GMAX) ? fmax(v, p[u]) : v + p[u];
+            for (int u = 0; u < 8; ++u) v = (k == SUM_GMAX) ? fmax(v, pv[u]) : v + pv[u];
         }
+        s_sub[x][j][k] = v;
     }
-    __syncthreads();       // (a previous round's totals have been consumed)
-    s_part[g][k] = v;
+    __syncthreads();
+    for (int w = threadIdx.x; w < PC_LEADERS * 16; w += PC_BLOCK) {
+        const int k = w & 15, x = w >> 4;
+        if (k >= PC_NSUM || x >= L) continue;
+        const double s0 = s_sub[x][0][k], s1 = s_sub[x][1][k], s2 = s_sub[x][2][k], s3 = s_sub[x][3][k];
+        s_S[x][k] = (k == SUM_GMAX) ? fmax(fmax(fmax(s0, s1), s2), s3) : ((s0 + s1) + s2) + s3;
+    }
     __syncthreads();
     if (threadIdx.x < PC_NSUM) {
-        double t = s_part[0][threadIdx.x];
-        for (int gg = 1; gg < 16; ++gg) t = (threadIdx.x == SUM_GMAX) ? fmax(t, s_part[gg][threadIdx.x]) : t + s_part[gg][threadIdx.x];
-        s_tot[threadIdx.x] = t;
+        const int k = threadIdx.x;
+        double t[4];
+        for (int j = 0; j < 4; ++j) {
+            double v = 0.0;
+            for (int x = 8 * j; x < 8 * j + 8 && x < L; ++x) v = (k == SUM_GMAX) ? fmax(v, s_S[x][k]) : v + s_S[x][k];
+            t[j] = v;
+        }
+        s_tot[k] = (k == SUM_GMAX) ? fmax(fmax(fmax(t[0], t[1]), t[2]), t[3]) : ((t[0] + t[1]) + t[2]) + t[3];
     }
     __syncthreads();
 }
@@ -514,149 +528,352 @@ __device__ __forceinline__ void pc_reduce_and_control(PsfmSolveCtrl* __restrict_
     *ctrl = C;
 }
 
+__device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const PsfmSolveCtrl& C, double* out_rows);
+__device__ __forceinline__ void pc_writeback_scalars(const PcParams& P, const PsfmSolveCtrl& C);
 
 // ------------------------------------------------------------------------------------------------
-// pc_persist: the launch chain's loop inside ONE launch.  Solves that reject steps take 20-40 trust-region iterations;
-// as launches each of them costs a launch gap, a tail behind the last block and a round trip for the control block
-// (~21 us per iteration at 1080p, of which ~5 are arithmetic).  Here the grid stays resident (every block co-resident:
-// <= PC_CHAIN_BLOCKS blocks of 256, the device to ourselves like the persistent frame loop) and the iterations are
-// separated by a device-wide hand-off with as few dependent memory operations as it takes:
-//   every block   per-block partial sums written through -> (acknowledged) -> one NON-RETURNING add on its shard's arrival
-//                 counter -> polls its shard's packet
-//   block 0       THE reducer, every round: polls the PC_BAR_SHARDS counters (one wave, one load per poll) -> reads the
-//                 partials in the fixed order of the launch chain -> runs pc_chain_control on the control block it keeps in
-//                 LDS -> publishes what the other blocks need for the next round (done, cur, kind_next, mu, dl_a, dl_b) as
-//                 seven data-tagged 8-byte granules per shard {round : 32 | half of the payload : 32} -- a granule is
-//                 valid by itself, so nothing orders the stores and the poll IS the read (MI355X_MICROARCH.md, form R2)
-// i.e. partial store ack -> counter visible -> partial loads -> packet visible: four hops.  (The first version elected
-// the last arriver through a second counter level and broadcast the whole control block behind a flag: two returning
-// atomics, a store acknowledgement between control block and flag, and a second load behind the poll -- seven hops,
-// EXPERIMENTS.md 5.2.)  The control block in memory is refreshed every round too (write-through, nobody waits for it):
-// it is what the launches behind a loop that gave up carry on from.
-// Same kernels' arithmetic, same reduction order, same control step: the iterates are the launch chain's bit for bit.
-// A block that waits longer than the spin limit (the grid was not co-resident after all) leaves; the control block then
-// still says "not done" and the pc_iter launches the host keeps behind this kernel carry on from it.
+// pc_resident: the launch chain's loop inside ONE launch, with the tracks' solver state ON CHIP.  Solves that reject steps take
+// 20-40 trust-region iterations.  As launches each of them is a launch gap, a tail behind the last block and a control block
+// round trip; round 3's persistent form removed those but still STREAMED the tracks through every round (88 B of state in,
+// 32 B of candidate out, per track and round: 46 MB at 1080p), walked a thread's 3-4 tracks one behind the other -- four
+// dependent round trips each -- and re-derived the system at x that the round before had already solved (16.5 us per round, the
+// SIMDs issuing VALU a quarter of the time).  Here:
+//   * a thread HOLDS its tracks: slot k of thread t is entry k * PC_BLOCK + t of the block's list (pc_build_list).  Per slot in
+//     registers: refs, weight, Jacobi scaling, the iterate x and its steepest-descent / Gauss-Newton directions (u, d); in LDS:
+//     (u', d') at the candidate.  A round is  x' = x + a u + b d  ->  ONE gather (the taps at x', every slot's in flight
+//     together)  ->  residuals, cost, the system at x' (evaluate-ahead: its sums and (u', d'))  ->  the sums.  Accepted: x <- x'
+//     (recomputed, same bits), (u, d) <- (u', d'); rejected: same x, same (u, d), new (a, b).  Nothing is loaded but taps,
+//     nothing stored.  Entries beyond NS slots per thread (grids larger than the register files) are streamed as the launch
+//     chain does it (pc_iter_tracks), behind the slots in the same order of summation.
+//   * the hand-off is an ALL-REDUCE of tagged granules, two hops: every block publishes its PC_RES_SUMS sums as 8-byte granules
+//     {tag : 32 | half of a double : 32} (valid by themselves: nothing orders the stores, the poll IS the read -- form R2 of
+//     MI355X_MICROARCH.md); the PC_LEADERS leaders add up their members' (pc_reduce_totals' first level) and publish theirs;
+//     EVERY block adds up the leaders' (the upper levels) and runs the control step itself on its own copy of the control block --
+//     same numbers, same function, same decisions everywhere; no reducer, no packet, no counter, no store acknowledgement.
+//     tag = {launch epoch : 20 | round : 12}: a granule left by an earlier launch never matches.
+// Same per-track functions, same order of summation, same control step as the launches: bit-identical iterates
+// (tests/test_gpu_solver.py::test_launch_chain_as_one_persistent_launch_is_the_same_solve).  A block whose poll exceeds the spin
+// limit (the grid was not co-resident after all) poisons its granules -- leaders pass the poison on -- and every block leaves
+// without having written anything: the control block still says "not done", the write-back kernel behind raises the stall
+// flag and the host redoes the solve with launches.
 // ------------------------------------------------------------------------------------------------
-#define PC_BAR_SHARDS 32
-#ifndef PC_PERSIST_WAVES
-#define PC_PERSIST_WAVES 3   // register target of the persistent solve: 3 waves per SIMD keeps the kernel's residency at 3 blocks per
-                             // CU, of which the grid uses 2 (see pc_persist_enqueue)
-#endif
-__device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const PsfmSolveCtrl& C, double* out_rows);
-#define PC_BAR_WORDS ((2 * PC_BAR_SHARDS + 1) * 32)     // counters / packets 128 bytes apart
+#define PC_RES_SUMS 11          // SUM_MCC .. SUM_FAIL: what a round reduces (SUM_CNT / SUM_COST0 belong to pc_init)
+#define PC_RES_ROW 32           // granules per row (256 B): 2 per sum
+#define PC_RES_NS_MAX 3         // slots per thread: 3 x 27 doubles of state + the arithmetic's working set is what 256 registers
+                                // and half a CU's LDS hold
+#define PC_RES_BLOCKS 512       // two blocks per CU
+static_assert(PC_RES_BLOCKS / PC_LEADERS / 4 <= 4, "a leader lane keeps its 4 members' granules in flight");
 static_assert(sizeof(PsfmSolveCtrl) % 8 == 0, "the control block is copied as 8-byte words");
 #define PC_CTRL_WORDS ((int)(sizeof(PsfmSolveCtrl) / 8))
-#define PC_PKT_GRANULES 7      // flags, mu, dl_a, dl_b (two halves each)
 
-struct PcRound { int done, cur, kind; double mu, a, b; };   // what a round of the loop needs from the control block
+struct PcRound { int done, cur, kind, accepted, giveup; double mu, a, b; };   // what a round of the loop needs from the control block
 
-__device__ __forceinline__ unsigned pc_pkt_half(const PsfmSolveCtrl& C, int g)
+__device__ __forceinline__ unsigned long long pc_gran_load(const unsigned long long* p)
 {
-    if (g == 0) return (unsigned)(C.done ? 1 : 0) | ((unsigned)C.cur << 1) | ((unsigned)(C.kind_next != 0 ? 1 : 0) << 8);
-    const double v = g <= 2 ? C.mu : (g <= 4 ? C.dl_a : C.dl_b);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void pc_gran_store(unsigned long long* p, unsigned tag, unsigned half)
+{
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned pc_half(double v, int lo)
+{
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    return (g & 1) ? (unsigned)bits : (unsigned)(bits >> 32);      // odd granule: low half, even: high half
+    return lo ? (unsigned)bits : (unsigned)(bits >> 32);
+}
+__device__ __forceinline__ double pc_unhalf(unsigned long long hi, unsigned long long lo)
+{
+    return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
 }
 
-__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(PC_PERSIST_WAVES, PC_PERSIST_WAVES))) void psfm_pc_persist_kernel(PcParams P, unsigned* bar, int spin_limit, int max_rounds, double* out_rows)
+// The all-reduce of one round, run by WAVE 0 of every block (the other waves wait at the caller's barrier): blk[] = this
+// block's sums (LDS), gran = [n_blocks rows of members][PC_LEADERS rows of leaders].  Returns 0 with the totals in tot[], 1
+// when the round is given up (this block timed out, or saw the poison of one that did).  Lane (k, j) = 4 k + j works on sum k.
+__device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long long* gran, int n_blocks, unsigned tag, unsigned poison,
+                                                int spin_limit, bool quit, double tot[PC_NSUM])
 {
-    // Behind psfm_pc_init_kernel (iteration 0 inside this kernel as round 0 was measured: 181 VGPRs and 107 spilled SGPRs in the
-    // iteration loop, 56.7 instead of 54.8 ms per hard 1080p sequence).  When the loop ends with the solve done, every block
-    // writes its tracks back (what psfm_pc_writeback_kernel does) and the control block says so.
-    if (*P.stall) return;
-    __shared__ PsfmSolveCtrl s_C;     // block 0: THE control block of the loop; others: the copy they started with
-    __shared__ PcRound s_R;
-    __shared__ unsigned s_pk[PC_PKT_GRANULES];
-    __shared__ int s_state;           // 0 go on, 2 give up
-    const int tid = threadIdx.x;
-    const int nblk = (int)gridDim.x;
-    const int nsh = nblk < PC_BAR_SHARDS ? nblk : PC_BAR_SHARDS;
-    const int sh = (int)blockIdx.x % nsh;
-    const bool reducer = blockIdx.x == 0;
-    if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
-    __syncthreads();
-    if (tid == 0) { s_R.done = s_C.done; s_R.cur = s_C.cur; s_R.kind = s_C.kind_next; s_R.mu = s_C.mu; s_R.a = s_C.dl_a; s_R.b = s_C.dl_b; }
-    __syncthreads();
-    for (unsigned it = 0; it < (unsigned)max_rounds; ++it) {
-        if (s_R.done) break;
-        double acc[PC_NSUM];
-        pc_iter_tracks(P, s_R.cur, s_R.mu, s_R.a, s_R.b, s_R.kind != 0, acc);
-        pc_block_reduce(acc, P.partials);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have been performed
-        __syncthreads();
-        if (tid == 0) {
-            (void)__hip_atomic_fetch_add(bar + sh * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (result unused: no return trip)
-            s_state = 0;
+    const int lane = threadIdx.x;            // (wave 0: lane == thread)
+    const int b = (int)blockIdx.x;
+    const int L = n_blocks < PC_LEADERS ? n_blocks : PC_LEADERS;
+    unsigned long long* mine = gran + (size_t)b * PC_RES_ROW;
+    unsigned long long* lead = gran + (size_t)n_blocks * PC_RES_ROW;
+    const int k = lane >> 2, j = lane & 3;
+    const bool work = lane < 4 * PC_RES_SUMS;
+    int bad = quit ? 1 : 0;
+    if (!bad && lane < 2 * PC_RES_SUMS) pc_gran_store(mine + lane, tag, pc_half(blk[lane >> 1], lane & 1));
+    if (!bad && b < L) {
+        // ---- leader: lane (k, j) adds the sums of its Q members in member order, then the four j's in order ----
+        const int Q = pc_tree_q(n_blocks);      // (<= 4: PC_RES_BLOCKS / PC_LEADERS / 4)
+        const int cnt = (n_blocks - b + PC_LEADERS - 1) / PC_LEADERS;
+        double v = 0.0;
+        for (int spins = 0;; ++spins) {
+            unsigned long long wh[4], wl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = j * Q + u;
+                const bool use = work && u < Q && m < cnt;
+                const unsigned long long* src = gran + (size_t)(b + PC_LEADERS * (use ? m : 0)) * PC_RES_ROW + 2 * (work ? k : 0);
+                wh[u] = pc_gran_load(src); wl[u] = pc_gran_load(src + 1);
+            }
+            bool ok = true, psn = false;
+            v = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = j * Q + u;
+                const bool use = work && u < Q && m < cnt;
+                if (!use) continue;
+                const unsigned th = (unsigned)(wh[u] >> 32), tl = (unsigned)(wl[u] >> 32);
+                if (th != tag || tl != tag) { ok = false; psn = psn || th == poison || tl == poison; }
+                const double val = pc_unhalf(wh[u], wl[u]);
+                v = (k == SUM_GMAX) ? fmax(v, val) : v + val;
+            }
+            if (__ballot(psn) != 0ull) { bad = 1; break; }
+            if (__ballot(!ok) == 0ull) break;
+            if (spins >= spin_limit) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (reducer) {
-            // ---- every block's partials are in memory once each shard counter has reached members x rounds ----
-            if (tid < PSFM_WAVE) {
-                const unsigned members = tid < nsh ? (unsigned)((nblk - tid + nsh - 1) / nsh) : 0u;
-                const unsigned long long want = nsh >= 64 ? ~0ull : ((1ull << nsh) - 1ull);
-                int spins = 0;
-                for (;;) {
-                    unsigned v = 0;
-                    if (tid < nsh) v = __hip_atomic_load(bar + tid * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((__ballot(tid < nsh && v >= (it + 1u) * members) & want) == want) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > spin_limit) { if (tid == 0) s_state = 2; break; }
-                }
-            }
-            __syncthreads();
-            if (s_state == 2) return;
-            pc_reduce_totals(P.partials, nblk);            // totals in the launch chain's order
-            if (tid == 0) {
-                PsfmSolveCtrl C = s_C;
-                pc_chain_control(C, pc_totals(), 1);
-                C.launches += 1;
-                s_C = C;
-                s_R.done = C.done; s_R.cur = C.cur; s_R.kind = C.kind_next; s_R.mu = C.mu; s_R.a = C.dl_a; s_R.b = C.dl_b;
-            }
-            __syncthreads();
-            if (tid < nsh * PC_PKT_GRANULES) {             // the packets: one tagged granule per lane, no order among them
-                const int s2 = tid / PC_PKT_GRANULES, g = tid - s2 * PC_PKT_GRANULES;
-                const unsigned long long w = ((unsigned long long)(it + 1u) << 32) | (unsigned long long)pc_pkt_half(s_C, g);
-                __hip_atomic_store((unsigned long long*)(bar + (PC_BAR_SHARDS + 1 + s2) * 32) + g, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            // the control block in memory (for the launches behind a loop that gives up, and for the end of this one)
-            if (tid < PC_CTRL_WORDS)
-                __hip_atomic_store((unsigned long long*)P.ctrl + tid, ((const unsigned long long*)&s_C)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else {
-            if (tid < PSFM_WAVE) {
-                const unsigned long long* pk = (const unsigned long long*)(bar + (PC_BAR_SHARDS + 1 + sh) * 32);
-                int spins = 0;
-                for (;;) {
-                    unsigned long long w = 0;
-                    if (tid < PC_PKT_GRANULES) w = __hip_atomic_load(pk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    const unsigned long long ok = __ballot(tid < PC_PKT_GRANULES && (unsigned)(w >> 32) == it + 1u);
-                    if ((ok & ((1ull << PC_PKT_GRANULES) - 1ull)) == ((1ull << PC_PKT_GRANULES) - 1ull)) {
-                        if (tid < PC_PKT_GRANULES) s_pk[tid] = (unsigned)w;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > spin_limit) { if (tid == 0) s_state = 2; break; }
-                }
-            }
-            __syncthreads();
-            if (s_state == 2) return;
-            if (tid == 0) {
-                const unsigned f = s_pk[0];
-                s_R.done = (int)(f & 1u); s_R.cur = (int)((f >> 1) & 0x7fu); s_R.kind = (int)((f >> 8) & 1u);
-                s_R.mu = __longlong_as_double((long long)(((unsigned long long)s_pk[2] << 32) | s_pk[1]));
-                s_R.a = __longlong_as_double((long long)(((unsigned long long)s_pk[4] << 32) | s_pk[3]));
-                s_R.b = __longlong_as_double((long long)(((unsigned long long)s_pk[6] << 32) | s_pk[5]));
-            }
-            __syncthreads();
+        if (!bad) {
+            const double s1 = __shfl(v, (lane & ~3) + 1), s2 = __shfl(v, (lane & ~3) + 2), s3 = __shfl(v, (lane & ~3) + 3);
+            const double S = (k == SUM_GMAX) ? fmax(fmax(fmax(v, s1), s2), s3) : ((v + s1) + s2) + s3;   // (valid in lanes 4k)
+            const double Sg = __shfl(S, 4 * (lane >> 1));        // granule lane g publishes sum g >> 1
+            if (lane < 2 * PC_RES_SUMS) pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, tag, pc_half(Sg, lane & 1));
         }
     }
-    if (!s_R.done) return;            // (ran out of rounds: the launches behind this one carry on from the control block)
-    // ---- write-back: a block copies the tracks it has been iterating on (block 0 holds the final control block: statistics) ----
-    if (!reducer && tid == 0) s_C.cur = s_R.cur;
+    double t = 0.0;
+    if (!bad) {
+        // ---- every block: lane (k, j) adds the leaders 8 j .. 8 j + 7 in order, then the four j's in order ----
+        for (int spins = 0;; ++spins) {
+            unsigned long long wh[8], wl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = 8 * j + u;
+                const unsigned long long* src = lead + (size_t)(work && x < L ? x : 0) * PC_RES_ROW + 2 * (work ? k : 0);
+                wh[u] = pc_gran_load(src); wl[u] = pc_gran_load(src + 1);
+            }
+            bool ok = true, psn = false;
+            t = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = 8 * j + u;
+                if (!work || x >= L) continue;
+                const unsigned th = (unsigned)(wh[u] >> 32), tl = (unsigned)(wl[u] >> 32);
+                if (th != tag || tl != tag) { ok = false; psn = psn || th == poison || tl == poison; }
+                const double S = pc_unhalf(wh[u], wl[u]);
+                t = (k == SUM_GMAX) ? fmax(t, S) : t + S;
+            }
+            if (__ballot(psn) != 0ull) { bad = 1; break; }
+            if (__ballot(!ok) == 0ull) break;
+            if (spins >= spin_limit) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (bad) {
+        // poison: whoever waits for this block (its leader; everybody, if it is a leader) leaves at its next poll
+        if (lane < 2 * PC_RES_SUMS) {
+            pc_gran_store(mine + lane, poison, 0u);
+            if (b < L) pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, poison, 0u);
+        }
+        return 1;
+    }
+    const double t1 = __shfl(t, (lane & ~3) + 1), t2 = __shfl(t, (lane & ~3) + 2), t3 = __shfl(t, (lane & ~3) + 3);
+    const double total = (k == SUM_GMAX) ? fmax(fmax(fmax(t, t1), t2), t3) : ((t + t1) + t2) + t3;       // (valid in lanes 4k)
+#pragma unroll
+    for (int q = 0; q < PC_NSUM; ++q) tot[q] = q < PC_RES_SUMS ? __shfl(total, 4 * q) : 0.0;
+    return 0;
+}
+
+struct PcSlot {                    // (slot k of thread t holds entry k * PC_BLOCK + t of the block's list, if the list is that long)
+    double s, S0q, S1q;            // weight, squared Jacobi scaling of columns 0, 1
+    double x[4], u[4], d[4];       // the iterate, and the system's solution there for the mu in force
+};
+
+// the candidate x + a u + b d of a slot, as the launch chain forms it (pc_core_step<false, false>), and |x - x'|^2
+__device__ __forceinline__ double pc_slot_candidate(const PcSlot& T, double a, double b, double xp[4])
+{
+    double v[PC_NSUM], r0[6], j0[4];      // (r0, j0, the constants: not read in this form of the step)
+    PcSys y;
+    PcConst c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { y.u[q] = T.u[q]; y.d[q] = T.d[q]; }
+    v[SUM_STEP2] = 0.0;
+    pc_core_step<false, false>(T.x, r0, j0, c, y, a, b, v, xp);
+    return v[SUM_STEP2];
+}
+
+template <int NS>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoch, int spin_limit, int max_rounds, int quit_code,
+                             double* out_rows)
+{
+    // Behind psfm_pc_init_kernel.  When the loop ends with the solve done, every block writes its tracks back (what
+    // psfm_pc_writeback_kernel does) and the control block says so.
+    if (*P.stall) return;
+    __shared__ PsfmSolveCtrl s_C;        // this block's copy of the control block (every block runs the same control step)
+    __shared__ PcRound s_R;
+    __shared__ double s_next[NS][8][PC_BLOCK];     // (u', d') at the candidate of the round
+    __shared__ double s_ref[NS][4][PC_BLOCK];      // refs (r1, r2) of the slots
+    __shared__ double s_blk[PC_RES_SUMS];
+    const int tid = threadIdx.x;
+    const int nblk = (int)gridDim.x;
+    const PcF2* F12 = (const PcF2*)P.flow12;
+    if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
     __syncthreads();
-    pc_writeback_tracks(P, s_C, out_rows);
-    if (reducer && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the round's copy of the control block first)
-        P.ctrl->written = 1;
+    if (tid == 0) {
+        s_R.done = s_C.done; s_R.cur = s_C.cur; s_R.kind = s_C.kind_next; s_R.mu = s_C.mu; s_R.a = s_C.dl_a; s_R.b = s_C.dl_b;
+        s_R.accepted = 0; s_R.giveup = 0;
+    }
+    __syncthreads();
+    const int cnt = P.list_n[blockIdx.x];
+    const int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
+    PcSlot T[NS];
+    if (!s_R.done) {
+        // ---- the slots: constants and the start values from memory (once), the system at x0 for the mu in force ----
+        // (an empty slot loads lane 0's state and computes on it; nothing of it is ever added or stored)
+        PcTaps tp[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = k * PC_BLOCK + tid < cnt ? lst[k * PC_BLOCK + tid] : 0;
+            const double2 r1 = P.ref1[i], r2 = P.ref2[i], js = P.jscale[i], p1 = P.x1a[i], p2 = P.x2a[i];
+            T[k].s = P.scale[i];
+            T[k].S0q = js.x; T[k].S1q = js.y;
+            s_ref[k][0][tid] = r1.x; s_ref[k][1][tid] = r1.y; s_ref[k][2][tid] = r2.x; s_ref[k][3][tid] = r2.y;
+            T[k].x[0] = p1.x; T[k].x[1] = p1.y; T[k].x[2] = p2.x; T[k].x[3] = p2.y;
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) tp[k] = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, T[k].x);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            double r[6], jac[4], unused[PC_NSUM];
+            PcSys y;
+#pragma unroll
+            for (int q = 0; q < PC_NSUM; ++q) unused[q] = 0.0;
+            const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
+            pc_core_eval_taps(tp[k], T[k].x, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
+            pc_core_system<false>(T[k].x, r, jac, c, s_R.mu, pc_core_iA22(c, s_R.mu), unused, y, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { T[k].u[q] = y.u[q]; T[k].d[q] = y.d[q]; }
+        }
+    }
+    const unsigned poison = (epoch << 12) | 0xfffu;
+    for (unsigned it = 0; it < (unsigned)max_rounds; ++it) {
+        if (s_R.done) break;
+        const double mu = s_R.mu, a = s_R.a, b = s_R.b;
+        const int cur = s_R.cur;
+        const bool refresh = s_R.kind != 0;
+        double acc[PC_NSUM];
+#pragma unroll
+        for (int q = 0; q < PC_NSUM; ++q) acc[q] = 0.0;
+        if (!refresh) {
+            // the candidate of (a, b), its cost and -- ahead of the decision -- the system there
+            const double mu_next = pc_mu_next(mu);
+            PcTaps tp[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {     // every slot's taps in flight together
+                double xe[4];
+                (void)pc_slot_candidate(T[k], a, b, xe);
+                tp[k] = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, xe);
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                // (a lane without a track in this slot skips it; the sums receive ONE term per track, in list order, like the launches')
+                if (k * PC_BLOCK + tid < cnt) {
+                    double xe[4], r[6], jac[4];
+                    PcSys y;
+                    acc[SUM_STEP2] += pc_slot_candidate(T[k], a, b, xe);      // (recomputed: the same bits, 8 registers fewer across the gather)
+                    const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
+                    pc_core_eval_taps(tp[k], xe, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
+                    acc[SUM_COST] += pc_core_cost(r);
+                    pc_core_system<true>(xe, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { s_next[k][q][tid] = y.u[q]; s_next[k][4 + q][tid] = y.d[q]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (one slot at a time: interleaving them costs more registers than it hides)
+            }
+        } else {
+            // the system at x for the mu an invalid step has raised: (u, d) of the slots are replaced (rare)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (k * PC_BLOCK + tid < cnt) {
+                    double r[6], jac[4];
+                    PcSys y;
+                    const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
+                    pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, T[k].x, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
+                    pc_core_system<true>(T[k].x, r, jac, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { T[k].u[q] = y.u[q]; T[k].d[q] = y.d[q]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // entries beyond the slots: streamed, as the launches do it
+        if (cnt > NS * PC_BLOCK) pc_iter_tracks(P, NS * PC_BLOCK + tid, cur, mu, a, b, refresh, acc);
+        pc_block_sums<PC_RES_SUMS>(acc, s_blk);
+        if (tid < PSFM_WAVE) {
+            double tot[PC_NSUM];
+            const bool quit = quit_code != 0 && (quit_code >> 16) == (int)blockIdx.x + 1 && (quit_code & 0xffff) == (int)it;
+            const int bad = pc_res_allreduce(s_blk, gran, nblk, (epoch << 12) | (it + 1u), poison, spin_limit, quit, tot);
+            if (tid == 0) {
+                if (bad) s_R.giveup = 1;
+                else {
+                    PsfmSolveCtrl C = s_C;
+                    pc_chain_control(C, tot, 1);
+                    C.launches += 1;
+                    s_R.accepted = C.cur != s_C.cur;
+                    s_C = C;
+                    s_R.done = C.done; s_R.cur = C.cur; s_R.kind = C.kind_next; s_R.mu = C.mu; s_R.a = C.dl_a; s_R.b = C.dl_b;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_R.giveup) return;
+        if (s_R.accepted) {
+            // x <- the candidate (the same operations: the same bits), (u, d) <- what was solved there
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                double xp[4];
+                (void)pc_slot_candidate(T[k], a, b, xp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { T[k].x[q] = xp[q]; T[k].u[q] = s_next[k][q][tid]; T[k].d[q] = s_next[k][4 + q][tid]; }
+            }
+        }
+    }
+    if (!s_R.done) return;            // (ran out of rounds: the write-back kernel behind raises the stall flag)
+    // ---- write-back (block 0 also: statistics, the control block) ----
+    const PsfmSolveCtrl C = s_C;
+    const bool moved = C.cur != 0 && !C.failed;          // (a failed solve hands the parameters back as they came in)
+    if (moved || out_rows) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (k * PC_BLOCK + tid >= cnt) continue;
+            const int i = lst[k * PC_BLOCK + tid];
+            double2 p1 = make_double2(T[k].x[0], T[k].x[1]), p2 = make_double2(T[k].x[2], T[k].x[3]);
+            if (!moved) { p1 = P.x1a[i]; p2 = P.x2a[i]; }
+            if (out_rows) {
+                out_rows[4 * (int64_t)i + 0] = p1.x; out_rows[4 * (int64_t)i + 1] = p1.y;
+                out_rows[4 * (int64_t)i + 2] = p2.x; out_rows[4 * (int64_t)i + 3] = p2.y;
+            } else {
+                P.x1a[i] = p1; P.x2a[i] = p2;
+            }
+        }
+        const int src = moved ? C.cur : 0;
+        const double2* xc1 = pc_buf1(P, src);
+        const double2* xc2 = pc_buf2(P, src);
+        for (int p = NS * PC_BLOCK + tid; p < cnt; p += PC_BLOCK) {
+            const int i = lst[p];
+            const double2 p1 = xc1[i], p2 = xc2[i];
+            if (out_rows) {
+                out_rows[4 * (int64_t)i + 0] = p1.x; out_rows[4 * (int64_t)i + 1] = p1.y;
+                out_rows[4 * (int64_t)i + 2] = p2.x; out_rows[4 * (int64_t)i + 3] = p2.y;
+            } else if (src != 0) {
+                P.x1a[i] = p1; P.x2a[i] = p2;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        pc_writeback_scalars(P, C);
+        PsfmSolveCtrl Cw = C;
+        Cw.written = 1;
+        *P.ctrl = Cw;
     }
 }
 
@@ -1112,10 +1329,10 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_flush_kernel(PcParams P)
 }
 __global__ void psfm_pc_clear_sel_kernel(int* sel, const int* stall) { if (!*stall) *sel = 0; }
 
-// final: if the accepted iterate lives in the scratch pair, copy it back (frame mode: into the log); C: the final control block
-__device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const PsfmSolveCtrl& C, double* out_rows)
+// what thread 0 of block 0 leaves behind a finished solve of the chain: the frame's statistics, PsfmCounters::sel, the lane snapshot
+__device__ __forceinline__ void pc_writeback_scalars(const PcParams& P, const PsfmSolveCtrl& C)
 {
-    if (P.stats_dev && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (P.stats_dev) {
         psfm_solve_stats st;
         st.iterations = C.iteration; st.successful_steps = C.successful;
         st.termination = C.n_tracks == 0 ? -1 : C.termination; st.dogleg_nonGN = C.nonGN;
@@ -1123,18 +1340,22 @@ __device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const Psf
         if (C.failed) st.termination = PSFM_TERM_FAILURE;
         P.stats_dev[P.frame] = st;
     }
-    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
-    // A failed solve is not an error (the reference ignores Ceres' FAILURE, trajectory_optimize.cpp:81-82) and Ceres
-    // hands the parameters back as they came in (solver.cc Minimize(), Summary::IsSolutionUsable()).  The failure that
-    // can happen here is the one at iteration 0 -- non-finite residuals: nothing was accepted, C.cur == 0, buffer 0
-    // still holds the initial values.  (A breakdown after accepted steps would need the 4x4 SPD system
-    // Js^T Js + mu diag^2 to lose definiteness, or an accepted iterate with finite cost and a non-finite Jacobian over
-    // the same four taps; the current iterate is what comes out then.)
-    const int cur = C.cur;
-    if (P.sel && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (P.sel) {
         *P.sel = 0;                                   // the iterate is (being) copied into buffer 0 right here
         if (P.n_lanes_snap) P.n_lanes_snap[(P.frame + 1) & 1] = *P.n_lanes_ptr;   // (no chain step is running: the lane count is final)
     }
+}
+
+// final: if the accepted iterate lives in the scratch pair, copy it back (frame mode: into the log); C: the final control block
+__device__ __forceinline__ void pc_writeback_tracks(const PcParams& P, const PsfmSolveCtrl& C, double* out_rows)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) pc_writeback_scalars(P, C);
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    // A failed solve is not an error (the reference ignores Ceres' FAILURE, trajectory_optimize.cpp:81-82) and Ceres
+    // hands the parameters back as they came in (solver.cc Minimize(), Summary::IsSolutionUsable() is false): buffer 0,
+    // which the chain never writes before this point, whatever was accepted on the way -- non-finite residuals at
+    // iteration 0, five invalid steps in a row or a system that lost definiteness behind accepted steps alike.
+    const int cur = C.failed ? 0 : C.cur;
     if (cur == 0 && !out_rows) return;
     const double2* xc1 = pc_buf1(P, cur);
     const double2* xc2 = pc_buf2(P, cur);
@@ -1199,6 +1420,13 @@ static psfm_status pc_setup(psfm_ctx* c, PcParams& P, hipStream_t s)
     P.ctrl = c->sol_ctrl.as<PsfmSolveCtrl>();
     P.ticket = (unsigned*)((char*)c->sol_ctrl.p + sizeof(PsfmSolveCtrl));
     if (!P.stall) P.stall = (int*)((char*)c->sol_ctrl.p + sizeof(PsfmSolveCtrl) + 16);
+    // the blocks' lists (pc_build_list): block b of the chain's grid sees the lane chunks b, b + n_blocks, ...
+    const int n_blocks = pc_blocks(P.n_rows);
+    const int chunks = (P.n_rows + PC_BLOCK - 1) / PC_BLOCK;
+    P.list_pitch = ((chunks + n_blocks - 1) / n_blocks) * PC_BLOCK;
+    if ((rc = c->sol_list.ensure(sizeof(int) * ((size_t)n_blocks * P.list_pitch + PC_MAX_BLOCKS))) != PSFM_OK) return rc;
+    P.list_n = c->sol_list.as<int>();
+    P.list = P.list_n + PC_MAX_BLOCKS;
     return PSFM_OK;
 }
 
@@ -1276,34 +1504,58 @@ static psfm_status pc_frame_params(psfm_ctx* c, const PsfmTrackDims& d, const fl
     return pc_setup(c, P, s);
 }
 
-// The trust-region loop of the launch chain as ONE persistent launch behind pc_init (psfm_pc_persist_kernel), when this call
+// The trust-region loop of the launch chain as ONE persistent launch behind pc_init (psfm_pc_resident_kernel), when this call
 // has the device to itself and the grid is co-resident; returns false when it is not used (the caller launches iterations).
 // PSFM_PC_PERSIST=0 keeps one launch per iteration (measurements, tests).
+template <int NS>
+static int pc_resident_capacity(psfm_ctx* c)
+{
+    if (c->pc_persist_blocks[NS] < 0) {
+        c->pc_persist_blocks[NS] = 0;
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, psfm_pc_resident_kernel<NS>, PC_BLOCK, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, c->device) == hipSuccess)
+            c->pc_persist_blocks[NS] = per_cu * prop.multiProcessorCount;
+    }
+    return c->pc_persist_blocks[NS];
+}
+
 static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, hipStream_t s)
 {
     const char* env = getenv("PSFM_PC_PERSIST");          // (read per call: the tests switch it inside one process)
-    if ((env && atoi(env) == 0) || !c->pc_persist_ok || P.export_sums) return false;
-    if (c->pc_persist_blocks < 0) {
-        c->pc_persist_blocks = 0;
-        int per_cu = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, psfm_pc_persist_kernel, PC_BLOCK, 0) == hipSuccess &&
-            hipGetDeviceProperties(&prop, c->device) == hipSuccess)
-            c->pc_persist_blocks = per_cu * prop.multiProcessorCount;
+    if ((env && atoi(env) == 0) || !c->pc_persist_ok || c->pc_giveups >= 2 || P.export_sums) return false;
+    if (n_blocks > PC_RES_BLOCKS) return false;
+    // slots per thread: what the longest possible list needs, at most PC_RES_NS_MAX (longer lists are streamed behind the slots)
+    int ns = P.list_pitch / PC_BLOCK;
+    if (getenv("PSFM_PC_SLOTS")) ns = atoi(getenv("PSFM_PC_SLOTS"));      // (measurements, tests: fewer slots = a streamed tail)
+    ns = ns < 1 ? 1 : (ns > PC_RES_NS_MAX ? PC_RES_NS_MAX : ns);
+    const int capacity = ns == 1 ? pc_resident_capacity<1>(c) : (ns == 2 ? pc_resident_capacity<2>(c) : pc_resident_capacity<3>(c));
+    if (n_blocks > capacity) return false;                 // (every block must be resident at once)
+    // granules: one row per block + one per leader; zeroed once -- tags carry the launch epoch, so what an earlier launch left
+    // never matches (the 20-bit epoch wraps after a million solves: cleared again then)
+    const size_t gbytes = sizeof(unsigned long long) * PC_RES_ROW * (PC_RES_BLOCKS + PC_LEADERS);
+    const bool fresh = c->sol_bar.bytes < gbytes;
+    if (c->sol_bar.ensure(gbytes) != PSFM_OK) return false;
+    c->pc_epoch += 1;
+    if (fresh || c->pc_epoch >= (1u << 20)) {
+        if (hipMemsetAsync(c->sol_bar.p, 0, gbytes, s) != hipSuccess) return false;
+        c->pc_epoch = 1;
     }
-#if PC_PERSIST_WAVES >= 3
-    if (n_blocks > c->pc_persist_blocks * 2 / 3 + 1 && !getenv("PSFM_PC_PERSIST_FULL")) return false;     // (see the spin limit below: never the full residency; the override is for measurements)
-#else
-    if (n_blocks > c->pc_persist_blocks) return false;                 // (measurement builds: 2 blocks per CU ARE the residency)
-#endif
-    if (c->sol_bar.ensure(sizeof(unsigned) * PC_BAR_WORDS) != PSFM_OK) return false;
-    if (hipMemsetAsync(c->sol_bar.p, 0, sizeof(unsigned) * PC_BAR_WORDS, s) != hipSuccess) return false;
-    // x (s_sleep 2 + one uncached load): ~10 ms.  The grid (PC_CHAIN_BLOCKS = 2 blocks per CU) leaves a third of the kernel's
-    // residency unused on purpose: at the full 3 blocks per CU the background flow_check of the side stream takes slots the
-    // barrier is waiting for (768 blocks measured: 192 instead of 55 ms per hard 1080p sequence, all of it spin-limit fall-backs)
-    const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 100000;      // (read per call: a test forces the give-up with 0)
+    // polls of (s_sleep 1 + a batch of uncached loads, ~1.5 us): ~10 ms
+    const int spin_limit = getenv("PSFM_PC_SPIN") ? atoi(getenv("PSFM_PC_SPIN")) : 8000;      // (read per call: a test forces the give-up with 0)
+    // tests: "block,round" makes that block give up in that round (what a grid that is not co-resident looks like to the others)
+    int quit_code = 0;
+    if (const char* q = getenv("PSFM_PC_QUIT")) {
+        int qb = 0, qr = 0;
+        if (sscanf(q, "%d,%d", &qb, &qr) == 2 && qb >= 0 && qr >= 0) quit_code = ((qb + 1) << 16) | (qr & 0xffff);
+    }
+    unsigned long long* gran = c->sol_bar.as<unsigned long long>();
+    const int max_rounds = 2 * 200 + 64;
     // (the write-back is in the launch too)
-    hipLaunchKernelGGL(psfm_pc_persist_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, c->sol_bar.as<unsigned>(), spin_limit, 2 * 200 + 64, out_rows);
+    if (ns == 1) hipLaunchKernelGGL(psfm_pc_resident_kernel<1>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, out_rows);
+    else if (ns == 2) hipLaunchKernelGGL(psfm_pc_resident_kernel<2>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, out_rows);
+    else hipLaunchKernelGGL(psfm_pc_resident_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, out_rows);
     return true;
 }
 
@@ -1330,8 +1582,12 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
 // The stalled solve of `frame`: clear the flag, iterate to termination with host polling, write back.
 psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                     const float* flow02, const uint8_t* occ02, int frame, psfm_solve_stats* st,
-                                    int try_fused_k, hipStream_t s)
+                                    int try_fused_k, bool chain_stalled, hipStream_t s)
 {
+    // chain_stalled: the solve that raised the flag was a launch-chain solve already -- it ran out of unrolled launches or its
+    // resident launch gave up (the grid was not co-resident: another process on the device); this redo uses launches, and a
+    // call that sees it happen twice stops trying the resident form
+    if (chain_stalled && c->pc_persist_ok) c->pc_giveups += 1;
     PcParams P;
     psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
     if (rc != PSFM_OK) return rc;
@@ -1358,7 +1614,7 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     }
     const int n_blocks = pc_blocks((int)d.cap);
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (!pc_persist_enqueue(c, P, n_blocks, nullptr, s))
+    if (chain_stalled || !pc_persist_enqueue(c, P, n_blocks, nullptr, s))
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
     return pc_finish_sync(c, P, n_blocks, nullptr, st, s);
