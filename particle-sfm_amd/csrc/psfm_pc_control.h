@@ -15,6 +15,7 @@ struct PsfmSolveCtrl {
     // trust-region state
     double radius, mu, x_cost, x_norm, gmax, initial_cost;
     double g2, jg2, gn2, dot;        // Gauss-Newton system sums at the current x (for the current mu)
+    double gnorm, gnn, alpha;        // sqrt(g2), sqrt(gn2), g2 / jg2: what every dogleg step of this iterate starts from (pc_sums_derive)
     double dl_a, dl_b;               // dogleg step = (dl_a * ghat + dl_b * gn) / diag when dl_fixed
     double dl_norm;                  // scaled norm of that step when known a priori (cases 1, 2); < 0 -> from the kernel
     int dl_fixed, done, termination, iteration;   // dl_fixed == 0: the kernel speculates the Gauss-Newton step (0, 1)
@@ -40,11 +41,20 @@ enum { CH_QUD = SUM_MCC, CH_QDD = SUM_DL2 };
 // ------------------------------------------------------------------------------------------------
 // pc_ctrl: reduce the partials in a fixed order and run Ceres' scalar control logic.
 // ------------------------------------------------------------------------------------------------
+// |ghat|, |gn| and the Cauchy step length alpha = |ghat|^2 / |Js ghat/diag|^2 (ComputeCauchyPoint) of the iterate whose sums
+// are in the control block: computed when the sums are adopted, not in every dogleg step (a rejected step shrinks the radius and
+// asks for another step of the SAME iterate -- same values)
+PC_HD void pc_sums_derive(PsfmSolveCtrl& C)
+{
+    C.gnorm = sqrt(C.g2); C.gnn = sqrt(C.gn2);
+    C.alpha = C.g2 / C.jg2;
+}
+
 PC_HD void pc_choose_dogleg(PsfmSolveCtrl& C)
 {
-    // ComputeTraditionalDoglegStep, with alpha = |ghat|^2 / |Js ghat/diag|^2 (ComputeCauchyPoint)
-    const double gnorm = sqrt(C.g2), gnn = sqrt(C.gn2);
-    const double alpha = C.g2 / C.jg2;
+    // ComputeTraditionalDoglegStep
+    const double gnorm = C.gnorm, gnn = C.gnn;
+    const double alpha = C.alpha;
     if (gnn <= C.radius) {
         C.dl_case = 1; C.dl_a = 0.0; C.dl_b = 1.0; C.dl_norm = gnn;
     } else if (gnorm * alpha >= C.radius) {
@@ -86,6 +96,7 @@ PC_HD void pc_control_step(PsfmSolveCtrl& C, const double* tot, int is_init, int
         C.x_norm = sqrt(tot[SUM_XN2]);
         C.gmax = tot[SUM_GMAX];
         C.g2 = tot[SUM_G2]; C.jg2 = tot[SUM_JG2]; C.gn2 = tot[SUM_GN2]; C.dot = tot[SUM_DOT];
+        pc_sums_derive(C);
         if (C.fresh_x) {   // FinalizeIterationAndCheckIfMinimizerCanContinue after a successful step (max_iter and
             C.fresh_x = 0; // radius were tested when the step was accepted; the gradient is only known now)
             if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; }
@@ -162,12 +173,35 @@ PC_HD void pc_control_step(PsfmSolveCtrl& C, const double* tot, int is_init, int
 // decision), every dogleg step of the iterate is priced from them, and a launch only contributes the candidate's cost
 // and step length.
 // ------------------------------------------------------------------------------------------------
-PC_HD void pc_chain_adopt(PsfmSolveCtrl& C, const double* tot)
+// The square roots and quotients a control step of the launch chain may need from a launch's totals -- all of them functions of
+// the totals and of what the control block held BEFORE the step, so they can be formed side by side (the resident solve: one
+// per lane of the wave that runs the control step) instead of one behind the other on the step's critical path.  Which of them
+// a step reads depends on its branch; the unread ones may be anything (NaN included).
+struct PcDerived {
+    double step_norm;      // sqrt(SUM_STEP2): |x - x'| of the candidate
+    double x_norm;         // sqrt(SUM_XN2) at the iterate whose sums the launch reduced
+    double gnorm, gnn;     // sqrt(SUM_G2), sqrt(SUM_GN2) there
+    double alpha;          // SUM_G2 / SUM_JG2 there (ComputeCauchyPoint)
+    double rho;            // (x_cost - SUM_COST) / mcc: the relative decrease of the candidate
+};
+PC_HD PcDerived pc_derive(const PsfmSolveCtrl& C, const double* tot)
 {
-    C.x_norm = sqrt(tot[SUM_XN2]);
+    PcDerived D;
+    D.step_norm = sqrt(tot[SUM_STEP2]);
+    D.x_norm = sqrt(tot[SUM_XN2]);
+    D.gnorm = sqrt(tot[SUM_G2]); D.gnn = sqrt(tot[SUM_GN2]);
+    D.alpha = tot[SUM_G2] / tot[SUM_JG2];
+    D.rho = (C.x_cost - tot[SUM_COST]) / C.mcc;
+    return D;
+}
+
+PC_HD void pc_chain_adopt(PsfmSolveCtrl& C, const double* tot, const PcDerived& D)
+{
+    C.x_norm = D.x_norm;
     C.gmax = tot[SUM_GMAX];
     C.g2 = tot[SUM_G2]; C.jg2 = tot[SUM_JG2]; C.gn2 = tot[SUM_GN2]; C.dot = tot[SUM_DOT];
     C.qud = tot[CH_QUD]; C.qdd = tot[CH_QDD];
+    C.gnorm = D.gnorm; C.gnn = D.gnn; C.alpha = D.alpha;
 }
 
 // The step pc_choose_dogleg has just fixed: its norm and model cost change from the sums at x; an invalid step
@@ -194,8 +228,8 @@ PC_HD void pc_chain_price(PsfmSolveCtrl& C)
     }
 }
 
-// kind 0: behind pc_init; 1: behind pc_iter (which did what C.kind_next said)
-PC_HD void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
+// kind 0: behind pc_init; 1: behind pc_iter (which did what C.kind_next said).  D = pc_derive(C, tot), formed before the call.
+PC_HD void pc_chain_control_d(PsfmSolveCtrl& C, const double* tot, const PcDerived& D, int kind)
 {
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     const double min_relative_decrease = 1e-3, min_radius = 1e-32;
@@ -209,7 +243,7 @@ PC_HD void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
         C.termination = PSFM_TERM_MAX_ITER;
         if (C.n_tracks == 0) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; return; }
         if (tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; return; }
-        pc_chain_adopt(C, tot);
+        pc_chain_adopt(C, tot, D);
         if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; return; }   // iteration 0
         pc_choose_dogleg(C);
         pc_chain_price(C);
@@ -218,7 +252,7 @@ PC_HD void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
     if (C.done) return;
     if (C.kind_next != 0) {     // the system at x for the raised mu
         if (tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; return; }
-        pc_chain_adopt(C, tot);
+        pc_chain_adopt(C, tot, D);
         pc_choose_dogleg(C);
         pc_chain_price(C);
         return;
@@ -229,13 +263,13 @@ PC_HD void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
     if (C.dl_case != 1) C.nonGN += 1;
     C.n_invalid = 0;
     const double cand = tot[SUM_COST];
-    const double step_norm = sqrt(tot[SUM_STEP2]);
+    const double step_norm = D.step_norm;
     if (step_norm <= parameter_tolerance * (C.x_norm + parameter_tolerance)) {
         C.done = 1; C.termination = PSFM_TERM_PARAMETER_TOL;
     } else if (fabs(C.x_cost - cand) <= function_tolerance * C.x_cost) {
         C.done = 1; C.termination = PSFM_TERM_FUNCTION_TOL;
     } else {
-        const double rho = (C.x_cost - cand) / C.mcc;
+        const double rho = D.rho;
         if (rho > min_relative_decrease) {
             // HandleSuccessfulStep + DoglegStrategy::StepAccepted
             C.cur = pc_other(C.cur);
@@ -257,7 +291,7 @@ PC_HD void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
     if (accepted && !C.done) {
         // the launch reduced the system at the candidate with the mu that is in force now: it is the current iterate's
         if (tot[SUM_FAIL] > 0.0) { C.done = 1; C.failed = 1; C.termination = PSFM_TERM_FAILURE; return; }
-        pc_chain_adopt(C, tot);
+        pc_chain_adopt(C, tot, D);
         if (C.gmax <= gradient_tolerance) { C.done = 1; C.termination = PSFM_TERM_GRADIENT_TOL; return; }
         pc_choose_dogleg(C);
         pc_chain_price(C);
@@ -276,3 +310,8 @@ PC_HD void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
     }
 }
 
+PC_HD void pc_chain_control(PsfmSolveCtrl& C, const double* tot, int kind)
+{
+    const PcDerived D = pc_derive(C, tot);
+    pc_chain_control_d(C, tot, D, kind);
+}

@@ -49,6 +49,7 @@
 #include "psfm_pc_control.h"
 
 #define PC_BLOCK 256
+#include "psfm_pc_reduce.h"
 #ifndef PC_FUSED_PAIR
 #define PC_FUSED_PAIR false  // ... and the fused solve's: its lanes are neighbours in the image, and the frame kernel spills 7 VGPRs with them
 #endif
@@ -146,61 +147,6 @@ __device__ __forceinline__ double pc_wave_max(double v)
     return v;
 }
 
-// Block reduction of acc[NS_] (slot SUM_GMAX by max, the others by sum) in a fixed order, in registers: inside a wave four
-// exchange steps on the DPP lanes (xor 1, xor 2, half-row mirror, row mirror: both partners of an exchange form the same
-// IEEE sum, so afterwards every lane of a 16-lane row holds the row's total), the four rows in order through v_readlane, the
-// block's four waves in order through 13 words of LDS each.  (Round 3 parked every thread's accumulators in LDS -- 27 KB, which
-// the resident solve needs for its tracks; a ds_bpermute tree -- 13 sums x 6 steps x 2 -- took ~4 us of every launch's tail.)
-// The block's sums are left in out[0 .. NS_) (LDS, valid for every thread after the call).  The launch chain reduces all
-// PC_NSUM slots, a round of the resident solve the first PC_RES_SUMS of them -- the slots are independent: same bits.
-template <int CTRL>
-__device__ __forceinline__ double pc_dpp(double v)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
-}
-__device__ __forceinline__ double pc_readlane(double v, int lane)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
-}
-template <bool MAX>
-__device__ __forceinline__ double pc_wave_total(double v)
-{
-#define PC_OP(a_, b_) (MAX ? fmax((a_), (b_)) : (a_) + (b_))
-    v = PC_OP(v, pc_dpp<0xB1>(v));       // quad_perm [1,0,3,2]
-    v = PC_OP(v, pc_dpp<0x4E>(v));       // quad_perm [2,3,0,1]
-    v = PC_OP(v, pc_dpp<0x141>(v));      // row_half_mirror
-    v = PC_OP(v, pc_dpp<0x140>(v));      // row_mirror
-    const double r0 = pc_readlane(v, 0), r1 = pc_readlane(v, 16), r2 = pc_readlane(v, 32), r3 = pc_readlane(v, 48);
-    return PC_OP(PC_OP(PC_OP(r0, r1), r2), r3);
-#undef PC_OP
-}
-template <int NS_>
-__device__ __forceinline__ void pc_block_sums(const double* acc, double* out)
-{
-    __shared__ double s_w[PC_BLOCK / PSFM_WAVE][NS_];
-    const int tid = threadIdx.x, w = tid / PSFM_WAVE, lane = tid & (PSFM_WAVE - 1);
-#pragma unroll
-    for (int k = 0; k < NS_; ++k) {
-        const double t = (k == SUM_GMAX) ? pc_wave_total<true>(acc[k]) : pc_wave_total<false>(acc[k]);
-        if (lane == 0) s_w[w][k] = t;
-    }
-    __syncthreads();
-    if (tid < NS_) {
-        double v = s_w[0][tid];
-#pragma unroll
-        for (int q = 1; q < PC_BLOCK / PSFM_WAVE; ++q) v = (tid == SUM_GMAX) ? fmax(v, s_w[q][tid]) : v + s_w[q][tid];
-        out[tid] = v;
-    }
-    __syncthreads();
-}
-
 // ... -> partials[blockIdx] (launch chain)
 __device__ __forceinline__ void pc_block_reduce(double acc[PC_NSUM], double* __restrict__ partials)
 {
@@ -290,8 +236,31 @@ __device__ __forceinline__ void pc_refs(const PcParams& P, double2 p0, double2& 
     r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
 }
 
-// iteration 0 for this block's tracks: the block's list, then per entry refs / scale (frame mode), Jacobi scaling, cost and
-// system at the start values
+// iteration 0 of ONE track (lane i): refs / scale (frame mode: from its p0; batch mode: given), Jacobi scaling from the Jacobian
+// at the start values, cost and system there (mu = min_mu); its terms go to acc[], what a solve keeps of it to o.
+struct PcInit { double2 r1, r2; double s; PcConst c; double x[4]; PcSys y; };
+__device__ __forceinline__ void pc_init_entry(const PcParams& P, int i, bool store, double acc[PC_NSUM], PcInit& o)
+{
+    const double mu = 1e-8;
+    if (P.p0) {
+        pc_refs(P, P.p0[i], o.r1, o.r2, o.s);
+        if (store) { P.ref1[i] = o.r1; P.ref2[i] = o.r2; P.scale[i] = o.s; }
+    } else {
+        o.r1 = P.ref1[i]; o.r2 = P.ref2[i]; o.s = P.scale[i];
+    }
+    const double2 p1 = P.x1a[i], p2 = P.x2a[i];
+    o.x[0] = p1.x; o.x[1] = p1.y; o.x[2] = p2.x; o.x[3] = p2.y;
+    // Jacobi scaling 1/(1+sqrt(colnorm^2)) from the Jacobian at x0, computed once (trust_region_minimizer.cc)
+    double r0[6], j0[4];
+    pc_core_eval((const PcF2*)P.flow12, P.H, P.W, o.x, o.r1.x, o.r1.y, o.r2.x, o.r2.y, o.s, r0, j0);
+    o.c = pc_core_const(o.s, j0);
+    if (store) P.jscale[i] = make_double2(o.c.S0q, o.c.S1q);
+    acc[SUM_CNT] += 1.0;
+    acc[SUM_COST0] += pc_core_cost(r0);
+    pc_core_system<true>(o.x, r0, j0, o.c, mu, pc_core_iA22(o.c, mu), acc, o.y, CH_QUD, CH_QDD);
+}
+
+// iteration 0 for this block's tracks: the block's list, then its entries
 __device__ __forceinline__ void pc_init_tracks(const PcParams& P, double acc[PC_NSUM])
 {
     // the chain step in front of this solve has consumed PsfmCounters::sel (positions of an earlier fused solve): the launch
@@ -302,28 +271,9 @@ __device__ __forceinline__ void pc_init_tracks(const PcParams& P, double acc[PC_
     for (int k = 0; k < PC_NSUM; ++k) acc[k] = 0.0;
     const int cnt = pc_build_list(P, n);
     const int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
-    const double mu = 1e-8;
     for (int p = threadIdx.x; p < cnt; p += PC_BLOCK) {
-        const int i = lst[p];
-        double2 r1, r2;
-        double s;
-        if (P.p0) {
-            pc_refs(P, P.p0[i], r1, r2, s);
-            P.ref1[i] = r1; P.ref2[i] = r2; P.scale[i] = s;
-        } else {
-            r1 = P.ref1[i]; r2 = P.ref2[i]; s = P.scale[i];
-        }
-        const double2 p1 = P.x1a[i], p2 = P.x2a[i];
-        const double x[4] = {p1.x, p1.y, p2.x, p2.y};
-        // Jacobi scaling 1/(1+sqrt(colnorm^2)) from the Jacobian at x0, computed once (trust_region_minimizer.cc)
-        double r0[6], j0[4];
-        pc_core_eval((const PcF2*)P.flow12, P.H, P.W, x, r1.x, r1.y, r2.x, r2.y, s, r0, j0);
-        const PcConst c = pc_core_const(s, j0);
-        P.jscale[i] = make_double2(c.S0q, c.S1q);
-        acc[SUM_CNT] += 1.0;
-        acc[SUM_COST0] += pc_core_cost(r0);
-        PcSys y;
-        pc_core_system<true>(x, r0, j0, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
+        PcInit o;
+        pc_init_entry(P, lst[p], true, acc, o);
     }
 }
 
@@ -415,8 +365,13 @@ extern "C" int psfm_debug_solver_timeline(unsigned long long* out_host, int* n_h
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_pc_tl), sizeof(unsigned long long) * 64 * 1024 * 4) != hipSuccess;
 }
 #define PC_TL(k) do { if (tl_slot >= 0 && threadIdx.x == 0) g_pc_tl[((size_t)tl_slot * 1024 + blockIdx.x) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// resident solve: rounds PC_RTL_R0 .. + 7 of the launch with epoch PC_RTL_EPOCH, 16 stamps per block and round: [8][512][16]
+#define PC_RTL_EPOCH 12u
+#define PC_RTL_R0 8u
+#define PC_RTL(k) do { if (rtl >= 0 && threadIdx.x == 0) g_pc_tl[((size_t)rtl * 512 + blockIdx.x) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PC_TL(k) do {} while (0)
+#define PC_RTL(k) do {} while (0)
 #endif
 
 __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
@@ -589,18 +544,21 @@ __device__ __forceinline__ double pc_unhalf(unsigned long long hi, unsigned long
 // The all-reduce of one round, run by WAVE 0 of every block (the other waves wait at the caller's barrier): blk[] = this
 // block's sums (LDS), gran = [n_blocks rows of members][PC_LEADERS rows of leaders].  Returns 0 with the totals in tot[], 1
 // when the round is given up (this block timed out, or saw the poison of one that did).  Lane (k, j) = 4 k + j works on sum k.
+template <int NSUMS>
 __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long long* gran, int n_blocks, unsigned tag, unsigned poison,
-                                                int spin_limit, bool quit, double tot[PC_NSUM])
+                                                int spin_limit, bool quit, double tot[PC_NSUM], int rtl)
 {
+    static_assert(4 * NSUMS <= PSFM_WAVE && 2 * NSUMS <= PC_RES_ROW, "one lane per (sum, quarter), two granules per sum");
     const int lane = threadIdx.x;            // (wave 0: lane == thread)
     const int b = (int)blockIdx.x;
     const int L = n_blocks < PC_LEADERS ? n_blocks : PC_LEADERS;
     unsigned long long* mine = gran + (size_t)b * PC_RES_ROW;
     unsigned long long* lead = gran + (size_t)n_blocks * PC_RES_ROW;
     const int k = lane >> 2, j = lane & 3;
-    const bool work = lane < 4 * PC_RES_SUMS;
+    const bool work = lane < 4 * NSUMS;
     int bad = quit ? 1 : 0;
-    if (!bad && lane < 2 * PC_RES_SUMS) pc_gran_store(mine + lane, tag, pc_half(blk[lane >> 1], lane & 1));
+    if (!bad && lane < 2 * NSUMS) pc_gran_store(mine + lane, tag, pc_half(blk[lane >> 1], lane & 1));
+    PC_RTL(4);
     if (!bad && b < L) {
         // ---- leader: lane (k, j) adds the sums of its Q members in member order, then the four j's in order ----
         const int Q = pc_tree_q(n_blocks);      // (<= 4: PC_RES_BLOCKS / PC_LEADERS / 4)
@@ -636,8 +594,9 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
             const double s1 = __shfl(v, (lane & ~3) + 1), s2 = __shfl(v, (lane & ~3) + 2), s3 = __shfl(v, (lane & ~3) + 3);
             const double S = (k == SUM_GMAX) ? fmax(fmax(fmax(v, s1), s2), s3) : ((v + s1) + s2) + s3;   // (valid in lanes 4k)
             const double Sg = __shfl(S, 4 * (lane >> 1));        // granule lane g publishes sum g >> 1
-            if (lane < 2 * PC_RES_SUMS) pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, tag, pc_half(Sg, lane & 1));
+            if (lane < 2 * NSUMS) pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, tag, pc_half(Sg, lane & 1));
         }
+        PC_RTL(5);
     }
     double t = 0.0;
     if (!bad) {
@@ -669,16 +628,17 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
     }
     if (bad) {
         // poison: whoever waits for this block (its leader; everybody, if it is a leader) leaves at its next poll
-        if (lane < 2 * PC_RES_SUMS) {
+        if (lane < 2 * NSUMS) {
             pc_gran_store(mine + lane, poison, 0u);
             if (b < L) pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, poison, 0u);
         }
         return 1;
     }
+    PC_RTL(6);
     const double t1 = __shfl(t, (lane & ~3) + 1), t2 = __shfl(t, (lane & ~3) + 2), t3 = __shfl(t, (lane & ~3) + 3);
     const double total = (k == SUM_GMAX) ? fmax(fmax(fmax(t, t1), t2), t3) : ((t + t1) + t2) + t3;       // (valid in lanes 4k)
 #pragma unroll
-    for (int q = 0; q < PC_NSUM; ++q) tot[q] = q < PC_RES_SUMS ? __shfl(total, 4 * q) : 0.0;
+    for (int q = 0; q < PC_NSUM; ++q) tot[q] = q < NSUMS ? __shfl(total, 4 * q) : 0.0;
     return 0;
 }
 
@@ -703,63 +663,118 @@ __device__ __forceinline__ double pc_slot_candidate(const PcSlot& T, double a, d
 template <int NS>
 __global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoch, int spin_limit, int max_rounds, int quit_code,
-                             double* out_rows)
+                             int init_inside, double* out_rows)
 {
-    // Behind psfm_pc_init_kernel.  When the loop ends with the solve done, every block writes its tracks back (what
-    // psfm_pc_writeback_kernel does) and the control block says so.
+    // init_inside: iteration 0 (what psfm_pc_init_kernel does) is this launch's first round; else it runs behind that kernel.
+    // When the loop ends with the solve done, every block writes its tracks back (what psfm_pc_writeback_kernel does) and the
+    // control block says so.
     if (*P.stall) return;
     __shared__ PsfmSolveCtrl s_C;        // this block's copy of the control block (every block runs the same control step)
     __shared__ PcRound s_R;
     __shared__ double s_next[NS][8][PC_BLOCK];     // (u', d') at the candidate of the round
     __shared__ double s_ref[NS][4][PC_BLOCK];      // refs (r1, r2) of the slots
-    __shared__ double s_blk[PC_RES_SUMS];
+    __shared__ double s_blk[PC_NSUM];
     const int tid = threadIdx.x;
     const int nblk = (int)gridDim.x;
     const PcF2* F12 = (const PcF2*)P.flow12;
-    if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
-    __syncthreads();
-    if (tid == 0) {
-        s_R.done = s_C.done; s_R.cur = s_C.cur; s_R.kind = s_C.kind_next; s_R.mu = s_C.mu; s_R.a = s_C.dl_a; s_R.b = s_C.dl_b;
-        s_R.accepted = 0; s_R.giveup = 0;
-    }
-    __syncthreads();
-    const int cnt = P.list_n[blockIdx.x];
+    const unsigned poison = (epoch << 12) | 0xfffu;
     const int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
     PcSlot T[NS];
-    if (!s_R.done) {
-        // ---- the slots: constants and the start values from memory (once), the system at x0 for the mu in force ----
-        // (an empty slot loads lane 0's state and computes on it; nothing of it is ever added or stored)
-        PcTaps tp[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int i = k * PC_BLOCK + tid < cnt ? lst[k * PC_BLOCK + tid] : 0;
-            const double2 r1 = P.ref1[i], r2 = P.ref2[i], js = P.jscale[i], p1 = P.x1a[i], p2 = P.x2a[i];
-            T[k].s = P.scale[i];
-            T[k].S0q = js.x; T[k].S1q = js.y;
-            s_ref[k][0][tid] = r1.x; s_ref[k][1][tid] = r1.y; s_ref[k][2][tid] = r2.x; s_ref[k][3][tid] = r2.y;
-            T[k].x[0] = p1.x; T[k].x[1] = p1.y; T[k].x[2] = p2.x; T[k].x[3] = p2.y;
+    int cnt;
+    if (init_inside) {
+        // ---- iteration 0: the block's list, the slots' tracks from their three buffered positions, the sums, Ceres' IterationZero ----
+        if (blockIdx.x == 0 && tid == 0) {
+            // (whatever gives up below must not leave an earlier solve's outcome to be read as this one's)
+            P.ctrl->done = 0; P.ctrl->written = 0;
+            if (P.sel) *P.sel = 0;      // (as pc_init_tracks)
         }
+        const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+        cnt = pc_build_list(P, n);
+        double acc[PC_NSUM];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) tp[k] = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, T[k].x);
+        for (int q = 0; q < PC_NSUM; ++q) acc[q] = 0.0;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            double r[6], jac[4], unused[PC_NSUM];
-            PcSys y;
+            if (k * PC_BLOCK + tid < cnt) {
+                PcInit o;
+                pc_init_entry(P, lst[k * PC_BLOCK + tid], false, acc, o);
+                T[k].s = o.s; T[k].S0q = o.c.S0q; T[k].S1q = o.c.S1q;
+                s_ref[k][0][tid] = o.r1.x; s_ref[k][1][tid] = o.r1.y; s_ref[k][2][tid] = o.r2.x; s_ref[k][3][tid] = o.r2.y;
 #pragma unroll
-            for (int q = 0; q < PC_NSUM; ++q) unused[q] = 0.0;
-            const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
-            pc_core_eval_taps(tp[k], T[k].x, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
-            pc_core_system<false>(T[k].x, r, jac, c, s_R.mu, pc_core_iA22(c, s_R.mu), unused, y, 0, 0);
+                for (int q = 0; q < 4; ++q) { T[k].x[q] = o.x[q]; T[k].u[q] = o.y.u[q]; T[k].d[q] = o.y.d[q]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int p = NS * PC_BLOCK + tid; p < cnt; p += PC_BLOCK) {     // (streamed entries: their constants go to memory)
+            PcInit o;
+            pc_init_entry(P, lst[p], true, acc, o);
+        }
+        pc_block_sums<PC_NSUM>(acc, s_blk);
+        if (tid < PSFM_WAVE) {
+            double tot[PC_NSUM];
+            const int bad = pc_res_allreduce<PC_NSUM>(s_blk, gran, nblk, (epoch << 12) | 0xffeu, poison, spin_limit, false, tot, -1);
+            if (tid == 0) {
+                s_R.giveup = bad; s_R.accepted = 0;
+                if (!bad) {
+                    PsfmSolveCtrl& C = s_C;          // (in place, in LDS: a private copy would not stay in registers behind the memset)
+                    pc_chain_control(C, tot, 0);
+                    C.launches = 1;
+                    s_R.done = C.done; s_R.cur = C.cur; s_R.kind = C.kind_next; s_R.mu = C.mu; s_R.a = C.dl_a; s_R.b = C.dl_b;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_R.giveup) return;
+    } else {
+        if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
+        __syncthreads();
+        if (tid == 0) {
+            s_R.done = s_C.done; s_R.cur = s_C.cur; s_R.kind = s_C.kind_next; s_R.mu = s_C.mu; s_R.a = s_C.dl_a; s_R.b = s_C.dl_b;
+            s_R.accepted = 0; s_R.giveup = 0;
+        }
+        __syncthreads();
+        cnt = P.list_n[blockIdx.x];
+        if (!s_R.done) {
+            // ---- the slots: constants and the start values from memory (once), the system at x0 for the mu in force ----
+            // (an empty slot loads lane 0's state and computes on it; nothing of it is ever added or stored)
+            PcTaps tp[NS];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { T[k].u[q] = y.u[q]; T[k].d[q] = y.d[q]; }
+            for (int k = 0; k < NS; ++k) {
+                const int i = k * PC_BLOCK + tid < cnt ? lst[k * PC_BLOCK + tid] : 0;
+                const double2 r1 = P.ref1[i], r2 = P.ref2[i], js = P.jscale[i], p1 = P.x1a[i], p2 = P.x2a[i];
+                T[k].s = P.scale[i];
+                T[k].S0q = js.x; T[k].S1q = js.y;
+                s_ref[k][0][tid] = r1.x; s_ref[k][1][tid] = r1.y; s_ref[k][2][tid] = r2.x; s_ref[k][3][tid] = r2.y;
+                T[k].x[0] = p1.x; T[k].x[1] = p1.y; T[k].x[2] = p2.x; T[k].x[3] = p2.y;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) tp[k] = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, T[k].x);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                double r[6], jac[4], unused[PC_NSUM];
+                PcSys y;
+#pragma unroll
+                for (int q = 0; q < PC_NSUM; ++q) unused[q] = 0.0;
+                const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
+                pc_core_eval_taps(tp[k], T[k].x, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
+                pc_core_system<false>(T[k].x, r, jac, c, s_R.mu, pc_core_iA22(c, s_R.mu), unused, y, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { T[k].u[q] = y.u[q]; T[k].d[q] = y.d[q]; }
+            }
         }
     }
-    const unsigned poison = (epoch << 12) | 0xfffu;
     for (unsigned it = 0; it < (unsigned)max_rounds; ++it) {
         if (s_R.done) break;
         const double mu = s_R.mu, a = s_R.a, b = s_R.b;
         const int cur = s_R.cur;
         const bool refresh = s_R.kind != 0;
+#ifdef PSFM_TIMELINE
+        const int rtl = (epoch == PC_RTL_EPOCH && it >= PC_RTL_R0 && it < PC_RTL_R0 + 8u) ? (int)(it - PC_RTL_R0) : -1;
+        if (rtl >= 0 && tid == 0 && blockIdx.x == 0) g_pc_tl_n = rtl + 1;
+#else
+        const int rtl = -1;
+#endif
+        PC_RTL(0);
         double acc[PC_NSUM];
 #pragma unroll
         for (int q = 0; q < PC_NSUM; ++q) acc[q] = 0.0;
@@ -773,6 +788,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
                 (void)pc_slot_candidate(T[k], a, b, xe);
                 tp[k] = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, xe);
             }
+            PC_RTL(1);
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 // (a lane without a track in this slot skips it; the sums receive ONE term per track, in list order, like the launches')
@@ -807,24 +823,41 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
         }
         // entries beyond the slots: streamed, as the launches do it
         if (cnt > NS * PC_BLOCK) pc_iter_tracks(P, NS * PC_BLOCK + tid, cur, mu, a, b, refresh, acc);
+        PC_RTL(2);
         pc_block_sums<PC_RES_SUMS>(acc, s_blk);
+        PC_RTL(3);
         if (tid < PSFM_WAVE) {
             double tot[PC_NSUM];
             const bool quit = quit_code != 0 && (quit_code >> 16) == (int)blockIdx.x + 1 && (quit_code & 0xffff) == (int)it;
-            const int bad = pc_res_allreduce(s_blk, gran, nblk, (epoch << 12) | (it + 1u), poison, spin_limit, quit, tot);
+            const int bad = pc_res_allreduce<PC_RES_SUMS>(s_blk, gran, nblk, (epoch << 12) | (it + 1u), poison, spin_limit, quit, tot, rtl);
+            PC_RTL(9);
+            // what the control step may need from the totals (pc_derive), one quantity per lane instead of one behind the other
+            PcDerived D;
+            {
+                const int lane = tid;
+                const double rad = lane == 0 ? tot[SUM_STEP2] : (lane == 1 ? tot[SUM_XN2] : (lane == 2 ? tot[SUM_G2] : tot[SUM_GN2]));
+                const double num = lane == 4 ? tot[SUM_G2] : s_C.x_cost - tot[SUM_COST];
+                const double den = lane == 4 ? tot[SUM_JG2] : s_C.mcc;
+                const double res = lane < 4 ? sqrt(rad) : num / den;
+                D.step_norm = __shfl(res, 0); D.x_norm = __shfl(res, 1); D.gnorm = __shfl(res, 2); D.gnn = __shfl(res, 3);
+                D.alpha = __shfl(res, 4); D.rho = __shfl(res, 5);
+            }
+            PC_RTL(10);
             if (tid == 0) {
                 if (bad) s_R.giveup = 1;
                 else {
-                    PsfmSolveCtrl C = s_C;
-                    pc_chain_control(C, tot, 1);
+                    PsfmSolveCtrl& C = s_C;          // (in place: the block's copy lives in LDS)
+                    const int cur0 = C.cur;
+                    pc_chain_control_d(C, tot, D, 1);
                     C.launches += 1;
-                    s_R.accepted = C.cur != s_C.cur;
-                    s_C = C;
+                    s_R.accepted = C.cur != cur0;
                     s_R.done = C.done; s_R.cur = C.cur; s_R.kind = C.kind_next; s_R.mu = C.mu; s_R.a = C.dl_a; s_R.b = C.dl_b;
                 }
             }
+            PC_RTL(7);
         }
         __syncthreads();
+        PC_RTL(8);
         if (s_R.giveup) return;
         if (s_R.accepted) {
             // x <- the candidate (the same operations: the same bits), (u, d) <- what was solved there
@@ -1521,7 +1554,7 @@ static int pc_resident_capacity(psfm_ctx* c)
     return c->pc_persist_blocks[NS];
 }
 
-static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, hipStream_t s)
+static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, bool init_inside, hipStream_t s)
 {
     const char* env = getenv("PSFM_PC_PERSIST");          // (read per call: the tests switch it inside one process)
     if ((env && atoi(env) == 0) || !c->pc_persist_ok || c->pc_giveups >= 2 || P.export_sums) return false;
@@ -1553,14 +1586,17 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
     unsigned long long* gran = c->sol_bar.as<unsigned long long>();
     const int max_rounds = 2 * 200 + 64;
     // (the write-back is in the launch too)
-    if (ns == 1) hipLaunchKernelGGL(psfm_pc_resident_kernel<1>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, out_rows);
-    else if (ns == 2) hipLaunchKernelGGL(psfm_pc_resident_kernel<2>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, out_rows);
-    else hipLaunchKernelGGL(psfm_pc_resident_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, out_rows);
+    if (ns == 1) hipLaunchKernelGGL(psfm_pc_resident_kernel<1>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, out_rows);
+    else if (ns == 2) hipLaunchKernelGGL(psfm_pc_resident_kernel<2>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, out_rows);
+    else hipLaunchKernelGGL(psfm_pc_resident_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, out_rows);
     return true;
 }
 
-// Enqueue one frame's solve with `unroll` iterations and NO host synchronisation: if the solve needs more, its
-// write-back kernel raises the device-side stall flag, which turns everything enqueued behind it into no-ops.
+// Enqueue one frame's solve with NO host synchronisation: the resident solve (iteration 0, the trust-region loop and the
+// write-back in ONE launch) when the call has the device to itself, else pc_init + `unroll` launches of one iteration each; a
+// solve that is not done behind them -- the loop gave up on its hand-off, the launches did not suffice -- has its write-back
+// kernel raise the device-side stall flag, which turns everything enqueued behind it into no-ops; the host redoes it at its
+// checkpoint.
 psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
                                      const float* flow02, const uint8_t* occ02, int frame, int unroll, hipStream_t s)
 {
@@ -1571,9 +1607,13 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
     // iteration 0, then the loop and the write-back in one launch when possible (a loop that gave up on its barrier leaves the
     // control block "not done": the write-back kernel behind it then raises the stall flag and the host redoes the solve at its
     // checkpoint), else `unroll` launches of one iteration each + write-back
-    hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (!pc_persist_enqueue(c, P, n_blocks, nullptr, s))
-        for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    // (PSFM_PC_INIT_INSIDE=0: iteration 0 as its own launch in front of the resident solve -- measurements, tests)
+    const bool inside = !(getenv("PSFM_PC_INIT_INSIDE") && atoi(getenv("PSFM_PC_INIT_INSIDE")) == 0);
+    if (!inside || !pc_persist_enqueue(c, P, n_blocks, nullptr, true, s)) {
+        hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+        if (!pc_persist_enqueue(c, P, n_blocks, nullptr, false, s))
+            for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+    }
     hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
@@ -1614,7 +1654,7 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     }
     const int n_blocks = pc_blocks((int)d.cap);
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (chain_stalled || !pc_persist_enqueue(c, P, n_blocks, nullptr, s))
+    if (chain_stalled || !pc_persist_enqueue(c, P, n_blocks, nullptr, false, s))
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
     return pc_finish_sync(c, P, n_blocks, nullptr, st, s);
@@ -1897,7 +1937,7 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     PSFM_HIP(hipMemcpyAsync(P.ref2, ref2, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
     PSFM_HIP(hipMemcpyAsync(P.scale, scale, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (!pc_persist_enqueue(c, P, n_blocks, out, s))
+    if (!pc_persist_enqueue(c, P, n_blocks, out, false, s))
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
     rc = pc_finish_sync(c, P, n_blocks, out, st, s);

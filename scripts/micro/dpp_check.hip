@@ -1,67 +1,56 @@
-// dpp_check.hip -- does the DPP exchange tree of pc_wave_total (csrc/psfm_solver.hip) count every lane of a wave exactly once?
-// Integer-valued doubles: every order of summation gives the same bits, so a wrong control word shows as a wrong number.
-//   hipcc --offload-arch=gfx950 -O2 -o scripts/micro/dpp_check.bin scripts/micro/dpp_check.hip && scripts/micro/dpp_check.bin
+// dpp_check.hip -- does the exchange tree of pc_block_sums (csrc/psfm_pc_reduce.h: DPP quad_perm / row_ror, ds_swizzle) count every
+// thread's term of every sum exactly once, and is SUM_GMAX the maximum?  Integer-valued doubles: every order of summation gives
+// the same bits, so a wrong control word or lane mapping shows as a wrong number.
+//   hipcc --offload-arch=gfx950 -O2 -I particle-sfm_amd/csrc -o scripts/micro/dpp_check.bin scripts/micro/dpp_check.hip && scripts/micro/dpp_check.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include "psfm_pc_reduce.h"
 
-template <int CTRL>
-__device__ __forceinline__ double pc_dpp(double v)
+// test t: thread i contributes v(t, k, i) to slot k
+__device__ __host__ inline double term(int t, int k, int i)
 {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    int lo = (int)(unsigned)b, hi = (int)(unsigned)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
-}
-__device__ __forceinline__ double pc_readlane(double v, int lane)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
-}
-template <bool MAX>
-__device__ __forceinline__ double pc_wave_total(double v)
-{
-#define PC_OP(a_, b_) (MAX ? fmax((a_), (b_)) : (a_) + (b_))
-    v = PC_OP(v, pc_dpp<0xB1>(v));
-    v = PC_OP(v, pc_dpp<0x4E>(v));
-    v = PC_OP(v, pc_dpp<0x141>(v));
-    v = PC_OP(v, pc_dpp<0x140>(v));
-    const double r0 = pc_readlane(v, 0), r1 = pc_readlane(v, 16), r2 = pc_readlane(v, 32), r3 = pc_readlane(v, 48);
-    return PC_OP(PC_OP(PC_OP(r0, r1), r2), r3);
-#undef PC_OP
+    if (t < 256) return i == t ? (double)(k + 1) : 0.0;                  // one thread at a time: every thread counted once, in the right slot
+    if (t == 256) return (double)((i * (k + 3) + 7 * k) % 1021);        // everybody, different per slot
+    return (double)(((i * 37 + k * 11) % 256) * (k == SUM_GMAX ? 1 : 1));
 }
 
-// out[0..63]: indicator of lane j summed; out[64]: sum of 2^lane (lanes < 52) ; out[65]: sum of lane ids; out[66]: max of (lane * 7) % 64
-__global__ void check(double* out)
+template <int NS_>
+__global__ void check(double* out, int t0, int nt)
 {
-    const int lane = threadIdx.x;
-    for (int j = 0; j < 64; ++j) {
-        const double t = pc_wave_total<false>(lane == j ? 1.0 : 0.0);
-        if (lane == 0) out[j] = t;
+    __shared__ double s_out[PC_NSUM];
+    for (int t = t0; t < t0 + nt; ++t) {
+        double acc[PC_NSUM];
+        for (int k = 0; k < PC_NSUM; ++k) acc[k] = term(t, k, (int)threadIdx.x);
+        pc_block_sums<NS_>(acc, s_out);
+        if (threadIdx.x < NS_) out[(size_t)t * PC_NSUM + threadIdx.x] = s_out[threadIdx.x];
+        __syncthreads();
     }
-    const double a = pc_wave_total<false>(lane < 52 ? (double)(1ull << lane) : 0.0);
-    const double b = pc_wave_total<false>((double)lane);
-    const double c = pc_wave_total<true>((double)((lane * 7) % 64));
-    // every lane must hold the same total
-    const double a2 = pc_wave_total<true>(a), a3 = -pc_wave_total<true>(-a);
-    if (lane == 0) { out[64] = a; out[65] = b; out[66] = c; out[67] = a2 == a3 ? 1.0 : 0.0; }
+}
+
+template <int NS_>
+static int run(const char* name)
+{
+    const int NT = 258;
+    double* d;
+    static double h[NT * PC_NSUM];
+    if (hipMalloc(&d, sizeof(h)) != hipSuccess) { printf("dpp_check: no device\n"); return 100; }
+    hipLaunchKernelGGL(check<NS_>, dim3(1), dim3(PC_BLOCK), 0, 0, d, 0, NT);
+    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { printf("dpp_check: copy failed\n"); return 100; }
+    int bad = 0;
+    for (int t = 0; t < NT; ++t)
+        for (int k = 0; k < NS_; ++k) {
+            double want = 0.0;
+            for (int i = 0; i < PC_BLOCK; ++i) { const double v = term(t, k, i); want = k == SUM_GMAX ? (v > want ? v : want) : want + v; }
+            if (h[t * PC_NSUM + k] != want) { if (bad < 12) printf("%s: test %d slot %d: got %.1f want %.1f\n", name, t, k, h[t * PC_NSUM + k], want); ++bad; }
+        }
+    printf("%s: %s (%d wrong)\n", name, bad ? "FAILED" : "ok", bad);
+    hipFree(d);
+    return bad;
 }
 
 int main()
 {
-    double* d;
-    double h[68];
-    if (hipMalloc(&d, sizeof(h)) != hipSuccess) { printf("dpp_check: no device\n"); return 2; }
-    hipLaunchKernelGGL(check, dim3(1), dim3(64), 0, 0, d);
-    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { printf("dpp_check: copy failed\n"); return 2; }
-    int bad = 0;
-    for (int j = 0; j < 64; ++j) if (h[j] != 1.0) { printf("lane %d counted %g times\n", j, h[j]); ++bad; }
-    if (h[64] != (double)((1ull << 52) - 1ull)) { printf("sum of 2^lane wrong: %.0f\n", h[64]); ++bad; }
-    if (h[65] != 2016.0) { printf("sum of lane ids wrong: %g\n", h[65]); ++bad; }
-    if (h[66] != 63.0) { printf("max wrong: %g\n", h[66]); ++bad; }
-    if (h[67] != 1.0) { printf("lanes disagree on the total\n"); ++bad; }
-    printf(bad ? "dpp_check: FAILED (%d)\n" : "dpp_check: ok\n", bad);
+    const int bad = run<PC_NSUM>("pc_block_sums<13>") + run<11>("pc_block_sums<11>");
+    printf(bad ? "dpp_check: FAILED\n" : "dpp_check: ok\n");
     return bad ? 1 : 0;
 }

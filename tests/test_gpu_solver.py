@@ -301,6 +301,17 @@ def test_launch_chain_as_one_persistent_launch_is_the_same_solve(pt, monkeypatch
             monkeypatch.setenv("PSFM_PC_PERSIST", persist)
             res[persist] = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
         A, B = res["1"], res["0"]
+        # the resident launch behind a separate iteration-0 launch, and with ONE slot per thread (the rest of a block's tracks
+        # streamed behind the slots): the same sums in the same order
+        for env, val in (("PSFM_PC_INIT_INSIDE", "0"), ("PSFM_PC_SLOTS", "1")):
+            monkeypatch.setenv("PSFM_PC_PERSIST", "1")
+            monkeypatch.setenv(env, val)
+            V = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+            monkeypatch.delenv(env)
+            assert np.array_equal(V.birth, A.birth) and np.array_equal(V.length, A.length) and float(np.abs(V.xy - A.xy).max()) <= 1e-9
+            if H * W < 100000:
+                assert np.array_equal(V.xy, A.xy), env
+            assert [s["iterations"] for s in V.solve_stats] == [s["iterations"] for s in A.solve_stats]
         # (bit-equal where the lanes are placed deterministically; on larger grids births pop lanes from the shared stacks in
         # atomic order, which permutes the partial sums of two runs of the SAME form as well)
         assert np.array_equal(A.birth, B.birth) and np.array_equal(A.length, B.length)
