@@ -426,24 +426,32 @@ __device__ __forceinline__ void pc_reduce_totals(double* partials, int n_blocks)
     double* s_tot = pc_totals();
     const int L = n_blocks < PC_LEADERS ? n_blocks : PC_LEADERS;
     const int Q = pc_tree_q(n_blocks);
-    // work item (x, j, k): PC_LEADERS x 4 x 16 of them, its loads independent (issued back to back), added in member order
-    for (int w = threadIdx.x; w < PC_LEADERS * 4 * 16; w += PC_BLOCK) {
+    // work item (x, j, k): PC_LEADERS x 4 x 16 of them, 8 per thread; ALL loads of a thread are issued before the first is used
+    // (they bypass the caches: every dependent batch would be a full round trip on the tail of the launch), then added in
+    // member order
+    constexpr int ITEMS = PC_LEADERS * 4 * 16 / PC_BLOCK, QMAX = PC_MAX_BLOCKS / PC_LEADERS / 4;
+    double pv[ITEMS][QMAX];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int w = threadIdx.x + it * PC_BLOCK;
+        const int k = w & 15, j = (w >> 4) & 3, x = w >> 6;
+        const int cnt = (n_blocks - x + PC_LEADERS - 1) / PC_LEADERS;
+#pragma unroll
+        for (int u = 0; u < QMAX; ++u) {
+            const int m = j * Q + u;
+            pv[it][u] = (k < PC_NSUM && x < L && u < Q && m < cnt)
+                            ? __hip_atomic_load(&partials[(int64_t)(x + PC_LEADERS * m) * PC_NSUM + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                            : 0.0;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int w = threadIdx.x + it * PC_BLOCK;
         const int k = w & 15, j = (w >> 4) & 3, x = w >> 6;
         if (k >= PC_NSUM || x >= L) continue;
-        const int cnt = (n_blocks - x + PC_LEADERS - 1) / PC_LEADERS;
         double v = 0.0;
-        for (int u0 = 0; u0 < Q; u0 += 8) {
-            double pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int m = j * Q + u0 + u;
-                pv[u] = (u0 + u < Q && m < cnt) ? __hip_atomic_load(&partials[(int64_t)(x + PC_LEADERS * m) * PC_NSUM + k], __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_SYSTEM)
-                                                : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v = (k == SUM_GMAX) ? fmax(v, pv[u]) : v + pv[u];
-        }
+        for (int u = 0; u < QMAX; ++u) v = (k == SUM_GMAX) ? fmax(v, pv[it][u]) : v + pv[it][u];
         s_sub[x][j][k] = v;
     }
     __syncthreads();
@@ -541,6 +549,9 @@ __device__ __forceinline__ double pc_unhalf(unsigned long long hi, unsigned long
     return __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
 }
 
+// The all-reduce of one round, run by WAVE 0 of every block (the other waves wait at the caller's barrier): blk[] = this
+// block's sums (LDS), gran = [n_blocks rows of members][PC_LEADERS rows of leaders].  Returns 0 with the totals in tot[], 1
+// when the round is given up (this block timed out, or saw the poison of one that did).  Lane (k, j) = 4 k + j works on sum k.
 // The all-reduce of one round, run by WAVE 0 of every block (the other waves wait at the caller's barrier): blk[] = this
 // block's sums (LDS), gran = [n_blocks rows of members][PC_LEADERS rows of leaders].  Returns 0 with the totals in tot[], 1
 // when the round is given up (this block timed out, or saw the poison of one that did).  Lane (k, j) = 4 k + j works on sum k.
@@ -642,6 +653,15 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
     return 0;
 }
 
+// A resident solve that ends without a result (its hand-off timed out: the grid was not co-resident; or it ran out of rounds) has
+// written nothing.  In a sequence it raises the device-side stall flag itself -- everything enqueued behind turns into no-ops and
+// the host redoes the solve with launches at its checkpoint; a batch solve just leaves its control block "not done" for the
+// polling loop of psfm_solve_batch.
+__device__ __forceinline__ void pc_res_stall(const PcParams& P)
+{
+    if (P.birth_frame && threadIdx.x == 0) *P.stall = P.frame + 1;
+}
+
 struct PcSlot {                    // (slot k of thread t holds entry k * PC_BLOCK + t of the block's list, if the list is that long)
     double s, S0q, S1q;            // weight, squared Jacobi scaling of columns 0, 1
     double x[4], u[4], d[4];       // the iterate, and the system's solution there for the mu in force
@@ -724,7 +744,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             }
         }
         __syncthreads();
-        if (s_R.giveup) return;
+        if (s_R.giveup) { pc_res_stall(P); return; }
     } else {
         if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
         __syncthreads();
@@ -846,7 +866,9 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             if (tid == 0) {
                 if (bad) s_R.giveup = 1;
                 else {
-                    PsfmSolveCtrl& C = s_C;          // (in place: the block's copy lives in LDS)
+                    // (in place, in LDS; run by every lane of the wave on private copies instead -- uniform branches, no one-lane exec
+                    // mask -- it takes the same 1.3 us: a dependent chain of ~150 f64 operations, a few of them square roots / quotients)
+                    PsfmSolveCtrl& C = s_C;
                     const int cur0 = C.cur;
                     pc_chain_control_d(C, tot, D, 1);
                     C.launches += 1;
@@ -858,7 +880,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
         }
         __syncthreads();
         PC_RTL(8);
-        if (s_R.giveup) return;
+        if (s_R.giveup) { pc_res_stall(P); return; }
         if (s_R.accepted) {
             // x <- the candidate (the same operations: the same bits), (u, d) <- what was solved there
 #pragma unroll
@@ -870,7 +892,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             }
         }
     }
-    if (!s_R.done) return;            // (ran out of rounds: the write-back kernel behind raises the stall flag)
+    if (!s_R.done) { pc_res_stall(P); return; }            // (ran out of rounds)
     // ---- write-back (block 0 also: statistics, the control block) ----
     const PsfmSolveCtrl C = s_C;
     const bool moved = C.cur != 0 && !C.failed;          // (a failed solve hands the parameters back as they came in)
@@ -1611,10 +1633,12 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
     const bool inside = !(getenv("PSFM_PC_INIT_INSIDE") && atoi(getenv("PSFM_PC_INIT_INSIDE")) == 0);
     if (!inside || !pc_persist_enqueue(c, P, n_blocks, nullptr, true, s)) {
         hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-        if (!pc_persist_enqueue(c, P, n_blocks, nullptr, false, s))
+        if (!pc_persist_enqueue(c, P, n_blocks, nullptr, false, s)) {
             for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+            // (the resident solve writes back, or raises the stall flag, itself)
+            hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
+        }
     }
-    hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
