@@ -35,6 +35,32 @@ VALU_PEAK_GWIPS = 256 * 4 * 2.4 / 4.0
 REFERENCE_SOLVER_THREADS = 8     # solver_options.num_threads at trajectory_optimize.cpp:79 (what BASELINE.md specifies)
 
 
+def source_sha16():
+    """Hash of the sources libpsfm_hip.so is built from (particle-sfm_amd/build.py::source_hash): what the PMC figures under
+    profiles/ are stamped with.  Counters cannot be collected inside a timed run, so those figures are REPLAYED from the file --
+    and the line says which sources they were measured on and whether they are this run's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("psfm_build", os.path.join(ROOT, "particle-sfm_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
+
+
+def replayed(path):
+    """A PMC summary under profiles/ + where it came from: (dict or None, provenance string)."""
+    if not os.path.exists(path):
+        return None, None
+    try:
+        v = json.load(open(path))
+    except Exception:
+        return None, None
+    mine = source_sha16()
+    theirs = v.get("source_sha16")
+    return v, {"file": "profiles/" + os.path.basename(path), "measured_on_sources": theirs, "this_run_sources": mine,
+               "same_sources": bool(theirs is not None and theirs == mine), "round": v.get("round"),
+               "how": "separate rocprofv3 --pmc passes (never inside the timed run), replayed"}
+
+
 def reference_python_on_this_box(flows_f, flows_b, frames=4):
     """The reference's OWN Python (point_trajectory/utils.py flow_check + track.py track, unmodified, through oracle/ref_shim.py)
     timed on THIS box's host cores on the first `frames` frame pairs of the same tensors -- only where a reference tree is
@@ -271,7 +297,8 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
         per_solve = tot / len(frames) + (cb if merged else 0.0)
         fused = cnt["fused"] + cnt["fused_redone"] > cnt["chain"]
         name = ("psfm_seq_kernel = the frame kernel, device-paced (ONE launch per frame: chain step + fused solve)" if merged else
-                "psfm_pc_fused_kernel (one launch per solve)") if fused else "pc_init + pc_iter chain (one span per solve)"
+                "psfm_pc_fused_kernel (one launch per solve)") if fused else \
+            "psfm_pc_resident_kernel (one launch per solve: iteration 0, the trust-region loop with the tracks' state on chip, write-back)"
         # What bounds these launches is f64 VALU issue, not bandwidth: wave-instructions per launch from the
         # PMC pass of the same kernel (SQ_INSTS_VALU, profiles/solver_valu.json: replayed, scaled by this run's track-iterations)
         # against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 instruction; the SURVEY 8(d) byte MODEL and the PMC traffic ride along.
@@ -286,27 +313,28 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
                                   "iterate in registers, so this is NOT its HBM utilisation (see traffic)"},
             "note": "the timed launches include the few that overlap a flow_check chunk of the side stream and the retries"}
         vfile = os.path.join(ROOT, "profiles", "solver_valu.json")
-        if fused and os.path.exists(vfile):
+        vall, vprov = replayed(vfile)
+        if fused and vall:
             try:
-                v = json.load(open(vfile))
+                v = vall
                 wi = (v["valu_per_wave_per_iteration"] * entry["avg_iterations"] + v["valu_per_wave_fixed"]) * \
                      (entry["track_iterations_per_launch"] / max(entry["avg_iterations"], 1e-9)) / 64.0
                 entry.update({"achieved": wi / (us * 1e-6) / 1e9, "frac": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS,
                               "valu_wave_instructions_per_launch": wi,
-                              "valu_source": "profiles/solver_valu.json (PMC SQ_INSTS_VALU of an earlier run of this binary, replayed; "
-                                             "scaled by this run's tracks x iterations)",
+                              "valu_source": dict(vprov, what="PMC SQ_INSTS_VALU of the frame kernel, scaled by this run's tracks x iterations; "
+                                                               + str(v.get("source", ""))[:200]),
                               "traffic": v.get("hbm_bytes_per_launch"),
                               "traffic_source": v.get("traffic_source", "profiles/solver_valu.json (replayed)")})
             except Exception:
                 pass
-        if not fused and os.path.exists(vfile):
+        if not fused and vall:
             try:
-                v = json.load(open(vfile))["chain"]
+                v = vall["chain"]
                 wi = v["valu_per_track_iteration"] * entry["track_iterations_per_launch"] / 64.0 + \
                      v["valu_per_wave_per_iteration_fixed"] * v["waves"] * entry["avg_iterations"]
                 entry.update({"achieved": wi / (us * 1e-6) / 1e9, "frac": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS,
                               "valu_wave_instructions_per_launch": wi,
-                              "valu_source": "profiles/solver_valu.json 'chain': " + v["source"]})
+                              "valu_source": dict(vprov, what="'chain': " + v["source"][:300])})
             except Exception:
                 pass
         if "frac" not in entry:
@@ -347,7 +375,7 @@ def stream_ceilings(dev):
     return out
 
 
-def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="configs[2] shape", dist=None):
+def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="configs[2] shape", dist=None, thres=THRES, n=5):
     """track_optimize (chaining + Ceres-compatible path-consistency solve) on a synthetic sequence -- by default a
     stand-in of configs[2] (Sintel alley_1 shape: 436x1024, 50 frames, sample_ratio 2): GPU time per sequence and the
     CPU oracle on the first k flows of the same tensors, with the parity of those flows checked on the spot."""
@@ -364,13 +392,12 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     from point_trajectory.trajectory import run_connect
 
     def step():
-        return run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], THRES, r, return_device=True)
+        return run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], thres, r, return_device=True)
 
     for _ in range(2):
         info = step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 5
     for _ in range(n):
         info = step()
     torch.cuda.synchronize()
@@ -386,8 +413,8 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     roof = solver_roofline(Rh, pr, cnt, h, w, t - 1)
     info_stats = list(Rh.solve_stats)
     del Rh
-    _, occ = flow_check_device(d["flows_f"], d["flows_b"], THRES)
-    _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], THRES)
+    _, occ = flow_check_device(d["flows_f"], d["flows_b"], thres)
+    _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], thres)
     ff, f2 = list(d["flows_f"][:k].cpu().numpy()), list(d["flows_f2"][:k - 1].cpu().numpy())
     oo, o2 = list(occ[:k].cpu().numpy()), list(occ2[:k - 1].cpu().numpy())
     t0 = time.perf_counter()
@@ -396,8 +423,9 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     Rg = _result_to_host(ctx, run_track(d["flows_f"][:k], occ[:k], d["flows_f2"][:k - 1], occ2[:k - 1], r, return_device=True))
     same = bool(np.array_equal(Rg.birth, Rc.birth) and np.array_equal(Rg.length, Rc.length))
     rej = int(sum(s_["iterations"] - s_["successful_steps"] for s_ in info_stats)) if info_stats else None
-    return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check x2 + track_optimize" % (label, h, w, t, r),
-            "flows": dict(dist), "rejected_steps": rej,
+    return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check_thres %.1f, flow_check x2 + track_optimize"
+                        % (label, h, w, t, r, thres),
+            "flows": dict(dist), "rejected_steps": rej, "chain_mode": int(info.chain_mode),
             "ms_per_sequence": ms, "trajectory_points_per_s": info.n_points / (ms * 1e-3), "points": int(info.n_points),
             "solves": int(info.n_solves), "trust_region_iterations": int(info.solver_iterations),
             "solver_counters": cnt, "roofline": roof,
@@ -406,6 +434,103 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
             "parity_first_flows": {"ids_lengths_equal": same,
                                    "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None,
                                    "tolerance_px": 1e-4}}
+
+
+def secondary_track(ctx, h, w, t, r, seed, label, thres=THRES, n=10):
+    """track only (flow_check + chaining + occlusion + ids: --skip_path_consistency) on a synthetic sequence: GPU time per sequence,
+    the chain step's roofline from HIP events on every launch, and the WHOLE sequence against the CPU oracle."""
+    import numpy as np
+    import torch
+    import psfm_synth
+    from oracle import oracle as orc
+    from point_trajectory.trajectory import run_connect, _result_to_host
+    d = psfm_synth.synth_sequence_torch(t, h, w, seed=seed, sigma=0.05, n_occluders=2, stride2=False, device="cuda")
+    ctx.set_profiling(0)
+
+    def step():
+        return run_connect(d["flows_f"], d["flows_b"], None, None, thres, r, return_device=True)
+
+    for _ in range(2):
+        info = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        info = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    ctx.set_profiling(1)
+    info = step()
+    torch.cuda.synchronize()
+    pr = ctx.profile()
+    ctx.set_profiling(0)
+    Rg = _result_to_host(ctx, info)
+    n_flows = t - 1
+    P = float(h * w)
+    last = Rg.birth.astype(np.int64) + Rg.length - 1
+    A = float(Rg.n_points - int((last == n_flows).sum())) / n_flows
+    cb = min(8 * P, 32 * A) + min(P, 4 * A) + 16 * A + 16 * A + A
+    persistent = int(info.chain_mode) == 2
+    ch = pr["chain_step"]
+    us = 1e3 * ch["total_ms"] / max(ch["launches"], 1) / (n_flows if persistent else 1)
+    fused = persistent and pr["flow_check"]["launches"] == 0
+    step_bytes = cb + (17.0 * P if fused else 0.0)
+    t0 = time.perf_counter()
+    _, occ = orc.flow_check(list(d["flows_f"].cpu().numpy()), list(d["flows_b"].cpu().numpy()), thres)
+    Rc = orc.track(list(d["flows_f"].cpu().numpy()), occ, r)
+    cpu_s = time.perf_counter() - t0
+    same = bool(Rg.birth.shape == Rc.birth.shape and np.array_equal(Rg.birth, Rc.birth) and np.array_equal(Rg.length, Rc.length))
+    return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check_thres %.1f, flow_check + track (no path consistency)"
+                        % (label, h, w, t, r, thres),
+            "ms_per_sequence": ms, "trajectory_points_per_s": info.n_points / (ms * 1e-3), "points": int(info.n_points),
+            "trajectories": int(info.n_traj), "chain_mode": int(info.chain_mode),
+            "roofline": {"chain_step": {"kernel": ("psfm_chain_persist_kernel" + (" (flow_check fused in)" if fused else "")) if persistent
+                                                  else "psfm_chain_step_kernel<R> (one launch per frame)",
+                                        "bound": "hbm", "bytes_per_step": step_bytes, "us_per_step": us,
+                                        "achieved": step_bytes / (us * 1e-6) / 1e9 if us > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": step_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None, "avg_alive_tracks": A},
+                         "flow_check_side_stream_ms": pr["flow_check"]["total_ms"], "finalize_ms": pr["finalize"]["total_ms"]},
+            "cpu_port_points_per_s": Rc.n_points / cpu_s, "cpu_port_sample": "whole sequence, %d thread(s), %.2f s" % (orc.num_threads(), cpu_s),
+            "parity": {"vs": "cpu oracle, whole sequence", "ids_lengths_equal": same,
+                       "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None}}
+
+
+def end_to_end(frames=N_FRAMES, workdir=None):
+    """the stage the user calls (main_connect_point_trajectories.py:27-62) disk to disk -- configs[1] written as
+    2 x 100 .flo files (3.3 GB) on tmpfs, then .flo -> HBM -> psfm_connect -> min-length filter + D2H -> track.npy (the reference's
+    pickle layout), the phases timed inside the entry point; the second (warm) pass is reported."""
+    import shutil
+    import tempfile
+    import torch
+    import psfm_synth
+    from point_trajectory.utils import write_flo
+    from point_trajectory.main_connect_point_trajectories import main_connect_point_trajectories
+    base = workdir or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
+    work = tempfile.mkdtemp(prefix="psfm_e2e_", dir=base)
+    try:
+        d = psfm_synth.synth_sequence_torch(frames, H, W, seed=0, sigma=0.05, n_occluders=2, stride2=False)
+        for name, key in (("flow_f", "flows_f"), ("flow_b", "flows_b")):
+            os.makedirs(os.path.join(work, "flows", name))
+            arr = d[key].cpu().numpy()
+            for i in range(frames - 1):
+                write_flo(os.path.join(work, "flows", name, "%05d.flo" % i), arr[i])
+        del d, arr
+        torch.cuda.empty_cache()
+        tm = {}
+        for _ in range(2):
+            tm = {}
+            t0 = time.perf_counter()
+            main_connect_point_trajectories(os.path.join(work, "flows"), os.path.join(work, "traj"), sample_ratio=RATIO,
+                                            flow_check_thres=THRES, skip_path_consistency=True, timings=tm)
+            tm["total_s"] = time.perf_counter() - t0
+        size = os.path.getsize(os.path.join(work, "traj", "track.npy"))
+        gb = 2 * (frames - 1) * H * W * 8 / 1e9
+        return {"workload": "configs[1] disk to disk: 2 x %d .flo files (%.2f GB) on %s -> track.npy (reference pickle layout, %.2f GB), "
+                            "warm second pass" % (frames - 1, gb, base, size / 1e9),
+                "total_s": tm["total_s"], "ingest_s": tm["ingest_s"], "compute_s": tm["compute_s"], "filter_d2h_s": tm["filter_d2h_s"],
+                "write_s": tm["write_s"], "ingest_GBs": gb / tm["ingest_s"], "write_GBs": size / 1e9 / tm["write_s"],
+                "trajectory_points_per_s_end_to_end": tm["n_points"] / tm["total_s"], "points": tm["n_points"], "trajectories": tm["n_traj"]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def main():
@@ -481,6 +606,8 @@ def main():
 
     if os.environ.get("PSFM_BENCH_TWO_CALLS"):      # profiling only: the stand-alone flow_check + the loop on its maps as the step
         step = step_two_calls
+    if os.environ.get("PSFM_BENCH_CHAIN_MODE"):     # profiling only: 1 = one chain_step launch per frame as the step
+        ctx.set_chain_mode(int(os.environ["PSFM_BENCH_CHAIN_MODE"]))
 
     def sync_all():
         if world > 1:
@@ -534,6 +661,18 @@ def main():
 
     points = int(info.n_points)
     import psfm_dist
+    # who took part: rank, device, and the collective library as torch reports it
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank), "points": points,
+          "pid": os.getpid()}
+    rank_info = [me]
+    if world > 1:
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, me)
+        try:
+            me_v = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            me_v = None
+        rank_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": me_v, "per_rank": rank_info}
     dt_max, total_points = psfm_dist.reduce_totals(dt, points, device=dev)   # max time, summed units over ranks
 
     # ---- ONE sequence over all ranks (exact track-sharded mode), outside the timed region ----
@@ -570,14 +709,10 @@ def main():
             frame_bytes = chain_bytes + (fc_step_bytes if fused else 0.0)
             chain_bytes = frame_bytes * n_flows
         achieved = chain_bytes / (chain_us * 1e-6) / 1e9 if chain_us > 0 else 0.0
-        traffic = None
         tfile = os.path.join(ROOT, "profiles", ("traffic_chain_fused.json" if fused else "traffic_chain_persist.json")
                              if persistent else "traffic_chain_step.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        tv, tprov = replayed(tfile)
+        traffic = tv.get("hbm_bytes_per_launch") if tv else None
         fc = prof["flow_check"]
         fc_us = 1e3 * fc["total_ms"] / max(fc["launches"], 1)
         fc_bytes = 17.0 * P * n_flows
@@ -600,9 +735,11 @@ def main():
                          if persistent else "psfm_chain_step_kernel",
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # physical HBM bytes of the same launch (PMC FETCH_SIZE x calibration + WRITE_SIZE) and the fraction of the
+                         # peak THEY amount to: below `frac` when re-reads are served on chip (the chain step's second look at F_t)
                          "traffic": traffic,
-                         "traffic_source": ("profiles/%s (PMC passes of an earlier run of this binary, replayed: counters cannot be "
-                                            "collected inside the timed run)" % os.path.basename(tfile)) if traffic is not None else None,
+                         "frac_physical": (traffic / (chain_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and chain_us > 0) else None,
+                         "traffic_source": tprov,
                          "bytes_per_launch": chain_bytes, "avg_launch_us": chain_us,
                          "steps_per_launch": n_flows if persistent else 1,
                          "us_per_step": chain_us / (n_flows if persistent else 1),
@@ -623,6 +760,8 @@ def main():
         }
         out["kernels"].pop("respawn_avg_us", None)   # respawn is fused into chain_step
         out["config"]["world_size"] = dist.get_world_size() if world > 1 else 1
+        out["config"]["ranks"] = rank_info     # what every rank of the job ran on (RCCL saw that many ranks)
+        out["config"]["source_sha16"] = source_sha16()
         if single is not None:
             out["single_sequence"] = single
         if world == 1 and not args.no_cpu:
@@ -656,6 +795,15 @@ def main():
                 out["secondary_hard"] = extra(secondary_track_optimize, ctx, H, W, n_frames, RATIO, seed=6, k=6, dist=psfm_synth.HARD,
                                               label="headline shape with path consistency, hard flows")
                 out["concurrent"] = extra(concurrent_sequences, 3, n_frames)
+                del flows_f
+                torch.cuda.empty_cache()
+                # BASELINE configs[0] (DAVIS shape, sample_ratio 4, track only) and configs[4] (ScanNet shape: 1000 frames, dense
+                # sample_ratio 1, flow_check_thres 3.0 per README.md:143, full optimize) on synthetic stacks of those shapes
+                out["secondary_davis"] = extra(secondary_track, ctx, 480, 854, 50, 4, 2, "configs[0] shape (DAVIS snowboard)")
+                out["secondary_scannet"] = extra(secondary_track_optimize, ctx, 480, 640, 1000, 1, seed=4, k=6, thres=3.0, n=2,
+                                                 label="configs[4] shape (ScanNet, dense)")
+                torch.cuda.empty_cache()
+                out["end_to_end"] = extra(end_to_end, n_frames)
         print(json.dumps(out), flush=True)
     if hung:            # a rank is stuck in a collective of the extra mode: the line is out, leave without the barrier
         sys.stdout.flush()

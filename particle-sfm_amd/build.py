@@ -24,6 +24,21 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources the library is built from (csrc/*, include/psfm.h, the compile flags): what
+    profiles/*.json stamp their PMC figures with and bench.py compares against, so that a replayed figure says which kernels it was
+    measured on.  (The .so itself is not hashed: it is git-ignored and rebuilt by the driver.)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "psfm.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -65,4 +80,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

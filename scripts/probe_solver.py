@@ -42,7 +42,18 @@ for name, mode, k in [(n, *MODES[n]) for n in names]:
     torch.cuda.synchronize()
     pr = ctx.profile()
     ctx.set_profiling(0)
-    out[name] = {"ms_per_sequence": ms, "points": int(info.n_points), "iters": int(info.solver_iterations),
+    import numpy as np
+    from point_trajectory.trajectory import _result_to_host
+    Rh = _result_to_host(ctx, info)
+    nf = T - 1
+    birth = Rh.birth.astype(np.int64); last = birth + Rh.length - 1
+    tb = np.bincount(birth, minlength=nf + 3).cumsum(); tl = np.bincount(last, minlength=nf + 3).cumsum()
+    its = [s_["iterations"] for s_ in Rh.solve_stats]
+    n3 = [float(tb[f - 1] - tl[f]) for f in range(1, nf)]
+    scale = {"tracks_per_solve": float(np.mean(n3)), "iterations_per_solve": float(np.mean(its)) if its else 0.0,
+             "track_iterations_per_solve": float(np.mean([k * n for k, n in zip(its, n3)])) if len(its) == len(n3) else None}
+    del Rh
+    out[name] = {"ms_per_sequence": ms, "points": int(info.n_points), "iters": int(info.solver_iterations), **scale,
                  "solves": int(info.n_solves), "counters": ctx.solver_counters(),
                  "solver_ms_per_seq": pr["solver"]["total_ms"] / n, "solver_launches_per_seq": pr["solver"]["launches"] / n,
                  "chain_ms_per_seq": pr["chain_step"]["total_ms"] / n}

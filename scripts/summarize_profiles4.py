@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""On the GPU box, right after scripts/profile_round4.sh: boil gpurun_out/<tag>/ down to what gets committed under profiles/
+(the raw per-dispatch CSVs are far beyond what travels back):
+    <tag>_kernel_stats.csv / _opt_kernel_stats.csv / _hard_kernel_stats.csv   product kernels of the rocprofv3 --kernel-trace --stats runs
+    <tag>_pmc_summary.json                                                       per-kernel, per-launch averages of every PMC pass
+    traffic_chain_{fused,persist,step}.json, solver_valu.json                    what bench.py replays, stamped with the source hash
+    <tag>_bench.json, <tag>_opt_probe.json, <tag>_hard_probe.json                the bench line / probe lines of the same binary
+Usage: python scripts/summarize_profiles4.py r04_x   ->   gpurun_out/<tag>_summary/
+"""
+import collections
+import csv
+import importlib.util
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "gpurun_out", tag + "_summary")
+os.makedirs(dst, exist_ok=True)
+csv.field_size_limit(1 << 30)
+spec = importlib.util.spec_from_file_location("psfm_build", os.path.join(ROOT, "particle-sfm_amd", "build.py"))
+_b = importlib.util.module_from_spec(spec); spec.loader.exec_module(_b)
+SHA = _b.source_hash()
+
+
+def short(name):
+    n = name.split("(")[0].strip()
+    return n[5:] if n.startswith("void ") else n
+
+
+def stats(sub, stem, out, cmd):
+    fn = os.path.join(src, sub, stem + "_kernel_stats.csv")
+    if not os.path.exists(fn):
+        return
+    rows = list(csv.DictReader(open(fn)))
+    keep = [r for r in rows if "psfm_" in r["Name"] or "rocprim" in r["Name"]]
+    with open(os.path.join(dst, out), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -f csv -- %s   (sources %s)\n" % (cmd, SHA))
+        f.write("# product kernels only (torch kernels of the synthetic-data generator omitted); durations in ns.\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+        for r in keep:
+            f.write('"%s",%s,%s,%s,%s,%s,%s,%s\n' % (short(r["Name"])[:80], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                                      r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]))
+
+
+def counters(sub, pre):
+    """{kernel: {counter: per-launch average over the launches that did real work}}"""
+    fn = os.path.join(src, sub, pre + "_counter_collection.csv")
+    if not os.path.exists(fn):
+        return {}
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(fn)):
+        if "psfm_" not in r["Kernel_Name"]:
+            continue
+        per[(r["Dispatch_Id"], short(r["Kernel_Name"]), r["Counter_Name"])] += float(r["Counter_Value"])
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for (_, k, cn), v in per.items():
+        acc[k][cn].append(v)
+    out = {}
+    for k, d in acc.items():
+        n = max(len(v) for v in d.values())
+        # launches that did real work only (no-op launches behind a stall flag / past the end of a sequence would dilute the averages)
+        ref = d.get("SQ_INSTS_VALU") or next(iter(d.values()))
+        big = [i for i, v in enumerate(ref) if v > 0.25 * max(ref)] if max(ref) > 0 else list(range(len(ref)))
+        out[k] = {cn: sum(v[i] for i in big if i < len(v)) / max(len(big), 1) for cn, v in d.items()}
+        out[k]["launches_sampled"] = n
+        out[k]["launches_with_work"] = len(big)
+    return out
+
+
+def probe_line(log):
+    p = os.path.join(src, log)
+    if not os.path.exists(p):
+        return None
+    lines = [l for l in open(p) if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+stats("stats", tag, tag + "_kernel_stats.csv", "python bench.py --steps 10 --warmup 2 --no-cpu --no-extras")
+stats("opt_stats", tag + "_opt", tag + "_opt_kernel_stats.csv", "PSFM_PROBE_MODES=adaptive python scripts/probe_solver.py  (1080p x 101 frames, flow_check x2 + track_optimize, clean flows)")
+stats("hard_stats", tag + "_hard", tag + "_hard_kernel_stats.csv", "PSFM_PROBE_HARD=1 PSFM_PROBE_MODES=adaptive python scripts/probe_solver.py  (1080p x 101 frames, sigma 0.3 + 5 % occluders: every solve rejects steps)")
+summary = {"source_sha16": SHA, "round": tag}
+for sub, pre in (("fused_fetch", "f"), ("fused_write", "w"), ("two_fetch", "f"), ("two_write", "w"), ("step_fetch", "f"), ("step_write", "w"),
+                 ("pmc_sq", "s"), ("opt_pmc_sq", "s"), ("hard_pmc_sq", "s")):
+    summary[sub] = counters(sub, pre)
+json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+
+# ---- HBM traffic of the chain kernels: FETCH_SIZE calibrated on the stand-alone flow_check launch (known read volume) ----
+H, W, NF = 1080, 1920, 100
+try:
+    tf, tw = summary["two_fetch"], summary["two_write"]
+    fc = [k for k in tf if "flow_check" in k][0]
+    cal = (16.0 * H * W * NF / 1024.0) / tf[fc]["FETCH_SIZE"]
+    note = ("FETCH_SIZE (KB) of the stand-alone flow_check launch against its exactly known read volume 16*H*W*100 bytes "
+            "(MI355X_MICROARCH.md: the counter is uncalibrated on gfx950 and depends on the access width); WRITE_SIZE used as is")
+
+    def traffic(fetch, write, pick, label, how):
+        k = [x for x in fetch if pick in x][0]
+        return {"kernel": k + label, "FETCH_SIZE_KB_per_launch": fetch[k]["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": write[k]["WRITE_SIZE"],
+                "fetch_calibration": cal, "hbm_bytes_per_launch": (fetch[k]["FETCH_SIZE"] * cal + write[k]["WRITE_SIZE"]) * 1024.0,
+                "source": "scripts/profile_round4.sh %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %s" % (tag, how),
+                "calibration_note": note, "flow_check_kernel": fc, "round": tag, "source_sha16": SHA}
+    base = "bench.py --steps 2 --warmup 1 --no-cpu --no-extras"
+    json.dump(traffic(summary["fused_fetch"], summary["fused_write"], "chain_persist", " (flow_check fused in)", base),
+              open(os.path.join(dst, "traffic_chain_fused.json"), "w"), indent=1)
+    json.dump(traffic(tf, tw, "chain_persist", "", "PSFM_BENCH_TWO_CALLS=1 " + base), open(os.path.join(dst, "traffic_chain_persist.json"), "w"), indent=1)
+    json.dump(traffic(summary["step_fetch"], summary["step_write"], "chain_step", "", "PSFM_BENCH_CHAIN_MODE=1 " + base),
+              open(os.path.join(dst, "traffic_chain_step.json"), "w"), indent=1)
+except Exception as e:      # noqa: BLE001
+    print("traffic files not written:", type(e).__name__, e)
+
+# ---- VALU wave-instructions of the solver launches (what bench.py scales by its own run's tracks x iterations) ----
+try:
+    opt, hard = probe_line("opt_stats.log"), probe_line("hard_stats.log")
+    sv = {"source_sha16": SHA, "round": tag}
+    ko = [k for k in summary["opt_pmc_sq"] if "psfm_seq_kernel" in k]
+    if ko and opt:
+        a = opt["adaptive"]
+        wi = summary["opt_pmc_sq"][ko[0]]["SQ_INSTS_VALU"]
+        waves = a["tracks_per_solve"] / 64.0
+        per_it = 320        # static census of the iteration loop (scripts/isa_count.py)
+        sv.update({"kernel": ko[0], "valu_per_wave_per_iteration": per_it,
+                   "valu_per_wave_fixed": wi / waves - per_it * a["iterations_per_solve"],
+                   "hbm_bytes_per_launch": None, "traffic_source": None,
+                   "source": "%s_pmc_summary.json opt_pmc_sq: SQ_INSTS_VALU %.2f M per launch with work, %.0f tracks (%.0f waves) and %.2f iterations "
+                             "per solve (probe of the same run); %d per wave and iteration from the static census, the rest fixed"
+                             % (tag, wi / 1e6, a["tracks_per_solve"], waves, a["iterations_per_solve"], per_it)})
+    kh = [k for k in summary["hard_pmc_sq"] if "psfm_pc_resident" in k]
+    if kh and hard:
+        a = hard["adaptive"]
+        c = summary["hard_pmc_sq"][kh[0]]
+        wi, fixed, nwaves = c["SQ_INSTS_VALU"], 190, 2048
+        rounds = a["iterations_per_solve"] + 1.0        # + iteration 0
+        sv["chain"] = {"kernel": kh[0] + " (the launch chain's trust-region loop as ONE launch, the tracks' state on chip)",
+                       "valu_per_track_iteration": (wi - fixed * nwaves * rounds) / (a["track_iterations_per_solve"] / 64.0),
+                       "valu_per_wave_per_iteration_fixed": fixed, "waves": nwaves,
+                       # (two waves per SIMD: the SIMD's time is half the summed wave time)
+                       "valu_issue_busy_frac": c.get("SQ_ACTIVE_INST_VALU", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0) / 2.0, 1.0),
+                       "wait_frac": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
+                       "source": "%s_pmc_summary.json hard_pmc_sq: SQ_INSTS_VALU %.2f M wave-instructions per solve (%.1f iterations, %.2f M "
+                                 "track-iterations per solve: probe of the same run; rocprofv3 --pmc with --kernel-include-regex psfm_pc_) = %d per "
+                                 "wave and round fixed (static census: block sums, hand-off, control; 512 blocks x 4 waves) + the rest per 64 "
+                                 "track-iterations" % (tag, wi / 1e6, a["iterations_per_solve"], a["track_iterations_per_solve"] / 1e6, fixed),
+                       "round": tag}
+    json.dump(sv, open(os.path.join(dst, "solver_valu.json"), "w"), indent=1)
+    for line, name in ((opt, "_opt_probe.json"), (hard, "_hard_probe.json")):
+        if line:
+            json.dump(line, open(os.path.join(dst, tag + name), "w"))
+except Exception as e:      # noqa: BLE001
+    print("solver_valu.json not written:", type(e).__name__, e)
+
+for name in ("bench.json", "bench.err"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, tag + "_" + name))
+shutil.rmtree(src, ignore_errors=True)
+print(json.dumps({k: v for k, v in summary.items() if k in ("source_sha16",)}))
