@@ -257,7 +257,7 @@ psfm_status psfm_shard_solve_restore(psfm_ctx* ctx, int frame, void* stream);
 psfm_status psfm_shard_solve_writeback(psfm_ctx* ctx, int frame, const psfm_solve_stats* stats, void* stream);
 psfm_status psfm_shard_solve_record(psfm_ctx* ctx, const psfm_solve_stats* stats);
 psfm_status psfm_shard_finish(psfm_ctx* ctx, psfm_track_info* info_host, void* stream);
-/* keys_dev (n_traj) i64 DEVICE: (last valid time << 51) | (birth frame << 40) | birth grid index of every trajectory of the
+/* keys_dev (n_traj) i64 DEVICE: (last valid time << 47) | (birth frame << 31) | birth grid index of every trajectory of the
  * result, ascending -- the order key of full_trajs (SURVEY a-17); a trajectory's id over all ranks = its key's rank. */
 psfm_status psfm_result_keys(psfm_ctx* ctx, int sample_ratio, int w, int64_t* keys_dev, void* stream);
 

@@ -4,6 +4,7 @@
 #include <string.h>
 #include <mutex>
 #include <shared_mutex>
+#include <atomic>
 #include <chrono>
 #include <stdlib.h>
 
@@ -13,6 +14,9 @@ static thread_local char g_err[512] = "";
 // The per-device gate of psfm_internal.h (the one piece of process-wide state in the library, documented in psfm.h).
 static std::shared_mutex g_dev_gate[16];
 std::shared_mutex& psfm_device_gate(int device) { return g_dev_gate[device & 15]; }
+static std::atomic<int> g_dev_waiters[16];
+int psfm_gate_waiters(int device) { return g_dev_waiters[device & 15].load(std::memory_order_relaxed); }
+void psfm_gate_waiters_add(int device, int d) { g_dev_waiters[device & 15].fetch_add(d, std::memory_order_relaxed); }
 // Would this call run the persistent loop?  0 no, 1 yes if the device is free, 2 yes, wait for the device.
 // Mode 0 decides by shape, from measurements on MI355X (scripts/probe_shapes.py; 100 frames, flow_check + recurrence +
 // finalize, persistent / per-frame): the loop costs ~14 us per frame whatever the frame size (a barrier and five
@@ -263,7 +267,9 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
                                               double* out, psfm_solve_stats* stats_host, void* stream)
 {
     PSFM_CHECK_CTX(c);
-    PsfmGate gate(c->device, 1);          // (exclusive if no other psfm call is in flight: the solve may then run as one persistent launch)
+    // exclusive if no other psfm call is in flight: the solve may then run as ONE resident launch; psfm_ctx_set_chain_mode(ctx, 1)
+    // -- what callers that overlap several solves from several host threads set -- keeps the gate shared and the solve on launches
+    PsfmGate gate(c->device, c->chain_mode == 1 ? 0 : 1);
     c->pc_persist_ok = gate.exclusive;
     c->pc_giveups = 0;
     if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
@@ -350,9 +356,10 @@ struct PsfmOccPipeline {
 
 static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_t* occ, const float* flows_f2,
                                    const uint8_t* occ_s2, int n_flows, int h, int w, int ratio, psfm_track_info* info,
-                                   void* stream, PsfmOccPipeline* pipe, bool device_is_ours,
+                                   void* stream, PsfmOccPipeline* pipe, PsfmGate& gate,
                                    const float* fuse_flows_b = nullptr, float fuse_thres = 0.f, int64_t occ_pitch = 0)
 {
+    const bool device_is_ours = gate.exclusive;   // (no other psfm call of this process is in flight on the device)
     // fuse_flows_b != NULL (psfm_connect): `occ` is still EMPTY -- the persistent loop computes the maps itself (fused
     // flow_check); any other way of running the recurrence first fills them with the stand-alone kernel.
     if (occ_pitch == 0) occ_pitch = (int64_t)h * w;
@@ -497,6 +504,10 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         PSFM_HIP(hipMemcpyAsync(hstats.data() + first_unchecked, c->sol_stats.as<psfm_solve_stats>() + first_unchecked,
                                 sizeof(psfm_solve_stats) * (size_t)(f_hi - first_unchecked + 1), hipMemcpyDeviceToHost, s));
         PSFM_HIP(hipStreamSynchronize(s));
+        // Nothing of this call is in flight now.  If other psfm calls of the process wait for the device (this sequence holds it
+        // exclusively for its resident solves), let them in: the rest of the sequence runs its solves as launches, which overlap
+        // with other sequences -- a late-comer waits for one window of frames at most, not for the whole sequence.
+        if (gate.yield_exclusive()) c->pc_persist_ok = false;
         const int stalled = hc->stall ? hc->stall - 1 : -1;   // (the redo below reuses the pinned block `hc` points at)
         int last_ok = f_hi;
         if (seq) {      // frames below the device's program counter are complete (it may be in the middle of the next solve)
@@ -658,7 +669,7 @@ extern "C" psfm_status psfm_track(psfm_ctx* c, const float* flows, const uint8_t
 {
     PSFM_CHECK_CTX(c);   // (selects the context's device: the residency query below is per device)
     PsfmGate gate(c->device, psfm_wants_persist(c, flows_f2 != nullptr, h, w, ratio, false));
-    return psfm_track_impl(c, flows, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, nullptr, gate.exclusive);
+    return psfm_track_impl(c, flows, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, nullptr, gate);
 }
 
 // The compute part of the stage entry (main_connect_point_trajectories.py:36-53): flow_check of the stride-1 (and
@@ -691,7 +702,7 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
             if ((st = c->occ_own.ensure((size_t)pitch * (size_t)n_flows)) != PSFM_OK) return st;
             occ = c->occ_own.as<uint8_t>();
         }
-        return psfm_track_impl(c, flows_f, occ, nullptr, nullptr, n_flows, h, w, ratio, info, stream, nullptr, true, flows_b,
+        return psfm_track_impl(c, flows_f, occ, nullptr, nullptr, n_flows, h, w, ratio, info, stream, nullptr, gate, flows_b,
                                thres, pitch);
     }
     if (!occ) {
@@ -751,7 +762,7 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
         }
     }
     c->prof.end(side);
-    st = psfm_track_impl(c, flows_f, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, &pipe, gate.exclusive);
+    st = psfm_track_impl(c, flows_f, occ, flows_f2, occ_s2, n_flows, h, w, ratio, info, stream, &pipe, gate);
     // psfm_track_impl synchronised `stream`, which waited on every chunk: the side stream is idle too
     c->prof.pool.push_back(e_in);
     for (auto e : pipe.ready) c->prof.pool.push_back(e);

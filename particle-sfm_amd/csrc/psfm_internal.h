@@ -27,14 +27,33 @@ void psfm_set_error(const char* fmt, ...);
 // sequences.  (Other PROCESSES on the device are not covered: there the loop's bounded spin and its hand-over to
 // per-frame launches are the safety net.)
 std::shared_mutex& psfm_device_gate(int device);
+int psfm_gate_waiters(int device);             // psfm calls of this process currently blocked behind an exclusive holder on the device
+void psfm_gate_waiters_add(int device, int d);
 struct PsfmGate {
     std::shared_mutex& m;
+    int device;
     bool exclusive = false;
-    PsfmGate(int device, int want_exclusive /* 0 no, 1 if free, 2 wait for it */) : m(psfm_device_gate(device))
+    PsfmGate(int dev, int want_exclusive /* 0 no, 1 if free, 2 wait for it */) : m(psfm_device_gate(dev)), device(dev)
     {
         if (want_exclusive == 2) { m.lock(); exclusive = true; }
         else if (want_exclusive == 1 && m.try_lock()) exclusive = true;
-        else m.lock_shared();
+        else if (!m.try_lock_shared()) {
+            // somebody holds the device exclusively (a persistent launch, or a track_optimize sequence running its solves as
+            // resident launches): say so -- a sequence gives the device up at its next checkpoint (yield_exclusive) -- and wait
+            psfm_gate_waiters_add(device, 1);
+            m.lock_shared();
+            psfm_gate_waiters_add(device, -1);
+        }
+    }
+    // An exclusive holder whose work can go on with plain launches lets the waiting calls in (call with nothing of this call in
+    // flight on the device: behind a stream synchronisation).  Returns true when it gave the device up.
+    bool yield_exclusive()
+    {
+        if (!exclusive || psfm_gate_waiters(device) <= 0) return false;
+        m.unlock();
+        exclusive = false;
+        m.lock_shared();
+        return true;
     }
     ~PsfmGate() { if (exclusive) m.unlock(); else m.unlock_shared(); }
     PsfmGate(const PsfmGate&) = delete;

@@ -23,6 +23,9 @@
         PSFM_HIP(hipSetDevice((c)->device));                                                                 \
     } while (0)
 
+#define PSFM_KEY_TIME_BITS 16
+#define PSFM_KEY_GRID_BITS 31
+
 void psfm_shard_abandon(psfm_ctx* c)
 {
     delete c->shard_dims;
@@ -39,15 +42,17 @@ extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, 
         psfm_set_error("psfm_shard_begin: bad argument (n_flows=%d h=%d w=%d ratio=%d)", n_flows, h, w, ratio);
         return PSFM_ERR_ARG;
     }
-    // the ids over ranks come from the key last << 51 | birth << 40 | grid index (psfm_result_keys): 11 bits per time field
-    if (n_flows + 2 >= (1 << 11)) {
-        psfm_set_error("psfm_shard_begin: %d flows: the (last, birth, grid) key of a sharded run holds times below 2046", n_flows);
+    // the ids over ranks come from the key last << 47 | birth << 31 | grid index (psfm_result_keys): 16 bits per time field, 31 for
+    // the grid index (a grid has fewer than 2^30 points: psfm_track_dims)
+    if (n_flows + 2 >= (1 << PSFM_KEY_TIME_BITS)) {
+        psfm_set_error("psfm_shard_begin: %d flows: the (last, birth, grid) key of a sharded run holds times below %d", n_flows,
+                       (1 << PSFM_KEY_TIME_BITS) - 2);
         return PSFM_ERR_ARG;
     }
     PsfmTrackDims d;
     psfm_status st;
     const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
-    if (G >= ((int64_t)1 << 40)) { psfm_set_error("psfm_shard_begin: %lld grid points", (long long)G); return PSFM_ERR_ARG; }
+    if (G >= ((int64_t)1 << PSFM_KEY_GRID_BITS)) { psfm_set_error("psfm_shard_begin: %lld grid points", (long long)G); return PSFM_ERR_ARG; }
     if (g0 < 0 || g1 < g0 || g1 > G || map_pitch < G + 1) {
         psfm_set_error("psfm_shard_begin: band [%lld, %lld) of %lld grid points, map pitch %lld", (long long)g0, (long long)g1,
                        (long long)G, (long long)map_pitch);
@@ -218,7 +223,8 @@ extern "C" psfm_status psfm_shard_finish(psfm_ctx* c, psfm_track_info* info, voi
 }
 
 // key (last valid time, birth frame, birth grid index) of every trajectory of the result, in result order (ascending):
-// what psfm_dist.global_ids ranks over all processes.  Layout: last << 51 | birth << 40 | grid index.
+// what psfm_dist.global_ids ranks over all processes.  Layout: last << 47 | birth << 31 | grid index (16 + 16 + 31 bits: sequences of
+// up to 65533 flows -- round 3 gave the times 11 bits each and the grid 40, and refused sequences beyond 2045 flows for no reason).
 __global__ __launch_bounds__(256) void psfm_shard_keys_kernel(const int* __restrict__ birth, const int* __restrict__ len,
                                                              const int64_t* __restrict__ off, const double2* __restrict__ xy, int64_t n,
                                                              int ratio, int GW, int64_t* __restrict__ keys)
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void psfm_shard_keys_kernel(const int* __restr
     if (i >= n) return;
     const double2 p = xy[off[i]];
     const int64_t g = (int64_t)((int)p.y / ratio) * GW + (int)p.x / ratio;
-    keys[i] = ((int64_t)(birth[i] + len[i] - 1) << 51) | ((int64_t)birth[i] << 40) | g;
+    keys[i] = ((int64_t)(birth[i] + len[i] - 1) << (PSFM_KEY_GRID_BITS + PSFM_KEY_TIME_BITS)) | ((int64_t)birth[i] << PSFM_KEY_GRID_BITS) | g;
 }
 
 extern "C" psfm_status psfm_result_keys(psfm_ctx* c, int ratio, int w, int64_t* keys_dev, void* stream)
@@ -236,8 +242,8 @@ extern "C" psfm_status psfm_result_keys(psfm_ctx* c, int ratio, int w, int64_t* 
     PSFM_HIP(hipSetDevice(c->device));
     PsfmGate gate(c->device, 0);
     const int64_t n = c->res_n_traj;
-    if (c->res_n_flows + 2 >= (1 << 11)) {     // (the result of a plain psfm_track of a longer sequence)
-        psfm_set_error("psfm_result_keys: the result spans %d flows: the packed key holds times below 2046", c->res_n_flows);
+    if (c->res_n_flows + 2 >= (1 << PSFM_KEY_TIME_BITS)) {     // (the result of a plain psfm_track of a longer sequence)
+        psfm_set_error("psfm_result_keys: the result spans %d flows: the packed key holds times below %d", c->res_n_flows, (1 << PSFM_KEY_TIME_BITS) - 2);
         return PSFM_ERR_ARG;
     }
     if (n > 0) {

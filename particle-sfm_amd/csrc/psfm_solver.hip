@@ -983,8 +983,8 @@ __device__ __forceinline__ void pc_fused_replay(const PcParams& P, const double*
         *P.stall = P.frame + 1;
         return;
     }
-    // (a failed solve hands the parameters back as they came in: nothing was accepted, C.cur == 0 -- see the write-back)
-    *P.sel = pc_phys(C.cur, e);
+    // (a failed solve hands the parameters back as they came in -- iterate 0 -- whatever it had accepted on the way: see the write-back)
+    *P.sel = pc_phys(C.failed ? 0 : C.cur, e);
     if (P.stats_dev) {
         psfm_solve_stats st;
         st.iterations = C.iteration; st.successful_steps = C.successful;

@@ -31,6 +31,11 @@ class HipShardEngine:
 
     def begin(self, n_flows, H, W, ratio, g0, g1, optimize):
         import torch
+        # a run of this engine that was aborted between solve() and checkpoint() (an exception in a collective, a solve that did
+        # not terminate) must not hand its enqueued solves -- frame numbers and flow tensors of ANOTHER sequence -- to this one
+        self._pending = []
+        self._need = []
+        self.counters = {"fused": 0, "fused_redone": 0}
         self.G = ((W + ratio - 1) // ratio) * ((H + ratio - 1) // ratio)
         self.pitch = (self.G + 1 + 255) // 256 * 256
         self.maps = torch.zeros(2 * self.pitch, dtype=torch.uint8, device=self.device)
@@ -145,7 +150,8 @@ class HipShardEngine:
     def finish(self):
         """the own trajectories on the HOST: (birth, length, off, xy, solve statistics)"""
         from .trajectory import _result_to_host
-        assert not self._pending, "HipShardEngine.finish: solves enqueued since the last checkpoint()"
+        if self._pending:      # (a real exception: assert is stripped under -O)
+            raise RuntimeError("HipShardEngine.finish: solves enqueued since the last checkpoint()")
         info = _hip.TrackInfo()
         _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
         R = _result_to_host(self.ctx, info)
@@ -154,7 +160,8 @@ class HipShardEngine:
     def finish_device(self, ratio, width):
         """the own trajectories stay in HBM (psfm_result_device); returns (track info, their order keys as a device tensor)"""
         import torch
-        assert not self._pending, "HipShardEngine.finish_device: solves enqueued since the last checkpoint()"
+        if self._pending:
+            raise RuntimeError("HipShardEngine.finish_device: solves enqueued since the last checkpoint()")
         info = _hip.TrackInfo()
         _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
         keys = torch.empty(int(info.n_traj), dtype=torch.int64, device=self.device)

@@ -207,6 +207,9 @@ def make_reduce(group=None, comm=None):
     return reduce
 
 
+KEY_TIME_BITS, KEY_GRID_BITS = 16, 31       # the packed id key: last << 47 | birth << 31 | grid index
+
+
 def global_ids(birth, length, first_xy, n_flows, ratio, grid_w, group=None, comm=None):
     """Ids of this rank's trajectories in the order of the single-process run: rank of the key (last valid time, birth
     frame, birth grid index) among the keys of all ranks (SURVEY a-17: dead tracks by frame, then the still active ones,
@@ -216,8 +219,10 @@ def global_ids(birth, length, first_xy, n_flows, ratio, grid_w, group=None, comm
     birth = np.asarray(birth, np.int64)
     last = birth + np.asarray(length, np.int64) - 1
     gidx = (np.asarray(first_xy[:, 1], np.int64) // ratio) * int(grid_w) + np.asarray(first_xy[:, 0], np.int64) // ratio
-    key = (last << 51) | (birth << 40) | gidx                   # 11 + 11 + 40 bits
-    assert n_flows + 2 < (1 << 11) and (len(key) == 0 or (np.diff(key) > 0).all()), "local trajectories must come in key order"
+    key = (last << (KEY_GRID_BITS + KEY_TIME_BITS)) | (birth << KEY_GRID_BITS) | gidx         # 16 + 16 + 31 bits (csrc/psfm_shard.hip)
+    if n_flows + 2 >= (1 << KEY_TIME_BITS) or (len(gidx) and int(gidx.max()) >= (1 << KEY_GRID_BITS)):
+        raise ValueError("global_ids: %d flows / grid index %d do not fit the packed (last, birth, grid) key" % (n_flows, int(gidx.max()) if len(gidx) else 0))
+    assert len(key) == 0 or (np.diff(key) > 0).all(), "local trajectories must come in key order"
     world = comm.world
     if world == 1:
         return np.arange(len(key), dtype=np.int64), len(key)
@@ -318,8 +323,8 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
         step(t, flow_t, occ_t) -> uint8 tensor (G marks of this rank's survivors + 1 survivor byte), exchanged here
         after_exchange(t, x); solve(t, flow_{t-1}, flow_t, flow2_{t-1}, occ2_{t-1}, reduce); finish() -> CSR + stats
     n_flows_total: the four stacks are OWNED by frame-pair slices -- every rank passes only its slice
-    [shard_range(n, rank, world)) of each stack (n = n_flows_total pairs, n - 1 stride-2 pairs; load_flows_device(dir,
-    rank=, world=) reads exactly that); Stage B's frames arrive by broadcast (FrameWindow).  Per-rank HBM for the
+    [shard_range(n, rank, world)) of each stack (n = n_flows_total pairs, n - 1 stride-2 pairs;
+    point_trajectory.utils.load_flows_device_slice(dir, rank, world) reads exactly that); Stage B's frames arrive by broadcast (FrameWindow).  Per-rank HBM for the
     stacks: 1 / world of the sequence + a window of a few frames.
     Returns {"birth","length","off","xy": this rank's trajectories; "ids": their ids in the single-process order;
     "n_traj": trajectories over all ranks; "solve_stats"; "occ","occ2"}."""

@@ -9,8 +9,12 @@
 
 #include "psfm_pc_control.h"
 
-extern "C" int pc_host_chain_solve(long n, const double* x0, const double* ref1, const double* ref2, const double* scale,
-                                   const float* flow, int H, int W, int pair, double* x_out, int* stats, double* costs)
+// inject_fail_after: >= 1: the totals of the round in which the inject_fail_after-th step is accepted report a system that lost
+// definiteness (SUM_FAIL) -- Ceres' FAILURE behind accepted steps, which no real batch of these tests produces: the solve must
+// hand the START values back (Summary::IsSolutionUsable() is false), not the iterate it had reached.
+extern "C" int pc_host_chain_solve_ex(long n, const double* x0, const double* ref1, const double* ref2, const double* scale,
+                                      const float* flow, int H, int W, int pair, int inject_fail_after, double* x_out, int* stats,
+                                      double* costs)
 {
     const PcF2* F = (const PcF2*)flow;
     std::vector<double> b1(4 * n), b2(4 * n), js(2 * n);
@@ -69,17 +73,25 @@ extern "C" int pc_host_chain_solve(long n, const double* x0, const double* ref1,
             tot[SUM_COST] += pc_core_cost(r);
             pc_core_system<true>(xp, r, jac, c, mu_next, pc_core_iA22(c, mu_next), tot, y, CH_QUD, CH_QDD);
         }
+        if (inject_fail_after > 0 && !refresh && C.successful + 1 == inject_fail_after) tot[SUM_FAIL] += 1.0;   // (counts if this round accepts)
         pc_chain_control(C, tot, 1);
         C.launches += 1;
     }
-    // ---- write-back (pc_writeback_tracks): the accepted iterate; a failed solve hands the start values back (C.cur == 0) ----
-    const double* xf = buf(C.cur);
+    // ---- write-back (pc_writeback_tracks): the accepted iterate; a failed solve hands the START values back, whatever it had
+    //      accepted on the way (buffer 0 is never written before this point) ----
+    const double* xf = buf(C.failed ? 0 : C.cur);
     for (long i = 0; i < 4 * n; ++i) x_out[i] = xf[i];
     stats[0] = C.iteration; stats[1] = C.successful; stats[2] = C.n_tracks == 0 ? -1 : C.termination; stats[3] = C.nonGN;
     stats[4] = C.launches; stats[5] = C.done; stats[6] = C.failed;
     if (C.failed) stats[2] = PSFM_TERM_FAILURE;
     costs[0] = C.initial_cost; costs[1] = C.x_cost;
     return C.done ? 0 : 1;
+}
+
+extern "C" int pc_host_chain_solve(long n, const double* x0, const double* ref1, const double* ref2, const double* scale,
+                                   const float* flow, int H, int W, int pair, double* x_out, int* stats, double* costs)
+{
+    return pc_host_chain_solve_ex(n, x0, ref1, ref2, scale, flow, H, W, pair, 0, x_out, stats, costs);
 }
 
 // ---- the FUSED solve (psfm_pc_fused_kernel / the frame kernels: pc_fused_body + pc_fused_replay of psfm_solver.hip) ----

@@ -133,7 +133,7 @@ def _sharded_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def _owned_worker(rank, world, port, ret):
+def _owned_worker(rank, world, port, ret, lean=False):
     """connect_sharded with the stacks OWNED by frame-pair slices: every rank holds (and passes) only its slice of the four
     stacks; Stage B's frames arrive by broadcast from their owners (psfm_dist.FrameWindow)."""
     for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
@@ -206,6 +206,8 @@ def _owned_worker(rank, world, port, ret):
                            eng.reruns > 0 and not eng.stall_at and not eng.queue)
         # (more ranks than stride-2 pairs in the last case: a rank with an EMPTY slice of a stack)
         cases = [(9, 38, 52, 2, 41, 0.3, 2, False), (8, 45, 60, 3, 42, 0.1, 1, True), (3, 30, 44, 1, 43, 0.2, 1, True)]
+        if lean:        # (eight processes on a small box: the rewinding sequence above + one optimising case)
+            cases = cases[1:2]
         for ci, (T, H, W, r, seed, sigma, nocc, optimize) in enumerate(cases):
             d = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=sigma, n_occluders=nocc, stride2=True)
             n, n2 = T - 1, T - 2
@@ -245,6 +247,22 @@ def test_connect_sharded_with_frame_pair_owned_stacks(world):
     assert len(ret) == world
     for r in range(world):
         for ci in (0, 1, 2, "deferred"):
+            assert all(ret[r][ci]), (r, ci, ret[r][ci])
+
+
+def test_connect_sharded_eight_ranks():
+    """The target machine has 8 GPUs (BASELINE configs[3]): the exact single-sequence mode with EIGHT ranks over gloo -- grids whose
+    row count is not a multiple of 8 (18 and 15 grid rows: bands of 3 / 2 rows), 13 frame pairs owned in slices of 2 and 1, an engine
+    that only enqueues its frames and rewinds the driver twice (the ranks must agree on when, every 4 frames, without talking).
+    Bit-identical to the single-process oracle."""
+    world = 8
+    port = 33500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_owned_worker, args=(world, port, ret, True), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        for ci in (0, "deferred"):
             assert all(ret[r][ci]), (r, ci, ret[r][ci])
 
 

@@ -72,7 +72,7 @@ def test_global_ids_rank_the_keys_of_all_ranks(seed, world, n, ratio):
         mine = np.nonzero((g >= g0) & (g < g1))[0]
         ids, tot = psfm_dist.global_ids(birth[mine], length[mine], first[mine], n_flows, ratio, gw, comm=comm)
         last = birth[mine] + length[mine] - 1
-        keys = torch.from_numpy((last << 51) | (birth[mine] << 40) | g[mine])
+        keys = torch.from_numpy((last << 47) | (birth[mine] << 31) | g[mine])
         ids_d, tot_d = psfm_dist.global_ids_device(keys, comm)
         return mine, ids, tot, ids_d.numpy(), tot_d
 

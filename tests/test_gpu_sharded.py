@@ -80,8 +80,14 @@ def test_connect_sharded_hip_engine_two_launches_per_frame(case, monkeypatch):
     test_connect_sharded_hip_engine(2, *CASES[case])
 
 
-@pytest.mark.parametrize("sigma", [0.05, 0.4])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", [1, 2])
+def test_connect_sharded_hip_engine_eight_thread_ranks(case):
+    """Eight ranks (the target node's GPU count; here eight threads on the one GPU): 30 / 15 grid rows in bands of 4 and 2 rows --
+    clean solves (fused export + control) and noisy ones (every solve redone by the chain protocol, one export per iteration)."""
+    test_connect_sharded_hip_engine(8, *CASES[case])
+
+
+@pytest.mark.parametrize("sigma,world", [(0.05, 2), (0.4, 2), (0.05, 3), (0.4, 3), (0.4, 8)])
 def test_connect_sharded_hip_engine_frame_pair_owned_stacks(world, sigma):
     """The sharded mode without replicated flows on the GPU engine: every thread-rank passes only its Stage-A slice of the four
     stacks (device tensors); Stage B's frames come by broadcast (psfm_dist.FrameWindow).  Same result as the oracle."""

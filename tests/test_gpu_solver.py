@@ -362,3 +362,90 @@ def test_persistent_solve_that_gives_up_is_redone_with_launches(pt, monkeypatch)
         assert float(np.abs(out_g - out_o).max()) <= 1e-8
     finally:
         ctx.set_solver(0, 0)
+
+
+@pytest.mark.parametrize("quit", ["40,2", "5,3", "0,1"])
+def test_resident_solve_with_one_block_giving_up_mid_solve(pt, monkeypatch, quit):
+    """PSFM_PC_QUIT="block,round": that block gives up in that round of every resident solve (what a grid that is not co-resident
+    looks like to the others) -- a member (block 40), a leader of the all-reduce (block 5), block 0.  It poisons its granules, its
+    leader passes the poison on, every block leaves at its next poll without having written anything and raises the stall flag;
+    the host redoes the solve with launches (and stops trying the resident form after two give-ups).  Same bits as launches only."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    T, H, W, r = 7, 120, 200, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=72, stride2=True, **psfm_synth.HARD)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    ctx = _hip.context()
+    ctx.set_solver(1, 0)
+    try:
+        monkeypatch.setenv("PSFM_PC_PERSIST", "0")
+        ref = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        monkeypatch.setenv("PSFM_PC_PERSIST", "1")
+        monkeypatch.setenv("PSFM_PC_QUIT", quit)
+        R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        assert np.array_equal(R.birth, ref.birth) and np.array_equal(R.length, ref.length) and np.array_equal(R.xy, ref.xy)
+        assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in ref.solve_stats]
+        assert max(s["iterations"] for s in ref.solve_stats) > int(quit.split(",")[1]) + 1      # (the round is reached)
+        uv, ref1, ref2, scale, flow12 = _batch(60, 80, 3000, 2, 0.5)
+        # (the batch of 3000 tracks runs on 12 blocks)
+        monkeypatch.setenv("PSFM_PC_QUIT", ("3," if int(quit.split(",")[0]) >= 12 else quit.split(",")[0] + ",") + quit.split(",")[1])
+        out_q = pt.particlesfm.optimize_location(uv, ref1, ref2, scale, flow12, uv.shape[0], 80, 60)
+        st_q = dict(pt.particlesfm.optimize_location.last_stats)
+        monkeypatch.delenv("PSFM_PC_QUIT")
+        monkeypatch.setenv("PSFM_PC_PERSIST", "0")
+        out_l = pt.particlesfm.optimize_location(uv, ref1, ref2, scale, flow12, uv.shape[0], 80, 60)
+        assert np.array_equal(out_q, out_l) and st_q == dict(pt.particlesfm.optimize_location.last_stats)
+    finally:
+        ctx.set_solver(0, 0)
+
+
+def test_exclusive_sequence_lets_other_host_threads_in(pt):
+    """A track_optimize call takes the device gate exclusively when it is free (its hard solves then run as resident launches);
+    a psfm call of another host thread that arrives meanwhile announces itself and is let in at the sequence's next checkpoint
+    (PsfmGate::yield_exclusive: the rest of the sequence runs its solves as launches).  Same results as when run alone."""
+    import threading
+    import time
+    from oracle import oracle as orc
+    from point_trajectory.track import track
+    T, H, W, r = 41, 120, 200, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=81, stride2=True, **psfm_synth.HARD)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    alone_a = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    alone_b = track(d["flows_f"], occ, r)
+    res, err = {}, []
+
+    def run_a():
+        import torch
+        from point_trajectory import _hip
+        try:
+            torch.cuda.set_device(0)
+            res["a"] = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+        finally:
+            _hip.release_thread_contexts()
+
+    def run_b():
+        import torch
+        from point_trajectory import _hip
+        try:
+            torch.cuda.set_device(0)
+            time.sleep(0.004)
+            res["b"] = [track(d["flows_f"], occ, r) for _ in range(3)]
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+        finally:
+            _hip.release_thread_contexts()
+
+    for _ in range(3):
+        ta, tb = threading.Thread(target=run_a), threading.Thread(target=run_b)
+        ta.start(); tb.start(); ta.join(); tb.join()
+        assert not err, err
+        A = res["a"]
+        assert np.array_equal(A.birth, alone_a.birth) and np.array_equal(A.length, alone_a.length) and np.array_equal(A.xy, alone_a.xy)
+        assert [s["iterations"] for s in A.solve_stats] == [s["iterations"] for s in alone_a.solve_stats]
+        for B in res["b"]:
+            assert np.array_equal(B.birth, alone_b.birth) and np.array_equal(B.xy, alone_b.xy)
+

@@ -28,6 +28,8 @@ def chain(tmp_path_factory):
     dp, fp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
     L.pc_host_chain_solve.argtypes = [ctypes.c_long, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp]
     L.pc_host_chain_solve.restype = ctypes.c_int
+    L.pc_host_chain_solve_ex.argtypes = [ctypes.c_long, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp]
+    L.pc_host_chain_solve_ex.restype = ctypes.c_int
     L.pc_host_fused_solve.argtypes = [ctypes.c_long, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp]
     L.pc_host_fused_solve.restype = ctypes.c_int
     return L
@@ -91,6 +93,30 @@ def test_device_launch_chain_on_the_host_hands_a_failed_solve_back(chain, all_tr
     assert st["termination"] == st_o["termination"] == st_n["termination"] == 5
     assert st["iterations"] == st_o["iterations"] == st_n["iterations"] == 0
     assert np.array_equal(got, uv) and np.array_equal(want, uv) and np.array_equal(second, uv)
+
+
+@pytest.mark.parametrize("after", [1, 3])
+def test_device_launch_chain_on_the_host_hands_the_start_values_back_when_it_fails_behind_accepted_steps(chain, after):
+    """Ceres' FAILURE behind accepted steps (a system that lost definiteness at an accepted iterate, five invalid steps in a row):
+    Summary::IsSolutionUsable() is false and Solve() leaves the parameter blocks as they came in -- the reference ignores the
+    failure (trajectory_optimize.cpp:81-82) and carries on with the INPUT, not with the last accepted iterate.  No batch of these
+    tests gets there by itself (the 4x4 blocks stay positive definite), so the harness reports a failed factorisation in the round
+    that accepts step number `after`: termination 5, `after` successful steps on record, the start values handed back.  The device's
+    write-back (pc_writeback_tracks, the resident solve's) applies the same rule: buffer 0 is never written before a solve is done."""
+    dp, fp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    uv, ref1, ref2, scale, flow12 = solver_batch(60, 80, 2000, 3, 0.3, False)
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 4)
+    clean, st_clean, _ = _solve(chain, uv, ref1, ref2, scale, flow12)
+    assert st_clean["successful_steps"] >= 3 and float(np.abs(clean - uv).max()) > 1e-3      # (the solve does move the tracks)
+    n = len(uv)
+    r1 = np.ascontiguousarray(ref1, np.float64).reshape(-1, 2); r2 = np.ascontiguousarray(ref2, np.float64).reshape(-1, 2)
+    sc = np.ascontiguousarray(scale, np.float64).reshape(-1); fl = np.ascontiguousarray(flow12, np.float32)
+    out = np.empty((n, 4)); stats = np.zeros(7, np.int32); costs = np.zeros(2)
+    rc = chain.pc_host_chain_solve_ex(n, uv.ctypes.data_as(dp), r1.ctypes.data_as(dp), r2.ctypes.data_as(dp), sc.ctypes.data_as(dp),
+                                      fl.ctypes.data_as(fp), fl.shape[0], fl.shape[1], 1, after, out.ctypes.data_as(dp),
+                                      stats.ctypes.data_as(ip), costs.ctypes.data_as(dp))
+    assert rc == 0 and stats[6] == 1 and stats[2] == 5 and stats[1] == after
+    assert np.array_equal(out, uv)
 
 
 def test_device_launch_chain_on_the_host_survives_candidates_that_do_not_evaluate(chain):
