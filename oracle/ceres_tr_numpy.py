@@ -45,6 +45,15 @@ K_MIN_MU, K_MAX_MU, MU_INCREASE_FACTOR = 1e-8, 1.0, 10.0
 INCREASE_THRESHOLD, DECREASE_THRESHOLD = 0.75, 0.25
 
 # TerminationType details, numbered like include/psfm.h PSFM_TERM_*
+# The readings of Ceres 2.0.0 this restatement (and oracle/psfm_oracle.c: orc_set_variant, same keys and values) rests on memory
+# for; defaults = what oracle and device implement.  tests/test_ref_ceres.py reports which combination a real Ceres build matches.
+VARIANTS = {"iter0_successful": 0,     # 0: GradientToleranceReached() is tested before the first iteration; 1: only behind an accepted step
+            "ftol_base": 0,            # FunctionToleranceReached() against 0: x_cost, 1: candidate_cost, 2: minimum_cost
+            "failure_returns": 0,      # after FAILURE 0: the input is handed back, 1: the best iterate
+            "min_cost_ties": 0}        # 0: `x_cost < minimum_cost` strictly, 1: <=
+VARIANT_KEYS = ("iter0_successful", "ftol_base", "failure_returns", "min_cost_ties")      # index = the C oracle's key
+VARIANT_VALUES = {"iter0_successful": (0, 1), "ftol_base": (0, 1, 2), "failure_returns": (0, 1), "min_cost_ties": (0, 1)}
+
 TERM_FUNCTION_TOL, TERM_PARAMETER_TOL, TERM_GRADIENT_TOL, TERM_MAX_ITER, TERM_MIN_RADIUS, TERM_FAILURE = 0, 1, 2, 3, 4, 5
 
 
@@ -189,7 +198,7 @@ class Dogleg:
         # ComputeCauchyPoint: alpha = |g|^2 / |J (g / diagonal)|^2
         Jg = np.einsum("nqc,nc->nq", J, self.gradient / self.diagonal)
         with np.errstate(divide="ignore", invalid="ignore"):
-            self.alpha = float(np.sum(self.gradient ** 2)) / float(np.sum(Jg ** 2))
+            self.alpha = float(np.float64(np.sum(self.gradient ** 2)) / np.float64(np.sum(Jg ** 2)))      # (0 / 0 = NaN, as in C)
         # ComputeGaussNewtonStep: retry with mu * 10 while the factorisation fails / the solution is not finite
         status = self.FAILURE
         while self.mu < K_MAX_MU:
@@ -294,13 +303,17 @@ class Minimizer:
             return False
         self.initial_cost = self.x_cost
         self.step_is_valid = True
-        self.step_is_successful = True
+        self.step_is_successful = VARIANTS["iter0_successful"] == 0
+        if not self.step_is_successful:          # (the variant must still record the start values as the best so far)
+            self.num_successful_steps += 1
+            self.minimum_cost = self.x_cost
+            self.parameters = self.x.copy()
         return True
 
     def _finalize_iteration_and_check_if_minimizer_can_continue(self):
         if self.step_is_successful:
             self.num_successful_steps += 1
-            if self.x_cost < self.minimum_cost:
+            if self.x_cost < self.minimum_cost or (VARIANTS["min_cost_ties"] and self.x_cost == self.minimum_cost):
                 self.minimum_cost = self.x_cost
                 self.parameters = self.x.copy()
         radius = self.strategy.radius
@@ -348,7 +361,8 @@ class Minimizer:
 
     def _function_tolerance_reached(self):
         cost_change = self.x_cost - self.candidate_cost
-        return abs(cost_change) <= FUNCTION_TOLERANCE * self.x_cost
+        base = (self.x_cost, self.candidate_cost, self.minimum_cost)[VARIANTS["ftol_base"]]
+        return abs(cost_change) <= FUNCTION_TOLERANCE * base
 
     def minimize(self):
         if not self._iteration_zero():
@@ -399,7 +413,7 @@ def optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num,
     m = Minimizer(prog, x0).minimize()
     # solver.cc: the user's parameters are written back only when Summary::IsSolutionUsable(); after FAILURE the state is
     # restored -- the reference ignores the summary (trajectory_optimize.cpp:81-82) and returns whatever is there
-    out = x0.copy() if m.termination == TERM_FAILURE else m.parameters
+    out = x0.copy() if (m.termination == TERM_FAILURE and VARIANTS["failure_returns"] == 0) else m.parameters
     stats = {"iterations": m.iteration, "successful_steps": max(m.num_successful_steps - 1, 0),
              "termination": m.termination, "dogleg_nonGN": m.nonGN,
              "initial_cost": getattr(m, "initial_cost", float("nan")),

@@ -80,6 +80,20 @@ def lib():
     return _lib
 
 
+def set_variant(key, value):
+    """Switch one of the readings of Ceres 2.0.0 the restatement rests on memory for (psfm_oracle.c: orc_set_variant; key = index
+    into ceres_tr_numpy.VARIANT_KEYS or its name).  Returns the previous value.  Test infrastructure: the defaults are what ships."""
+    from . import ceres_tr_numpy as ct
+    k = ct.VARIANT_KEYS.index(key) if isinstance(key, str) else int(key)
+    L = lib()
+    L.orc_set_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.orc_set_variant.restype = ctypes.c_int
+    old = L.orc_set_variant(k, int(value))
+    if old < 0:
+        raise KeyError(key)
+    return old
+
+
 def set_num_threads(n):
     """Cap the host threads of the oracle's parallel loops (beyond ~16-32 the fork/join per loop costs more than it gains)."""
     L = lib()

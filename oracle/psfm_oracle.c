@@ -313,6 +313,27 @@ typedef struct {
     double initial_cost, final_cost;
 } orc_solve_stats_t;
 
+/* ---- the places where this restatement of Ceres 2.0.0's trust-region loop rests on MEMORY of trust_region_minimizer.cc /
+ * solver.cc rather than on anything in the reference tree (parity unpinned: DESIGN.md section 3), each behind a switch, so that
+ * the day a real Ceres build exists tests/test_ref_ceres.py can say WHICH reading it agrees with.  Defaults = what the oracle
+ * (and the device, and oracle/ceres_tr_numpy.py) implement:
+ *   ORC_VAR_ITER0_SUCCESSFUL  0: IterationZero() leaves step_is_successful = true, so GradientToleranceReached() is tested
+ *                                before the first iteration;                       1: the test is only due behind a real accepted step
+ *   ORC_VAR_FTOL_BASE         0: FunctionToleranceReached(): |x_cost - candidate_cost| <= function_tolerance * x_cost;
+ *                             1: ... * candidate_cost;                             2: ... * minimum_cost
+ *   ORC_VAR_FAILURE_RETURNS   0: after FAILURE the parameters are handed back as they came in (Summary::IsSolutionUsable());
+ *                             1: the best iterate seen is written back
+ *   ORC_VAR_MIN_COST_TIES     0: `if (x_cost_ < minimum_cost_)` strictly;          1: <=  (a later iterate of equal cost wins) */
+enum { ORC_VAR_ITER0_SUCCESSFUL = 0, ORC_VAR_FTOL_BASE = 1, ORC_VAR_FAILURE_RETURNS = 2, ORC_VAR_MIN_COST_TIES = 3, ORC_N_VARIANTS = 4 };
+static int orc_variant[ORC_N_VARIANTS] = {0, 0, 0, 0};
+ORC_API int orc_set_variant(int key, int value)     /* returns the previous value, -1 for an unknown key */
+{
+    if (key < 0 || key >= ORC_N_VARIANTS) return -1;
+    const int old = orc_variant[key];
+    orc_variant[key] = value;
+    return old;
+}
+
 /* trajectory_optimize.cpp:30-96.  flow12 is the (H,W,2) f32 map (exactly what
  * the reference force-casts to double).  Restates Ceres 2.0.0:
  * TrustRegionMinimizer::Minimize with DoglegStrategy(TRADITIONAL_DOGLEG),
@@ -428,7 +449,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
     memcpy(best, x, sizeof(double) * P);
     double minimum_cost = x_cost;
     int iteration = 0;
-    int step_successful = 1;       /* iteration 0 counts as successful */
+    int step_successful = orc_variant[ORC_VAR_ITER0_SUCCESSFUL] == 0;       /* iteration 0 counts as successful (default) */
     st.termination = 3;
     /* IterationZero(): EvaluateGradientAndJacobian fails when a residual (or Jacobian entry) of ANY block is not finite
      * (residual_block.cc ResidualBlock::Evaluate -> IsEvaluationValid / IsArrayValid) -- "Residual and Jacobian evaluation
@@ -440,7 +461,8 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
 
     while (!eval0_failed) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue */
-        if (step_successful && x_cost < minimum_cost) { /* trust_region_minimizer.cc: `if (x_cost_ < minimum_cost_)` -- strictly */
+        if (step_successful && (x_cost < minimum_cost ||       /* trust_region_minimizer.cc: `if (x_cost_ < minimum_cost_)` -- strictly */
+                                (orc_variant[ORC_VAR_MIN_COST_TIES] && x_cost == minimum_cost))) {
             minimum_cost = x_cost;
             memcpy(best, x, sizeof(double) * P);
         }
@@ -618,7 +640,10 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
             if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { st.termination = 1; break; }
         }
         /* FunctionToleranceReached */
-        if (fabs(x_cost - cand_cost) <= function_tolerance * x_cost) { st.termination = 0; break; }
+        {
+            const double ftol_base = orc_variant[ORC_VAR_FTOL_BASE] == 1 ? cand_cost : (orc_variant[ORC_VAR_FTOL_BASE] == 2 ? minimum_cost : x_cost);
+            if (fabs(x_cost - cand_cost) <= function_tolerance * ftol_base) { st.termination = 0; break; }
+        }
         /* IsStepSuccessful (monotonic step evaluator) */
         const double rho = (x_cost - cand_cost) / model_cost_change;
         if (rho > min_relative_decrease) {
@@ -642,7 +667,7 @@ ORC_API int orc_optimize_location(const double* uv12, const double* ref1, const 
     st.final_cost = minimum_cost;
     /* solver.cc Minimize(): the user's parameters are only updated when Summary::IsSolutionUsable() -- after a FAILURE
      * Ceres restores the values it was called with; the reference ignores the failure (trajectory_optimize.cpp:81-82) */
-    memcpy(out, st.termination == 5 ? uv12 : best, sizeof(double) * P);
+    memcpy(out, (st.termination == 5 && orc_variant[ORC_VAR_FAILURE_RETURNS] == 0) ? uv12 : best, sizeof(double) * P);
     if (stats) *stats = st;
     free(x); free(xc); free(res); free(jac); free(S); free(diag); free(ghat); free(gn); free(step); free(best); free(part);
     return st.termination == 5 ? 1 : 0;

@@ -81,6 +81,26 @@ def test_global_ids_rank_the_keys_of_all_ranks(seed, world, n, ratio):
         assert np.array_equal(ids, mine) and np.array_equal(ids_d, mine)
 
 
+def test_global_ids_of_a_three_thousand_flow_sequence_on_eight_ranks():
+    """The packed (last, birth, grid) key holds 16 bits per time field (round 3: 11 -- sharded runs refused sequences beyond 2045
+    flows): 3000 flows on a 1080p / sample_ratio 2 grid (518 400 points: 20 bits of the 31), eight ranks; 65 534 flows do not fit."""
+    rng = np.random.default_rng(7)
+    n_flows, gh, gw, ratio = 3000, 540, 960, 2
+    birth, length, first, g = _random_trajectories(rng, n_flows, gh, gw, ratio, 4000)
+    assert (birth + length - 1).max() > 2046
+
+    def rank_fn(comm):
+        g0, g1 = psfm_dist.band_range(gh, gw, comm.rank, comm.world)
+        mine = np.nonzero((g >= g0) & (g < g1))[0]
+        ids, tot = psfm_dist.global_ids(birth[mine], length[mine], first[mine], n_flows, ratio, gw, comm=comm)
+        return mine, ids, tot
+
+    for mine, ids, tot in run_ranks(8, rank_fn):
+        assert tot == len(birth) and np.array_equal(ids, mine)
+    with pytest.raises(ValueError):
+        psfm_dist.global_ids(birth[:4], length[:4], first[:4], 65534, ratio, gw, comm=psfm_dist._comm(None, None))
+
+
 @FAST
 @given(seed=st.integers(0, 2**31 - 1), world=st.integers(1, 4), k=st.integers(1, 8))
 def test_reduce_adds_in_rank_order_and_takes_maxima(seed, world, k):

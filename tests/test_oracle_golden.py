@@ -212,3 +212,47 @@ def test_reference_python_with_the_second_restatement_as_solver():
     birth, length, off, xy = ref_shim.trajs_to_csr(full)
     assert np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
     assert float(np.abs(xy - O.xy).max()) <= 1e-9
+
+
+def test_ceres_assumption_switches_are_mirrored_in_both_restatements():
+    """The places where the restatements rest on memory of trust_region_minimizer.cc / solver.cc are switches
+    (psfm_oracle.c orc_set_variant, ceres_tr_numpy.VARIANTS); tests/test_ref_ceres.py walks them against a real Ceres build when
+    one exists.  Here: under every setting of every switch the two restatements still agree with each other, and the switches
+    do what they say on batches built to hit them."""
+    import itertools
+    from oracle import oracle as orc
+    from oracle import ceres_tr_numpy as ct
+    from _common import solver_batch
+    batches = [solver_batch(40, 50, 300, 3, 0.3, False), solver_batch(40, 50, 200, 4, 0.05, True)]
+    # tracks that sit in the optimum already (zero field, refs = positions): gradient 0 at iteration 0
+    n = 50
+    rng = np.random.default_rng(0)
+    p1 = rng.uniform(5, 30, (n, 2)); uv0 = np.concatenate([p1, p1], 1)
+    batches.append((uv0, p1.copy(), p1.copy(), np.ones((n, 1)), np.zeros((40, 50, 2), np.float32)))
+    # a NaN patch under some tracks: FAILURE in IterationZero
+    uvn, r1n, r2n, scn, fln = solver_batch(40, 50, 100, 9, 0.1, False)
+    fln = fln.copy(); fln[10:14, 20:24] = np.nan
+    uvn[:, 0] = np.clip(uvn[:, 0], 20.2, 22.8); uvn[:, 1] = np.clip(uvn[:, 1], 10.2, 12.8)
+    batches.append((uvn, r1n, r2n, scn, fln))
+    seen = {}
+    try:
+        for key in ct.VARIANT_KEYS:
+            for val in ct.VARIANT_VALUES[key]:
+                orc.set_variant(key, val); ct.VARIANTS[key] = val
+                for bi, (uv, r1, r2, sc, fl) in enumerate(batches):
+                    a, sa = orc.optimize_location(uv, r1, r2, sc, fl, return_stats=True)
+                    b, sb = ct.optimize_location(uv, r1, r2, sc, fl, len(uv), fl.shape[1], fl.shape[0])
+                    for k in ("iterations", "successful_steps", "termination"):
+                        assert sa[k] == sb[k], (key, val, bi, k, sa, sb)
+                    fin = np.isfinite(a) & np.isfinite(b)
+                    assert np.array_equal(np.isfinite(a), np.isfinite(b)) and float(np.abs(a[fin] - b[fin]).max()) <= 1e-9
+                    seen[(key, val, bi)] = (sa["iterations"], sa["termination"], a.copy())
+                orc.set_variant(key, 0); ct.VARIANTS[key] = 0
+    finally:
+        for key in ct.VARIANT_KEYS:
+            orc.set_variant(key, 0); ct.VARIANTS[key] = 0
+    # iteration 0 in the optimum: gradient convergence before the first iteration by default, one iteration otherwise
+    assert seen[("iter0_successful", 0, 2)][:2] == (0, 2) and seen[("iter0_successful", 1, 2)][0] > 0      # (five invalid steps: no decrease to model)
+    # FAILURE: the input handed back by default
+    assert seen[("failure_returns", 0, 3)][1] == 5 and np.array_equal(seen[("failure_returns", 0, 3)][2], uvn)
+

@@ -44,6 +44,35 @@ def test_real_ceres_vs_both_restatements(H, W, n, seed, sigma, kink):
     assert float(np.abs(out_r - out_n).max()) <= TOL
 
 
+def test_which_reading_of_ceres_the_real_module_agrees_with(capsys):
+    """Every combination of the switches of oracle/ceres_tr_numpy.VARIANTS (= psfm_oracle.c orc_set_variant: the places the
+    restatements rest on memory of Ceres' sources) against the real module on the solver batches: prints the table of max |dx|
+    per combination, and requires the SHIPPED reading (all zeros) to be among the combinations that agree to 1e-9 px."""
+    import itertools
+    import json
+    from oracle import oracle as orc
+    from oracle import ceres_tr_numpy as ct
+    real = _real_module()
+    rows = {}
+    try:
+        for combo in itertools.product(*(ct.VARIANT_VALUES[k] for k in ct.VARIANT_KEYS)):
+            for k, v in zip(ct.VARIANT_KEYS, combo):
+                orc.set_variant(k, v); ct.VARIANTS[k] = v
+            worst = 0.0
+            for (H, W, n, seed, sigma, kink) in SOLVER_BATCHES:
+                uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, seed, sigma, kink)
+                out_r = np.asarray(real.optimize_location(uv, ref1, ref2, scale, flow12.astype(np.float64), n, W, H))
+                out_c = orc.optimize_location(uv, ref1, ref2, scale, flow12)
+                worst = max(worst, float(np.abs(out_r - out_c).max()))
+            rows["".join(str(v) for v in combo)] = worst
+    finally:
+        for k in ct.VARIANT_KEYS:
+            orc.set_variant(k, 0); ct.VARIANTS[k] = 0
+    with capsys.disabled():
+        print("\nreal Ceres vs the C oracle, max |dx| px per reading %s:\n%s" % ("/".join(ct.VARIANT_KEYS), json.dumps(rows, indent=1)))
+    assert rows["0" * len(ct.VARIANT_KEYS)] <= 1e-9, rows
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("H,W,n,seed,sigma,kink", SOLVER_BATCHES)
 def test_real_ceres_vs_hip(H, W, n, seed, sigma, kink):
