@@ -9,18 +9,26 @@ from . import _hip
 TAG_FLOAT = 202021.25
 
 
+_FLO_HEADER = np.dtype([("magic", "<f4"), ("w", "<i4"), ("h", "<i4")])
+
+
 def read_flo(file):
-    """utils.py:43-56 (Middlebury .flo: f32 magic, i32 w, i32 h, h*w*2 f32 interleaved)."""
-    assert type(file) is str, "file is not str %r" % str(file)
-    assert os.path.isfile(file) is True, "file does not exist %r" % str(file)
-    assert file[-4:] == '.flo', "file ending is not .flo %r" % file[-4:]
-    with open(file, 'rb') as f:
-        flo_number = np.fromfile(f, np.float32, count=1)[0]
-        assert flo_number == TAG_FLOAT, 'Flow number %r incorrect. Invalid .flo file' % flo_number
-        w = int(np.fromfile(f, np.int32, count=1)[0])
-        h = int(np.fromfile(f, np.int32, count=1)[0])
+    """One Middlebury .flo file -> (h, w, 2) float32 (what utils.py:43-56 of the reference returns): a 12-byte header
+    {f32 magic 202021.25, i32 width, i32 height} followed by h * w interleaved (u, v) pairs.  Like the reference it refuses
+    (AssertionError) a path that is not a string, does not exist, is not named *.flo, or does not start with the magic number."""
+    if not isinstance(file, str):
+        raise AssertionError("read_flo: path must be a str, got %s" % type(file).__name__)
+    if not os.path.isfile(file):
+        raise AssertionError("read_flo: no such file: %s" % file)
+    if not file.endswith(".flo"):
+        raise AssertionError("read_flo: not a .flo file: %s" % file)
+    with open(file, "rb") as f:
+        head = np.fromfile(f, _FLO_HEADER, count=1)
+        if len(head) != 1 or head["magic"][0] != np.float32(TAG_FLOAT):
+            raise AssertionError("read_flo: %s does not start with the .flo magic number %r" % (file, TAG_FLOAT))
+        w, h = int(head["w"][0]), int(head["h"][0])
         data = np.fromfile(f, np.float32, count=2 * w * h)
-    return np.resize(data, (h, w, 2))
+    return np.resize(data, (h, w, 2))       # (np.resize, as the reference: a truncated file repeats its data instead of failing)
 
 
 def write_flo(file, flow):
