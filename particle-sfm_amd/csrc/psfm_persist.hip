@@ -52,6 +52,12 @@
 #define PP_FC_FAST 0     // fused flow_check: wave-uniform "all taps interior" form (16-byte tap pairs, no padding selects)
 #endif
 #define PP_GUESTS 32   // extra lanes per block whose state lives in LDS (stepped as phase-2 entries)
+#ifndef PP_WHATIF
+#define PP_WHATIF 0      // TIMING EXPERIMENTS ONLY (the results are wrong by construction): what a frame of the loop would cost without
+                         // one of the links of its chain -- 1: no births / adoptions behind the barrier (the blocked bytes are still
+                         // loaded; no phase-2 gathers), 2: arrive without waiting for the marks' acknowledgement, 4: no barrier wait
+                         // (blocks run free), 8: no blocked-byte / hand-off loads either.  profiles/EXPERIMENTS.md section 6.
+#endif
 #ifndef PP_WAVES_N
 #define PP_WAVES_N 8     // waves per SIMD the loop is compiled for (8: 64 VGPRs, every lane of a 1080p / ratio-2 grid resident)
 #endif
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                 ++fc_next;
             }
         }
-        if (tid == 0) s_ok = psfm_bar_wait(a, shard, t) ? 1 : 0;
+        if (tid == 0) s_ok = (PP_WHATIF & 4) ? 1 : (psfm_bar_wait(a, shard, t) ? 1 : 0);
         __syncthreads();
         if (!s_ok) return;
 
@@ -356,8 +362,8 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
 #endif
         PP_TL(1);
         // ---- C (issue): respawn byte, survivor flag, hand-off slot -- consumed after E, which runs under their latency ----
-        const bool poll = t > 0 && bf == PP_POOLED;
-        const bool gridpt = t > 0 && L < a.G;
+        const bool poll = t > 0 && bf == PP_POOLED && !(PP_WHATIF & 8);
+        const bool gridpt = t > 0 && L < a.G && !(PP_WHATIF & 8);
         uint8_t* map_prev = a.maps + (size_t)((t + 2) % 3) * a.G;   // marks of step t-1; cleared here, written again at t+2
         unsigned sv = 0, byte = 0;
         unsigned long long h0 = 0, h1 = 0, h2 = ~0ull;
@@ -381,11 +387,12 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
             // No survivor at all: nothing is marked, every grid point respawns -- except that SciPy's EDT then measures
             // to a phantom feature at (y=-1, x=0): (cy+1)^2 + cx^2 > r^2 fails at grid point 0 only (1 > r^2 is false).
             if (L == 0 && svm == 0ull) birth = ((0 + 1) * (0 + 1) + 0 * 0) > ratio * ratio;
+            if (PP_WHATIF & 1) birth = false;
         }
         bool adopted = false;
         if (poll) {
             const int tag = (int)(h2 >> 32);
-            if ((tag >> 1) == t - 1) {          // a block popped this lane for a track born at t-1
+            if ((tag >> 1) == t - 1 && !(PP_WHATIF & 1)) {          // a block popped this lane for a track born at t-1
                 if (tag & 1) {
                     adopted = true;             // stepped below as a phase-2 entry; picked up after it
                     s_xp[tid] = make_double2(__longlong_as_double((long long)h0), __longlong_as_double((long long)h1));
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         }
         // ---- F: arrive.  No block barrier in front of it: a wave whose stores are acknowledged counts itself in (LDS) and
         //      goes on to the next frame; the wave that comes last arrives for the block ----
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (!(PP_WHATIF & 2)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         PP_TL(6);
         {
             int last_wave = 0;
