@@ -15,12 +15,17 @@ PR="python $GRAFT_REPO_ROOT/scripts/probe_solver.py"
 run() { d=$1; shift; timeout 300 rocprofv3 --kernel-trace "$@" > $OUT/$d.log 2>&1 < /dev/null; }
 # ---- headline step ----
 run stats --stats -f csv -d $OUT/stats -o $TAG -- $B1
-run fused_fetch --pmc FETCH_SIZE -f csv -d $OUT/fused_fetch -o f -- $B2
-run fused_write --pmc WRITE_SIZE -f csv -d $OUT/fused_write -o w -- $B2
-PSFM_BENCH_TWO_CALLS=1 run two_fetch --pmc FETCH_SIZE -f csv -d $OUT/two_fetch -o f -- $B2
-PSFM_BENCH_TWO_CALLS=1 run two_write --pmc WRITE_SIZE -f csv -d $OUT/two_write -o w -- $B2
-PSFM_BENCH_CHAIN_MODE=1 run step_fetch --pmc FETCH_SIZE -f csv -d $OUT/step_fetch -o f -- $B2
-PSFM_BENCH_CHAIN_MODE=1 run step_write --pmc WRITE_SIZE -f csv -d $OUT/step_write -o w -- $B2
+# HBM-side bytes: the L2s' fabric request counters in 32-byte units (a 128-byte request counts 4) -- exact on the stand-alone flow_check
+# launch (3.330 GB counted for 3.318 GB read, 207.4 MB for 207.4 MB written), unlike FETCH_SIZE, which tallies this chip's 128-byte
+# requests at 64 bytes (MI355X_MICROARCH.md: "reports exactly 1/2 of a wide coalesced read"; rounds 2-3 calibrated it on flow_check)
+RD="TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_sum"
+WR="TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum TCC_EA0_WRREQ_sum"
+run fused_fetch --pmc $RD -f csv -d $OUT/fused_fetch -o f -- $B2
+run fused_write --pmc $WR -f csv -d $OUT/fused_write -o w -- $B2
+PSFM_BENCH_TWO_CALLS=1 run two_fetch --pmc $RD -f csv -d $OUT/two_fetch -o f -- $B2
+PSFM_BENCH_TWO_CALLS=1 run two_write --pmc $WR -f csv -d $OUT/two_write -o w -- $B2
+PSFM_BENCH_CHAIN_MODE=1 run step_fetch --pmc $RD -f csv -d $OUT/step_fetch -o f -- $B2
+PSFM_BENCH_CHAIN_MODE=1 run step_write --pmc $WR -f csv -d $OUT/step_write -o w -- $B2
 run pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM -f csv -d $OUT/pmc_sq -o s -- $B2
 # ---- track_optimize on clean flows (the device-paced frame kernel) ----
 export PSFM_PROBE_MODES=adaptive

@@ -88,21 +88,29 @@ for sub, pre in (("fused_fetch", "f"), ("fused_write", "w"), ("two_fetch", "f"),
     summary[sub] = counters(sub, pre)
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
-# ---- HBM traffic of the chain kernels: FETCH_SIZE calibrated on the stand-alone flow_check launch (known read volume) ----
+# ---- HBM-side traffic of the chain kernels: the L2s' fabric request counters in 32-byte units, checked against the stand-alone
+#      flow_check launch, whose read and write volumes are known exactly ----
 H, W, NF = 1080, 1920, 100
 try:
     tf, tw = summary["two_fetch"], summary["two_write"]
     fc = [k for k in tf if "flow_check" in k][0]
-    cal = (16.0 * H * W * NF / 1024.0) / tf[fc]["FETCH_SIZE"]
-    note = ("FETCH_SIZE (KB) of the stand-alone flow_check launch against its exactly known read volume 16*H*W*100 bytes "
-            "(MI355X_MICROARCH.md: the counter is uncalibrated on gfx950 and depends on the access width); WRITE_SIZE used as is")
+    rd_ok = tf[fc]["TCC_EA0_RDREQ_DRAM_32B_sum"] * 32.0 / (16.0 * H * W * NF)
+    wr_ok = tw[fc]["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] * 32.0 / (1.0 * H * W * NF)
+    note = ("bytes = 32 x (TCC_EA0_RDREQ_DRAM_32B + TCC_EA0_WRREQ_WRITE_DRAM_32B + TCC_EA0_WRREQ_ATOMIC_DRAM_32B), the L2s' fabric-side "
+            "requests in 32-byte units (a 128-byte request counts 4; Infinity-Cache hits are included).  Checked on the stand-alone "
+            "flow_check launch of the same run: counted / known = %.4f for its reads (16*H*W*100 bytes), %.4f for its writes (H*W*100).  "
+            "FETCH_SIZE (= 64 bytes x TCC_EA0_RDREQ on this chip, whose requests are 128 bytes) would report half of the reads" % (rd_ok, wr_ok))
 
     def traffic(fetch, write, pick, label, how):
         k = [x for x in fetch if pick in x][0]
-        return {"kernel": k + label, "FETCH_SIZE_KB_per_launch": fetch[k]["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": write[k]["WRITE_SIZE"],
-                "fetch_calibration": cal, "hbm_bytes_per_launch": (fetch[k]["FETCH_SIZE"] * cal + write[k]["WRITE_SIZE"]) * 1024.0,
-                "source": "scripts/profile_round4.sh %s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %s" % (tag, how),
-                "calibration_note": note, "flow_check_kernel": fc, "round": tag, "source_sha16": SHA}
+        rd = fetch[k]["TCC_EA0_RDREQ_DRAM_32B_sum"] * 32.0
+        wr = (write[k]["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] + write[k].get("TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum", 0.0)) * 32.0
+        return {"kernel": k + label, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                "read_requests_per_launch": fetch[k].get("TCC_EA0_RDREQ_sum"),
+                "FETCH_SIZE_KB_per_launch_equivalent": fetch[k].get("TCC_EA0_RDREQ_sum", 0.0) * 64.0 / 1024.0,     # (what FETCH_SIZE reports here)
+                "counter_check_on_flow_check": {"reads_counted_over_known": rd_ok, "writes_counted_over_known": wr_ok},
+                "source": "scripts/profile_round4.sh %s: rocprofv3 --pmc, reads and writes in separate passes, %s" % (tag, how),
+                "note": note, "flow_check_kernel": fc, "round": tag, "source_sha16": SHA}
     base = "bench.py --steps 2 --warmup 1 --no-cpu --no-extras"
     json.dump(traffic(summary["fused_fetch"], summary["fused_write"], "chain_persist", " (flow_check fused in)", base),
               open(os.path.join(dst, "traffic_chain_fused.json"), "w"), indent=1)
