@@ -83,6 +83,7 @@ struct PsfmPersistArgs {
     // fused flow_check (psfm_connect): the blocks compute the occlusion maps themselves, in the time they would spend
     // waiting at the frame barriers, always at least three frames ahead of the step that samples them
     const float2* flows_b; uint8_t* occ_w; float thres, t2; int fc; int fc_xcd_per;
+    int xcd_per;                               // > 0: blocks below 8 * xcd_per own the lanes / grid points of block (b % 8) * xcd_per + b / 8 (see psfm_vblock)
     int64_t occ_pitch; PsfmFastDiv wdiv;
     int H, W; float cw, ch, rcw, rch;
     int ratio, GW, GH, G;
@@ -236,6 +237,18 @@ __device__ __forceinline__ void psfm_fc_slice(const PsfmPersistArgs& a, int f, i
     }
 }
 
+// Which 256 lanes (= grid points) a block owns.  Workgroups go to the eight XCDs round-robin and each XCD has a private L2; with
+// block b on lanes [256 b, 256 b + 256) vertically adjacent grid rows -- 3.75 blocks apart at 1080p / sample_ratio 2 -- sit on
+// different XCDs, and a flow row between two grid rows (tracks have sub-pixel positions: their taps span rows floor(y), floor(y) + 1)
+// is pulled through two L2s: 31.0 MB of reads per step counted at the fabric for 19.2 MB of taps (profiles/r04_o_*).  Banded like
+// flow_check's chunks (block b -> virtual block (b % 8) * per + b / 8), an XCD owns one band of grid rows.  Blocks beyond the grid's
+// (spare lanes only) keep their own index; ids do not depend on which lane hosts which track.
+__device__ __forceinline__ int psfm_vblock(const PsfmPersistArgs& a)
+{
+    const int b = (int)blockIdx.x;
+    return (a.xcd_per > 0 && b < 8 * a.xcd_per) ? (b & 7) * a.xcd_per + (b >> 3) : b;
+}
+
 // entry k of the phase-2 list: kind 1 newborn (ex = grid index, host = local PEND thread or -1), kind 2 adopted
 // track (ex = owner thread), kind 3 live guest (ex = guest slot), kind 0 none
 struct PsfmEntry { int kind, ex, host; };
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
     __shared__ int s_glive[PP_GUESTS], s_gfree[PP_GUESTS], s_nglive, s_ngfree;   // this frame's live / free slots
 
     int tid = threadIdx.x;
-    int L = blockIdx.x * PP_BLOCK + tid;
+    int L = psfm_vblock(a) * PP_BLOCK + tid;
     const int ratio = R > 0 ? R : a.ratio;
     const int shard = blockIdx.x % PSFM_NSHARD;
     const size_t P = (size_t)a.H * a.W;
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
 
     for (int t = 0; t < a.n_flows; ++t) {
         asm volatile("" : "+v"(tid));
-        L = blockIdx.x * PP_BLOCK + tid;
+        L = psfm_vblock(a) * PP_BLOCK + tid;
         const int lane = tid & (PSFM_WAVE - 1), wave = tid / PSFM_WAVE;
         PsfmFrameView v;
         v.flow = a.flows + (size_t)t * P; v.occ = a.occ + (size_t)t * a.occ_pitch;
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                     bfk = t; gik = e.ex;
                     // lane of the newborn: the block's k-th PEND lane, else a free guest lane, else a popped / fresh lane
                     if (k < matched) {
-                        col = blockIdx.x * PP_BLOCK + e.host;
+                        col = psfm_vblock(a) * PP_BLOCK + e.host;
                     } else if (k < matched + gmatched) {
                         gs = s_gfree[k - matched];
                         col = a.cap_main + blockIdx.x * PP_GUESTS + gs;
@@ -572,7 +585,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
                 } else if (e.kind == 2) {
                     q = s_xp[e.ex];
                     bfk = t - 1; gik = s_xg[e.ex];
-                    col = blockIdx.x * PP_BLOCK + e.ex;
+                    col = psfm_vblock(a) * PP_BLOCK + e.ex;
                 } else {
                     q = s_gp[e.ex];
                     bfk = s_gbf[e.ex]; gik = s_ggi[e.ex];
@@ -761,6 +774,13 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
         static const int xcd_on = getenv("PSFM_FC_XCD") ? atoi(getenv("PSFM_FC_XCD")) : 1;
         const int64_t nch = ((int64_t)d.H * d.W + 1023) / 1024;
         a.fc_xcd_per = xcd_on && nch >= 64 ? (int)((nch + 7) / 8) : 0;
+    }
+    {
+        // XCD-banded lane ownership (psfm_vblock): the blocks of the grid in eight bands, when every banded index is a block of the launch
+        static const int pp_xcd = getenv("PSFM_PP_XCD") ? atoi(getenv("PSFM_PP_XCD")) : 1;
+        const int64_t gb = (d.G + PP_BLOCK - 1) / PP_BLOCK;
+        const int per = (int)((gb + 7) / 8);
+        a.xcd_per = (pp_xcd && gb >= 64 && 8 * per <= d.nblk) ? per : 0;
     }
     a.wdiv = psfm_fastdiv_make((unsigned)d.W);
     a.H = d.H; a.W = d.W; a.cw = d.cw; a.ch = d.ch; a.rcw = psfm_rcp_host(d.cw); a.rch = psfm_rcp_host(d.ch);
