@@ -33,6 +33,9 @@ struct PsfmChainArgs {
     // device-paced sequence (psfm_seq_kernel): no host-side clear of the blocked map at the stamp wrap -- the grid point's
     // owner thread zeroes the byte it has just read when the map is about to be written with recycled stamps
     int owner_clear;
+    // XCD-banded tiles (psfm_xcd_tile): > 0 = blocks of the grid (ceil(Gband / tile)); block b below it works on tile
+    // band(b % 8) + b / 8 instead of tile b -- each XCD's private L2 then serves one band of grid rows (see psfm_persist.hip)
+    int xcd_tiles;
 };
 
 // What changes from one frame to the next in the arguments of a chain step (everything else is per-sequence): strides of
@@ -101,7 +104,16 @@ void psfm_fill_chain_args_nolaunch(psfm_ctx* c, const PsfmTrackDims& d, const fl
 // What the merged frame kernel (psfm_solver.hip) takes over from the chain step of a thread's lane: does the lane's track
 // take part in the path-consistency solve of this frame (alive after the step, born at least two frames ago), and its
 // three buffered positions p0 (time frame-1), p1 (the tail, time frame), p2 (= p1 + flow, time frame+1).
-struct PsfmChainOut { bool solve; double2 p0, p1, p2; };
+struct PsfmChainOut { bool solve; double2 p0, p1, p2; int tile; };     // tile: first lane of the block's tile
+
+// Tile of block b: a bijection on the n grid blocks [0, n) that hands XCD x (= b % 8: workgroups go to the XCDs round-robin) the
+// x-th of eight contiguous bands of tiles -- sizes differ by at most one --; blocks beyond the grid (spare lanes) keep their own.
+__device__ __forceinline__ int psfm_xcd_tile(int b, int n)
+{
+    if (n <= 0 || b >= n) return b;
+    const int q0 = n >> 3, r0 = n & 7, x = b & 7;
+    return x * q0 + (x < r0 ? x : r0) + (b >> 3);
+}
 
 // One chain step of the block's lanes (+ the births of the frame): the body of psfm_chain_step_kernel, also the first
 // part of the merged frame kernel.  MERGED: the tile bound comes from the lane-count snapshot of the previous launch
@@ -118,7 +130,8 @@ __device__ __forceinline__ bool psfm_chain_step_body(const PsfmChainArgs& a, Psf
     __shared__ int s_seg_end[PSFM_PROBE + 1];
     __shared__ int s_nseg, s_alive_any, s_base_fin, s_base_free;
     const int tid = threadIdx.x, lane = psfm_lane_id(), wave = tid / PSFM_WAVE;
-    const int tile = blockIdx.x * PSFM_CHAIN_TILE;
+    const int tile = psfm_xcd_tile((int)blockIdx.x, a.xcd_tiles) * PSFM_CHAIN_TILE;
+    o.tile = tile;
     const int frame = a.frame;
     const int ratio = R > 0 ? R : a.ratio;
 #ifdef PSFM_TL_ON

@@ -1191,11 +1191,11 @@ __device__ __forceinline__ const double* pc_grid_totals(const PcParams& P, PcWav
 // lane count for the next frame's launch.  pc / launch_id: device-paced sequence (see pc_fused_replay); there the K-th
 // candidate is stored too (a continuation launch starts from it).
 __device__ __forceinline__ void pc_fused_body(const PcParams& P, bool part, double2 p0, double2 p1, double2 p2, int n_active,
-                                              int* snap_next, const int* n_lanes_live, PsfmCounters* pc, int launch_id)
+                                              int* snap_next, const int* n_lanes_live, PsfmCounters* pc, int launch_id, int lane0)
 {
     const int K = P.K;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * PC_BLOCK + tid;
+    const int i = lane0 + tid;          // (lane0: first lane of the block's tile -- XCD-banded in the merged kernels, psfm_xcd_tile)
     const double mu = 1e-8;
     const int e = K - 1;            // (pc_phys: iterate e goes straight into the log slabs, the start values into buffer e)
     PcWaveRed& s_red = pc_shared_red();
@@ -1283,7 +1283,7 @@ void psfm_pc_fused_kernel(PcParams P)
     // (state loaded alongside the birth frame that decides whether the lane takes part: one round trip less)
     double2 p0 = make_double2(0.0, 0.0), p1 = p0, p2 = p0;
     if (i < n) { p0 = P.p0[i]; p1 = P.x1a[i]; p2 = P.x2a[i]; }
-    pc_fused_body(P, pc_participates(P, i, n), p0, p1, p2, n_active, nullptr, nullptr, nullptr, 0);
+    pc_fused_body(P, pc_participates(P, i, n), p0, p1, p2, n_active, nullptr, nullptr, nullptr, 0, (int)blockIdx.x * PC_BLOCK);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1301,7 +1301,7 @@ void psfm_frame_kernel(PsfmChainArgs a, PcParams P)
     PsfmChainOut o;
     if (!psfm_chain_step_body<R, true, true>(a, o)) return;
     const int n_active = (max(a.ctr->n_lanes_snap[a.frame & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
-    pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &a.ctr->n_lanes_snap[(a.frame + 1) & 1], &a.ctr->n_lanes, nullptr, 0);
+    pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &a.ctr->n_lanes_snap[(a.frame + 1) & 1], &a.ctr->n_lanes, nullptr, 0, o.tile);
 }
 
 // What changes from one frame to the next in the solver's arguments (frame mode)
@@ -1343,7 +1343,7 @@ void psfm_seq_kernel(PsfmChainArgs a, PcParams P, PsfmSeqStride st, int64_t occ2
     if (phase == 0) {
         PsfmChainOut o;
         if (!psfm_chain_step_body<R, true, true>(a, o)) return;
-        pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &ctr->n_lanes_snap[(f + 1) & 1], &ctr->n_lanes, ctr, launch_id);
+        pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &ctr->n_lanes_snap[(f + 1) & 1], &ctr->n_lanes, ctr, launch_id, o.tile);
     } else {
         if ((int)blockIdx.x >= n_active) return;
         pc_more_body(P, n_active, ctr, launch_id);

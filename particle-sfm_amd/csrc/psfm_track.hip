@@ -474,6 +474,11 @@ static void psfm_fill_chain_args_impl(psfm_ctx* c, const PsfmTrackDims& d, const
     a.log_prev = lg + (int64_t)(frame > 0 ? frame - 1 : 0) * d.cap;
     a.xs = c->sol_x.as<double2>(); a.xs_stride = d.cap;
     a.owner_clear = 0;
+    {
+        static const int on = getenv("PSFM_XCD_TILES") ? atoi(getenv("PSFM_XCD_TILES")) : 1;     // (0: tiles in block order; measurements)
+        const int gb = (a.Gband + PSFM_CHAIN_TILE - 1) / PSFM_CHAIN_TILE;
+        a.xcd_tiles = (on && gb >= 64) ? gb : 0;
+    }
 }
 
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
