@@ -102,7 +102,7 @@ struct PcParams {
     double* partials;         // [PC_MAX_BLOCKS][PC_NSUM]
     // launch chain / resident solve: the lanes that take part in this solve, compacted per block by pc_init (pc_build_list):
     // block b's entries are list[b * list_pitch + 0 .. list_n[b]), thread t walks entries t, t + PC_BLOCK, ...
-    int* list; int* list_n; int list_pitch;
+    int* list; int* list_n; int list_pitch; int list_banded;
     PsfmSolveCtrl* ctrl;
     int* stall;               // != 0: an earlier solve of this sequence ran out of unrolled iterations -> do nothing
     unsigned* ticket;         // last-block detection
@@ -177,16 +177,27 @@ __device__ __forceinline__ int pc_build_list(const PcParams& P, int n)
     __shared__ int s_wc[PC_BLOCK / PSFM_WAVE];
     int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
     const int lane = threadIdx.x & (PSFM_WAVE - 1), w = threadIdx.x / PSFM_WAVE;
+    // Which chunks: by default XCD-BANDED -- blocks go to the eight XCDs round-robin, each XCD has a private L2, and lanes are
+    // (roughly) in image order: the blocks of XCD x = b % 8 share the x-th eighth of the chunks (block b takes chunks
+    // x * per + b / 8 + k * (blocks per XCD)), so the taps of an XCD's tracks come from one band of the flow field (2 MB of 16.6 at
+    // 1080p: it stays in that XCD's 4 MB L2 across the rounds of a solve) instead of from all of it.  P.list_banded == 0 or a
+    // grid that is not a multiple of 8: chunks b, b + gridDim.x, ...
+    const int nchunk = (n + PC_BLOCK - 1) / PC_BLOCK;
+    const bool banded = P.list_banded && (gridDim.x & 7u) == 0u && nchunk >= 64;
+    const int per = banded ? (nchunk + 7) / 8 : nchunk;                 // chunks of a band
+    const int first = banded ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // first chunk of this block inside its band
+    const int step = banded ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int band0 = banded ? (int)(blockIdx.x & 7u) * per : 0;
     int base = 0;
-    for (int c0 = blockIdx.x * PC_BLOCK; c0 < n; c0 += gridDim.x * PC_BLOCK) {
-        const int i = c0 + threadIdx.x;
+    for (int q = first; q < per && band0 + q < nchunk; q += step) {
+        const int i = (band0 + q) * PC_BLOCK + (int)threadIdx.x;
         const bool part = pc_participates(P, i, n);
         const unsigned long long m = __ballot(part);
         if (lane == 0) s_wc[w] = __popcll(m);
         __syncthreads();
         int off = base, tot = 0;
 #pragma unroll
-        for (int q = 0; q < PC_BLOCK / PSFM_WAVE; ++q) { if (q < w) off += s_wc[q]; tot += s_wc[q]; }
+        for (int qq = 0; qq < PC_BLOCK / PSFM_WAVE; ++qq) { if (qq < w) off += s_wc[qq]; tot += s_wc[qq]; }
         if (part) lst[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
         base += tot;
         __syncthreads();      // (s_wc is rewritten by the next chunk; the list entries are visible to the block behind it)
@@ -1478,7 +1489,12 @@ static psfm_status pc_setup(psfm_ctx* c, PcParams& P, hipStream_t s)
     // the blocks' lists (pc_build_list): block b of the chain's grid sees the lane chunks b, b + n_blocks, ...
     const int n_blocks = pc_blocks(P.n_rows);
     const int chunks = (P.n_rows + PC_BLOCK - 1) / PC_BLOCK;
-    P.list_pitch = ((chunks + n_blocks - 1) / n_blocks) * PC_BLOCK;
+    // (a banded block takes every (n_blocks / 8)-th chunk of a band of ceil(chunks / 8): at most one chunk more than in block order)
+    P.list_pitch = ((chunks + n_blocks - 1) / n_blocks + 1) * PC_BLOCK;
+    {
+        static const int band = getenv("PSFM_PC_BAND") ? atoi(getenv("PSFM_PC_BAND")) : 1;      // (0: chunks in block order; measurements)
+        P.list_banded = band;
+    }
     if ((rc = c->sol_list.ensure(sizeof(int) * ((size_t)n_blocks * P.list_pitch + PC_MAX_BLOCKS))) != PSFM_OK) return rc;
     P.list_n = c->sol_list.as<int>();
     P.list = P.list_n + PC_MAX_BLOCKS;
@@ -1582,7 +1598,7 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
     if ((env && atoi(env) == 0) || !c->pc_persist_ok || c->pc_giveups >= 2 || P.export_sums) return false;
     if (n_blocks > PC_RES_BLOCKS) return false;
     // slots per thread: what the longest possible list needs, at most PC_RES_NS_MAX (longer lists are streamed behind the slots)
-    int ns = P.list_pitch / PC_BLOCK;
+    int ns = P.list_pitch / PC_BLOCK - 1;           // (the pitch has one chunk of head-room, see pc_setup)
     if (getenv("PSFM_PC_SLOTS")) ns = atoi(getenv("PSFM_PC_SLOTS"));      // (measurements, tests: fewer slots = a streamed tail)
     ns = ns < 1 ? 1 : (ns > PC_RES_NS_MAX ? PC_RES_NS_MAX : ns);
     const int capacity = ns == 1 ? pc_resident_capacity<1>(c) : (ns == 2 ? pc_resident_capacity<2>(c) : pc_resident_capacity<3>(c));
