@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 4: the members' rows of the all-reduce through their XCD's L2 (PSFM_PC_FASTHOP=0: over the fabric): parity + hard-sequence timing A/B
+O=$GRAFT_REPO_ROOT/gpurun_out/r04_u; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_gpu_solver.py -x -q -m gpu > $O/tests.log 2>&1; echo "tests rc $?" >> $O/tests.log; tail -4 $O/tests.log
+for v in 1 0 1 0; do
+  PSFM_PC_FASTHOP=$v PSFM_PROBE_HARD=1 PSFM_PROBE_MODES=adaptive timeout 300 python scripts/probe_solver.py 2> /dev/null | python -c "import json,sys; d=json.load(sys.stdin); a=d['adaptive']; print('PSFM_PC_FASTHOP=$v', 'ms/seq %.3f' % a['ms_per_sequence'], a['counters'])" | tee -a $O/ab.txt
+done
