@@ -323,8 +323,12 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
                               "valu_wave_instructions_per_launch": wi,
                               "valu_source": dict(vprov, what="PMC SQ_INSTS_VALU of the frame kernel, scaled by this run's tracks x iterations; "
                                                                + str(v.get("source", ""))[:200]),
-                              "traffic": v.get("hbm_bytes_per_launch"),
-                              "traffic_source": v.get("traffic_source", "profiles/solver_valu.json (replayed)")})
+                              # (the PMC passes run the 1080p, sample_ratio-2 workload: no figure for another shape)
+                              "traffic": v.get("hbm_bytes_per_launch") if (h, w) == (1080, 1920) and merged else None,
+                              "traffic_source": v.get("traffic_source") if (h, w) == (1080, 1920) and merged else
+                              "not measured for this shape (profiles/solver_valu.json holds the 1080p launch's PMC traffic)"})
+                if entry["traffic"]:
+                    entry["frac_physical"] = entry["traffic"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
             except Exception:
                 pass
         if not fused and vall:

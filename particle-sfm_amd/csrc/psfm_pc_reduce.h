@@ -36,12 +36,13 @@ __device__ __forceinline__ double pc_xchg(double v)      // the value of the lan
 }
 #define PC_ADDED 12      // slots that are added: all of PC_NSUM but SUM_GMAX, in slot order
 __host__ __device__ constexpr int pc_added_slot(int i) { return i < SUM_GMAX ? i : i + 1; }
+// The exchange tree over the 16 lanes of a row: returns the row total this lane ends up holding and the slot it belongs to
+// (PC_NSUM: the spare column -- the rows' maximum lands in four lanes, one of them keeps it under SUM_GMAX).
 template <int NS_>
-__device__ __forceinline__ void pc_block_sums(const double* acc, double* out)
+__device__ __forceinline__ double pc_row_tree(const double* acc, int& slot)
 {
     static_assert(PC_NSUM == PC_ADDED + 1 && SUM_GMAX == 5, "the exchange tree below is laid out for 12 added slots + the maximum");
-    __shared__ double s_row[4 * (PC_BLOCK / PSFM_WAVE)][PC_NSUM + 1];
-    const int tid = threadIdx.x, lane = tid & (PSFM_WAVE - 1);
+    const int lane = threadIdx.x & (PSFM_WAVE - 1);
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
     double c[6], e[4], f[2];
 #pragma unroll
@@ -66,12 +67,20 @@ __device__ __forceinline__ void pc_block_sums(const double* acc, double* out)
         const double keep = b3 ? f[1] : f[0], recv = pc_xchg<3>(b3 ? f[0] : f[1]);
         g = (b2 && b3) ? fmax(keep, recv) : keep + recv;
     }
-    {
-        const int t = (b2 ? 2 : 0) + (b3 ? 1 : 0);
-        const int idx = (b0 ? 6 : 0) + (b1 ? 3 : 0) + t;
-        const int slot = t == 3 ? ((b0 || b1) ? PC_NSUM : SUM_GMAX) : (idx < SUM_GMAX ? idx : idx + 1);      // (PC_NSUM: the spare column)
-        s_row[tid >> 4][slot] = g;
-    }
+    const int t = (b2 ? 2 : 0) + (b3 ? 1 : 0);
+    const int idx = (b0 ? 6 : 0) + (b1 ? 3 : 0) + t;
+    slot = t == 3 ? ((b0 || b1) ? PC_NSUM : SUM_GMAX) : (idx < SUM_GMAX ? idx : idx + 1);
+    return g;
+}
+
+template <int NS_>
+__device__ __forceinline__ void pc_block_sums(const double* acc, double* out)
+{
+    __shared__ double s_row[4 * (PC_BLOCK / PSFM_WAVE)][PC_NSUM + 1];
+    const int tid = threadIdx.x;
+    int slot;
+    const double g = pc_row_tree<NS_>(acc, slot);
+    s_row[tid >> 4][slot] = g;
     __syncthreads();
     if (tid < NS_) {
         double v = s_row[0][tid];
@@ -81,4 +90,3 @@ __device__ __forceinline__ void pc_block_sums(const double* acc, double* out)
     }
     __syncthreads();
 }
-

@@ -1014,6 +1014,17 @@ struct PcTrack {            // one track's solve state in registers
     double iA22;            // 1 / (H22 (1 + mu)) at the mu the fused solve speculates
 };
 
+// (Round 4 tried a tap NEIGHBOURHOOD per track in LDS -- 3 rows x 4 columns of F12 around the start position, brought in by six
+// global_load_lds_dwordx4 per lane at the setup, so that the K evaluations behind it take their taps from LDS instead of a dependent
+// gather each: bit-identical, and 2 % SLOWER (frame kernel 66.7 vs 65.4 us at 1080p).  The taps of an iterate lie in the cache
+// lines its predecessor touched: those gathers are L1 hits, not round trips to L2 / HBM.  profiles/EXPERIMENTS.md 6.5.)
+// residuals and Jacobian of T at T.x
+__device__ __forceinline__ void pc_track_eval(const PcParams& P, PcTrack& T)
+{
+    const PcTaps t = pc_core_taps<PC_FUSED_PAIR>((const PcF2*)P.flow12, P.H, P.W, T.x);
+    pc_core_eval_taps(t, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
+}
+
 // sums of one trust-region iteration at T.x (already evaluated: T.r, T.jac) into v[]; the candidate goes to (xn1, xn2)[i]
 // and becomes T.x, evaluated.  The same function as the launch chain's iteration, with (a, b) = (0, 1) at compile time.
 __device__ __forceinline__ void pc_fused_iteration(const PcParams& P, PcTrack& T, double mu, double2* xn1, double2* xn2, int i,
@@ -1027,15 +1038,39 @@ __device__ __forceinline__ void pc_fused_iteration(const PcParams& P, PcTrack& T
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) T.x[k] = xp[k];
-    pc_core_eval<PC_FUSED_PAIR>((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
+    pc_track_eval(P, T);
     v[SUM_COST] += pc_core_cost(T.r);
 }
 
-// Sums of one iteration over the 64 tracks of a WAVE, through LDS, without a block barrier (the four waves of a block
-// stay independent inside the iteration loop): every lane parks its 13 values; lane 4k+q adds the values of lanes
-// q, q+4, ... of slot k in lane order; lanes k < 13 add the four quarter sums.  Fixed order.  LDS operations of one wave
-// execute in order, so the wave only has to wait for its own stores.
+// Sums of one iteration over the 64 tracks of a WAVE, without a block barrier (the four waves of a block stay independent
+// inside the iteration loop).  Round 4: the transposed exchange tree of psfm_pc_reduce.h inside each 16-lane row (registers, DPP),
+// the four row totals of a slot through 450 bytes of LDS per wave, added in row order by lane k < 13.  Fixed order.  (Rounds 2-3
+// parked every lane's 13 values in LDS -- 27 KB per block, the space the tap neighbourhoods below need; PC_WAVE_PARK keeps
+// that form for A/B builds.)  LDS operations of one wave execute in order, so the wave only has to wait for its own stores.
 #define PC_NW (PC_BLOCK / PSFM_WAVE)
+#ifndef PC_WAVE_PARK
+struct PcWaveRed {
+    double row[PC_NW][4][PC_NSUM + 1];
+    double wsum[PC_NW][PC_KMAX][PC_NSUM];
+};
+__device__ __forceinline__ void pc_wave_reduce(PcWaveRed& R, const double v[PC_NSUM], int iter)
+{
+    const int lane = threadIdx.x & (PSFM_WAVE - 1), w = threadIdx.x / PSFM_WAVE;
+    int slot;
+    const double g = pc_row_tree<PC_NSUM>(v, slot);
+    R.row[w][lane >> 4][slot] = g;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < PC_NSUM) {
+        const double q0 = R.row[w][0][lane], q1 = R.row[w][1][lane], q2 = R.row[w][2][lane], q3 = R.row[w][3][lane];
+        R.wsum[w][iter][lane] = (lane == SUM_GMAX) ? fmax(fmax(fmax(q0, q1), q2), q3) : ((q0 + q1) + q2) + q3;
+    }
+    // (the next iteration's row stores come behind these loads in the wave's LDS queue)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#else
 #define PC_WROW 66          // row pitch in doubles: 2-way instead of 13-way bank conflicts in the quarter sums
 struct PcWaveRed {
     double park[PC_NW][PC_NSUM][PC_WROW];
@@ -1074,6 +1109,7 @@ __device__ __forceinline__ void pc_wave_reduce(PcWaveRed& R, const double v[PC_N
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+#endif
 
 // drain this block's write-through stores, then take a ticket: true for the last of `members` arrivals (which also
 // resets the counter for the next launch)
@@ -1112,7 +1148,8 @@ __device__ __forceinline__ double pc_track_setup(const PcParams& P, PcTrack& T, 
     T.r1 = make_double2(p0.x + (double)f01.x, p0.y + (double)f01.y);
     T.r2 = make_double2(p0.x + (double)f02.x, p0.y + (double)f02.y);
     T.x[0] = p1.x; T.x[1] = p1.y; T.x[2] = p2.x; T.x[3] = p2.y;
-    pc_core_eval<PC_FUSED_PAIR>((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, (double)sf, T.r, T.jac);
+    T.c.s = (double)sf;
+    pc_track_eval(P, T);
     // Jacobi scaling from the Jacobian at x0 (what psfm_pc_init_kernel stores in P.jscale)
     T.c = pc_core_const((double)sf, T.jac);
     T.iA22 = pc_core_iA22(T.c, mu);
@@ -1262,7 +1299,7 @@ __device__ __forceinline__ void pc_more_body(const PcParams& P, int n_active, Ps
         (void)pc_track_setup(P, T, p0, s1, s2, mu);
         const double2 c1 = pc_buf1(P, pc_phys(base, e))[i], c2 = pc_buf2(P, pc_phys(base, e))[i];  // the current iterate
         T.x[0] = c1.x; T.x[1] = c1.y; T.x[2] = c2.x; T.x[3] = c2.y;
-        pc_core_eval<PC_FUSED_PAIR>((const PcF2*)P.flow12, P.H, P.W, T.x, T.r1.x, T.r1.y, T.r2.x, T.r2.y, T.c.s, T.r, T.jac);
+        pc_track_eval(P, T);
     }
     for (int j = 0; j < n_it; ++j) {
         double v[PC_NSUM];

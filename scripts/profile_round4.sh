@@ -31,6 +31,9 @@ run pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST
 export PSFM_PROBE_MODES=adaptive
 run opt_stats --stats -f csv -d $OUT/opt_stats -o ${TAG}_opt -- $PR
 run opt_pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM --kernel-include-regex "psfm_" -f csv -d $OUT/opt_pmc_sq -o s -- $PR
+# (the frame kernel has no device-wide hand-off -- its last block to arrive does the control step -- so the L2 counters are safe on it)
+run opt_fetch --pmc $RD --kernel-include-regex "psfm_seq" -f csv -d $OUT/opt_fetch -o f -- $PR
+run opt_write --pmc $WR --kernel-include-regex "psfm_seq" -f csv -d $OUT/opt_write -o w -- $PR
 # ---- hard flows (sigma 0.3, 5 % occluders): the resident solve.  SQ counters only: TA / TCC passes hang kernels with a device-wide hand-off ----
 export PSFM_PROBE_HARD=1
 run hard_stats --stats -f csv -d $OUT/hard_stats -o ${TAG}_hard -- $PR
