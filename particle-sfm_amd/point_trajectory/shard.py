@@ -4,6 +4,7 @@ exchange tensors -- the stamped grid-resolution `blocked` maps (+ survivor byte)
 be torch tensors for torch.distributed, and sequences the export -> reduce -> control steps of a solve.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -20,6 +21,9 @@ class HipShardEngine:
         self._pending = []                 # solves enqueued since the last checkpoint: (frame, the tensors a redo needs)
         self.check_every = 16              # frames between two checkpoints (earlier when stalled() says a solve has to be redone)
         self.counters = {"fused": 0, "fused_redone": 0}
+        # iterations speculated beyond what the clean solves of the last 16 frames needed: an iteration more costs a few us per frame,
+        # a solve that needed one more than speculated costs a redo through the launch chain and the frames behind it once again
+        self.k_margin = int(os.environ.get("PSFM_SHARD_K_MARGIN", "0"))
 
     @property
     def device(self):
@@ -145,7 +149,7 @@ class HipShardEngine:
                                                                   (st.termination == 2 and st.iterations == st.successful_steps))
         if st.termination >= 0 and clean:
             self._need = (self._need + [min(K_MAX, st.successful_steps + 1)])[-16:]
-            self.k = max(self._need)
+            self.k = min(K_MAX, max(self._need) + self.k_margin)
 
     def finish(self):
         """the own trajectories on the HOST: (birth, length, off, xy, solve statistics)"""

@@ -340,6 +340,8 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     occ = flow_check_sharded(flows_f, flows_b, thres, check_fn, comm=comm, n_total=n_flows if owned else None)
     occ2 = (flow_check_sharded(flows_f2, flows_b2, thres, check_fn, comm=comm, n_total=n2 if owned else None)
             if optimize and n2 > 0 else None)
+    # (Stage A stays up front also at world size 1: in chunks on a side stream, a chunk ahead of the recurrence -- the way the one-GPU call
+    # hides two thirds of its flow_check -- ONE sequence of configs[3] took 40.3-41.9 ms instead of 38.1-38.3: profiles/EXPERIMENTS.md 6.6)
     # ---- Stage B: the recurrence, tracks split by birth row band ----
     # n_flows_total given: the four stacks are owned by Stage A's frame-pair shards (every rank passed its slice only); the
     # forward stacks reach the other ranks frame by frame, broadcast from their owner two frames ahead of the recurrence
@@ -354,8 +356,11 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     has_ck = optimize and hasattr(engine, "checkpoint")
     merged = has_ck and hasattr(engine, "frame") and os.environ.get("PSFM_SHARD_MERGED", "1") != "0"
     if has_ck:
-        # one rank sees a stall early (_any_stalled); several ranks must agree without talking: a short fixed window
-        engine.check_every = 16 if world == 1 else 4
+        # one rank sees a stall early (_any_stalled: the flag follows every control step into pinned memory), so its window is the
+        # sequence -- every synchronisation drains the launch queue, and the speculated K only moves at a checkpoint (16 frames per
+        # window: 39.0 ms for configs[3], 7 solves redone; 64: 39.4; the sequence: 37.8, none).  Several ranks must agree on when
+        # to rewind without talking: a short fixed window.
+        engine.check_every = int(os.environ.get("PSFM_SHARD_CHECK_EVERY", "0")) or (max(16, n_flows) if world == 1 else 4)
     confirmed = 0                  # frames below this are final
     since = 0                      # frames enqueued since the last checkpoint
     t = 0
