@@ -56,7 +56,8 @@
 #define PP_WHATIF 0      // TIMING EXPERIMENTS ONLY (the results are wrong by construction): what a frame of the loop would cost without
                          // one of the links of its chain -- 1: no births / adoptions behind the barrier (the blocked bytes are still
                          // loaded; no phase-2 gathers), 2: arrive without waiting for the marks' acknowledgement, 4: no barrier wait
-                         // (blocks run free), 8: no blocked-byte / hand-off loads either.  profiles/EXPERIMENTS.md section 6.
+                         // (blocks run free), 8: no blocked-byte / hand-off loads either, 16: no mandatory flow_check slices in front of the arrival,
+                         // 32: none in the barrier wait (16 / 48: the maps stay incomplete).  profiles/EXPERIMENTS.md sections 6.2, 6.8.
 #endif
 #ifndef PP_WAVES_N
 #define PP_WAVES_N 8     // waves per SIMD the loop is compiled for (8: 64 VGPRs, every lane of a 1080p / ratio-2 grid resident)
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
             const unsigned* flag = a.bar + (65 + shard) * 32;
             const int fc_lim = t + PP_FC_AHEAD < a.n_flows ? t + PP_FC_AHEAD : a.n_flows;
             while (fc_next < fc_lim) {
-                if (__builtin_amdgcn_readfirstlane((int)psfm_coh_ld(flag)) >= t + 1) break;
+                if (__builtin_amdgcn_readfirstlane((int)psfm_coh_ld(flag)) >= t + 1 || (PP_WHATIF & 32)) break;
                 psfm_fc_slice(a, fc_next, tid);
                 ++fc_next;
             }
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(PP_BLOCK) PP_WAVES void psfm_chain_persist_kernel(P
         // barrier before that one is known to be complete: maps up to t+2 must be finished before arriving at #t+1)
         if (a.fc) {
             const int need = t + 3 < a.n_flows ? t + 3 : a.n_flows;
-            for (; fc_next < need; ++fc_next) psfm_fc_slice(a, fc_next, tid);
+            if (!(PP_WHATIF & 16)) for (; fc_next < need; ++fc_next) psfm_fc_slice(a, fc_next, tid);
         }
         // ---- F: arrive.  No block barrier in front of it: a wave whose stores are acknowledged counts itself in (LDS) and
         //      goes on to the next frame; the wave that comes last arrives for the block ----

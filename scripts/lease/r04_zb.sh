@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4: the fused loop's flow_check slices with the taps of 2 / 4 pixels in flight together (product = 2; variants fcb0 = pixel by pixel
+# as in rounds 1-3, fcb4): exactness on every shape + us per step of the fused launch
+O=$GRAFT_REPO_ROOT/gpurun_out/r04_zb; mkdir -p $O
+cd $GRAFT_REPO_ROOT
+V=$GRAFT_REPO_ROOT/particle-sfm_amd/lib/variants
+P=$GRAFT_REPO_ROOT/particle-sfm_amd/lib/libpsfm_hip.so
+for lib in $P $V/libpsfm_hip_fcb0.so $V/libpsfm_hip_fcb4.so $P $V/libpsfm_hip_fcb0.so; do
+  PSFM_HIP_LIB=$lib timeout 300 python scripts/probe_persist_variant.py 2> /dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); t=d['timing_1080p']
+print(d['lib'], 'exact' if d['ok'] else 'NOT EXACT', 'track us/step %.2f' % t['track_chain_us_per_step'], 'connect us/step %.2f' % t['connect_us_per_step'], 'connect ms %.3f' % t['connect_ms'], 'modes', t['track_mode'], t['connect_mode'])" | tee -a $O/ab.txt
+done

@@ -280,7 +280,8 @@ def test_track_optimize_full_size_properties(pt):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("H,W,T,r,seed", [(120, 200, 9, 2, 61), (90, 140, 8, 3, 62), (436, 1024, 6, 2, 63)])
+# (the dense 436 x 640 grid: 545 tracks per block -- with ONE slot per thread more than half of them are streamed behind the slots)
+@pytest.mark.parametrize("H,W,T,r,seed", [(120, 200, 9, 2, 61), (90, 140, 8, 3, 62), (436, 1024, 6, 2, 63), (436, 640, 5, 1, 64)])
 def test_launch_chain_as_one_persistent_launch_is_the_same_solve(pt, monkeypatch, H, W, T, r, seed):
     """Solves that reject steps run the launch chain; with the device to itself the chain's loop is ONE persistent launch
     (psfm_pc_persist_kernel: a device-wide barrier per trust-region iteration) instead of one launch per iteration.  Both forms
