@@ -19,13 +19,15 @@ int psfm_gate_waiters(int device) { return g_dev_waiters[device & 15].load(std::
 void psfm_gate_waiters_add(int device, int d) { g_dev_waiters[device & 15].fetch_add(d, std::memory_order_relaxed); }
 // Would this call run the persistent loop?  0 no, 1 yes if the device is free, 2 yes, wait for the device.
 // Mode 0 decides by shape, from measurements on MI355X (scripts/probe_shapes.py; 100 frames, flow_check + recurrence +
-// finalize, persistent / per-frame): the loop costs ~14 us per frame whatever the frame size (a barrier and five
-// dependent memory operations), a per-frame launch 7-16 us.
-//   psfm_track on ready maps: 1080p r=2 0.93, 1080p r=4 0.93, 720p r=2 0.94, 436x1024 r=2 0.98, 4K r=4 0.92 -- but
-//     480x854 r=4 (25 k grid points) 1.03 and every r=1 shape 1.13-1.14  ->  sample_ratio >= 2 and >= 100 k grid points;
-//   psfm_connect with flow_check fused in: 1080p r=2 0.94 -- 720p r=2 1.01, 1080p r=4 1.42, 4K r=4 1.09 (flow_check
-//     inside the loop only runs where waves wait; beside a short or flow_check-heavy step the side stream is better)
-//     ->  additionally >= 400 k grid points and at most 6 pixels per grid point.
+// finalize, persistent / per-frame; round-4 sources, profiles/r04/r04_y_probe_shapes.txt): a frame is one dependent chain in
+// either form -- the loop ~8 us of barrier + own step and ~5.5 us of births behind it whatever the frame size, a per-frame
+// launch ~10 us + 22 us per million lanes -- so the loop wins where the lanes are many and births the exception:
+//   psfm_track on ready maps: 1080p r=2 0.90, 4K r=4 0.93, 720p r=2 0.96, 1080p r=4 0.99 -- 436x1024 r=2 1.02, 480x854 r=4
+//     (25 k grid points) 1.06, and r=1 (every pixel a grid point: a death is a birth one frame later, births are the bulk)
+//     720p 1.00, 540x960 1.07, 480x640 1.11  ->  sample_ratio >= 2 and >= 100 k grid points;
+//   psfm_connect with flow_check fused in: 1080p r=2 0.94 -- 720p r=2 1.02, 1080p r=4 1.62, 4K r=4 1.20 (inside the loop
+//     flow_check costs its full bandwidth time, profiles/EXPERIMENTS.md 6.8; beside a short or flow_check-heavy step the
+//     side stream of the per-frame path is better)  ->  additionally >= 400 k grid points and at most 6 pixels per grid point.
 static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int ratio, bool fused)
 {
     if (c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;
