@@ -1,8 +1,9 @@
 """Random sequences through track_optimize on the device vs the CPU oracle: ids / lengths / per-solve iteration counts
-and terminations must be equal, positions within 1e-5 px (the device's solver arithmetic differs from the restatement's by
-rounding since round 3; long noisy solves amplify that to ~1e-7).  A third of the cases drift ~10 px per frame (the 20 px gate
+and terminations must be equal, positions within the 1e-4 px of the parity tests (the device's solver arithmetic and the order of its
+sums differ from the restatement's by rounding; long noisy solves amplify that to ~1e-5 on maps with 10^5 tracks: the worst case is reported).  A third of the cases drift ~10 px per frame (the 20 px gate
 of loss02_scale, tracks leaving the image).  Prints one JSON line at the end.
-Usage: python scripts/stress_optimize.py [n_cases] [seed]"""
+Usage: python scripts/stress_optimize.py [n_cases] [seed] [big]      (big: 300-540 x 400-960 maps at sample_ratio 1-2, up to 500 k tracks per
+solve -- the resident solve with one to three tracks per thread and a streamed tail)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "particle-sfm_amd"))
@@ -12,7 +13,8 @@ from point_trajectory.track_optimize import track_optimize
 from oracle import oracle as orc
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-orc.set_num_threads(min(8, os.cpu_count() or 1))    # (tiny maps: the OpenMP loops of the oracle crawl on all 256 cores of a GPU box)
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
+orc.set_num_threads(min(32 if big else 8, os.cpu_count() or 1))    # (tiny maps: the OpenMP loops of the oracle crawl on all 256 cores of a GPU box)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = exact = iters = rejected = 0
 worst = 0.0
@@ -20,6 +22,8 @@ t0 = time.time()
 for k in range(n_cases):
     H, W = int(rng.integers(40, 200)), int(rng.integers(40, 240))
     T, r = int(rng.integers(4, 14)), int(rng.integers(1, 5))
+    if big:
+        H, W, T, r = int(rng.integers(300, 540)), int(rng.integers(400, 960)), int(rng.integers(4, 8)), int(rng.integers(1, 3))
     sigma, nocc = float(rng.uniform(0.02, 0.6)), int(rng.integers(0, 4))
     drift = (float(rng.uniform(-11, 11)), float(rng.uniform(-4, 4))) if rng.uniform() < 0.33 else (0.0, 0.0)
     d = psfm_synth.synth_sequence(T, H, W, seed=int(rng.integers(1 << 30)), sigma=sigma, n_occluders=nocc, stride2=True,
@@ -35,7 +39,7 @@ for k in range(n_cases):
     non_gn = sum(s["dogleg_nonGN"] for s in O.solves)
     worst = max(worst, err if same else 0.0)
     iters += sum(s["iterations"] for s in O.solves); rejected += sum(s["iterations"] - s["successful_steps"] for s in O.solves)
-    if not same or err > 1e-5:
+    if not same or err > 1e-4:
         bad += 1
         print("MISMATCH case %d: %dx%d T=%d r=%d sigma=%.3f occluders=%d: same=%s err=%.3e nonGN=%d" % (k, H, W, T, r, sigma, nocc, same, err, non_gn))
     exact += int(err == 0.0)
