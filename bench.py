@@ -813,7 +813,10 @@ def main():
         sys.stdout.flush()
         os._exit(0)
     if world > 1:
-        dist.barrier()
+        # (a rank that left early -- an error in its extra mode -- must not keep the others in this barrier for ever)
+        _, stuck = guarded(lambda: (dist.barrier(), torch.cuda.synchronize()), 120)
+        if stuck:
+            os._exit(0)
         dist.destroy_process_group()
 
 
