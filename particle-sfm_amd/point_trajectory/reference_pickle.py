@@ -21,6 +21,7 @@ template instance, so it is whatever this NumPy / this class produce.
 import pickle
 import pickletools
 import struct
+import threading
 
 import numpy as np
 
@@ -70,21 +71,9 @@ def can_stream(ts):
             and (len(csr[0]) == 0 or (int(np.max(csr[0])) < (1 << 31) and int(np.min(csr[0])) >= 0)))
 
 
-def dump(fp, ts):
-    """Write the object array holding `ts` (what np.save(path, ts) writes behind the .npy header) to the open binary file."""
-    ids, birth, length, off, xy, _ = ts._csr
-    n = len(ids)
-    # the container: pickle a template instance whose state is a sentinel, cut the stream at the sentinel
-    tmpl = type(ts).__new__(type(ts))
-    tmpl.__dict__["_state_override"] = _SENTINEL
-    arr = np.empty((), dtype=object)
-    arr[()] = tmpl
-    stream = pickle.dumps(arr, protocol=3)
-    mark = b"C" + bytes([len(_SENTINEL)]) + _SENTINEL
-    i = stream.index(mark)
-    j = i + len(mark)
-    assert stream[j:j + 1] == b"q" and stream.count(mark) == 1, "unexpected pickle layout of the template"
-    prefix, suffix = stream[:i], stream[j + 2:]
+def _write_front(fp, prefix, xy):
+    """Everything in front of the records: the container's prefix, the shared objects (the point array among them), the dict's MARK.
+    Returns (file offset of the raw point bytes or -1, the point array as written, file offset of the first record)."""
     fp.write(prefix)
     # preamble: the shared objects, each memoised and popped again
     xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
@@ -107,19 +96,54 @@ def dump(fp, ts):
              + _key(b"frame_ids", _M_KF) + _key(b"locations", _M_KL) + _key(b"labels", _M_KB))
     # the state: one dict, all records under one MARK ... SETITEMS
     fp.write(b"}(")
+    return xy_data, xy, fp.tell()
+
+
+def dump(fp, ts):
+    """Write the object array holding `ts` (what np.save(path, ts) writes behind the .npy header) to the open binary file."""
+    ids, birth, length, off, xy, _ = ts._csr
+    n = len(ids)
+    # the container: pickle a template instance whose state is a sentinel, cut the stream at the sentinel
+    tmpl = type(ts).__new__(type(ts))
+    tmpl.__dict__["_state_override"] = _SENTINEL
+    arr = np.empty((), dtype=object)
+    arr[()] = tmpl
+    stream = pickle.dumps(arr, protocol=3)
+    mark = b"C" + bytes([len(_SENTINEL)]) + _SENTINEL
+    i = stream.index(mark)
+    j = i + len(mark)
+    assert stream[j:j + 1] == b"q" and stream.count(mark) == 1, "unexpected pickle layout of the template"
+    prefix, suffix = stream[:i], stream[j + 2:]
+    # The records (66 bytes per trajectory, filled in with NumPy) are built on a helper thread while this one writes the point array --
+    # the bulk of the file, a single write() that spends its time in the kernel's page-cache copy with the GIL released.
     rec, at = _record_template()
     R = len(rec)
-    rec_start = fp.tell()
     step = 1 << 18
     ids = np.asarray(ids, np.int64); birth = np.asarray(birth, np.int64); length = np.asarray(length, np.int64); off = np.asarray(off, np.int64)
-    for lo in range(0, n, step):
-        hi = min(n, lo + step)
-        buf = np.tile(np.frombuffer(rec, np.uint8), hi - lo).reshape(hi - lo, R)
-        fields = {"id": ids[lo:hi], "b": birth[lo:hi], "bn": birth[lo:hi] + length[lo:hi], "s": off[lo:hi], "e": off[lo + 1:hi + 1],
-                  "n": length[lo:hi]}
-        for name, v in fields.items():
-            buf[:, at[name]:at[name] + 4] = v.astype("<i4").view(np.uint8).reshape(-1, 4)
-        fp.write(buf.tobytes())
+    chunks, failed = [], []
+
+    def build_records():
+        try:
+            for lo in range(0, n, step):
+                hi = min(n, lo + step)
+                buf = np.tile(np.frombuffer(rec, np.uint8), hi - lo).reshape(hi - lo, R)
+                fields = {"id": ids[lo:hi], "b": birth[lo:hi], "bn": birth[lo:hi] + length[lo:hi], "s": off[lo:hi], "e": off[lo + 1:hi + 1],
+                          "n": length[lo:hi]}
+                for name, v in fields.items():
+                    buf[:, at[name]:at[name] + 4] = v.astype("<i4").view(np.uint8).reshape(-1, 4)
+                chunks.append(buf)
+        except BaseException as e:      # noqa: BLE001  (handed to the writing thread: a short record list must not reach the file)
+            failed.append(e)
+    builder = threading.Thread(target=build_records)
+    builder.start()
+    try:
+        xy_data, xy, rec_start = _write_front(fp, prefix, xy)
+    finally:
+        builder.join()
+    if failed:
+        raise failed[0]
+    for buf in chunks:
+        fp.write(memoryview(buf).cast("B"))
     fp.write(b"u")
     fp.write(suffix)
     # footer: where the raw point bytes are

@@ -54,7 +54,7 @@ def load_flows_device_slice(dir, rank, world, device=None, **kw):
     return load_flows_device(dir, device=device, _names=names[lo:hi], _probe=names[:1], **kw), len(names)
 
 
-def load_flows_device(dir, device=None, n_staging=8, n_readers=4, _names=None, _probe=None):
+def load_flows_device(dir, device=None, n_staging=16, n_readers=8, _names=None, _probe=None):
     """`load_flows` (utils.py:26-32) straight into HBM: the .flo files are read by a few reader threads into pinned
     host buffers (owned by the context, reused across calls) and copied to their slot of one (n,H,W,2) device tensor with
     asynchronous H2D copies on a side stream, so disk / page-cache reads and PCIe transfers overlap (at
@@ -62,6 +62,8 @@ def load_flows_device(dir, device=None, n_staging=8, n_readers=4, _names=None, _
     Returns a float32 device tensor (empty (0,0,0,2) if no files)."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
+    n_staging = int(os.environ.get("PSFM_FLO_STAGING", n_staging))      # (measurement knobs)
+    n_readers = int(os.environ.get("PSFM_FLO_READERS", n_readers))
     names = sorted(glob.glob(dir + "/*.flo")) if _names is None else list(_names)
     ctx = _hip.context(device)
     dev = torch.device("cuda", ctx.device)
