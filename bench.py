@@ -575,6 +575,11 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the job has %d rank(s) (WORLD_SIZE): refusing to report a line for another size"
                  % (args.gpus, world))
+    # PSFM_BENCH_DRYRUN_ONE_GPU=1: every rank on cuda:0, collectives over gloo -- a dry run of the multi-rank CONTROL FLOW on a box with
+    # one GPU (the ranks fight for the device: the line it prints is marked and is not a measurement)
+    dryrun = world > 1 and os.environ.get("PSFM_BENCH_DRYRUN_ONE_GPU", "0") == "1"
+    if dryrun:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit("bench.py: rank %d needs cuda:%d, %d device(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     if world > 1:
@@ -583,7 +588,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if dryrun:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     import psfm_synth
     from point_trajectory import _hip
@@ -765,6 +773,8 @@ def main():
         out["kernels"].pop("respawn_avg_us", None)   # respawn is fused into chain_step
         out["config"]["world_size"] = dist.get_world_size() if world > 1 else 1
         out["config"]["ranks"] = rank_info     # what every rank of the job ran on (RCCL saw that many ranks)
+        if dryrun:
+            out["dryrun"] = "%d ranks on ONE GPU over gloo: the multi-rank control flow only, NOT a measurement" % world
         out["config"]["source_sha16"] = source_sha16()
         if single is not None:
             out["single_sequence"] = single

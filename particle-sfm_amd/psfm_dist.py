@@ -170,6 +170,8 @@ def reduce_totals(seconds, units, device=None, group=None):
     """bench.py's reduction: max over ranks of the elapsed time, sum over ranks of the processed units."""
     import torch
     import torch.distributed as dist
+    if dist.is_initialized() and dist.get_backend(group) == "gloo":
+        device = None                      # (gloo moves host memory)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -191,3 +191,25 @@ def test_rccl_operations_of_the_sharded_mode_on_a_one_rank_group():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_rccl_ops.py")], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode == 0 and "rccl ops ok: nccl" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def test_bench_multi_rank_control_flow_dry_run_on_one_gpu():
+    """`bench.py --gpus 2` end to end on the one GPU of the box (PSFM_BENCH_DRYRUN_ONE_GPU=1: every rank on cuda:0, collectives over
+    gloo): the rank bookkeeping, the max-time / summed-units reduction, `single_sequence` over frame-pair-owned stacks with their
+    broadcasts, the guarded closing barrier -- the line is marked as a dry run and its figures mean nothing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PSFM_BENCH_DRYRUN_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "11",
+                        "--single-seq-frames", "13"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "dryrun" in line and line["value"] > 0
+    ranks = line["config"]["ranks"]
+    assert ranks["world_size"] == 2 and ranks["backend"] == "gloo" and [q["rank"] for q in ranks["per_rank"]] == [0, 1]
+    ss = line["single_sequence"]
+    assert ss["world_size"] == 2 and ss["trajectories"] > 0 and 0 < ss["local_trajectories_rank0"] < ss["trajectories"]
