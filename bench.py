@@ -264,7 +264,7 @@ def guarded(fn, timeout_s):
     return box["r"], False
 
 
-def solver_roofline(R, prof, cnt, h, w, n_flows):
+def solver_roofline(R, prof, cnt, h, w, n_flows, ratio=RATIO):
     """SURVEY 8(d) algorithmic bytes of the track_optimize kernels / their HIP-event launch time / 8 TB/s.
     Per solve of frame f (N3 = tracks with three buffered points, k = trust-region iterations of that solve, P = H*W):
       pc_prepare = 2 min(8P, 32 N3) + min(P, 4 N3) + 16 N3 + 40 N3        (refs + scale: flow01, flow02, occ02 at p0)
@@ -317,16 +317,22 @@ def solver_roofline(R, prof, cnt, h, w, n_flows):
         if fused and vall:
             try:
                 v = vall
+                shape_key = "%dx%dx%d" % (h, w, ratio)
+                shape_traffic = (v.get("hbm_bytes_per_launch_by_shape") or {}).get(shape_key)
+                if shape_traffic is None and (h, w) == (1080, 1920):
+                    shape_traffic = v.get("hbm_bytes_per_launch")
                 wi = (v["valu_per_wave_per_iteration"] * entry["avg_iterations"] + v["valu_per_wave_fixed"]) * \
                      (entry["track_iterations_per_launch"] / max(entry["avg_iterations"], 1e-9)) / 64.0
                 entry.update({"achieved": wi / (us * 1e-6) / 1e9, "frac": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS,
                               "valu_wave_instructions_per_launch": wi,
                               "valu_source": dict(vprov, what="PMC SQ_INSTS_VALU of the frame kernel, scaled by this run's tracks x iterations; "
                                                                + str(v.get("source", ""))[:200]),
-                              # (the PMC passes run the 1080p, sample_ratio-2 workload: no figure for another shape)
-                              "traffic": v.get("hbm_bytes_per_launch") if (h, w) == (1080, 1920) and merged else None,
-                              "traffic_source": v.get("traffic_source") if (h, w) == (1080, 1920) and merged else
-                              "not measured for this shape (profiles/solver_valu.json holds the 1080p launch's PMC traffic)"})
+                              # (per shape: the PMC passes run scripts/probe_solver.py on 1080p, configs[2]'s and configs[4]'s shapes)
+                              "traffic": shape_traffic if merged else None,
+                              "traffic_source": (v.get("traffic_source") if (h, w) == (1080, 1920) else
+                                                 "profiles/solver_valu.json hbm_bytes_per_launch_by_shape[%r]: the same fabric-side "
+                                                 "counters on scripts/probe_solver.py at this shape (clean flows)" % shape_key)
+                              if merged and shape_traffic else "not measured for this shape"})
                 if entry["traffic"]:
                     entry["frac_physical"] = entry["traffic"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
             except Exception:
@@ -414,7 +420,7 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     ctx.set_profiling(0)
     cnt = ctx.solver_counters()
     Rh = _result_to_host(ctx, info)
-    roof = solver_roofline(Rh, pr, cnt, h, w, t - 1)
+    roof = solver_roofline(Rh, pr, cnt, h, w, t - 1, r)
     info_stats = list(Rh.solve_stats)
     del Rh
     _, occ = flow_check_device(d["flows_f"], d["flows_b"], thres)

@@ -34,6 +34,12 @@ run opt_pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_
 # (the frame kernel has no device-wide hand-off -- its last block to arrive does the control step -- so the L2 counters are safe on it)
 run opt_fetch --pmc $RD --kernel-include-regex "psfm_seq" -f csv -d $OUT/opt_fetch -o f -- $PR
 run opt_write --pmc $WR --kernel-include-regex "psfm_seq" -f csv -d $OUT/opt_write -o w -- $PR
+# ... and on the other two shapes bench.py reports a frame-kernel roofline for (configs[2]: 436 x 1024, configs[4]: dense 480 x 640)
+for SH in "436 1024 50 2" "480 640 200 1"; do
+  T=$(echo $SH | tr ' ' 'x')
+  run opt_fetch_$T --pmc $RD --kernel-include-regex "psfm_seq" -f csv -d $OUT/opt_fetch_$T -o f -- $PR $SH
+  run opt_write_$T --pmc $WR --kernel-include-regex "psfm_seq" -f csv -d $OUT/opt_write_$T -o w -- $PR $SH
+done
 # ---- hard flows (sigma 0.3, 5 % occluders): the resident solve.  SQ counters only: TA / TCC passes hang kernels with a device-wide hand-off ----
 export PSFM_PROBE_HARD=1
 run hard_stats --stats -f csv -d $OUT/hard_stats -o ${TAG}_hard -- $PR

@@ -84,7 +84,8 @@ stats("opt_stats", tag + "_opt", tag + "_opt_kernel_stats.csv", "PSFM_PROBE_MODE
 stats("hard_stats", tag + "_hard", tag + "_hard_kernel_stats.csv", "PSFM_PROBE_HARD=1 PSFM_PROBE_MODES=adaptive python scripts/probe_solver.py  (1080p x 101 frames, sigma 0.3 + 5 % occluders: every solve rejects steps)")
 summary = {"source_sha16": SHA, "round": tag}
 for sub, pre in (("fused_fetch", "f"), ("fused_write", "w"), ("two_fetch", "f"), ("two_write", "w"), ("step_fetch", "f"), ("step_write", "w"),
-                 ("pmc_sq", "s"), ("opt_pmc_sq", "s"), ("opt_fetch", "f"), ("opt_write", "w"), ("hard_pmc_sq", "s")):
+                 ("pmc_sq", "s"), ("opt_pmc_sq", "s"), ("opt_fetch", "f"), ("opt_write", "w"), ("hard_pmc_sq", "s"),
+                 ("opt_fetch_436x1024x50x2", "f"), ("opt_write_436x1024x50x2", "w"), ("opt_fetch_480x640x200x1", "f"), ("opt_write_480x640x200x1", "w")):
     summary[sub] = counters(sub, pre)
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
@@ -142,9 +143,21 @@ try:
                     "%.1f MB written per launch with work; sources %s" % (tag, rd / 1e6, wr / 1e6, SHA))
         except Exception:       # noqa: BLE001
             pass
+        by_shape = {}
+        if hbm:
+            by_shape["1080x1920x2"] = hbm
+        for shp, key in (("436x1024x2", "436x1024x50x2"), ("480x640x1", "480x640x200x1")):
+            try:
+                fo = [v for k, v in summary["opt_fetch_" + key].items() if "psfm_seq_kernel" in k][0]
+                wo = [v for k, v in summary["opt_write_" + key].items() if "psfm_seq_kernel" in k][0]
+                by_shape[shp] = fo["TCC_EA0_RDREQ_DRAM_32B_sum"] * 32.0 + (wo["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] +
+                                                                           wo.get("TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum", 0.0)) * 32.0
+            except Exception:       # noqa: BLE001
+                pass
         sv.update({"kernel": ko[0], "valu_per_wave_per_iteration": per_it,
                    "valu_per_wave_fixed": wi / waves - per_it * a["iterations_per_solve"],
                    "hbm_bytes_per_launch": hbm, "traffic_source": hsrc, "hbm_bytes_measured_at": "1080p, sample_ratio 2",
+                   "hbm_bytes_per_launch_by_shape": by_shape,      # "HxWxsample_ratio": same counters, scripts/probe_solver.py on that shape
                    "source": "%s_pmc_summary.json opt_pmc_sq: SQ_INSTS_VALU %.2f M per launch with work, %.0f tracks (%.0f waves) and %.2f iterations "
                              "per solve (probe of the same run); %d per wave and iteration from the static census, the rest fixed"
                              % (tag, wi / 1e6, a["tracks_per_solve"], waves, a["iterations_per_solve"], per_it)})
