@@ -284,7 +284,7 @@ def test_track_optimize_full_size_properties(pt):
 @pytest.mark.parametrize("H,W,T,r,seed", [(120, 200, 9, 2, 61), (90, 140, 8, 3, 62), (436, 1024, 6, 2, 63), (436, 640, 5, 1, 64)])
 def test_launch_chain_as_one_persistent_launch_is_the_same_solve(pt, monkeypatch, H, W, T, r, seed):
     """Solves that reject steps run the launch chain; with the device to itself the chain's loop is ONE persistent launch
-    (psfm_pc_persist_kernel: a device-wide barrier per trust-region iteration) instead of one launch per iteration.  Both forms
+    (psfm_pc_resident_kernel: the tracks' state on chip, a two-hop all-reduce per trust-region round) instead of one launch per iteration.  Both forms
     run the same per-track code, the same reduction order and the same control step: identical bits -- and the oracle's
     decisions.  Hard flows (sigma 0.3, 5 % occluders): every solve takes 20-40 iterations with rejections and dogleg steps."""
     from oracle import oracle as orc

@@ -1,4 +1,4 @@
-"""The device's launch chain -- the trust-region loop psfm_pc_init_kernel / psfm_pc_iter_kernel / psfm_pc_persist_kernel run,
+"""The device's launch chain -- the trust-region loop psfm_pc_init_kernel / psfm_pc_iter_kernel / psfm_pc_resident_kernel run,
 i.e. particle-sfm_amd/csrc/psfm_pc_core.h (per-track arithmetic) + psfm_pc_control.h (Ceres' control flow from the global sums,
 evaluate-ahead form) -- compiled for the HOST and run against the CPU oracle (oracle/psfm_oracle.c: the restatement of
 trajectory_optimize.cpp:30-96 under Ceres 2.0.0) on the batches the GPU tests use and on random ones.  Every decision of the
