@@ -161,7 +161,7 @@ def _owned_worker(rank, world, port, ret, lean=False):
 
             def __init__(self, stall_at):
                 super().__init__()
-                self.queue, self.stall_at, self.check_every, self.reruns = [], set(stall_at), 16, 0
+                self.queue, self.stall_at, self.check_every, self.reruns, self.windows = [], set(stall_at), 16, 0, []
 
             def frame(self, t, flow_prev, flow_cur, occ, flow2_prev, occ2_prev, reduce_first, reduce):
                 self.queue.append((t, flow_prev, flow_cur, occ, flow2_prev, occ2_prev, reduce_first))
@@ -171,6 +171,7 @@ def _owned_worker(rank, world, port, ret, lean=False):
 
             def checkpoint(self, reduce):
                 redo = None
+                self.windows.append(len(self.queue))
                 for k, (t, fp, fc, oc, f2, o2, reduce_first) in enumerate(self.queue):
                     x = orc.ShardEngine.step(self, t, fc, oc)
                     reduce_first(x)
@@ -185,15 +186,17 @@ def _owned_worker(rank, world, port, ret, lean=False):
                 return redo
 
         out = {}
-        # the same sequence through an engine that only enqueues its frames and rewinds the driver twice (frames 3 and 9; the
-        # checkpoints fall every 4 frames with several ranks): owned stacks, so the frame window has to keep what a redo needs
-        T, H, W, r = 14, 36, 50, 2
+        # the same sequence through an engine that only enqueues its frames and rewinds the driver three times (frames 3, 9 and 26; with
+        # several ranks the checkpoints start 4 frames apart, the distance doubles behind every window without a stall and falls back to
+        # 4 behind one -- every rank derives it from the stalls, which all ranks see alike): owned stacks, so the frame window has to
+        # keep what a redo needs, across windows of 8 and 16 frames too
+        T, H, W, r = 31, 36, 50, 2
         d = psfm_synth.synth_sequence(T, H, W, seed=44, sigma=0.25, n_occluders=2, stride2=True)
         n, n2 = T - 1, T - 2
         lo, hi = psfm_dist.shard_range(n, rank, world)
         lo2, hi2 = psfm_dist.shard_range(n2, rank, world)
         sl = lambda k, a, b: (torch.from_numpy(np.stack(d[k][a:b])) if b > a else torch.zeros((0, H, W, 2), dtype=torch.float32))
-        eng = DeferredEngine([3, 9])
+        eng = DeferredEngine([3, 9, 26])
         part = psfm_dist.connect_sharded(eng, sl("flows_f", lo, hi), sl("flows_b", lo, hi), sl("flows_f2", lo2, hi2),
                                          sl("flows_b2", lo2, hi2), 1.0, r, check, n_flows_total=n)
         birth, length, off, xy = psfm_dist.gather_result(part)
@@ -203,7 +206,9 @@ def _owned_worker(rank, world, port, ret, lean=False):
         out["deferred"] = (bool(len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
                                 and np.array_equal(xy, O.xy)),
                            [s["iterations"] for s in part["solve_stats"]] == [s["iterations"] for s in O.solves],
-                           eng.reruns > 0 and not eng.stall_at and not eng.queue)
+                           eng.reruns > 0 and not eng.stall_at and not eng.queue,
+                           (eng.windows[0] <= 4 and max(eng.windows) >= 8 and max(eng.windows) <= 32) if world > 1 else True)
+        out["windows"] = list(eng.windows)
         # (more ranks than stride-2 pairs in the last case: a rank with an EMPTY slice of a stack)
         cases = [(9, 38, 52, 2, 41, 0.3, 2, False), (8, 45, 60, 3, 42, 0.1, 1, True), (3, 30, 44, 1, 43, 0.2, 1, True)]
         if lean:        # (eight processes on a small box: the rewinding sequence above + one optimising case)
