@@ -362,9 +362,9 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
         # sequence -- every synchronisation drains the launch queue, and the speculated K only moves at a checkpoint (16 frames per
         # window: 39.0 ms for configs[3], 7 solves redone; 64: 39.4; the sequence: 37.8, none).  Several ranks must agree on when
         # to rewind without talking: a window every rank derives from what every rank has seen -- the stalls, which are the same
-        # everywhere because the control step runs on the same totals: 4 frames to start with and behind every redone solve (the frames
-        # enqueued behind a stall are no-ops, but each of them still costs its launches and exchanges), doubled after every window
-        # without one, up to 32.
+        # everywhere because the control step runs on the same totals: 4 frames to start with, ONE behind a redone solve (the frames
+        # enqueued behind a stall are no-ops, but each of them still costs its launches and exchanges -- on flows whose every solve
+        # rejects steps a longer window would run each frame several times), doubled after every window without a stall, up to 32.
         fixed_window = int(os.environ.get("PSFM_SHARD_CHECK_EVERY", "0"))
         engine.check_every = fixed_window or (max(16, n_flows) if world == 1 else 4)
     confirmed = 0                  # frames below this are final
@@ -395,7 +395,7 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
             confirmed = t + 1
             since = 0
             if world > 1 and not fixed_window:
-                engine.check_every = 4 if redone is not None else min(32, 2 * engine.check_every)
+                engine.check_every = 1 if redone is not None else min(32, 2 * engine.check_every)
         elif not has_ck:
             confirmed = t + 1
         if owned:                            # keep what a redo of an unconfirmed frame needs: its flow01 is frame - 1

@@ -188,7 +188,7 @@ def _owned_worker(rank, world, port, ret, lean=False):
         out = {}
         # the same sequence through an engine that only enqueues its frames and rewinds the driver three times (frames 3, 9 and 26; with
         # several ranks the checkpoints start 4 frames apart, the distance doubles behind every window without a stall and falls back to
-        # 4 behind one -- every rank derives it from the stalls, which all ranks see alike): owned stacks, so the frame window has to
+        # 1 behind one -- every rank derives it from the stalls, which all ranks see alike): owned stacks, so the frame window has to
         # keep what a redo needs, across windows of 8 and 16 frames too
         T, H, W, r = 31, 36, 50, 2
         d = psfm_synth.synth_sequence(T, H, W, seed=44, sigma=0.25, n_occluders=2, stride2=True)
