@@ -245,7 +245,8 @@ int psfm_solve_kmax(void);
 void psfm_shard_abandon(psfm_ctx* c);   // a run that was begun and never finished (context teardown)
 psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,
                               const uint8_t* occ02, int frame, int kind, int K, double* sums_out, hipStream_t s);
-psfm_status psfm_solve_control(psfm_ctx* c, const PsfmTrackDims& d, int frame, int kind, int K, const double* totals, hipStream_t s);
+psfm_status psfm_solve_control(psfm_ctx* c, const PsfmTrackDims& d, int frame, int kind, int K, const double* totals, hipStream_t s,
+                               int* stall_host = nullptr);
 psfm_status psfm_solve_state(psfm_ctx* c, int* done, int* stall, psfm_solve_stats* st, hipStream_t s);
 psfm_status psfm_solve_restore(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);

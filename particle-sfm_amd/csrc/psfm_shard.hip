@@ -132,12 +132,17 @@ extern "C" psfm_status psfm_shard_solve_control_async(psfm_ctx* c, int frame, in
 {
     PSFM_SHARD_CHECK(c);
     PsfmGate gate(c->device, 0);
+    // the stall flag follows the control step into pinned memory (the control kernel stores it there itself):
+    // psfm_shard_peek_stall reads it without a synchronisation
+    int32_t* peek = (int32_t*)((char*)c->host_pinned + c->host_pinned_bytes - 64);
+#ifdef PSFM_SHARD_STALL_MEMCPY      // (A/B builds: round 3's form)
     psfm_status st = psfm_solve_control(c, *c->shard_dims, frame, 0, k, totals, (hipStream_t)stream);
     if (st != PSFM_OK) return st;
-    // the stall flag follows the control step into pinned memory: psfm_shard_peek_stall reads it without a synchronisation
-    int32_t* peek = (int32_t*)((char*)c->host_pinned + c->host_pinned_bytes - 64);
     PSFM_HIP(hipMemcpyAsync(peek, &c->counters.as<PsfmCounters>()->stall, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return PSFM_OK;
+#else
+    return psfm_solve_control(c, *c->shard_dims, frame, 0, k, totals, (hipStream_t)stream, (int*)peek);
+#endif
 }
 
 // The stall flag as of the last control step the device has COMPLETED (no synchronisation: the value lags the queue by the

@@ -967,9 +967,9 @@ __device__ __forceinline__ int pc_phys(int m, int e) { return m == e ? 0 : (m ==
 // a continuation behind `C.cur` accepted steps.  pc != NULL (device-paced sequence): the outcome also says what the NEXT
 // launch does -- the next frame, or more iterations of this solve when every one so far was accepted and none terminated.
 __device__ __forceinline__ void pc_fused_replay(const PcParams& P, const double* tot, int n_it, bool first, PsfmCounters* pc,
-                                                int launch_id)
+                                                int launch_id, const PsfmSolveCtrl* c_in = nullptr)
 {
-    PsfmSolveCtrl C = *P.ctrl;
+    PsfmSolveCtrl C = c_in ? *c_in : *P.ctrl;      // (c_in: the caller's copy of the control block, loaded with everything else it needs)
     const int base = first ? 0 : C.cur;
     const int k_first = first ? n_it : C.k_first;
     for (int j = 1; j <= n_it; ++j) {
@@ -1401,14 +1401,31 @@ void psfm_seq_kernel(PsfmChainArgs a, PcParams P, PsfmSeqStride st, int64_t occ2
 
 // Track-sharded runs: the control step on the totals over all ranks (every rank runs it on the same numbers).
 // mode 0: replay over the K iterations of a fused launch; 1 / 2: one step behind pc_init / pc_iter.
-__global__ void psfm_pc_control_kernel(PcParams P, const double* totals, int K, int mode)
+// stall_host (mode 0, may be NULL): the stall flag as this control step leaves it, written straight into pinned host memory, where
+// psfm_shard_peek_stall reads it without a synchronisation (round 3 sent a 4-byte copy behind every control launch: one more
+// command on the stream per frame)
+__global__ __launch_bounds__(128) void psfm_pc_control_kernel(PcParams P, const double* totals, int K, int mode, int* stall_host)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     if (mode == 0) {
-        if (*P.stall) return;
-        pc_fused_replay(P, totals, K, true, nullptr, 0);
+        // one round trip for everything the replay reads -- the stall flag, the control block, the K x 13 totals -- instead of three
+        // dependent ones by a single lane (7.7 us per frame of a sharded sequence went into this launch)
+        __shared__ double s_tot[PC_KMAX * PC_NSUM];
+        __shared__ PsfmSolveCtrl s_ctrl;
+        __shared__ int s_stall;
+        const int tid = threadIdx.x;
+        const int kk = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
+        if (tid < kk * PC_NSUM) s_tot[tid] = totals[tid];
+        static_assert(sizeof(PsfmSolveCtrl) % 4 == 0 && PC_KMAX * PC_NSUM <= 128, "control kernel: one load per thread");
+        for (int q = tid; q < (int)(sizeof(PsfmSolveCtrl) / 4); q += 128) ((unsigned*)&s_ctrl)[q] = ((const unsigned*)P.ctrl)[q];
+        if (tid == 0) s_stall = *P.stall;
+        __syncthreads();
+        if (tid != 0) return;
+        if (!s_stall) pc_fused_replay(P, s_tot, kk, true, nullptr, 0, &s_ctrl);
+        if (stall_host) __hip_atomic_store(stall_host, *P.stall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
+    if (threadIdx.x != 0) return;
     PsfmSolveCtrl C = *P.ctrl;
     if (mode == 2 && C.done) return;
     pc_chain_control(C, totals, mode == 1 ? 0 : 1);
@@ -1810,12 +1827,13 @@ psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* 
     return PSFM_OK;
 }
 
-psfm_status psfm_solve_control(psfm_ctx* c, const PsfmTrackDims& d, int frame, int kind, int K, const double* totals, hipStream_t s)
+psfm_status psfm_solve_control(psfm_ctx* c, const PsfmTrackDims& d, int frame, int kind, int K, const double* totals, hipStream_t s,
+                               int* stall_host)
 {
     PcParams P;
     psfm_status rc = pc_frame_params(c, d, nullptr, nullptr, nullptr, nullptr, frame, P, s);
     if (rc != PSFM_OK) return rc;
-    hipLaunchKernelGGL(psfm_pc_control_kernel, dim3(1), dim3(64), 0, s, P, totals, K, kind);
+    hipLaunchKernelGGL(psfm_pc_control_kernel, dim3(1), dim3(128), 0, s, P, totals, K, kind, kind == 0 ? stall_host : nullptr);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
