@@ -14,6 +14,7 @@
  *                           (+ the IncrementalTrajectorySet / Trajectory bookkeeping they
  *                           drive: trajectory.py:98-194, optimize/src/trajectory_base.cpp:21-93)
  *   psfm_connect            point_trajectory/main_connect_point_trajectories.py:36-53 (flow_check + track[_optimize])
+ *   psfm_connect_batch      the same for a batch of sequences: the loop of run_particlesfm.py:168-176
  *   psfm_result_*           the list of Trajectory objects those functions return and the
  *                           id / min-length rule of main_connect_point_trajectories.py:56-60
  *
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PSFM_VERSION 131   /* round 3: psfm_shard_solve_control_async, psfm_shard_window_state, psfm_shard_peek_stall, psfm_shard_frame */
+#define PSFM_VERSION 140   /* round 5: psfm_connect_batch */
 
 typedef enum psfm_status {
     PSFM_OK = 0,
@@ -80,7 +81,8 @@ typedef struct psfm_track_info {
     int64_t lane_capacity;
     int64_t solver_iterations; /* total trust-region iterations over all frames (track_optimize) */
     int32_t n_solves;
-    int32_t chain_mode;        /* how the frame recurrence ran: 1 one launch per frame, 2 one persistent launch */
+    int32_t chain_mode;        /* how the frame recurrence ran: 1 one launch per frame, 2 one persistent launch, 3 one launch per
+                                  frame for a whole batch of sequences (psfm_connect_batch) */
 } psfm_track_info;
 
 const char* psfm_last_error(void);
@@ -161,6 +163,25 @@ psfm_status psfm_track(psfm_ctx* ctx, const float* flows, const uint8_t* occ, co
 psfm_status psfm_connect(psfm_ctx* ctx, const float* flows_f, const float* flows_b, const float* flows_f2,
                          const float* flows_b2, int n_flows, int h, int w, float thres, int sample_ratio,
                          uint8_t* occ, uint8_t* occ_s2, psfm_track_info* info_host, void* stream);
+
+/* The loop of the reference's driver over a directory of sequences (run_particlesfm.py:168-176 -> connect_point_trajectory ->
+ * main_connect_point_trajectories.py:36-53 per sequence) for n_seq sequences of the SAME frame size and sample ratio (any
+ * lengths) in ONE call: psfm_connect for every one of them, with every frame launch covering the whole batch (block (x, y) = tile
+ * x of sequence y).  A frame of a small sequence -- DAVIS, Sintel, ScanNet sizes -- is one dependent chain of memory round trips on
+ * a few hundred of the device's block slots; a batch fills them.  One host synchronisation per window of 16 frames and one
+ * segmented finalize (one sort) for all sequences.
+ *   ctxs[i]      one context per sequence, all on one device, each given once; afterwards context i holds sequence i's result
+ *                exactly as after psfm_connect (psfm_result_*, psfm_result_filter, psfm_traj_to_matches, psfm_window_sample work
+ *                on it); ctxs[0] also owns the batch's shared workspace
+ *   flows_f[i], flows_b[i]    (n_flows[i],H,W,2) f32      n_flows[i] >= 1
+ *   flows_f2, flows_b2        NULL (track) or arrays of n_seq pointers to (n_flows[i]-1,H,W,2) stacks (track_optimize, every sequence)
+ *   infos_host   n_seq entries or NULL
+ * track_optimize: a sequence whose solves reject steps has them redone by the launch chain at the checkpoint, like psfm_track; when
+ * a whole window of it is like that (or its context is set to the launch chain, psfm_ctx_set_solver mode 1) it leaves the batch
+ * and is run alone by psfm_connect behind it.  Results do not depend on the batching.  n_seq <= 64.  Synchronises `stream`. */
+psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, const float* const* flows_f, const float* const* flows_b,
+                               const float* const* flows_f2, const float* const* flows_b2, const int* n_flows, int h, int w,
+                               float thres, int sample_ratio, psfm_track_info* infos_host, void* stream);
 
 /* Device-resident result of the last psfm_track: CSR over trajectories in id order.
  *   birth (n_traj) i32 first frame; len (n_traj) i32; off (n_traj+1) i64; xy (n_points,2) f64.

@@ -1,0 +1,286 @@
+// psfm_batch.hip -- psfm_connect_batch: B same-shape sequences through ONE set of launches.
+//
+// The reference's driver walks a directory of sequences (run_particlesfm.py:168-176: connect_point_trajectory per sequence), and the
+// sequences real data has are small: DAVIS 480x854 at sample_ratio 4 is 25 k grid points, Sintel 436x1024 at 2 is 112 k, ScanNet
+// 640x480 dense 307 k (BASELINE configs[0] / [2] / [4]).  A frame of such a sequence is ONE dependent chain of memory round trips
+// that occupies 100-1200 of the device's >= 2048 block slots for 8-45 us whatever its size: one sequence at a
+// time leaves 75-97 % of the machine idle, and host threads + streams (point_trajectory.batch) buy back at most 2x
+// (profiles/r05/r05_a_concurrent_small.txt) because every sequence still pays its own launches, checkpoints and finalize.
+// Here blockIdx.y of every frame launch is the sequence:
+//   * every sequence keeps its OWN context -- lane tables, log, counters, shard tables, solver buffers, result -- so a block only
+//     needs its sequence's row of a small table in device memory (chain-step arguments of frame 1 + strides: the device-side
+//     rebase of the device-paced sequence, psfm_chain_args_rebase / pc_params_rebase, turns them into any frame's);
+//   * track mode: one psfm_chain_step_batch_kernel launch per frame index; track_optimize: psfm_seq_batch_kernel launches, every
+//     sequence with its own device-side program counter and K -- sequences advance independently (one may continue a solve while
+//     its neighbours take their next frame; a finished or stalled one turns its blocks into no-ops);
+//   * ONE checkpoint (one packed copy, one synchronisation) per window of frames for all sequences, and ONE segmented finalize
+//     (psfm_finalize_batch: one sort over the records of all sequences);
+//   * a sequence whose solves reject steps (what the launch chain / the resident solve are for) is redone at the checkpoint like in
+//     psfm_track; when a whole window of it is like that it leaves the batch and runs alone through psfm_connect afterwards.
+// Results are those of psfm_connect, sequence by sequence (tests/test_gpu_batch.py: bit-identical to the oracle's).
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "psfm_internal.h"
+#include "psfm_chain_step.h"
+
+namespace {
+struct SeqState {
+    int f = 0;                   // first frame whose launch has not completed
+    int first_unchecked = 1;     // first solve whose statistics have not been folded in
+    bool resync = false;         // the device-side program counter must be set before the next window
+    bool dropped = false;        // runs alone through psfm_connect behind the batch
+    int k_dev = 3;               // solve_K as the device has it
+    int64_t total_iters = 0;
+    std::vector<psfm_solve_stats> hstats;
+};
+}  // namespace
+
+static psfm_status batch_host_staging(psfm_ctx* own, size_t need)
+{
+    if (own->host_batch_bytes >= need) return PSFM_OK;
+    if (own->host_batch) (void)hipHostFree(own->host_batch);
+    own->host_batch = nullptr; own->host_batch_bytes = 0;
+    PSFM_HIP(hipHostMalloc(&own->host_batch, need + 4096, hipHostMallocDefault));
+    own->host_batch_bytes = need + 4096;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, const float* const* flows_f, const float* const* flows_b,
+                                          const float* const* flows_f2, const float* const* flows_b2, const int* n_flows, int h, int w,
+                                          float thres, int ratio, psfm_track_info* infos, void* stream)
+{
+    if (!ctxs || n_seq < 1 || n_seq > PSFM_BATCH_MAX || !flows_f || !flows_b || !n_flows || h < 2 || w < 2 || ratio < 1 || ratio > 64 ||
+        ((flows_f2 == nullptr) != (flows_b2 == nullptr))) {
+        psfm_set_error("psfm_connect_batch: bad argument (n_seq=%d of at most %d, h=%d w=%d sample_ratio=%d)", n_seq, PSFM_BATCH_MAX, h, w, ratio);
+        return PSFM_ERR_ARG;
+    }
+    const bool optimize = flows_f2 != nullptr;
+    for (int i = 0; i < n_seq; ++i) {
+        if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device) { psfm_set_error("psfm_connect_batch: context %d is NULL or on another device", i); return PSFM_ERR_ARG; }
+        for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) { psfm_set_error("psfm_connect_batch: context %d given twice (one per sequence)", i); return PSFM_ERR_ARG; }
+        if (n_flows[i] < 1 || !flows_f[i] || !flows_b[i] || (optimize && n_flows[i] > 1 && (!flows_f2[i] || !flows_b2[i]))) {
+            psfm_set_error("psfm_connect_batch: bad sequence %d (n_flows=%d)", i, n_flows[i]);
+            return PSFM_ERR_ARG;
+        }
+    }
+    psfm_ctx* own = ctxs[0];
+    PSFM_HIP(hipSetDevice(own->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int B = n_seq;
+    const int64_t P = (int64_t)h * w;
+    std::vector<int> redo;
+    std::vector<SeqState> S((size_t)B);
+    psfm_status st;
+    {
+        PsfmGate gate(own->device, 0);        // launches only: nothing here needs the device to itself
+        // ---- dimensions (one key format for the whole batch: the time bits of its longest sequence), workspaces ----
+        std::vector<PsfmTrackDims> D((size_t)B);
+        int n_max = 0;
+        for (int i = 0; i < B; ++i) n_max = n_flows[i] > n_max ? n_flows[i] : n_max;
+        int tbits = 1;
+        while ((1ll << tbits) < (long long)n_max + 2) ++tbits;
+        int64_t cap_max = 0;
+        for (int i = 0; i < B; ++i) {
+            psfm_ctx* c = ctxs[i];
+            psfm_shard_abandon(c);
+            if ((st = psfm_track_dims(c, n_flows[i], h, w, ratio, -1, D[i])) != PSFM_OK) return st;
+            D[i].shift_d = D[i].shift_b + tbits;
+            if (D[i].shift_d + tbits > 63) { psfm_set_error("psfm_connect_batch: key does not fit 64 bits"); return PSFM_ERR_ARG; }
+            if ((st = psfm_track_alloc(c, D[i])) != PSFM_OK) return st;
+            if ((st = c->occ_own.ensure((size_t)P * (size_t)n_flows[i])) != PSFM_OK) return st;
+            if (optimize) {
+                if ((st = c->occ2_own.ensure((size_t)P * (size_t)(n_flows[i] > 1 ? n_flows[i] - 1 : 1))) != PSFM_OK) return st;
+                if ((st = psfm_solve_prepare(c, D[i])) != PSFM_OK) return st;
+            }
+            c->solve_stats.clear();
+            c->res_n_traj = c->res_n_points = 0;
+            c->res_n_flows = n_flows[i];
+            c->pc_persist_ok = false;
+            c->pc_giveups = 0;
+            c->n_fused_ok = c->n_fused_redone = c->n_chain = 0;
+            if (D[i].cap > cap_max) cap_max = D[i].cap;
+            S[i].hstats.assign((size_t)n_flows[i] + 1, psfm_solve_stats());
+            // a context told to use the launch chain for every solve has nothing to gain from the batch: it runs alone
+            if (optimize && c->solver_mode == 1 && n_flows[i] >= 2) S[i].dropped = true;
+        }
+        // ---- flow_check of every stack (utils.py:94-105); bandwidth-bound, one launch per stack ----
+        own->prof.begin(PSFM_PROF_FLOW_CHECK, s);
+        for (int i = 0; i < B; ++i) {
+            if (S[i].dropped) continue;
+            psfm_ctx* c = ctxs[i];
+            if ((st = psfm_launch_flow_check(flows_f[i], flows_b[i], n_flows[i], h, w, thres, c->occ_own.as<uint8_t>(), nullptr, s)) != PSFM_OK) return st;
+            if (optimize && n_flows[i] > 1 &&
+                (st = psfm_launch_flow_check(flows_f2[i], flows_b2[i], n_flows[i] - 1, h, w, thres, c->occ2_own.as<uint8_t>(), nullptr, s)) != PSFM_OK) return st;
+        }
+        own->prof.end(s);
+        // ---- the table of sequences ----
+        const int CHECK = 16;
+        const int win_max = CHECK + 2;
+        const size_t row_opt = psfm_batch_seq_opt_bytes();
+        const size_t tab_bytes = sizeof(PsfmBatchSeq) * (size_t)B, tabo_bytes = optimize ? row_opt * (size_t)B : 0;
+        const size_t pack_row = psfm_batch_pack_row_bytes(win_max), pack_bytes = pack_row * (size_t)B;
+        if ((st = batch_host_staging(own, tab_bytes + tabo_bytes + pack_bytes)) != PSFM_OK) return st;
+        if ((st = own->batch_tab.ensure(tab_bytes + tabo_bytes)) != PSFM_OK) return st;
+        if ((st = own->batch_ws.ensure(pack_bytes)) != PSFM_OK) return st;
+        PsfmBatchSeq* htab = (PsfmBatchSeq*)own->host_batch;
+        char* htabo = (char*)own->host_batch + tab_bytes;
+        char* hpack = htabo + tabo_bytes;
+        PsfmBatchSeq* dtab = own->batch_tab.as<PsfmBatchSeq>();
+        char* dtabo = (char*)own->batch_tab.p + tab_bytes;
+        for (int i = 0; i < B; ++i) {
+            psfm_ctx* c = ctxs[i];
+            // (a sequence that has left the batch keeps a row -- blockIdx.y indexes the table -- with no frames to run)
+            psfm_batch_fill_seq(c, D[i], flows_f[i], c->occ_own.as<uint8_t>(), P, &htab[i]);
+            if (S[i].dropped) htab[i].n_flows = 0;
+            if (optimize) {
+                const float* f2 = n_flows[i] > 1 ? flows_f2[i] : flows_f[i];      // (a one-pair sequence has no stride-2 stack: never read)
+                if ((st = psfm_batch_fill_seq_opt(c, D[i], flows_f[i], c->occ_own.as<uint8_t>(), P, f2, c->occ2_own.as<uint8_t>(),
+                                                  htabo + row_opt * (size_t)i, s)) != PSFM_OK) return st;
+            }
+        }
+        PSFM_HIP(hipMemcpyAsync(dtab, htab, tab_bytes + tabo_bytes, hipMemcpyHostToDevice, s));
+        // (dropped sequences: n_flows = 0 in the chain table keeps the init kernel's survivor loop short; their lane tables are
+        // re-initialised by the psfm_connect that redoes them)
+        if ((st = psfm_launch_track_init_batch(dtab, B, cap_max, s)) != PSFM_OK) return st;
+
+        if (!optimize) {
+            // ---- track.py:31-47: one launch per frame index for the whole batch ----
+            for (int f = 0; f < n_max; ++f)
+                if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, cap_max, f, false, s)) != PSFM_OK) return st;
+        } else {
+            // ---- track_optimize.py:31-50: frame 0 is a plain chain step; from frame 1 on device-paced launches ----
+            if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, cap_max, 0, true, s)) != PSFM_OK) return st;
+            int launch_id = 0;
+            int v[PSFM_BATCH_MAX][4];
+            for (int i = 0; i < B; ++i) {
+                S[i].f = 1;
+                S[i].resync = true;       // (track_init left pc = {frame 1, phase 0, launch 0, K 3}: set this context's K)
+            }
+            for (;;) {
+                int left_max = 0;
+                bool any_set = false;
+                for (int i = 0; i < B; ++i) {
+                    psfm_ctx* c = ctxs[i];
+                    v[i][0] = -1; v[i][1] = 0; v[i][2] = launch_id; v[i][3] = 0;
+                    const int n_i = S[i].dropped ? 0 : n_flows[i];
+                    const int k_now = c->solver_K > 0 ? c->solver_K : c->solve_K;
+                    if (S[i].f < n_i) {
+                        if (n_i - S[i].f > left_max) left_max = n_i - S[i].f;
+                        if (S[i].resync) { v[i][0] = S[i].f; v[i][3] = k_now; any_set = true; }
+                        else if (k_now != S[i].k_dev) { v[i][0] = -2; v[i][3] = k_now; any_set = true; }      // (K only: the device may be inside a solve)
+                        S[i].k_dev = k_now;
+                    } else if (S[i].resync) {   // finished or left the batch behind a redone solve: park its program counter at the end
+                        v[i][0] = n_flows[i]; v[i][3] = k_now; any_set = true;
+                    }
+                    S[i].resync = false;
+                }
+                if (left_max == 0) break;
+                if (any_set && (st = psfm_launch_batch_set_pc(dtabo, v, B, s)) != PSFM_OK) return st;
+                const int n_launch = (left_max < CHECK ? left_max : CHECK) + 2;      // two spare: continuation launches of the window
+                if ((st = psfm_launch_seq_batch(own, dtabo, B, ratio, cap_max, n_launch, launch_id, s)) != PSFM_OK) return st;
+                launch_id += n_launch;
+                // ---- ONE checkpoint for all sequences ----
+                int lo[PSFM_BATCH_MAX];
+                for (int i = 0; i < B; ++i) lo[i] = S[i].first_unchecked;
+                if ((st = psfm_launch_batch_pack(dtabo, lo, B, win_max, own->batch_ws.as<char>(), s)) != PSFM_OK) return st;
+                PSFM_HIP(hipMemcpyAsync(hpack, own->batch_ws.p, pack_bytes, hipMemcpyDeviceToHost, s));
+                PSFM_HIP(hipStreamSynchronize(s));
+                bool progress = false;
+                for (int i = 0; i < B; ++i) {
+                    if (S[i].dropped || S[i].f >= n_flows[i]) continue;
+                    psfm_ctx* c = ctxs[i];
+                    const PsfmCounters hc = *(const PsfmCounters*)(hpack + pack_row * (size_t)i);
+                    const psfm_solve_stats* hw = (const psfm_solve_stats*)(hpack + pack_row * (size_t)i + sizeof(PsfmCounters));
+                    const int n_i = n_flows[i];
+                    for (int k = 0; k < win_max && lo[i] + k <= n_i; ++k) S[i].hstats[(size_t)(lo[i] + k)] = hw[k];
+                    const int stalled = hc.stall ? hc.stall - 1 : -1;
+                    int last_ok = (hc.pc_frame < n_i ? hc.pc_frame : n_i) - 1;     // frames below the device's program counter are complete
+                    if (stalled >= 0) {
+                        // a solve that did not go as speculated (a rejected step, a dogleg interpolation, more iterations than the
+                        // continuation launches cover): redone by the launch chain from the values it started with, as in psfm_track
+                        const int fs = stalled;
+                        psfm_solve_stats ss;
+                        memset(&ss, 0, sizeof(ss));
+                        psfm_status st2 = psfm_solve_frame_resume(c, D[i], flows_f[i] + (size_t)(fs - 1) * P * 2, flows_f[i] + (size_t)fs * P * 2,
+                                                                  flows_f2[i] + (size_t)(fs - 1) * P * 2, c->occ2_own.as<uint8_t>() + (size_t)(fs - 1) * P,
+                                                                  fs, &ss, 0, false, s);
+                        if (st2 != PSFM_OK) return st2;
+                        S[i].hstats[(size_t)fs] = ss;
+                        last_ok = fs;
+                        S[i].resync = true;
+                    }
+                    int n_solved = 0, n_unclean = 0;
+                    int hist[16] = {0};
+                    for (int k = S[i].first_unchecked; k <= last_ok; ++k) {
+                        const psfm_solve_stats& q = S[i].hstats[(size_t)k];
+                        if (q.termination < 0) continue;      // -1: no track had a full buffer, nothing was solved
+                        c->solve_stats.push_back(q);
+                        S[i].total_iters += q.iterations;
+                        const bool clean = q.dogleg_nonGN == 0 && q.termination != PSFM_TERM_FAILURE &&
+                                           (q.iterations == q.successful_steps + 1 ||
+                                            (q.termination == PSFM_TERM_GRADIENT_TOL && q.iterations == q.successful_steps)) &&
+                                           q.successful_steps + 1 <= psfm_solve_kmax();
+                        ++n_solved;
+                        if (!clean) ++n_unclean;
+                        ++hist[q.successful_steps + 1 < 15 ? q.successful_steps + 1 : 15];
+                        if (k == stalled) ++c->n_fused_redone; else ++c->n_fused_ok;
+                    }
+                    if (n_solved > 0) {
+                        c->solve_mode = (n_unclean * 8 > n_solved) ? 1 : 0;
+                        int best = 2;
+                        for (int q = 2; q <= psfm_solve_kmax(); ++q) if (hist[q] > hist[best]) best = q;
+                        c->solve_K = best;       // the most common need of the window (an iteration more costs one more launch)
+                    }
+                    if (last_ok + 1 > S[i].f) progress = true;
+                    S[i].first_unchecked = last_ok + 1;
+                    S[i].f = last_ok + 1;
+                    // a window of solves that reject steps: this sequence belongs to the launch chain / the resident solve -- it leaves the
+                    // batch and runs alone behind it (psfm_ctx_set_solver(ctx, 2, k) keeps it in)
+                    if (c->solve_mode == 1 && c->solver_mode != 2 && S[i].f < n_i) { S[i].dropped = true; S[i].resync = true; }
+                }
+                if (!progress) { psfm_set_error("psfm_connect_batch: no sequence advanced in a window of launches"); return PSFM_ERR_SOLVER; }
+            }
+            if ((st = psfm_launch_flush_batch(dtabo, B, cap_max, s)) != PSFM_OK) return st;
+        }
+        // ---- ONE segmented finalize for the sequences that stayed ----
+        std::vector<psfm_ctx*> kc;
+        std::vector<PsfmTrackDims> kd;
+        std::vector<int> ki;
+        for (int i = 0; i < B; ++i) {
+            if (S[i].dropped) redo.push_back(i);
+            else { kc.push_back(ctxs[i]); kd.push_back(D[i]); ki.push_back(i); }
+        }
+        if (!kc.empty()) {
+            own->prof.begin(PSFM_PROF_FINALIZE, s);
+            st = psfm_finalize_batch(own, kc.data(), kd.data(), (int)kc.size(), s);
+            own->prof.end(s);
+            if (st != PSFM_OK) return st;
+        }
+        PSFM_HIP(hipStreamSynchronize(s));
+        own->prof.collect();
+        if (infos) {
+            for (size_t q = 0; q < ki.size(); ++q) {
+                const int i = ki[q];
+                psfm_ctx* c = ctxs[i];
+                psfm_track_info* info = &infos[i];
+                memset(info, 0, sizeof(*info));
+                info->n_traj = c->res_n_traj;
+                info->n_points = c->res_n_points;
+                info->n_lanes_peak = ((PsfmCounters*)c->host_pinned)->n_lanes;
+                info->lane_capacity = D[i].cap;
+                info->solver_iterations = S[i].total_iters;
+                info->n_solves = (int32_t)c->solve_stats.size();
+                info->chain_mode = 3;
+            }
+        }
+    }
+    // ---- sequences that left the batch: alone, with everything psfm_connect has for them (the gate is released above) ----
+    for (int i : redo) {
+        st = psfm_connect(ctxs[i], flows_f[i], flows_b[i], optimize ? flows_f2[i] : nullptr, optimize ? flows_b2[i] : nullptr, n_flows[i], h, w, thres,
+                          ratio, nullptr, nullptr, infos ? &infos[i] : nullptr, stream);
+        if (st != PSFM_OK) return st;
+    }
+    return PSFM_OK;
+}

@@ -59,6 +59,12 @@ __host__ __device__ inline void psfm_chain_args_rebase(PsfmChainArgs& a, const P
     a.frame = f;
 }
 
+// One sequence of a BATCH (psfm_connect_batch: B same-shape sequences -- the directory of sequences the reference's driver walks,
+// run_particlesfm.py:168-176 -- through ONE launch per frame, blockIdx.y = sequence): the arguments of its chain step at frame
+// a.frame and the strides that turn them into any other frame's.  Every sequence keeps its own context (lane tables, log,
+// counters, result), so a block only ever needs its sequence's row of this table.
+struct PsfmBatchSeq { PsfmChainArgs a; PsfmSeqStride st; int n_flows; int pad; };
+
 #ifndef PSFM_CHAIN_BLOCK
 #define PSFM_CHAIN_BLOCK 256
 #endif

@@ -19,7 +19,7 @@
 
 #define PSFM_BLOCK 256
 
-__global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_kernel(
+__device__ __forceinline__ void psfm_collect_alive_body(
     const int* __restrict__ birth_frame, const int* __restrict__ birth_idx, PsfmCounters* __restrict__ ctr,
     PsfmShard* __restrict__ shards, unsigned long long* __restrict__ fin_keys, int* __restrict__ fin_lanes, int cap,
     int shard_cap, int last_time, int shift_b, int shift_d)
@@ -60,6 +60,14 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_kernel(
             atomicOr(&ctr->overflow, 2);
         }
     }
+}
+
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_kernel(
+    const int* __restrict__ birth_frame, const int* __restrict__ birth_idx, PsfmCounters* __restrict__ ctr,
+    PsfmShard* __restrict__ shards, unsigned long long* __restrict__ fin_keys, int* __restrict__ fin_lanes, int cap,
+    int shard_cap, int last_time, int shift_b, int shift_d)
+{
+    psfm_collect_alive_body(birth_frame, birth_idx, ctr, shards, fin_keys, fin_lanes, cap, shard_cap, last_time, shift_b, shift_d);
 }
 
 // The sort key (last << shift_d | birth << shift_b | idx) has birth <= last: the pair (last, birth) is re-coded as the
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_decode32_kernel(const unsigne
 #ifndef TILE_K
 #define TILE_K 32
 #endif
-__global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* __restrict__ log, int64_t cap,
+__device__ __forceinline__ void psfm_gather_body(const double2* __restrict__ log, int64_t cap,
                                                                  const int* __restrict__ lanes,
                                                                  const int* __restrict__ birth,
                                                                  const int* __restrict__ len,
@@ -194,6 +202,16 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* 
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* __restrict__ log, int64_t cap,
+                                                                 const int* __restrict__ lanes,
+                                                                 const int* __restrict__ birth,
+                                                                 const int* __restrict__ len,
+                                                                 const int64_t* __restrict__ off, int64_t n,
+                                                                 double2* __restrict__ out)
+{
+    psfm_gather_body(log, cap, lanes, birth, len, off, n, out);
 }
 
 // The persistent loop logs the sampled flow of every survived step instead of positions (half the bytes, written once,
@@ -472,4 +490,241 @@ psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fal
                        kdst, c->sort_lanes.as<int>() + n, fmt);
     PSFM_HIP(hipGetLastError());
     return psfm_finalize_sorted(c, d, n, npts, true, s);   // the persistent loop logs flows, not positions
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segmented finalize of a BATCH (psfm_connect_batch): what psfm_finalize does for one sequence, for B same-shape sequences with ONE
+// host synchronisation, ONE radix sort and ONE scan.  A frame of a small sequence leaves a few ten thousand records: per
+// sequence the finalize is a dozen launch-latency-bound kernels and a host round trip -- as much time as its whole frame loop
+// takes inside a batch.  Here the records of all sequences go into one array under the key (sequence : key), are sorted once, and
+// the decode / offset / gather kernels scatter into every context's own result buffers (so psfm_result_* and the consumers work
+// on a batch member as on any other context).
+// ------------------------------------------------------------------------------------------------
+struct PsfmFinSeq {
+    // the sequence's tables (known before the synchronisation)
+    const int* birth_frame; const int* birth_idx; PsfmCounters* ctr; PsfmShard* shards;
+    unsigned long long* fin_keys; int* fin_lanes;
+    const double2* log; int64_t cap;
+    int shard_cap, last_time;
+    // behind the synchronisation: where its records sit in the combined arrays, where its result goes
+    int64_t rec_start, n;
+    int* res_birth; int* res_len; int64_t* res_off; double2* res_xy;
+};
+
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_collect_alive_batch_kernel(const PsfmFinSeq* __restrict__ T, int shift_b, int shift_d)
+{
+    const PsfmFinSeq& q = T[blockIdx.y];
+    psfm_collect_alive_body(q.birth_frame, q.birth_idx, q.ctr, q.shards, q.fin_keys, q.fin_lanes, (int)q.cap, q.shard_cap, q.last_time,
+                            shift_b, shift_d);
+}
+
+// per sequence: {records, trajectory points, overflow flags, lanes used} -> counts[seq * 4 ..] (one block of one wave per sequence)
+__global__ __launch_bounds__(PSFM_WAVE) void psfm_batch_counts_kernel(const PsfmFinSeq* __restrict__ T, long long* __restrict__ counts)
+{
+    const PsfmFinSeq& q = T[blockIdx.x];
+    const int k = threadIdx.x;
+    static_assert(PSFM_NSHARD == PSFM_WAVE, "one lane per shard");
+    const int fc = q.shards[k].fin_cnt;
+    long long n = fc > q.shard_cap ? q.shard_cap : fc;
+    long long pts = q.shards[k].points;
+    int over = fc > q.shard_cap ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n += __shfl_down(n, o); pts += __shfl_down(pts, o); over |= __shfl_down(over, o); }
+    if (k == 0) {
+        counts[blockIdx.x * 4 + 0] = n;
+        counts[blockIdx.x * 4 + 1] = pts;
+        counts[blockIdx.x * 4 + 2] = (long long)(q.ctr->overflow | (over ? 2 : 0));
+        counts[blockIdx.x * 4 + 3] = (long long)q.ctr->n_lanes;
+    }
+}
+
+// combined key = (sequence << seq_shift) | key of the sequence (32- or 64-bit format, psfm_key_fmt)
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_compact_shards_batch_kernel(const PsfmFinSeq* __restrict__ T, unsigned long long* __restrict__ keys,
+                                                                               int* __restrict__ lanes, PsfmKeyFmt fmt, int seq_shift)
+{
+    __shared__ int s_cnt[PSFM_NSHARD];
+    const int shard = blockIdx.y, seq = blockIdx.z;
+    const PsfmFinSeq& q = T[seq];
+    if (threadIdx.x < PSFM_NSHARD) { const int fc = q.shards[threadIdx.x].fin_cnt; s_cnt[threadIdx.x] = fc > q.shard_cap ? q.shard_cap : fc; }
+    __syncthreads();
+    int64_t start = q.rec_start;
+    for (int k = 0; k < shard; ++k) start += s_cnt[k];
+    const int n = s_cnt[shard];
+    for (int i = blockIdx.x * PSFM_BLOCK + threadIdx.x; i < n; i += gridDim.x * PSFM_BLOCK) {
+        const unsigned long long k = q.fin_keys[(int64_t)shard * q.shard_cap + i];
+        if (fmt.use32) ((unsigned*)keys)[start + i] = psfm_key32(k, fmt) | (seq_shift < 32 ? (unsigned)seq << seq_shift : 0u);
+        else keys[start + i] = k | ((unsigned long long)seq << seq_shift);
+        lanes[start + i] = q.fin_lanes[(int64_t)shard * q.shard_cap + i];
+    }
+}
+
+// sorted combined record i -> (sequence, local id): birth / length into the sequence's result, length into the combined scan input
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_decode_batch_kernel(const PsfmFinSeq* __restrict__ T, const void* __restrict__ keys, int64_t n,
+                                                                       PsfmKeyFmt fmt, int seq_shift, int64_t* __restrict__ len64)
+{
+    const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { len64[i] = 0; return; }
+    int seq, b, last;
+    if (fmt.use32) {
+        const unsigned k = ((const unsigned*)keys)[i];
+        seq = seq_shift < 32 ? (int)(k >> seq_shift) : 0;       // (a batch of one sequence whose key fills the word)
+        const unsigned tri = (seq_shift < 32 ? k & ((1u << seq_shift) - 1u) : k) >> fmt.shift_b;
+        int l = (int)((sqrtf(8.0f * (float)tri + 1.0f) - 1.0f) * 0.5f);      // (as psfm_decode32_kernel)
+        while (l > 0 && (unsigned)l * (unsigned)(l + 1) / 2u > tri) --l;
+        while ((unsigned)(l + 1) * (unsigned)(l + 2) / 2u <= tri) ++l;
+        last = l;
+        b = (int)(tri - (unsigned)l * (unsigned)(l + 1) / 2u);
+    } else {
+        const unsigned long long kk = ((const unsigned long long*)keys)[i];
+        seq = (int)(kk >> seq_shift);
+        const unsigned long long k = kk & ((1ull << seq_shift) - 1ull);
+        last = (int)(k >> fmt.shift_d);
+        b = (int)((k >> fmt.shift_b) & ((1ull << (fmt.shift_d - fmt.shift_b)) - 1ull));
+    }
+    const PsfmFinSeq& q = T[seq];
+    const int64_t local = i - q.rec_start;
+    q.res_birth[local] = b;
+    q.res_len[local] = last - b + 1;
+    len64[i] = (int64_t)(last - b + 1);
+}
+
+// the sequence's offsets = the combined scan minus its value at the sequence's first record
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_offsets_batch_kernel(const PsfmFinSeq* __restrict__ T, const int64_t* __restrict__ scan)
+{
+    const PsfmFinSeq& q = T[blockIdx.y];
+    const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    if (i > q.n) return;
+    q.res_off[i] = scan[q.rec_start + i] - scan[q.rec_start];
+}
+
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_batch_kernel(const PsfmFinSeq* __restrict__ T, const int* __restrict__ lanes)
+{
+    const PsfmFinSeq& q = T[blockIdx.y];
+    if ((int64_t)blockIdx.x * TILE_J >= q.n) return;
+    psfm_gather_body(q.log, q.cap, lanes + q.rec_start, q.res_birth, q.res_len, q.res_off, q.n, q.res_xy);
+}
+
+psfm_status psfm_finalize_batch(psfm_ctx* own, psfm_ctx* const* ctxs, const PsfmTrackDims* dims, int n_seq, hipStream_t s)
+{
+    if (n_seq < 1 || n_seq > PSFM_BATCH_MAX) { psfm_set_error("psfm_finalize_batch: bad batch size %d", n_seq); return PSFM_ERR_ARG; }
+    psfm_status st;
+    // the table: device copy in the owner's batch workspace behind the frame loop's table, host copy in its pinned staging
+    const size_t tbytes = sizeof(PsfmFinSeq) * (size_t)n_seq, cbytes = sizeof(long long) * 4 * (size_t)n_seq;
+    const size_t need_host = tbytes + cbytes;
+    if (own->host_seg_bytes < need_host) {
+        if (own->host_seg) (void)hipHostFree(own->host_seg);
+        own->host_seg = nullptr; own->host_seg_bytes = 0;
+        PSFM_HIP(hipHostMalloc(&own->host_seg, need_host + 4096, hipHostMallocDefault));
+        own->host_seg_bytes = need_host + 4096;
+    }
+    if ((st = own->seg_table.ensure(tbytes + cbytes)) != PSFM_OK) return st;
+    PsfmFinSeq* hT = (PsfmFinSeq*)own->host_seg;
+    long long* hcnt = (long long*)((char*)own->host_seg + tbytes);
+    PsfmFinSeq* dT = own->seg_table.as<PsfmFinSeq>();
+    long long* dcnt = (long long*)((char*)own->seg_table.p + tbytes);
+    int64_t cap_max = 0;
+    PsfmTrackDims dk = dims[0];       // the batch's key format: common shifts, the longest sequence's time range
+    for (int i = 0; i < n_seq; ++i) {
+        const PsfmTrackDims& d = dims[i];
+        psfm_ctx* c = ctxs[i];
+        if (d.shift_b != dk.shift_b || d.shift_d != dk.shift_d) { psfm_set_error("psfm_finalize_batch: sequences with different key formats"); return PSFM_ERR_ARG; }
+        if (d.n_flows > dk.n_flows) dk.n_flows = d.n_flows;
+        memset(&hT[i], 0, sizeof(PsfmFinSeq));
+        hT[i].birth_frame = c->birth_frame.as<int>(); hT[i].birth_idx = c->birth_idx.as<int>();
+        hT[i].ctr = c->counters.as<PsfmCounters>(); hT[i].shards = c->shards.as<PsfmShard>();
+        hT[i].fin_keys = c->fin_keys.as<unsigned long long>(); hT[i].fin_lanes = c->fin_lanes.as<int>();
+        hT[i].log = c->log.as<double2>(); hT[i].cap = d.cap;
+        hT[i].shard_cap = d.shard_cap; hT[i].last_time = d.n_flows;
+        if (d.cap > cap_max) cap_max = d.cap;
+    }
+    PSFM_HIP(hipMemcpyAsync(dT, hT, tbytes, hipMemcpyHostToDevice, s));
+    // 1. survivors -> records; 2. the counts of every sequence in one copy, ONE synchronisation
+    hipLaunchKernelGGL(psfm_collect_alive_batch_kernel, dim3((unsigned)((cap_max + PSFM_BLOCK - 1) / PSFM_BLOCK), (unsigned)n_seq), dim3(PSFM_BLOCK),
+                       0, s, dT, dk.shift_b, dk.shift_d);
+    hipLaunchKernelGGL(psfm_batch_counts_kernel, dim3((unsigned)n_seq), dim3(PSFM_WAVE), 0, s, dT, dcnt);
+    PSFM_HIP(hipGetLastError());
+    PSFM_HIP(hipMemcpyAsync(hcnt, dcnt, cbytes, hipMemcpyDeviceToHost, s));
+    PSFM_HIP(hipStreamSynchronize(s));
+    int64_t N = 0, n_max = 0;
+    for (int i = 0; i < n_seq; ++i) {
+        psfm_ctx* c = ctxs[i];
+        const int64_t n = hcnt[4 * i + 0], npts = hcnt[4 * i + 1];
+        PsfmCounters* hc = (PsfmCounters*)c->host_pinned;      // (psfm_track_info reads the lane count from here)
+        hc->n_lanes = (int)hcnt[4 * i + 3]; hc->overflow = (int)hcnt[4 * i + 2];
+        if (hcnt[4 * i + 2] != 0 || hcnt[4 * i + 3] > dims[i].cap) {
+            psfm_set_error("capacity exceeded (sequence %d of the batch): lanes used %lld of %lld, trajectory records %lld of %lld, overflow bits %lld; "
+                           "raise psfm_ctx_set_capacity", i, hcnt[4 * i + 3], (long long)dims[i].cap, (long long)n, (long long)dims[i].traj_cap,
+                           hcnt[4 * i + 2]);
+            return PSFM_ERR_CAPACITY;
+        }
+        c->res_n_traj = n;
+        c->res_n_points = npts;
+        hT[i].rec_start = N; hT[i].n = n;
+        N += n;
+        if (n > n_max) n_max = n;
+        if ((st = c->res_birth.ensure(sizeof(int) * (size_t)(n > 0 ? n : 1))) != PSFM_OK) return st;
+        if ((st = c->res_len.ensure(sizeof(int) * (size_t)(n > 0 ? n : 1))) != PSFM_OK) return st;
+        if ((st = c->res_off.ensure(sizeof(int64_t) * (size_t)(n + 1))) != PSFM_OK) return st;
+        if ((st = c->res_xy.ensure(sizeof(double2) * (size_t)(npts > 0 ? npts : 1))) != PSFM_OK) return st;
+        hT[i].res_birth = c->res_birth.as<int>(); hT[i].res_len = c->res_len.as<int>();
+        hT[i].res_off = c->res_off.as<int64_t>(); hT[i].res_xy = c->res_xy.as<double2>();
+    }
+    PSFM_HIP(hipMemcpyAsync(dT, hT, tbytes, hipMemcpyHostToDevice, s));
+    if (N == 0) {
+        for (int i = 0; i < n_seq; ++i) PSFM_HIP(hipMemsetAsync(ctxs[i]->res_off.p, 0, sizeof(int64_t), s));
+        return PSFM_OK;
+    }
+    // 3. the combined (sequence : key, lane) array, sorted once
+    unsigned end_bit = 0;
+    PsfmKeyFmt fmt = psfm_key_fmt(dk, &end_bit);
+    int seq_bits = 0;
+    while ((1 << seq_bits) < n_seq) ++seq_bits;
+    if (fmt.use32 && (int)end_bit + seq_bits > 32) {        // the sequence number does not fit beside a 32-bit key: 64-bit keys
+        fmt.use32 = 0;
+        int tbits = 1;
+        while ((1ll << tbits) < (long long)dk.n_flows + 2) ++tbits;
+        end_bit = (unsigned)(dk.shift_d + tbits);
+    }
+    if (!fmt.use32 && (int)end_bit + seq_bits > 64) { psfm_set_error("psfm_finalize_batch: key does not fit 64 bits"); return PSFM_ERR_ARG; }
+    const int seq_shift = (int)end_bit;
+    const unsigned sort_end = end_bit + (unsigned)seq_bits;
+    if ((st = own->sort_keys.ensure(sizeof(unsigned long long) * (size_t)N * 2)) != PSFM_OK) return st;
+    if ((st = own->sort_lanes.ensure(sizeof(int) * (size_t)N * 2)) != PSFM_OK) return st;
+    if ((st = own->scan_tmp.ensure(sizeof(int64_t) * (size_t)(N + 1) * 2)) != PSFM_OK) return st;
+    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(own->sort_keys.as<unsigned>() + N) : own->sort_keys.as<unsigned long long>() + N;
+    hipLaunchKernelGGL(psfm_compact_shards_batch_kernel, dim3(8, PSFM_NSHARD, (unsigned)n_seq), dim3(PSFM_BLOCK), 0, s, dT, kdst,
+                       own->sort_lanes.as<int>() + N, fmt, seq_shift);
+    PSFM_HIP(hipGetLastError());
+    int* l_in = own->sort_lanes.as<int>() + N;
+    int* l_out = own->sort_lanes.as<int>();
+    size_t tmp_bytes = 0, scan_bytes = 0;
+    PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(N + 1),
+                                     rocprim::plus<int64_t>(), s));
+    if (fmt.use32) {
+        unsigned* k_in = own->sort_keys.as<unsigned>() + N;
+        unsigned* k_out = own->sort_keys.as<unsigned>();
+        PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)N, 0u, sort_end, s));
+        if ((st = own->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
+        PSFM_HIP(rocprim::radix_sort_pairs(own->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)N, 0u, sort_end, s));
+    } else {
+        unsigned long long* k_in = own->sort_keys.as<unsigned long long>() + N;
+        unsigned long long* k_out = own->sort_keys.as<unsigned long long>();
+        PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)N, 0u, sort_end, s));
+        if ((st = own->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
+        PSFM_HIP(rocprim::radix_sort_pairs(own->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)N, 0u, sort_end, s));
+    }
+    // 4. decode -> per-sequence birth / length, combined lengths -> ONE scan -> per-sequence offsets; 5. the transpose gather
+    int64_t* len64 = own->scan_tmp.as<int64_t>();
+    int64_t* scan = len64 + (N + 1);
+    hipLaunchKernelGGL(psfm_decode_batch_kernel, dim3((unsigned)((N + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s, dT,
+                       (const void*)own->sort_keys.p, N, fmt, seq_shift, len64);
+    PSFM_HIP(hipGetLastError());
+    PSFM_HIP(rocprim::exclusive_scan(own->sort_tmp.p, scan_bytes, len64, scan, (int64_t)0, (size_t)(N + 1), rocprim::plus<int64_t>(), s));
+    hipLaunchKernelGGL(psfm_offsets_batch_kernel, dim3((unsigned)((n_max + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK), (unsigned)n_seq), dim3(PSFM_BLOCK), 0, s,
+                       dT, (const int64_t*)scan);
+    hipLaunchKernelGGL(psfm_gather_batch_kernel, dim3((unsigned)((n_max + TILE_J - 1) / TILE_J), (unsigned)n_seq), dim3(PSFM_BLOCK), 0, s, dT,
+                       (const int*)own->sort_lanes.as<int>());
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
 }

@@ -169,6 +169,9 @@ struct psfm_ctx {
     bool shard_optimize = false;
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
     PsfmBuf occ_own, occ2_own;           // occlusion maps of psfm_connect when the caller passes none
+    PsfmBuf batch_tab, batch_ws;         // psfm_connect_batch (this context as the batch's owner): the table of sequences, packed checkpoints
+    void* host_batch = nullptr;          // ... and their pinned staging
+    size_t host_batch_bytes = 0;
     PsfmBuf win_ws;                      // psfm_window_sample / psfm_result_filter workspace
     PsfmBuf flt_ids, flt_birth, flt_len, flt_off, flt_xy;   // psfm_result_filter: the saved set (length >= traj_min_len), CSR
     int64_t flt_n_traj = 0, flt_n_points = 0;
@@ -211,6 +214,27 @@ psfm_status psfm_track_alloc(psfm_ctx* c, const PsfmTrackDims& d);
 psfm_status psfm_launch_track_init(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
 psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const float* flow, const uint8_t* occ,
                                    int frame, bool optimize, hipStream_t s);
+
+// ---- batch: B same-shape sequences per launch (psfm_batch.hip; kernels beside their single-sequence forms) --------------------
+#define PSFM_BATCH_MAX 64
+struct PsfmBatchSeq;      // psfm_chain_step.h: one row of the batch table (chain-step arguments of frame 1 + strides)
+void psfm_batch_fill_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch, PsfmBatchSeq* row);
+psfm_status psfm_launch_track_init_batch(const PsfmBatchSeq* tab_dev, int n_seq, int64_t cap_max, hipStream_t s);
+psfm_status psfm_launch_chain_step_batch(psfm_ctx* owner, const PsfmBatchSeq* tab_dev, int n_seq, int ratio, int64_t cap_max, int frame,
+                                         bool optimize, hipStream_t s);
+// track_optimize rows (psfm_solver.hip: chain-step arguments + solver parameters of frame 1 + strides) and their launches
+size_t psfm_batch_seq_opt_bytes(void);
+psfm_status psfm_batch_fill_seq_opt(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
+                                    const float* flows_f2, const uint8_t* occ_s2, void* row_host, hipStream_t s);
+psfm_status psfm_launch_seq_batch(psfm_ctx* owner, const void* tab_dev, int n_seq, int ratio, int64_t cap_max, int n_launches, int launch_id0,
+                                  hipStream_t s);
+psfm_status psfm_launch_flush_batch(const void* tab_dev, int n_seq, int64_t cap_max, hipStream_t s);
+psfm_status psfm_launch_batch_set_pc(const void* tab_dev, const int (*v)[4], int n_seq, hipStream_t s);
+size_t psfm_batch_pack_row_bytes(int win);
+psfm_status psfm_launch_batch_pack(const void* tab_dev, const int* lo, int n_seq, int win, char* out_dev, hipStream_t s);
+// one segmented finalize for all sequences of a batch (psfm_finalize.hip): ONE host synchronisation, ONE sort.  dims[i] are the
+// sequences' dimensions (same key format); the shared workspace is `own`'s, results land in every context's own res_* buffers
+psfm_status psfm_finalize_batch(psfm_ctx* own, psfm_ctx* const* ctxs, const PsfmTrackDims* dims, int n_seq, hipStream_t s);
 
 // ---- persistent frame loop (psfm_persist.hip) ---------------------------------------------------
 int psfm_persist_max_blocks(psfm_ctx* c);

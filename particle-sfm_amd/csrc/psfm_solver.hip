@@ -575,7 +575,12 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
     const int b = (int)blockIdx.x;
     const int L = n_blocks < PC_LEADERS ? n_blocks : PC_LEADERS;
     unsigned long long* mine = gran + (size_t)b * PC_RES_ROW;
-    unsigned long long* lead = gran + (size_t)n_blocks * PC_RES_ROW;
+    // leader rows: TWO sets, used by alternate rounds (consecutive tags differ in bit 0).  A leader may publish its round r + 1 sums as
+    // soon as its own members are through round r -- with one set, a block under another leader that has not yet seen every leader's
+    // round-r granules would find tag r + 1 there, never match, and poison the solve at its spin limit (a spurious give-up under
+    // preemption).  Round r + 2 cannot be published before every block has read round r: it needs every leader's r + 1 row, which
+    // needs every member's r + 1 granule, which a member only writes behind its round-r totals.
+    unsigned long long* lead = gran + ((size_t)n_blocks + (size_t)(tag & 1u) * PC_LEADERS) * PC_RES_ROW;
     const int k = lane >> 2, j = lane & 3;
     const bool work = lane < 4 * NSUMS;
     int bad = quit ? 1 : 0;
@@ -665,12 +670,13 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
 }
 
 // A resident solve that ends without a result (its hand-off timed out: the grid was not co-resident; or it ran out of rounds) has
-// written nothing.  In a sequence it raises the device-side stall flag itself -- everything enqueued behind turns into no-ops and
-// the host redoes the solve with launches at its checkpoint; a batch solve just leaves its control block "not done" for the
-// polling loop of psfm_solve_batch.
-__device__ __forceinline__ void pc_res_stall(const PcParams& P)
+// written nothing.  ENQUEUED inside a sequence (raise_stall) it raises the device-side stall flag itself -- everything enqueued
+// behind turns into no-ops and the host redoes the solve with launches at its checkpoint.  A launch the host POLLS behind --
+// a batch solve, the redo of a stalled solve (psfm_solve_frame_resume) -- must not: it just leaves its control block "not done"
+// and pc_finish_sync goes on with one launch per iteration (which return at once behind a raised flag).
+__device__ __forceinline__ void pc_res_stall(const PcParams& P, int raise_stall)
 {
-    if (P.birth_frame && threadIdx.x == 0) *P.stall = P.frame + 1;
+    if (raise_stall && P.birth_frame && threadIdx.x == 0) *P.stall = P.frame + 1;
 }
 
 struct PcSlot {                    // (slot k of thread t holds entry k * PC_BLOCK + t of the block's list, if the list is that long)
@@ -694,7 +700,7 @@ __device__ __forceinline__ double pc_slot_candidate(const PcSlot& T, double a, d
 template <int NS>
 __global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoch, int spin_limit, int max_rounds, int quit_code,
-                             int init_inside, double* out_rows)
+                             int init_inside, int raise_stall, double* out_rows)
 {
     // init_inside: iteration 0 (what psfm_pc_init_kernel does) is this launch's first round; else it runs behind that kernel.
     // When the loop ends with the solve done, every block writes its tracks back (what psfm_pc_writeback_kernel does) and the
@@ -755,7 +761,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             }
         }
         __syncthreads();
-        if (s_R.giveup) { pc_res_stall(P); return; }
+        if (s_R.giveup) { pc_res_stall(P, raise_stall); return; }
     } else {
         if (tid < PC_CTRL_WORDS) ((unsigned long long*)&s_C)[tid] = ((const unsigned long long*)P.ctrl)[tid];    // (written by the launch in front)
         __syncthreads();
@@ -891,7 +897,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
         }
         __syncthreads();
         PC_RTL(8);
-        if (s_R.giveup) { pc_res_stall(P); return; }
+        if (s_R.giveup) { pc_res_stall(P, raise_stall); return; }
         if (s_R.accepted) {
             // x <- the candidate (the same operations: the same bits), (u, d) <- what was solved there
 #pragma unroll
@@ -903,7 +909,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             }
         }
     }
-    if (!s_R.done) { pc_res_stall(P); return; }            // (ran out of rounds)
+    if (!s_R.done) { pc_res_stall(P, raise_stall); return; }            // (ran out of rounds)
     // ---- write-back (block 0 also: statistics, the control block) ----
     const PsfmSolveCtrl C = s_C;
     const bool moved = C.cur != 0 && !C.failed;          // (a failed solve hands the parameters back as they came in)
@@ -1375,9 +1381,10 @@ __host__ __device__ inline void pc_params_rebase(PcParams& P, const PsfmSeqStrid
 // launch_id: a block that is dispatched after the control thread has moved the counter on (only blocks beyond the lane
 // snapshot can be) sees pc_owner != launch_id and leaves.
 // ------------------------------------------------------------------------------------------------
-template <int R, int WAVES>
-__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-void psfm_seq_kernel(PsfmChainArgs a, PcParams P, PsfmSeqStride st, int64_t occ2_stride, int n_flows, int launch_id)
+// what one block of a device-paced launch does for ITS sequence (psfm_seq_kernel: the launch's only sequence; psfm_seq_batch_kernel:
+// sequence blockIdx.y of the batch)
+template <int R>
+__device__ __forceinline__ void psfm_seq_body(PsfmChainArgs a, PcParams P, const PsfmSeqStride st, int64_t occ2_stride, int n_flows, int launch_id)
 {
     PsfmCounters* ctr = a.ctr;
     if (ctr->stall || ctr->pc_owner != launch_id) return;
@@ -1396,6 +1403,82 @@ void psfm_seq_kernel(PsfmChainArgs a, PcParams P, PsfmSeqStride st, int64_t occ2
         if ((int)blockIdx.x >= n_active) return;
         pc_more_body(P, n_active, ctr, launch_id);
     }
+}
+
+template <int R, int WAVES>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void psfm_seq_kernel(PsfmChainArgs a, PcParams P, PsfmSeqStride st, int64_t occ2_stride, int n_flows, int launch_id)
+{
+    psfm_seq_body<R>(a, P, st, occ2_stride, n_flows, launch_id);
+}
+
+// ------------------------------------------------------------------------------------------------
+// B same-shape sequences per launch (psfm_connect_batch; run_particlesfm.py:168-176 walks a directory of sequences): a frame of a
+// DAVIS / Sintel / ScanNet-sized sequence is a few hundred blocks -- 10-40 % of the device's block slots -- for one dependent chain
+// of round trips.  blockIdx.y = sequence: every sequence keeps its own context (lanes, log, counters, tickets, control block), its
+// own device-side program counter and K, so the sequences advance independently -- one may be continuing a solve while its
+// neighbours take their next frame, a stalled or finished one turns its blocks into no-ops -- and the launches fill the machine.
+// gridDim.x is a multiple of 8: block (x, y) sits on XCD x % 8, as psfm_xcd_tile assumes.
+// ------------------------------------------------------------------------------------------------
+struct PsfmBatchSeqOpt { PsfmChainArgs a; PcParams P; PsfmSeqStride st; int64_t occ2_stride; int n_flows; int pad; };
+
+template <int R, int WAVES>
+__global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void psfm_seq_batch_kernel(const PsfmBatchSeqOpt* __restrict__ seqs, int launch_id)
+{
+    const PsfmBatchSeqOpt& q = seqs[blockIdx.y];
+    psfm_seq_body<R>(q.a, q.P, q.st, q.occ2_stride, q.n_flows, launch_id);
+}
+
+// behind the last solve of every sequence of a batch (what psfm_solve_flush does for one): the accepted iterate into the log
+__global__ __launch_bounds__(PC_BLOCK) void psfm_pc_flush_batch_kernel(const PsfmBatchSeqOpt* __restrict__ seqs, int clear_sel)
+{
+    const PsfmBatchSeqOpt& q = seqs[blockIdx.y];
+    if (q.n_flows < 2) return;
+    PcParams P = q.P;
+    pc_params_rebase(P, q.st, q.occ2_stride, q.n_flows - 1);
+    if (*P.stall) return;
+    if (clear_sel) { if (blockIdx.x == 0 && threadIdx.x == 0) *P.sel = 0; return; }
+    const int m = *P.sel;
+    if (m == 0) return;
+    const int n = P.n_lanes_ptr ? min(*P.n_lanes_ptr, P.n_rows) : P.n_rows;
+    for (int i = blockIdx.x * PC_BLOCK + threadIdx.x; i < n; i += gridDim.x * PC_BLOCK) {
+        if (pc_participates(P, i, n)) {
+            P.x1a[i] = pc_buf1(P, m)[i];
+            P.x2a[i] = pc_buf2(P, m)[i];
+        }
+    }
+}
+
+// per-sequence device-side program counters of a batch, set by the host at a checkpoint (a redone solve, an adapted K):
+// v[i] = {pc_frame, pc_phase, pc_owner, solve_K}; pc_frame -1 = leave sequence i alone, -2 = its K only (the device may be inside a
+// solve of that sequence: continuation launches do not read K)
+struct PsfmBatchPc { int v[PSFM_BATCH_MAX][4]; };
+__global__ void psfm_batch_set_pc_kernel(const PsfmBatchSeqOpt* __restrict__ seqs, PsfmBatchPc pc, int n_seq)
+{
+    const int i = threadIdx.x;
+    if (i >= n_seq || pc.v[i][0] == -1) return;
+    PsfmCounters* ctr = seqs[i].a.ctr;
+    if (pc.v[i][0] == -2) { ctr->solve_K = pc.v[i][3]; return; }
+    ctr->pc_frame = pc.v[i][0]; ctr->pc_phase = pc.v[i][1]; ctr->pc_owner = pc.v[i][2]; ctr->solve_K = pc.v[i][3];
+}
+
+// a checkpoint of the batch in ONE device-to-host copy: every sequence's counters and the statistics of the solves of frames
+// [lo[i], lo[i] + win) packed into out[i * row_bytes ..]
+struct PsfmBatchWin { int lo[PSFM_BATCH_MAX]; };
+__global__ __launch_bounds__(64) void psfm_batch_pack_kernel(const PsfmBatchSeqOpt* __restrict__ seqs, PsfmBatchWin w, int win, int row_bytes,
+                                                            char* __restrict__ out)
+{
+    const PsfmBatchSeqOpt& q = seqs[blockIdx.x];
+    char* dst = out + (size_t)blockIdx.x * row_bytes;
+    const int* src = (const int*)q.a.ctr;
+    for (int k = threadIdx.x; k < (int)(sizeof(PsfmCounters) / 4); k += 64) ((int*)dst)[k] = src[k];
+    const int lo = w.lo[blockIdx.x];
+    const int n = min(win, q.n_flows + 1 - lo);
+    if (!q.P.stats_dev || n <= 0) return;
+    const int* ssrc = (const int*)(q.P.stats_dev + lo);
+    int* sdst = (int*)(dst + sizeof(PsfmCounters));
+    for (int k = threadIdx.x; k < n * (int)(sizeof(psfm_solve_stats) / 4); k += 64) sdst[k] = ssrc[k];
 }
 
 
@@ -1566,7 +1649,10 @@ static void pc_fill_stats(const PsfmSolveCtrl* h, psfm_solve_stats* st)
 }
 
 // Keep launching iterations, polling `done` between chunks, until the solve terminates; then write back.
-static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double* out_rows, psfm_solve_stats* st, hipStream_t s)
+// resident: a resident launch is what has been enqueued -- not done behind it means its hand-off gave up (it has written nothing: the
+// control block is as iteration 0 left it, the launches below take the solve from there); a call that sees that twice stops trying
+static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double* out_rows, psfm_solve_stats* st, hipStream_t s,
+                                  bool resident = false)
 {
     PsfmSolveCtrl* hctrl = (PsfmSolveCtrl*)((char*)c->host_pinned + 512 + sizeof(PsfmShard) * PSFM_NSHARD);
     int launched = 0, chunk = 6;
@@ -1574,6 +1660,7 @@ static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double
         PSFM_HIP(hipMemcpyAsync(hctrl, P.ctrl, sizeof(PsfmSolveCtrl), hipMemcpyDeviceToHost, s));
         PSFM_HIP(hipStreamSynchronize(s));
         if (hctrl->done) break;
+        if (resident && launched == 0) c->pc_giveups += 1;
         if (launched > 2 * 200 + 64) { psfm_set_error("path-consistency solver did not terminate"); return PSFM_ERR_SOLVER; }
         for (int k = 0; k < chunk; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
         PSFM_HIP(hipGetLastError());
@@ -1646,7 +1733,7 @@ static int pc_resident_capacity(psfm_ctx* c)
     return c->pc_persist_blocks[NS];
 }
 
-static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, bool init_inside, hipStream_t s)
+static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, bool init_inside, bool raise_stall, hipStream_t s)
 {
     const char* env = getenv("PSFM_PC_PERSIST");          // (read per call: the tests switch it inside one process)
     if ((env && atoi(env) == 0) || !c->pc_persist_ok || c->pc_giveups >= 2 || P.export_sums) return false;
@@ -1659,7 +1746,7 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
     if (n_blocks > capacity) return false;                 // (every block must be resident at once)
     // granules: one row per block + one per leader; zeroed once -- tags carry the launch epoch, so what an earlier launch left
     // never matches (the 20-bit epoch wraps after a million solves: cleared again then)
-    const size_t gbytes = sizeof(unsigned long long) * PC_RES_ROW * (PC_RES_BLOCKS + PC_LEADERS);
+    const size_t gbytes = sizeof(unsigned long long) * PC_RES_ROW * (PC_RES_BLOCKS + 2 * PC_LEADERS);      // (two sets of leader rows)
     const bool fresh = c->sol_bar.bytes < gbytes;
     if (c->sol_bar.ensure(gbytes) != PSFM_OK) return false;
     c->pc_epoch += 1;
@@ -1678,9 +1765,9 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
     unsigned long long* gran = c->sol_bar.as<unsigned long long>();
     const int max_rounds = 2 * 200 + 64;
     // (the write-back is in the launch too)
-    if (ns == 1) hipLaunchKernelGGL(psfm_pc_resident_kernel<1>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, out_rows);
-    else if (ns == 2) hipLaunchKernelGGL(psfm_pc_resident_kernel<2>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, out_rows);
-    else hipLaunchKernelGGL(psfm_pc_resident_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, out_rows);
+    if (ns == 1) hipLaunchKernelGGL(psfm_pc_resident_kernel<1>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
+    else if (ns == 2) hipLaunchKernelGGL(psfm_pc_resident_kernel<2>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
+    else hipLaunchKernelGGL(psfm_pc_resident_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
     return true;
 }
 
@@ -1701,9 +1788,9 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
     // checkpoint), else `unroll` launches of one iteration each + write-back
     // (PSFM_PC_INIT_INSIDE=0: iteration 0 as its own launch in front of the resident solve -- measurements, tests)
     const bool inside = !(getenv("PSFM_PC_INIT_INSIDE") && atoi(getenv("PSFM_PC_INIT_INSIDE")) == 0);
-    if (!inside || !pc_persist_enqueue(c, P, n_blocks, nullptr, true, s)) {
+    if (!inside || !pc_persist_enqueue(c, P, n_blocks, nullptr, true, true, s)) {
         hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-        if (!pc_persist_enqueue(c, P, n_blocks, nullptr, false, s)) {
+        if (!pc_persist_enqueue(c, P, n_blocks, nullptr, false, true, s)) {
             for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
             // (the resident solve writes back, or raises the stall flag, itself)
             hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
@@ -1748,10 +1835,12 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     }
     const int n_blocks = pc_blocks((int)d.cap);
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (chain_stalled || !pc_persist_enqueue(c, P, n_blocks, nullptr, false, s))
+    // (the host polls behind this launch: a resident solve that gives up must leave the stall flag alone -- see pc_res_stall)
+    bool resident = false;
+    if (chain_stalled || !(resident = pc_persist_enqueue(c, P, n_blocks, nullptr, false, false, s)))
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
-    return pc_finish_sync(c, P, n_blocks, nullptr, st, s);
+    return pc_finish_sync(c, P, n_blocks, nullptr, st, s, resident);
 }
 
 int psfm_solve_kmax(void) { return PC_KMAX; }
@@ -1913,13 +2002,12 @@ psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* 
     return PSFM_OK;
 }
 
-// Device-paced sequence: `n_launches` launches of psfm_seq_kernel (ids launch_id0 ..), every one with the arguments of
-// frame 1 and the strides; what each of them does is decided on the device (PsfmCounters::pc_*).
-psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
-                            const float* flows_f2, const uint8_t* occ_s2, int n_launches, int launch_id0, hipStream_t s)
+// The arguments every launch of a device-paced sequence carries: those of frame 1 + the strides of the per-frame stacks
+// (psfm_seq_kernel gets them as kernel arguments, psfm_seq_batch_kernel from its sequence's row of the batch table).
+static psfm_status pc_seq_args(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
+                               const float* flows_f2, const uint8_t* occ_s2, PcParams& P, PsfmChainArgs& a, PsfmSeqStride& st, hipStream_t s)
 {
     const int64_t Pix = (int64_t)d.H * d.W;
-    PcParams P;
     psfm_status rc = pc_frame_params(c, d, flows, flows + Pix * 2, flows_f2, occ_s2, 1, P, s);
     if (rc != PSFM_OK) return rc;
     const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
@@ -1933,11 +2021,92 @@ psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* fl
     P.partials = c->sol_partials.as<double>();
     P.gticket = c->sol_fused.as<unsigned>();
     P.gpart = (double*)((char*)c->sol_fused.p + tbytes);
-    PsfmChainArgs a;
-    psfm_fill_chain_args(c, d, flows + Pix * 2, occ + occ_pitch, 1, a, s);
+    psfm_fill_chain_args_nolaunch(c, d, flows + Pix * 2, occ + occ_pitch, 1, a);
     a.owner_clear = 1;
-    PsfmSeqStride st;
     st.flow = Pix; st.occ = occ_pitch; st.cap = d.cap;          // (float2 / byte / double2 elements per frame)
+    return PSFM_OK;
+}
+
+// ---- batch (psfm_batch.hip): rows of the table, the batched launches ----
+size_t psfm_batch_seq_opt_bytes(void) { return sizeof(PsfmBatchSeqOpt); }
+psfm_status psfm_batch_fill_seq_opt(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
+                                    const float* flows_f2, const uint8_t* occ_s2, void* row_host, hipStream_t s)
+{
+    PsfmBatchSeqOpt* q = (PsfmBatchSeqOpt*)row_host;
+    memset(q, 0, sizeof(*q));
+    psfm_status rc = pc_seq_args(c, d, flows, occ, occ_pitch, flows_f2, occ_s2, q->P, q->a, q->st, s);
+    if (rc != PSFM_OK) return rc;
+    q->occ2_stride = (int64_t)d.H * d.W;
+    q->n_flows = d.n_flows;
+    return PSFM_OK;
+}
+
+psfm_status psfm_launch_seq_batch(psfm_ctx* owner, const void* tab_dev, int n_seq, int ratio, int64_t cap_max, int n_launches, int launch_id0,
+                                  hipStream_t s)
+{
+    const unsigned gx = (unsigned)(((cap_max + PC_BLOCK - 1) / PC_BLOCK + 7) / 8 * 8);
+    const dim3 grid(gx, (unsigned)n_seq), block(PC_BLOCK);
+    const PsfmBatchSeqOpt* tab = (const PsfmBatchSeqOpt*)tab_dev;
+    for (int k = 0; k < n_launches; ++k) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        owner->prof.kernel_span(PSFM_PROF_SOLVER, &e0, &e1, true);
+        const int id = launch_id0 + k;
+        switch (ratio) {
+            case 1: hipExtLaunchKernelGGL((psfm_seq_batch_kernel<1, PSFM_SEQ_WAVES_DEFAULT>), grid, block, 0, s, e0, e1, 0, tab, id); break;
+            case 2: hipExtLaunchKernelGGL((psfm_seq_batch_kernel<2, PSFM_SEQ_WAVES_DEFAULT>), grid, block, 0, s, e0, e1, 0, tab, id); break;
+            case 4: hipExtLaunchKernelGGL((psfm_seq_batch_kernel<4, PSFM_SEQ_WAVES_DEFAULT>), grid, block, 0, s, e0, e1, 0, tab, id); break;
+            default: hipExtLaunchKernelGGL((psfm_seq_batch_kernel<0, PSFM_SEQ_WAVES_DEFAULT>), grid, block, 0, s, e0, e1, 0, tab, id); break;
+        }
+    }
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+psfm_status psfm_launch_flush_batch(const void* tab_dev, int n_seq, int64_t cap_max, hipStream_t s)
+{
+    int64_t nb = (cap_max + PC_BLOCK - 1) / PC_BLOCK;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(psfm_pc_flush_batch_kernel, dim3((unsigned)nb, (unsigned)n_seq), dim3(PC_BLOCK), 0, s, (const PsfmBatchSeqOpt*)tab_dev, 0);
+    hipLaunchKernelGGL(psfm_pc_flush_batch_kernel, dim3(1, (unsigned)n_seq), dim3(PC_BLOCK), 0, s, (const PsfmBatchSeqOpt*)tab_dev, 1);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+psfm_status psfm_launch_batch_set_pc(const void* tab_dev, const int (*v)[4], int n_seq, hipStream_t s)
+{
+    PsfmBatchPc pc;
+    memset(&pc, 0, sizeof(pc));
+    for (int i = 0; i < PSFM_BATCH_MAX; ++i) pc.v[i][0] = -1;
+    for (int i = 0; i < n_seq; ++i) for (int k = 0; k < 4; ++k) pc.v[i][k] = v[i][k];
+    hipLaunchKernelGGL(psfm_batch_set_pc_kernel, dim3(1), dim3(PSFM_BATCH_MAX), 0, s, (const PsfmBatchSeqOpt*)tab_dev, pc, n_seq);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+size_t psfm_batch_pack_row_bytes(int win) { return sizeof(PsfmCounters) + sizeof(psfm_solve_stats) * (size_t)win; }
+psfm_status psfm_launch_batch_pack(const void* tab_dev, const int* lo, int n_seq, int win, char* out_dev, hipStream_t s)
+{
+    PsfmBatchWin w;
+    memset(&w, 0, sizeof(w));
+    for (int i = 0; i < n_seq; ++i) w.lo[i] = lo[i];
+    hipLaunchKernelGGL(psfm_batch_pack_kernel, dim3((unsigned)n_seq), dim3(64), 0, s, (const PsfmBatchSeqOpt*)tab_dev, w, win,
+                       (int)psfm_batch_pack_row_bytes(win), out_dev);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// Device-paced sequence: `n_launches` launches of psfm_seq_kernel (ids launch_id0 ..), every one with the arguments of
+// frame 1 and the strides; what each of them does is decided on the device (PsfmCounters::pc_*).
+psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
+                            const float* flows_f2, const uint8_t* occ_s2, int n_launches, int launch_id0, hipStream_t s)
+{
+    const int64_t Pix = (int64_t)d.H * d.W;
+    PcParams P;
+    PsfmChainArgs a;
+    PsfmSeqStride st;
+    psfm_status rc = pc_seq_args(c, d, flows, occ, occ_pitch, flows_f2, occ_s2, P, a, st, s);
+    if (rc != PSFM_OK) return rc;
+    const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
     if (getenv("PSFM_SEQ_CHECK")) {     // the device-side rebase against the host's own per-frame arguments
         const int fs[] = {2, 3, 17, 254, 255, 256, 509, 510};
         for (int f : fs) {
@@ -2032,10 +2201,11 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     PSFM_HIP(hipMemcpyAsync(P.ref2, ref2, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));
     PSFM_HIP(hipMemcpyAsync(P.scale, scale, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
-    if (!pc_persist_enqueue(c, P, n_blocks, out, false, s))
+    bool resident = false;
+    if (!(resident = pc_persist_enqueue(c, P, n_blocks, out, false, false, s)))
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     PSFM_HIP(hipGetLastError());
-    rc = pc_finish_sync(c, P, n_blocks, out, st, s);
+    rc = pc_finish_sync(c, P, n_blocks, out, st, s, resident);
     if (rc != PSFM_OK) return rc;
     PSFM_HIP(hipStreamSynchronize(s));
     return PSFM_OK;

@@ -18,6 +18,7 @@
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 #include <vector>
 
 #include "psfm_internal.h"
@@ -408,6 +409,97 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
 {
     PsfmChainOut o;
     (void)psfm_chain_step_body<R, OPT, false>(a, o);
+}
+
+// ---- batched forms (psfm_batch.hip): B same-shape sequences, blockIdx.y = sequence, gridDim.x a multiple of 8 (workgroups go to
+// the XCDs round-robin by linear id: block (x, y) then still sits on XCD x % 8, which psfm_xcd_tile counts on) ----
+template <int R, bool OPT>
+__global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_step_batch_kernel(const PsfmBatchSeq* __restrict__ seqs, int frame)
+{
+    const PsfmBatchSeq& q = seqs[blockIdx.y];
+    if (frame >= q.n_flows) return;
+    PsfmChainArgs a = q.a;
+    psfm_chain_args_rebase(a, q.st, frame);
+    PsfmChainOut o;
+    (void)psfm_chain_step_body<R, OPT, false>(a, o);
+}
+
+// what psfm_launch_track_init does (two memsets + psfm_track_init_kernel) for every sequence of the batch, from its table row
+// (the arguments of frame 1: slab 0 of the log, map 0 and survivor word 0 lie one stride below)
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_track_init_batch_kernel(const PsfmBatchSeq* __restrict__ seqs)
+{
+    const PsfmBatchSeq& q = seqs[blockIdx.y];
+    const PsfmChainArgs& a = q.a;
+    const int64_t stride = (int64_t)gridDim.x * PSFM_BLOCK;
+    const int64_t i0 = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    const int df = a.frame;                                   // (1: the table holds the arguments of frame 1)
+    double2* log0 = a.log_cur - (int64_t)df * q.st.cap;
+    uint8_t* maps = (df & 1) ? const_cast<uint8_t*>(a.blocked_prev) : a.blocked_cur;     // map 0 (map 1 follows at + G)
+    int* surv = a.surv_cur - df;
+    if (i0 == 0) {
+        PsfmCounters* ctr = a.ctr;
+        ctr->n_lanes = a.G; ctr->n_lanes_snap[0] = ctr->n_lanes_snap[1] = a.G; ctr->overflow = 0; ctr->stall = 0; ctr->sel = 0;
+        ctr->abort = 0; ctr->spill_cnt = 0;
+        ctr->pc_frame = 1; ctr->pc_phase = 0; ctr->pc_owner = 0; ctr->solve_K = 3;
+    }
+    if (i0 < 2 * PSFM_NSHARD) { a.sh_fin[i0].fin_cnt = 0; a.sh_fin[i0].free_top = 0; a.sh_fin[i0].points = (i0 == 0) ? (unsigned)a.G : 0u; }
+    for (int64_t i = i0; i < 2 * (int64_t)a.G; i += stride) maps[i] = 0;
+    for (int64_t i = i0; i <= q.n_flows; i += stride) surv[i] = 0;
+    for (int64_t i = i0; i < a.cap; i += stride) {
+        if (i < a.G) {
+            a.birth_frame[i] = 0;
+            a.birth_idx[i] = (int)i;
+            log0[i] = make_double2((double)((int)(i % a.GW) * a.ratio), (double)((int)(i / a.GW) * a.ratio));
+        } else {
+            a.birth_frame[i] = -1;
+        }
+    }
+}
+
+// one row of the batch table: the sequence's chain-step arguments at frame 1 (device-side stamp-wrap clear, as psfm_seq_kernel)
+void psfm_batch_fill_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch, PsfmBatchSeq* row)
+{
+    const int64_t Pix = (int64_t)d.H * d.W;
+    memset(row, 0, sizeof(*row));
+    psfm_fill_chain_args_nolaunch(c, d, flows + Pix * 2, occ + occ_pitch, 1, row->a);
+    row->a.owner_clear = 1;
+    row->st.flow = Pix; row->st.occ = occ_pitch; row->st.cap = d.cap;
+    row->n_flows = d.n_flows;
+}
+
+psfm_status psfm_launch_track_init_batch(const PsfmBatchSeq* tab_dev, int n_seq, int64_t cap_max, hipStream_t s)
+{
+    int64_t nb = (cap_max + PSFM_BLOCK - 1) / PSFM_BLOCK;
+    if (nb > 4096) nb = 4096;       // (grid-stride inside)
+    hipLaunchKernelGGL(psfm_track_init_batch_kernel, dim3((unsigned)nb, (unsigned)n_seq), dim3(PSFM_BLOCK), 0, s, tab_dev);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+psfm_status psfm_launch_chain_step_batch(psfm_ctx* owner, const PsfmBatchSeq* tab_dev, int n_seq, int ratio, int64_t cap_max, int frame,
+                                         bool optimize, hipStream_t s)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    owner->prof.kernel_span(PSFM_PROF_CHAIN, &e0, &e1);
+    const unsigned gx = (unsigned)(((cap_max + PSFM_CHAIN_TILE - 1) / PSFM_CHAIN_TILE + 7) / 8 * 8);
+    const dim3 grid(gx, (unsigned)n_seq), block(PSFM_CHAIN_BLOCK);
+    if (optimize) {
+        switch (ratio) {
+            case 1: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<1, true>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+            case 2: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<2, true>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+            case 4: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<4, true>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+            default: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<0, true>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+        }
+    } else {
+        switch (ratio) {
+            case 1: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<1, false>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+            case 2: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<2, false>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+            case 4: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<4, false>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+            default: hipExtLaunchKernelGGL((psfm_chain_step_batch_kernel<0, false>), grid, block, 0, s, e0, e1, 0, tab_dev, frame); break;
+        }
+    }
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
 }
 
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_clear_map_kernel(const PsfmCounters* __restrict__ ctr,

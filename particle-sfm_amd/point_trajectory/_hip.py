@@ -22,6 +22,7 @@ EXPORTS = [
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
+    "psfm_connect_batch",
 ]
 
 
@@ -78,6 +79,8 @@ def lib():
     L.psfm_optimize_location.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, ctypes.POINTER(SolveStats), vp]
     L.psfm_track.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(TrackInfo), vp]
     L.psfm_connect.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, ctypes.POINTER(TrackInfo), vp]
+    L.psfm_connect_batch.argtypes = [ctypes.POINTER(vp), i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                     ctypes.POINTER(i32), i32, i32, f32, i32, ctypes.POINTER(TrackInfo), vp]
     L.psfm_result_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.psfm_result_copy.argtypes = [vp, vp, vp, vp, vp, vp]
     L.psfm_result_solve_stats.argtypes = [vp, ctypes.POINTER(SolveStats), i32, ctypes.POINTER(ctypes.c_int32)]
@@ -193,6 +196,24 @@ def context(device=None):
         with _contexts_lock:
             _contexts[key] = ctx
     return ctx
+
+
+def batch_contexts(n, device=None):
+    """n psfm contexts of the calling thread on `device` for psfm_connect_batch (one per sequence of a batch; the first is the
+    thread's ordinary context and owns the batch's shared workspace).  Cached: workspaces stay warm across batches."""
+    import threading
+    first = context(device)
+    out = [first]
+    for k in range(1, int(n)):
+        key = (first.device, threading.get_ident(), "batch", k)
+        with _contexts_lock:
+            ctx = _contexts.get(key)
+        if ctx is None:
+            ctx = Context(first.device)
+            with _contexts_lock:
+                _contexts[key] = ctx
+        out.append(ctx)
+    return out
 
 
 def release_thread_contexts():

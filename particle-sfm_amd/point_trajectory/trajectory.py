@@ -247,6 +247,55 @@ def run_connect(flows_f, flows_b, flows_f2, flows_b2, thres, sample_ratio, retur
     return _result_to_host(ctx, info)
 
 
+def run_connect_batch(seqs, thres, sample_ratio):
+    """psfm_connect_batch: flow_check + track / track_optimize for a BATCH of same-shape sequences (the directory of sequences the
+    reference's driver walks, run_particlesfm.py:168-176) with every frame launch covering the whole batch.
+    seqs: list of (flows_f, flows_b, flows_f2 | None, flows_b2 | None) device tensors (n_i,H,W,2) -- all with stride-2 stacks or
+    none.  Returns (contexts, infos): context i holds sequence i's result (`_result_to_host(ctx, info)`,
+    `result_to_trajectory_set(ctx, info)`) until the calling thread's next batch."""
+    import torch
+    n_seq = len(seqs)
+    if n_seq < 1:
+        return [], []
+    H, W = int(seqs[0][0].shape[1]), int(seqs[0][0].shape[2])
+    opt = seqs[0][2] is not None
+    keep = []           # (tensors created here must outlive the call)
+    nf = (ctypes.c_int * n_seq)()
+    vp = ctypes.c_void_p
+    ff, fb, f2, b2 = (vp * n_seq)(), (vp * n_seq)(), (vp * n_seq)(), (vp * n_seq)()
+    for i, (a, b, a2, b2_) in enumerate(seqs):
+        if int(a.shape[1]) != H or int(a.shape[2]) != W or (a2 is not None) != opt:
+            raise ValueError("connect_batch: sequence %d differs in frame size / stride-2 stacks from sequence 0" % i)
+        n = min(int(a.shape[0]), int(b.shape[0]))
+        if n < 1:
+            raise ValueError("connect_batch: sequence %d has no flow field" % i)
+        if opt and n > 1 and (a2.shape[0] < n - 1 or b2_.shape[0] < n - 1):
+            raise ValueError("connect_batch: sequence %d needs %d stride-2 flows" % (i, n - 1))
+        nf[i] = n
+        ff[i], fb[i] = a.data_ptr(), b.data_ptr()
+        if opt:
+            if a2.numel() == 0:
+                a2 = b2_ = torch.zeros((1, H, W, 2), dtype=torch.float32, device=a.device)
+                keep.append(a2)
+            f2[i], b2[i] = a2.data_ptr(), b2_.data_ptr()
+    ctxs = _hip.batch_contexts(n_seq)
+    handles = (vp * n_seq)(*[c.handle for c in ctxs])
+    infos = (_hip.TrackInfo * n_seq)()
+    cap_key = ("batch", H, W, int(sample_ratio), opt)
+    lane_f, traj_f = _capacity_of(ctxs[0], cap_key)
+    for attempt in range(6):
+        for c in ctxs:
+            c.set_capacity(lane_f, traj_f)
+        ctxs[0]._capacity[cap_key] = (lane_f, traj_f)
+        st = _hip.lib().psfm_connect_batch(handles, n_seq, ff, fb, f2 if opt else None, b2 if opt else None, nf, H, W, float(thres),
+                                           int(sample_ratio), infos, _hip.current_stream_ptr(ctxs[0].device))
+        if st != _hip.PSFM_ERR_CAPACITY:
+            break
+        lane_f, traj_f = lane_f * 2.0, traj_f * 4.0      # tables too small for one of the sequences: grow all and rerun
+    _hip.check(st)
+    return ctxs, [infos[i] for i in range(n_seq)]
+
+
 def run_track(flows, occ_maps, flows_f2, occ_maps_s2, sample_ratio, return_device=False):
     """Shared driver of track() / track_optimize(): one psfm_track call (whole frame loop on the device)."""
     import torch

@@ -31,6 +31,15 @@ def read_flo(file):
     return np.resize(data, (h, w, 2))       # (np.resize, as the reference: a truncated file repeats its data instead of failing)
 
 
+def _flo_shape(f, name):
+    """(h, w) from the 12-byte header of an open .flo file (the same header dtype read_flo parses); AssertionError when the
+    file does not start with the magic number."""
+    head = np.fromfile(f, _FLO_HEADER, count=1)
+    if len(head) != 1 or head["magic"][0] != np.float32(TAG_FLOAT):
+        raise AssertionError("%s does not start with the .flo magic number %r" % (name, TAG_FLOAT))
+    return int(head["h"][0]), int(head["w"][0])
+
+
 def write_flo(file, flow):
     flow = np.ascontiguousarray(flow, dtype=np.float32)
     with open(file, 'wb') as f:
@@ -70,21 +79,12 @@ def load_flows_device(dir, device=None, n_staging=16, n_readers=8, _names=None, 
     if not names:
         if _probe:          # an empty slice of a non-empty stack keeps the frame shape
             with open(_probe[0], 'rb') as f:
-                tag = np.fromfile(f, np.float32, count=1)[0]
-                assert tag == TAG_FLOAT, 'Flow number %r incorrect. Invalid .flo file %r' % (tag, _probe[0])
-                w = int(np.fromfile(f, np.int32, count=1)[0]); h = int(np.fromfile(f, np.int32, count=1)[0])
+                h, w = _flo_shape(f, _probe[0])
             return torch.zeros((0, h, w, 2), dtype=torch.float32, device=dev)
         return torch.zeros((0, 0, 0, 2), dtype=torch.float32, device=dev)
 
-    def header(f, name):
-        tag = np.fromfile(f, np.float32, count=1)[0]
-        assert tag == TAG_FLOAT, 'Flow number %r incorrect. Invalid .flo file %r' % (tag, name)
-        w = int(np.fromfile(f, np.int32, count=1)[0])
-        h = int(np.fromfile(f, np.int32, count=1)[0])
-        return h, w
-
     with open(names[0], 'rb') as f:
-        h, w = header(f, names[0])
+        h, w = _flo_shape(f, names[0])
     out = torch.empty((len(names), h, w, 2), dtype=torch.float32, device=dev)
     n_staging = max(2, min(int(n_staging), len(names)))
     key = (h, w, n_staging)
@@ -97,10 +97,12 @@ def load_flows_device(dir, device=None, n_staging=16, n_readers=8, _names=None, 
     def read(i, k):
         name = names[i]
         with open(name, 'rb') as f:
-            assert header(f, name) == (h, w), "flow size mismatch in %r" % name
+            if _flo_shape(f, name) != (h, w):
+                raise AssertionError("%s: frame size differs from the first file's %d x %d" % (name, w, h))
             buf = staging[k].numpy().reshape(-1)
             got = f.readinto(memoryview(buf).cast('B'))
-            assert got == buf.nbytes, "truncated .flo file %r" % name
+            if got != buf.nbytes:
+                raise AssertionError("%s: truncated (%d of %d data bytes)" % (name, got, buf.nbytes))
         return i
 
     done = [None] * n_staging          # H2D copy out of staging buffer k

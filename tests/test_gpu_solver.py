@@ -401,6 +401,39 @@ def test_resident_solve_with_one_block_giving_up_mid_solve(pt, monkeypatch, quit
         ctx.set_solver(0, 0)
 
 
+@pytest.mark.parametrize("env,val", [("PSFM_PC_SPIN", "0"), ("PSFM_PC_QUIT", "0,1"), ("PSFM_PC_QUIT", "5,2")])
+def test_redo_of_a_fused_solve_survives_a_resident_launch_that_gives_up(pt, monkeypatch, env, val):
+    """The DEFAULT adaptive path on flows whose solves reject steps: the fused solve of a frame stalls at the first rejection and
+    the host redoes it (psfm_solve_frame_resume, chain_stalled = false) with iteration 0 + the resident launch, polling behind it.
+    When that launch gives up (spin limit 0 / one block quitting: a grid that is not co-resident) it must leave the stall flag
+    alone -- raised, every pc_iter launch of the polling loop would return at once and the call would end in PSFM_ERR_SOLVER
+    ("did not terminate") -- and the launches take the solve from iteration 0.  Same results as the oracle."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    T, H, W, r = 7, 120, 200, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=73, stride2=True, **psfm_synth.HARD)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    assert sum(s["iterations"] - s["successful_steps"] for s in O.solves) > 0
+    ctx = _hip.context()
+    ctx.set_solver(0, 0)
+    # (the adaptive mode remembers what the last window of the context's previous sequence looked like: a clean sequence first, so
+    # that this one starts with the fused solve)
+    c = psfm_synth.synth_sequence(5, H, W, seed=74, sigma=0.02, n_occluders=0, stride2=True)
+    _, co = orc.flow_check(c["flows_f"], c["flows_b"], 1.0)
+    _, co2 = orc.flow_check(c["flows_f2"], c["flows_b2"], 1.0)
+    pt.track_optimize(c["flows_f"], c["flows_f2"], co, co2, r)        # (may itself run as the chain; its clean window brings the fused solve back)
+    monkeypatch.setenv("PSFM_PC_PERSIST", "1")
+    monkeypatch.setenv(env, val)
+    R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    cnt = ctx.solver_counters()
+    assert cnt["fused_redone"] >= 1, cnt        # (the path under test ran)
+    assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and float(np.abs(R.xy - O.xy).max()) <= TOL
+    assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+    assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
+
+
 def test_exclusive_sequence_lets_other_host_threads_in(pt):
     """A track_optimize call takes the device gate exclusively when it is free (its hard solves then run as resident launches);
     a psfm call of another host thread that arrives meanwhile announces itself and is let in at the sequence's next checkpoint
