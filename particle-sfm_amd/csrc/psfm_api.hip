@@ -163,7 +163,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
                        &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
                        &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->sol_fused, &c->sol_bar, &c->sol_list, &c->occ_own, &c->occ2_own,
-                       &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar, &c->batch_tab, &c->batch_ws, &c->win_ws, &c->flt_ids, &c->flt_birth, &c->flt_len, &c->flt_off, &c->flt_xy,
+                       &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar, &c->batch_tab, &c->batch_ws, &c->batch_fc, &c->win_ws, &c->flt_ids, &c->flt_birth, &c->flt_len, &c->flt_off, &c->flt_xy,
                        &c->mt_kp_off, &c->mt_q, &c->mt_pts, &c->mt_kp_ind, &c->mt_kp_xy, &c->mt_moff, &c->mt_keys, &c->mt_rows, &c->mt_gid, &c->mt_pairs};
     for (auto b : bufs) b->release();
     psfm_shard_abandon(c);
@@ -172,6 +172,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->host_seg) (void)hipHostFree(c->host_seg);
     if (c->host_batch) (void)hipHostFree(c->host_batch);
+    if (c->host_batch2) (void)hipHostFree(c->host_batch2);
     delete c;
     return PSFM_OK;
 }

@@ -37,6 +37,16 @@ struct SeqState {
 };
 }  // namespace
 
+static psfm_status batch_host_staging2(psfm_ctx* own, size_t need)
+{
+    if (own->host_batch2_bytes >= need) return PSFM_OK;
+    if (own->host_batch2) (void)hipHostFree(own->host_batch2);
+    own->host_batch2 = nullptr; own->host_batch2_bytes = 0;
+    PSFM_HIP(hipHostMalloc(&own->host_batch2, need + 1024, hipHostMallocDefault));
+    own->host_batch2_bytes = need + 1024;
+    return PSFM_OK;
+}
+
 static psfm_status batch_host_staging(psfm_ctx* own, size_t need)
 {
     if (own->host_batch_bytes >= need) return PSFM_OK;
@@ -73,6 +83,13 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
     std::vector<int> redo;
     std::vector<SeqState> S((size_t)B);
     psfm_status st;
+    // events of the flow_check pipeline: back into the owner's pool when the call ends, however it ends (the stream is synchronised
+    // or the call failed; a recycled event is re-recorded before anything waits on it)
+    struct EventReturn {
+        psfm_ctx* c; std::vector<hipEvent_t> ev;
+        void push_back(hipEvent_t e) { ev.push_back(e); }
+        ~EventReturn() { for (auto e : ev) c->prof.pool.push_back(e); }
+    } fc_events{own, {}};
     {
         PsfmGate gate(own->device, 0);        // launches only: nothing here needs the device to itself
         // ---- dimensions (one key format for the whole batch: the time bits of its longest sequence), workspaces ----
@@ -105,14 +122,74 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             // a context told to use the launch chain for every solve has nothing to gain from the batch: it runs alone
             if (optimize && c->solver_mode == 1 && n_flows[i] >= 2) S[i].dropped = true;
         }
-        // ---- flow_check of every stack (utils.py:94-105); bandwidth-bound, one launch per stack ----
-        own->prof.begin(PSFM_PROF_FLOW_CHECK, s);
-        for (int i = 0; i < B; ++i) {
+        // ---- flow_check of every stack (utils.py:94-105) ----
+        // Bandwidth-bound work beside a latency-bound frame loop: the maps are produced on the owner's side stream in chunks of
+        // frame pairs -- ONE launch per chunk for all sequences (psfm_flow_check_x2v_batch_kernel) -- and the frame loop only waits
+        // for the chunk it is about to read (what psfm_connect does for one sequence).  PSFM_BATCH_FC_CHUNK=0, or stacks the
+        // 16-byte-load kernel cannot take: every stack up front on the launch stream.
+        const int fc_env = getenv("PSFM_BATCH_FC_CHUNK") ? atoi(getenv("PSFM_BATCH_FC_CHUNK")) : -1;
+        int fc_chunk = fc_env >= 0 ? fc_env : (optimize ? 6 : 8);
+        for (int i = 0; i < B && fc_chunk > 0; ++i) {
             if (S[i].dropped) continue;
-            psfm_ctx* c = ctxs[i];
-            if ((st = psfm_launch_flow_check(flows_f[i], flows_b[i], n_flows[i], h, w, thres, c->occ_own.as<uint8_t>(), nullptr, s)) != PSFM_OK) return st;
-            if (optimize && n_flows[i] > 1 &&
-                (st = psfm_launch_flow_check(flows_f2[i], flows_b2[i], n_flows[i] - 1, h, w, thres, c->occ2_own.as<uint8_t>(), nullptr, s)) != PSFM_OK) return st;
+            if (!psfm_flow_check_batch_ok(h, w, flows_f[i], flows_b[i], ctxs[i]->occ_own.p)) fc_chunk = 0;
+            if (optimize && n_flows[i] > 1 && !psfm_flow_check_batch_ok(h, w, flows_f2[i], flows_b2[i], ctxs[i]->occ2_own.p)) fc_chunk = 0;
+        }
+        std::vector<hipEvent_t> fc_ready, fc_ready2;      // chunk c of the stride-1 / stride-2 maps: pairs [c * fc_chunk, (c + 1) * fc_chunk)
+        int fc_waited = -1, fc_waited2 = -1;
+        auto fc_need = [&](int pair, bool s2) -> psfm_status {
+            if (fc_chunk <= 0) return PSFM_OK;
+            std::vector<hipEvent_t>& ev = s2 ? fc_ready2 : fc_ready;
+            int& wv = s2 ? fc_waited2 : fc_waited;
+            const int cidx = pair / fc_chunk;
+            while (wv < cidx && wv + 1 < (int)ev.size()) {
+                ++wv;
+                PSFM_HIP(hipStreamWaitEvent(s, ev[(size_t)wv], 0));
+            }
+            return PSFM_OK;
+        };
+        own->prof.begin(PSFM_PROF_FLOW_CHECK, s);
+        if (fc_chunk <= 0) {
+            for (int i = 0; i < B; ++i) {
+                if (S[i].dropped) continue;
+                psfm_ctx* c = ctxs[i];
+                if ((st = psfm_launch_flow_check(flows_f[i], flows_b[i], n_flows[i], h, w, thres, c->occ_own.as<uint8_t>(), nullptr, s)) != PSFM_OK) return st;
+                if (optimize && n_flows[i] > 1 &&
+                    (st = psfm_launch_flow_check(flows_f2[i], flows_b2[i], n_flows[i] - 1, h, w, thres, c->occ2_own.as<uint8_t>(), nullptr, s)) != PSFM_OK) return st;
+            }
+        } else {
+            const size_t fbytes = sizeof(PsfmFcSeq) * (size_t)B * 2;
+            if ((st = batch_host_staging2(own, fbytes)) != PSFM_OK) return st;
+            if ((st = own->batch_fc.ensure(fbytes)) != PSFM_OK) return st;
+            PsfmFcSeq* hfc = (PsfmFcSeq*)own->host_batch2;
+            for (int i = 0; i < B; ++i) {
+                psfm_ctx* c = ctxs[i];
+                hfc[i].ff = flows_f[i]; hfc[i].fb = flows_b[i]; hfc[i].occ = c->occ_own.as<uint8_t>(); hfc[i].n_pairs = S[i].dropped ? 0 : n_flows[i]; hfc[i].pad = 0;
+                hfc[B + i].ff = optimize ? flows_f2[i] : nullptr; hfc[B + i].fb = optimize ? flows_b2[i] : nullptr;
+                hfc[B + i].occ = optimize ? c->occ2_own.as<uint8_t>() : nullptr;
+                hfc[B + i].n_pairs = (optimize && !S[i].dropped && n_flows[i] > 1) ? n_flows[i] - 1 : 0; hfc[B + i].pad = 0;
+            }
+            PSFM_HIP(hipMemcpyAsync(own->batch_fc.p, hfc, fbytes, hipMemcpyHostToDevice, s));
+            if (!own->side_stream) PSFM_HIP(hipStreamCreateWithFlags(&own->side_stream, hipStreamNonBlocking));
+            hipStream_t side = own->side_stream;
+            hipEvent_t e_in = own->prof.get();      // the side stream starts behind whatever the caller enqueued on `stream` (the inputs, the table)
+            PSFM_HIP(hipEventRecord(e_in, s));
+            PSFM_HIP(hipStreamWaitEvent(side, e_in, 0));
+            fc_events.push_back(e_in);
+            const PsfmFcSeq* dfc = own->batch_fc.as<PsfmFcSeq>();
+            for (int p0 = 0; p0 < n_max; p0 += fc_chunk) {
+                const int np = n_max - p0 < fc_chunk ? n_max - p0 : fc_chunk;
+                if ((st = psfm_launch_flow_check_batch(dfc, B, p0, np, h, w, thres, side)) != PSFM_OK) return st;
+                hipEvent_t e = own->prof.get();
+                PSFM_HIP(hipEventRecord(e, side));
+                fc_ready.push_back(e); fc_events.push_back(e);
+                if (optimize && p0 < n_max - 1) {     // the stride-2 maps of the same time range follow their stride-1 chunk
+                    const int np2 = n_max - 1 - p0 < fc_chunk ? n_max - 1 - p0 : fc_chunk;
+                    if ((st = psfm_launch_flow_check_batch(dfc + B, B, p0, np2, h, w, thres, side)) != PSFM_OK) return st;
+                    hipEvent_t e2 = own->prof.get();
+                    PSFM_HIP(hipEventRecord(e2, side));
+                    fc_ready2.push_back(e2); fc_events.push_back(e2);
+                }
+            }
         }
         own->prof.end(s);
         // ---- the table of sequences ----
@@ -147,10 +224,13 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
 
         if (!optimize) {
             // ---- track.py:31-47: one launch per frame index for the whole batch ----
-            for (int f = 0; f < n_max; ++f)
+            for (int f = 0; f < n_max; ++f) {
+                if ((st = fc_need(f, false)) != PSFM_OK) return st;
                 if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, cap_max, f, false, s)) != PSFM_OK) return st;
+            }
         } else {
             // ---- track_optimize.py:31-50: frame 0 is a plain chain step; from frame 1 on device-paced launches ----
+            if ((st = fc_need(0, false)) != PSFM_OK) return st;
             if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, cap_max, 0, true, s)) != PSFM_OK) return st;
             int launch_id = 0;
             int v[PSFM_BATCH_MAX][4];
@@ -159,7 +239,7 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                 S[i].resync = true;       // (track_init left pc = {frame 1, phase 0, launch 0, K 3}: set this context's K)
             }
             for (;;) {
-                int left_max = 0;
+                int left_max = 0, f_top = 0;
                 bool any_set = false;
                 for (int i = 0; i < B; ++i) {
                     psfm_ctx* c = ctxs[i];
@@ -168,6 +248,7 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                     const int k_now = c->solver_K > 0 ? c->solver_K : c->solve_K;
                     if (S[i].f < n_i) {
                         if (n_i - S[i].f > left_max) left_max = n_i - S[i].f;
+                        if (S[i].f > f_top) f_top = S[i].f;
                         if (S[i].resync) { v[i][0] = S[i].f; v[i][3] = k_now; any_set = true; }
                         else if (k_now != S[i].k_dev) { v[i][0] = -2; v[i][3] = k_now; any_set = true; }      // (K only: the device may be inside a solve)
                         S[i].k_dev = k_now;
@@ -179,6 +260,11 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                 if (left_max == 0) break;
                 if (any_set && (st = psfm_launch_batch_set_pc(dtabo, v, B, s)) != PSFM_OK) return st;
                 const int n_launch = (left_max < CHECK ? left_max : CHECK) + 2;      // two spare: continuation launches of the window
+                {   // the furthest frame a launch of this window can reach, and the maps it reads
+                    const int f_hi = f_top + n_launch - 1 < n_max - 1 ? f_top + n_launch - 1 : n_max - 1;
+                    if ((st = fc_need(f_hi, false)) != PSFM_OK) return st;
+                    if ((st = fc_need(f_hi - 1, true)) != PSFM_OK) return st;
+                }
                 if ((st = psfm_launch_seq_batch(own, dtabo, B, ratio, cap_max, n_launch, launch_id, s)) != PSFM_OK) return st;
                 launch_id += n_launch;
                 // ---- ONE checkpoint for all sequences ----
@@ -244,6 +330,10 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             }
             if ((st = psfm_launch_flush_batch(dtabo, B, cap_max, s)) != PSFM_OK) return st;
         }
+        // (every chunk of the side stream has been waited for by now unless all sequences left the batch early: the redo below
+        // writes the same maps)
+        if ((st = fc_need(n_max - 1, false)) != PSFM_OK) return st;
+        if (optimize && n_max >= 2 && (st = fc_need(n_max - 2, true)) != PSFM_OK) return st;
         // ---- ONE segmented finalize for the sequences that stayed ----
         std::vector<psfm_ctx*> kc;
         std::vector<PsfmTrackDims> kd;

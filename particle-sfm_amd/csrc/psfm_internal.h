@@ -169,9 +169,12 @@ struct psfm_ctx {
     bool shard_optimize = false;
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)
     PsfmBuf occ_own, occ2_own;           // occlusion maps of psfm_connect when the caller passes none
-    PsfmBuf batch_tab, batch_ws;         // psfm_connect_batch (this context as the batch's owner): the table of sequences, packed checkpoints
+    PsfmBuf batch_tab, batch_ws, batch_fc;   // psfm_connect_batch (this context as the batch's owner): the table of sequences, packed
+                                         // checkpoints, the table of stacks for flow_check
     void* host_batch = nullptr;          // ... and their pinned staging
     size_t host_batch_bytes = 0;
+    void* host_batch2 = nullptr;
+    size_t host_batch2_bytes = 0;
     PsfmBuf win_ws;                      // psfm_window_sample / psfm_result_filter workspace
     PsfmBuf flt_ids, flt_birth, flt_len, flt_off, flt_xy;   // psfm_result_filter: the saved set (length >= traj_min_len), CSR
     int64_t flt_n_traj = 0, flt_n_points = 0;
@@ -218,6 +221,9 @@ psfm_status psfm_launch_chain_step(psfm_ctx* c, const PsfmTrackDims& d, const fl
 // ---- batch: B same-shape sequences per launch (psfm_batch.hip; kernels beside their single-sequence forms) --------------------
 #define PSFM_BATCH_MAX 64
 struct PsfmBatchSeq;      // psfm_chain_step.h: one row of the batch table (chain-step arguments of frame 1 + strides)
+struct PsfmFcSeq { const float* ff; const float* fb; uint8_t* occ; int n_pairs; int pad; };      // one stack of a batch for flow_check
+bool psfm_flow_check_batch_ok(int h, int w, const void* ff, const void* fb, const void* occ);
+psfm_status psfm_launch_flow_check_batch(const PsfmFcSeq* tab_dev, int n_seq, int pair0, int n_pairs, int h, int w, float thres, hipStream_t s);
 void psfm_batch_fill_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch, PsfmBatchSeq* row);
 psfm_status psfm_launch_track_init_batch(const PsfmBatchSeq* tab_dev, int n_seq, int64_t cap_max, hipStream_t s);
 psfm_status psfm_launch_chain_step_batch(psfm_ctx* owner, const PsfmBatchSeq* tab_dev, int n_seq, int ratio, int64_t cap_max, int frame,

@@ -145,14 +145,10 @@ static inline int psfm_xcd_per(int64_t chunks)
 }
 
 template <bool NT>     // NT: non-temporal F loads / mask stores (streamed once: keep them out of the way of the B taps in L2)
-__global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_kernel(
-    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q, uint8_t* __restrict__ occ_out, PsfmFastDiv wdiv,
-    int xcd_per)
+__device__ __forceinline__ void psfm_flow_check_x2v_body(const float2* __restrict__ F, const float2* __restrict__ B, const PsfmFcParams& q,
+                                                         uint8_t* __restrict__ occ_pair, const PsfmFastDiv& wdiv, int xcd_per)
 {
     const int P = q.H * q.W;                      // (even: the launcher falls back to the x4 kernel otherwise)
-    const int64_t base = (int64_t)blockIdx.y * P;
-    const float2* __restrict__ F = flows_f + base;
-    const float2* __restrict__ B = flows_b + base;
     const int bx = psfm_xcd_chunk((int)blockIdx.x, xcd_per);
     if ((int64_t)bx * (PSFM_BLOCK * PSFM_FC2_UNROLL * 2) >= P) return;
     const int p0 = (bx * (PSFM_BLOCK * PSFM_FC2_UNROLL) + threadIdx.x) * 2;
@@ -183,9 +179,29 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_kernel(
             o.x = psfm_flow_check_px16<false>(B, fa, ga, q);
             o.y = psfm_flow_check_px16<false>(B, fb, gb, q);
         }
-        if (NT) __builtin_nontemporal_store(*(unsigned short*)&o, (unsigned short*)(occ_out + base + p));
-        else *(uchar2*)(occ_out + base + p) = o;
+        if (NT) __builtin_nontemporal_store(*(unsigned short*)&o, (unsigned short*)(occ_pair + p));
+        else *(uchar2*)(occ_pair + p) = o;
     }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_kernel(
+    const float2* __restrict__ flows_f, const float2* __restrict__ flows_b, PsfmFcParams q, uint8_t* __restrict__ occ_out, PsfmFastDiv wdiv,
+    int xcd_per)
+{
+    const int64_t base = (int64_t)blockIdx.y * (q.H * q.W);
+    psfm_flow_check_x2v_body<NT>(flows_f + base, flows_b + base, q, occ_out + base, wdiv, xcd_per);
+}
+
+// the same for the stacks of a BATCH of sequences (psfm_connect_batch): blockIdx.y = frame pair pair0 + y, blockIdx.z = sequence
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_flow_check_x2v_batch_kernel(const PsfmFcSeq* __restrict__ T, PsfmFcParams q, PsfmFastDiv wdiv,
+                                                                               int xcd_per, int pair0)
+{
+    const PsfmFcSeq& t = T[blockIdx.z];
+    const int pair = pair0 + (int)blockIdx.y;
+    if (pair >= t.n_pairs) return;
+    const int64_t base = (int64_t)pair * (q.H * q.W);
+    psfm_flow_check_x2v_body<false>((const float2*)t.ff + base, (const float2*)t.fb + base, q, t.occ + base, wdiv, xcd_per);
 }
 
 PsfmFcParams psfm_fc_params(int h, int w, float thres);
@@ -304,6 +320,27 @@ psfm_status psfm_launch_flow_check(const float* ff, const float* fb, int n_pairs
             hipLaunchKernelGGL(psfm_flow_check_kernel<false>, grid, dim3(PSFM_BLOCK), 0, s, (const float2*)ff, (const float2*)fb,
                                q, occ, err);
     }
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
+// can the stacks of a batch go through psfm_flow_check_x2v_batch_kernel?  (what psfm_launch_flow_check asks of the mask-only kernel)
+bool psfm_flow_check_batch_ok(int h, int w, const void* ff, const void* fb, const void* occ)
+{
+    const int64_t P = (int64_t)h * w;
+    return (P % 2) == 0 && P >= PSFM_BLOCK * PSFM_FC2_UNROLL * 2 && ((uintptr_t)ff % 16) == 0 && ((uintptr_t)fb % 16) == 0 && ((uintptr_t)occ % 2) == 0;
+}
+
+psfm_status psfm_launch_flow_check_batch(const PsfmFcSeq* tab_dev, int n_seq, int pair0, int n_pairs, int h, int w, float thres, hipStream_t s)
+{
+    if (n_pairs <= 0 || n_seq <= 0) return PSFM_OK;
+    const int64_t P = (int64_t)h * w;
+    const PsfmFcParams q = psfm_fc_params(h, w, thres);
+    const int64_t per_block = (int64_t)PSFM_BLOCK * PSFM_FC2_UNROLL * 2;
+    const int64_t chunks = (P + per_block - 1) / per_block;
+    const int xcd_per = psfm_xcd_per(chunks);
+    dim3 grid((unsigned)(xcd_per > 0 ? 8 * xcd_per : chunks), (unsigned)n_pairs, (unsigned)n_seq);
+    hipLaunchKernelGGL(psfm_flow_check_x2v_batch_kernel, grid, dim3(PSFM_BLOCK), 0, s, tab_dev, q, psfm_fastdiv_make((unsigned)w), xcd_per, pair0);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }

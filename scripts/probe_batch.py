@@ -65,5 +65,5 @@ for key in which:
                                                               us, row["frame_launches"], row["flow_check_ms"], row["finalize_ms"], row["modes"], same), flush=True)
     del data, seqs
     torch.cuda.empty_cache()
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1]:
     json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -49,5 +49,5 @@ for label, H, W, T, R, opt, thres in SHAPES:
             c.close()
     del data
     torch.cuda.empty_cache()
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1]:
     json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -23,6 +23,10 @@ def input_hash(d):
 
 def regen_inputs(g, stride2):
     """Re-synthesise a fixture's inputs from its seed and check they are the bytes it was made from."""
+    if "realistic" in g:
+        d = psfm_synth.synth_realistic(int(g["T"]), int(g["H"]), int(g["W"]), seed=int(g["seed"]), stride2=stride2, **psfm_synth.REALISTIC)
+        assert input_hash(d) == str(g["input_hash"]), "psfm_synth.synth_realistic no longer reproduces this fixture's inputs"
+        return d
     d = psfm_synth.synth_sequence(int(g["T"]), int(g["H"]), int(g["W"]), seed=int(g["seed"]),
                                   amp=float(g["amp"]) if "amp" in g else 3.0,
                                   sigma=float(g["sigma"]) if "sigma" in g else 0.05,
@@ -64,6 +68,11 @@ def solver_batch(H, W, n, seed, sigma, kink=False):
 # reference-python fixtures with ~10 px of drift per frame: stride-2 flows on both sides of the 20 px gate of trajectory.py:179,
 # fractional occ02 weights, tracks leaving the image (tests/golden/make_golden.py::make_large_motion)
 LARGE_MOTION = ["opt_largemotion_96x128_r2", "opt_largemotion_90x140_r3"]
+
+# reference-python fixtures on psfm_synth.REALISTIC (tests/golden/make_golden.py::make_realistic): depth-ordered layers with true
+# (dis)occlusion, correlated flow error, outlier blobs -- solves that reject steps at the motion boundaries
+REALISTIC_OPT = ["opt_realistic_96x160_r2", "opt_realistic_84x132_r1"]
+REALISTIC_TRACK = ["track_realistic_100x150_r2"]
 
 # the batches every solver test runs (GPU vs oracle, oracle vs the second restatement, real Ceres when available)
 SOLVER_BATCHES = [

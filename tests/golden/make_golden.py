@@ -150,9 +150,48 @@ def make_large_motion(ref):
         ref.particlesfm.optimize_location = real_opt
 
 
+REALISTIC_CASES = [
+    # name, T, H, W, ratio, seed, optimize: psfm_synth.REALISTIC (layers in depth order with true (dis)occlusion, correlated flow error,
+    # outlier blobs -- what RAFT on real video looks like to flow_check and to the solver)
+    ("opt_realistic_96x160_r2", 8, 96, 160, 2, 91, True),
+    ("opt_realistic_84x132_r1", 6, 84, 132, 1, 92, True),
+    ("track_realistic_100x150_r2", 9, 100, 150, 2, 93, False),
+]
+
+
+def make_realistic(ref):
+    """the reference's own flow_check + track / track_optimize on the third distribution.  The fixture records what the
+    sequence exercised: occluded fractions of both strides, trajectories that ended early, solves that rejected steps (statistics of
+    the C restatement the shim forwards optimize_location to)."""
+    from oracle import oracle as orc
+    for name, T, H, W, r, seed, opt in REALISTIC_CASES:
+        d = psfm_synth.synth_realistic(T, H, W, seed=seed, stride2=opt, **psfm_synth.REALISTIC)
+        _, occ = ref.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        extra = {}
+        if opt:
+            _, occ2 = ref.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+            tr = ref.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+            O = orc.track_optimize(d["flows_f"], d["flows_f2"], [np.asarray(o) for o in occ], [np.asarray(o) for o in occ2], r)
+            extra = dict(occ2=np.packbits(np.stack(occ2)), occluded2=float(np.stack(occ2).mean()),
+                         solve_iterations=np.asarray([s_["iterations"] for s_ in O.solves], np.int32),
+                         solve_successful=np.asarray([s_["successful_steps"] for s_ in O.solves], np.int32))
+        else:
+            tr = ref.track(d["flows_f"], occ, r)
+        b, l, off, xy = ref_shim.trajs_to_csr(tr)
+        early = int((b + l - 1 < T - 1).sum())
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), T=T, H=H, W=W, ratio=r, seed=seed, realistic=1, input_hash=input_hash(d),
+                            birth=b, length=l, xy=xy, occ=np.packbits(np.stack(occ)), occluded=float(np.stack(occ).mean()),
+                            ended_early=early, **extra)
+        print(name, len(tr), "tracks,", int(l.sum()), "points,", early, "ended early, occluded", round(float(np.stack(occ).mean()), 3),
+              ("occluded (stride 2) %.3f, iterations %s, accepted %s" % (extra["occluded2"], list(extra["solve_iterations"]),
+                                                                           list(extra["solve_successful"]))) if opt else "")
+
+
 def main():
     import torch
     ref = ref_shim.load()
+    if sys.argv[1:] == ["realistic"]:
+        return make_realistic(ref)
     if sys.argv[1:] == ["nonfinite"]:
         return make_nonfinite(ref)
     if sys.argv[1:] == ["largemotion"]:
@@ -241,6 +280,7 @@ def main():
     make_nonfinite(ref)
     make_track_large_motion(ref)
     make_large_motion(ref)
+    make_realistic(ref)
 
 
 if __name__ == "__main__":

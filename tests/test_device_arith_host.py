@@ -112,7 +112,7 @@ def test_device_flow_check_bit_exact_in_its_three_forms(dev):
 
 
 @pytest.mark.parametrize("name", ["track_48x64_r2", "track_45x70_r1", "track_50x66_r3", "track_52x61_r4",
-                                  "track_largemotion_80x120_r2", "track_largemotion_75x110_r1"])
+                                  "track_largemotion_80x120_r2", "track_largemotion_75x110_r1", "track_realistic_100x150_r2"])
 def test_device_chain_arithmetic_reproduces_the_reference_track(dev, name):
     """Births on the stride-r grid, the step, deaths, the respawn rule as grid-resolution marks, ids by the key: every trajectory
     of the reference's own track() -- ids, lengths, f64 positions -- bit for bit."""
@@ -148,7 +148,8 @@ def test_device_arithmetic_on_nonfinite_flows(dev):
     assert_csr_equal(birth, length, xy, g)
 
 
-@pytest.mark.parametrize("name", ["opt_48x64_r2", "opt_45x70_r3", "opt_largemotion_96x128_r2", "opt_largemotion_90x140_r3"])
+@pytest.mark.parametrize("name", ["opt_48x64_r2", "opt_45x70_r3", "opt_largemotion_96x128_r2", "opt_largemotion_90x140_r3",
+                                  "opt_realistic_96x160_r2"])
 def test_device_arithmetic_reproduces_the_reference_track_optimize(dev, name):
     """track_optimize.py:24-53 with the device's arithmetic end to end: chain step, references / weight of optimize_buffer from
     the fp32 sampler (both sides of the 20 px gate of trajectory.py:179 in the large-motion fixtures), every frame's solve by the

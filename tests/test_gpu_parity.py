@@ -3,7 +3,7 @@ golden vectors produced by the reference's own Python.  Bit-exact for everything
 import numpy as np
 import pytest
 
-from _common import golden, regen_inputs, assert_csr_equal
+from _common import golden, regen_inputs, assert_csr_equal, REALISTIC_TRACK
 import psfm_synth
 
 pytestmark = pytest.mark.gpu
@@ -76,7 +76,7 @@ def test_flow_check_vs_oracle_odd_sizes(pt):
 
 
 @pytest.mark.parametrize("name", ["track_48x64_r2", "track_45x70_r1", "track_50x66_r3", "track_52x61_r4",
-                                  "track_largemotion_80x120_r2", "track_largemotion_75x110_r1"])   # (the last two: ~10 px of drift per frame)
+                                  "track_largemotion_80x120_r2", "track_largemotion_75x110_r1"] + REALISTIC_TRACK)   # (~10 px of drift per frame; layered scene)
 def test_track_golden(pt, name):
     g = golden(name)
     d = regen_inputs(g, stride2=False)

@@ -4,7 +4,7 @@ sides run the same Ceres-compatible control flow in f64 and differ only in round
 import numpy as np
 import pytest
 
-from _common import golden, regen_inputs, assert_csr_equal, solver_batch, SOLVER_BATCHES, LARGE_MOTION
+from _common import golden, regen_inputs, assert_csr_equal, solver_batch, SOLVER_BATCHES, LARGE_MOTION, REALISTIC_OPT
 import psfm_synth
 
 pytestmark = pytest.mark.gpu
@@ -101,6 +101,23 @@ def test_track_optimize_large_motion_golden(pt, solver_mode, name):
     # (sigma 0.25 on 90 x 140: solves of 20-30 iterations through bilinear kinks amplify the rounding differences between the
     # device's and the restatement's arithmetic to a few 1e-7 px; the bar is 1e-4)
     assert float(np.abs(R.xy - g["xy"]).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", REALISTIC_OPT)
+def test_track_optimize_realistic_golden(pt, solver_mode, name):
+    """The third distribution (psfm_synth.REALISTIC: layers with true (dis)occlusion, correlated flow error, outlier blobs) against
+    the fixture of the reference's own Python, every way of running the solve: masks of both strides, ids, lengths, positions, and
+    the iteration count of every solve (all of them reject steps: the launch chain / resident solve, or the redo of a fused solve)."""
+    g = golden(name)
+    d = regen_inputs(g, stride2=True)
+    _, occ = pt.utils.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = pt.utils.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    assert np.array_equal(np.packbits(np.stack(occ)), g["occ"]) and np.array_equal(np.packbits(np.stack(occ2)), g["occ2"])
+    R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g, tol=TOL)
+    assert float(np.abs(R.xy - g["xy"]).max()) <= 1e-5
+    assert [s["iterations"] for s in R.solve_stats] == list(g["solve_iterations"])
+    assert [s["successful_steps"] for s in R.solve_stats] == list(g["solve_successful"])
 
 
 @pytest.mark.parametrize("H,W,T,r,seed,sigma,nocc", [

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from _common import solver_batch, SOLVER_BATCHES, LARGE_MOTION, golden, regen_inputs, assert_csr_equal
+from _common import solver_batch, SOLVER_BATCHES, LARGE_MOTION, REALISTIC_OPT, REALISTIC_TRACK, golden, regen_inputs, assert_csr_equal
 import psfm_synth
 
 
@@ -52,7 +52,7 @@ def test_flow_check_bit_exact():
 
 
 @pytest.mark.parametrize("name", ["track_48x64_r2", "track_45x70_r1", "track_50x66_r3", "track_52x61_r4",
-                                  "track_largemotion_80x120_r2", "track_largemotion_75x110_r1"])   # (the last two: ~10 px of drift per frame)
+                                  "track_largemotion_80x120_r2", "track_largemotion_75x110_r1"] + REALISTIC_TRACK)   # (~10 px of drift per frame; layered scene)
 def test_track_bit_exact(name):
     g = golden(name)
     d = regen_inputs(g, stride2=False)
@@ -121,6 +121,23 @@ def test_track_optimize_large_motion(name):
     R = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
     assert_csr_equal(R.birth, R.length, R.xy, g)
     assert len(R.solves) == int(g["T"]) - 2
+
+
+@pytest.mark.parametrize("name", REALISTIC_OPT)
+def test_track_optimize_realistic(name):
+    """psfm_synth.REALISTIC -- depth-ordered layers with true (dis)occlusion, correlated flow error, outlier blobs -- through the
+    reference's own flow_check + track_optimize: masks of both strides, ids, lengths, positions; and the fixture says what the solver
+    went through (every solve rejects steps at the motion boundaries: the launch chain's / the resident solve's case)."""
+    g = golden(name)
+    d = regen_inputs(g, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    assert np.array_equal(np.packbits(np.stack(occ)), g["occ"]) and np.array_equal(np.packbits(np.stack(occ2)), g["occ2"])
+    assert 0.05 < float(g["occluded"]) < 0.3 and int(g["ended_early"]) > 1000
+    R = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, int(g["ratio"]))
+    assert_csr_equal(R.birth, R.length, R.xy, g)
+    assert [s["iterations"] for s in R.solves] == list(g["solve_iterations"])
+    assert sum(s["iterations"] - s["successful_steps"] for s in R.solves) > 20
 
 
 def test_solver_properties():
