@@ -87,32 +87,64 @@ def reference_python_on_this_box(flows_f, flows_b, frames=4):
                       % (frames, N_FRAMES - 1, torch.get_num_threads(), pts, t2 - t0)}
 
 
+def cpu_threads_wide():
+    """Threads of the 'wide' CPU figure: PSFM_CPU_THREADS, else min(32, host cores) -- the C restatement stops scaling there (the
+    per-track list bookkeeping of extend_all is serial)."""
+    return int(os.environ.get("PSFM_CPU_THREADS", "0")) or min(32, os.cpu_count() or 1)
+
+
+def cpu_port_timed(fn, points_of):
+    """fn() under the oracle at the reference's OWN thread count (8: solver_options.num_threads, trajectory_optimize.cpp:79 -- what
+    BASELINE.md specifies) and at the wide count; every figure says how many threads it ran on (orc.num_threads() after setting it).
+    Returns (result of the wide run, {"threads_8": {...}, "threads_wide": {...}})."""
+    from oracle import oracle as orc
+    out, res = {}, None
+    for key, want in (("threads_8", min(REFERENCE_SOLVER_THREADS, os.cpu_count() or 1)), ("threads_wide", cpu_threads_wide())):
+        orc.set_num_threads(want)
+        t0 = time.perf_counter()
+        res = fn()
+        dt = time.perf_counter() - t0
+        out[key] = {"points_per_s": points_of(res) / dt, "threads": orc.num_threads(), "seconds": dt}
+    return res, out
+
+
 def cpu_baseline(flows_f, flows_b, n_pairs):
     """The CPU oracle ("port": C restatement of the reference path, OpenMP over independent tracks / pixels) on the first
-    n_pairs frame pairs of the same tensors.  Threads: PSFM_CPU_THREADS, else min(32, host cores) -- the restatement stops
-    scaling there (the per-track list bookkeeping of extend_all is serial); the reference itself runs its solver on 8 threads
-    (trajectory_optimize.cpp:79) and everything else of the chain-only path on torch's intra-op pool."""
+    n_pairs frame pairs of the same tensors, at the wide thread count (`value`, `cores`) and -- on a third of the sample -- at the
+    reference's own 8 threads (`port_8_threads`); the reference runs its solver on 8 threads (trajectory_optimize.cpp:79) and
+    everything else of the chain-only path on torch's intra-op pool."""
     import numpy as np
     from oracle import oracle as orc
-    want = int(os.environ.get("PSFM_CPU_THREADS", "0")) or min(32, os.cpu_count() or 1)
-    orc.set_num_threads(want)
     ff = [f for f in flows_f[:n_pairs].cpu().numpy()]
     fb = [f for f in flows_b[:n_pairs].cpu().numpy()]
+
+    def run(n):
+        _, occ = orc.flow_check(ff[:n], fb[:n], THRES)
+        return orc.track(ff[:n], occ, RATIO)
+
+    n8 = max(2, n_pairs // 3)
+    orc.set_num_threads(min(REFERENCE_SOLVER_THREADS, os.cpu_count() or 1))
     t0 = time.perf_counter()
-    _, occ = orc.flow_check(ff, fb, THRES)
-    R = orc.track(ff, occ, RATIO)
+    R8 = run(n8)
+    dt8 = time.perf_counter() - t0
+    port8 = {"value": R8.n_points / dt8, "unit": "trajectory-points/s", "cores": orc.num_threads(),
+             "sample": "first %d of %d frame pairs: %d points in %.1f s" % (n8, N_FRAMES - 1, R8.n_points, dt8),
+             "why": "the reference's solver_options.num_threads = 8 (trajectory_optimize.cpp:79), BASELINE.md section 2"}
+    orc.set_num_threads(cpu_threads_wide())
+    t0 = time.perf_counter()
+    R = run(n_pairs)
     dt = time.perf_counter() - t0
     out = {"value": R.n_points / dt, "unit": "trajectory-points/s", "cores": orc.num_threads(), "host_cores": os.cpu_count(),
-           "kind": "port", "reference_solver_threads": REFERENCE_SOLVER_THREADS,
+           "kind": "port", "reference_solver_threads": REFERENCE_SOLVER_THREADS, "port_8_threads": port8,
            "sample": "first %d of %d frame pairs at 1080p, sample_ratio=2: flow_check + track + id order; %d points in %.1f s "
-                     "(C restatement, OpenMP over tracks / pixels; the per-track list bookkeeping of extend_all is serial)"
-                     % (n_pairs, N_FRAMES - 1, R.n_points, dt)}
+                     "(C restatement, OpenMP over tracks / pixels on %d threads; the per-track list bookkeeping of extend_all is serial)"
+                     % (n_pairs, N_FRAMES - 1, R.n_points, dt, orc.num_threads())}
     try:
         here = reference_python_on_this_box(flows_f, flows_b)
     except Exception as e:     # noqa: BLE001
         here = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-    if here is not None:
-        out["reference_python_this_box"] = here
+    out["reference_python_this_box"] = here if here is not None else \
+        "absent (PSFM_REFERENCE_ROOT: no reference tree on this box -- it is not shipped to the GPU box and its sources are never copied here)"
     ref = os.path.join(ROOT, "BASELINE_MEASURED.json")
     if os.path.exists(ref):     # the reference's own Python, timed in the build container (scripts/measure_reference_baseline.py)
         try:
@@ -175,7 +207,7 @@ def concurrent_sequences(n_seq, n_frames, reps=4):
             "trajectory_points_per_s": sum(pts) * reps / dt}
 
 
-def single_sequence_sharded(dev, rank, world, frames, reps=2):
+def single_sequence_sharded(dev, rank, world, frames, reps=2, dist=None, label="configs[3] shape"):
     """BASELINE.json configs[3]: ONE 1080p sequence with the full path-consistency optimize over all ranks, exactly
     (psfm_dist.connect_sharded: flow_check by frame pair + all-gather, tracks by birth row band, one all-reduce(max) of
     the blocked map per frame, solver sums all-gathered per launch; RCCL when world > 1).  Every rank synthesises the same
@@ -189,7 +221,7 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2):
     from point_trajectory.shard import HipShardEngine, flow_check_slice
     from point_trajectory.trajectory import run_connect
     torch.cuda.set_device(dev)
-    d = psfm_synth.synth_sequence_torch(frames, H, W, seed=1, sigma=0.05, n_occluders=2, stride2=True, device=dev)
+    d = psfm_synth.synth_sequence_torch(frames, H, W, seed=1, stride2=True, device=dev, **(dist or dict(sigma=0.05, n_occluders=2)))
     comm = psfm_dist.TorchComm()
     eng = HipShardEngine()
 
@@ -224,8 +256,8 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2):
     dt, pts = psfm_dist.reduce_totals(dt, float(part["n_points_local"]), device=dev)
     out = {"mode": "single-sequence", "world_size": dist.get_world_size() if world > 1 else 1,
            "backend": (dist.get_backend() if world > 1 else None),
-           "workload": "configs[3] shape: synthetic %dx(1920x1080) flow pairs + stride-2 stacks, sample_ratio=2, flow_check x2 + "
-                       "track_optimize, ONE sequence over %d rank(s)" % (frames - 1, world),
+           "workload": "%s: synthetic %dx(1920x1080) flow pairs + stride-2 stacks, sample_ratio=2, flow_check x2 + "
+                       "track_optimize, ONE sequence over %d rank(s)" % (label, frames - 1, world), "flows": dict(dist or dict(sigma=0.05, n_occluders=2)),
            "partition": "flow_check by frame pair (all-gather of bit-packed maps); tracks by birth row band; per frame one "
                         "all-reduce(max) of %d bytes; per fused solve one all-gather of k x 13 doubles" % (((W + RATIO - 1) // RATIO) * ((H + RATIO - 1) // RATIO) + 1),
            "ms_per_sequence": 1e3 * dt, "trajectory_points_per_s": pts / dt, "points": int(pts), "trajectories": int(part["n_traj"]),
@@ -240,6 +272,7 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2):
         info = run_connect(d["flows_f"], d["flows_b"], d["flows_f2"], d["flows_b2"], THRES, RATIO, return_device=True)
         torch.cuda.synchronize()
         out["one_gpu_psfm_connect_ms_per_sequence"] = 1e3 * (time.perf_counter() - t0)
+        out["ratio_to_one_gpu_call"] = out["ms_per_sequence"] / out["one_gpu_psfm_connect_ms_per_sequence"]
         out["counts_equal_one_gpu"] = bool(int(info.n_traj) == int(part["n_traj"]) and int(info.n_points) == int(pts))
     return out
 
@@ -296,9 +329,14 @@ def solver_roofline(R, prof, cnt, h, w, n_flows, ratio=RATIO):
         us = 1e3 * prof["solver"]["total_ms"] / prof["solver"]["launches"]
         per_solve = tot / len(frames) + (cb if merged else 0.0)
         fused = cnt["fused"] + cnt["fused_redone"] > cnt["chain"]
+        # which kernels the non-fused windows ran: counted by the library (psfm_solver_launches), not assumed
+        n_res, n_itl = int(cnt.get("resident_launches", 0)), int(cnt.get("iteration_launches", 0))
+        resident = (not fused) and n_res > 0 and n_itl < n_res * 4
         name = ("psfm_seq_kernel = the frame kernel, device-paced (ONE launch per frame: chain step + fused solve)" if merged else
                 "psfm_pc_fused_kernel (one launch per solve)") if fused else \
-            "psfm_pc_resident_kernel (one launch per solve: iteration 0, the trust-region loop with the tracks' state on chip, write-back)"
+            ("psfm_pc_resident_kernel (one launch per solve: iteration 0, the trust-region loop with the tracks' state on chip, write-back)"
+             if resident else "the launch chain: psfm_pc_init_kernel + one psfm_pc_iter_kernel launch per trust-region iteration "
+                              "(%d iteration launches, %d resident launches of which %d gave up)" % (n_itl, n_res, int(cnt.get("resident_giveups", 0))))
         # What bounds these launches is f64 VALU issue, not bandwidth: wave-instructions per launch from the
         # PMC pass of the same kernel (SQ_INSTS_VALU, profiles/solver_valu.json: replayed, scaled by this run's track-iterations)
         # against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 f64 instruction; the SURVEY 8(d) byte MODEL and the PMC traffic ride along.
@@ -337,7 +375,7 @@ def solver_roofline(R, prof, cnt, h, w, n_flows, ratio=RATIO):
                     entry["frac_physical"] = entry["traffic"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
             except Exception:
                 pass
-        if not fused and vall:
+        if not fused and vall and resident:       # (the replayed PMC figures were measured on the resident form)
             try:
                 v = vall["chain"]
                 wi = v["valu_per_track_iteration"] * entry["track_iterations_per_launch"] / 64.0 + \
@@ -396,7 +434,10 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     from point_trajectory.utils import flow_check_device
     from point_trajectory.trajectory import run_track, _result_to_host
     dist = dist or dict(sigma=0.05, n_occluders=2)
-    d = psfm_synth.synth_sequence_torch(t, h, w, seed=seed, stride2=True, device="cuda", **dist)
+    if dist.get("realistic"):      # psfm_synth.REALISTIC: layers with true (dis)occlusion, correlated flow error, outlier blobs
+        d = psfm_synth.synth_realistic_torch(t, h, w, seed=seed, stride2=True, device="cuda", **{k_: v for k_, v in dist.items() if k_ != "realistic"})
+    else:
+        d = psfm_synth.synth_sequence_torch(t, h, w, seed=seed, stride2=True, device="cuda", **dist)
     ctx.set_profiling(0)
 
     from point_trajectory.trajectory import run_connect
@@ -427,20 +468,27 @@ def secondary_track_optimize(ctx, h=436, w=1024, t=50, r=2, seed=2, k=6, label="
     _, occ2 = flow_check_device(d["flows_f2"], d["flows_b2"], thres)
     ff, f2 = list(d["flows_f"][:k].cpu().numpy()), list(d["flows_f2"][:k - 1].cpu().numpy())
     oo, o2 = list(occ[:k].cpu().numpy()), list(occ2[:k - 1].cpu().numpy())
-    t0 = time.perf_counter()
-    Rc = orc.track_optimize(ff, f2, oo, o2, r)
-    cpu_s = time.perf_counter() - t0
+    Rc, cpu = cpu_port_timed(lambda: orc.track_optimize(ff, f2, oo, o2, r), lambda R_: R_.n_points)
     Rg = _result_to_host(ctx, run_track(d["flows_f"][:k], occ[:k], d["flows_f2"][:k - 1], occ2[:k - 1], r, return_device=True))
     same = bool(np.array_equal(Rg.birth, Rc.birth) and np.array_equal(Rg.length, Rc.length))
     rej = int(sum(s_["iterations"] - s_["successful_steps"] for s_ in info_stats)) if info_stats else None
+    occl = {"stride1": float(occ.float().mean()), "stride2": float(occ2.float().mean())}
+    its = [s_["iterations"] for s_ in info_stats]
     return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check_thres %.1f, flow_check x2 + track_optimize"
                         % (label, h, w, t, r, thres),
-            "flows": dict(dist), "rejected_steps": rej, "chain_mode": int(info.chain_mode),
+            "flows": dict(dist), "rejected_steps": rej, "chain_mode": int(info.chain_mode), "occluded_fraction": occl,
+            "iterations_per_solve": {"mean": float(np.mean(its)) if its else None, "min": int(min(its)) if its else None,
+                                     "max": int(max(its)) if its else None,
+                                     "solves_with_a_rejected_step": int(sum(1 for s_ in info_stats if s_["iterations"] > s_["successful_steps"] + 1))},
+            "mean_trajectory_length": float(info.n_points) / max(int(info.n_traj), 1),
             "ms_per_sequence": ms, "trajectory_points_per_s": info.n_points / (ms * 1e-3), "points": int(info.n_points),
             "solves": int(info.n_solves), "trust_region_iterations": int(info.solver_iterations),
             "solver_counters": cnt, "roofline": roof,
-            "cpu_port_points_per_s": Rc.n_points / cpu_s,
-            "gpu_over_cpu_port": (info.n_points / (ms * 1e-3)) / (Rc.n_points / cpu_s), "cpu_port_sample": "first %d flows, 1 core, %.2f s" % (k, cpu_s),
+            "cpu_port_points_per_s": cpu["threads_wide"]["points_per_s"], "cpu_port": cpu,
+            "gpu_over_cpu_port": (info.n_points / (ms * 1e-3)) / cpu["threads_wide"]["points_per_s"],
+            "gpu_over_cpu_port_8_threads": (info.n_points / (ms * 1e-3)) / cpu["threads_8"]["points_per_s"],
+            "cpu_port_sample": "first %d flows: %d threads %.2f s, %d threads (the reference's solver count) %.2f s"
+                               % (k, cpu["threads_wide"]["threads"], cpu["threads_wide"]["seconds"], cpu["threads_8"]["threads"], cpu["threads_8"]["seconds"]),
             "parity_first_flows": {"ids_lengths_equal": same,
                                    "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None,
                                    "tolerance_px": 1e-4}}
@@ -484,10 +532,13 @@ def secondary_track(ctx, h, w, t, r, seed, label, thres=THRES, n=10):
     us = 1e3 * ch["total_ms"] / max(ch["launches"], 1) / (n_flows if persistent else 1)
     fused = persistent and pr["flow_check"]["launches"] == 0
     step_bytes = cb + (17.0 * P if fused else 0.0)
-    t0 = time.perf_counter()
-    _, occ = orc.flow_check(list(d["flows_f"].cpu().numpy()), list(d["flows_b"].cpu().numpy()), thres)
-    Rc = orc.track(list(d["flows_f"].cpu().numpy()), occ, r)
-    cpu_s = time.perf_counter() - t0
+    hf, hb = list(d["flows_f"].cpu().numpy()), list(d["flows_b"].cpu().numpy())
+
+    def cpu_run():
+        _, occ = orc.flow_check(hf, hb, thres)
+        return orc.track(hf, occ, r)
+
+    Rc, cpu = cpu_port_timed(cpu_run, lambda R_: R_.n_points)
     same = bool(Rg.birth.shape == Rc.birth.shape and np.array_equal(Rg.birth, Rc.birth) and np.array_equal(Rg.length, Rc.length))
     return {"workload": "%s: synthetic %dx%d x %d frames, sample_ratio=%d, flow_check_thres %.1f, flow_check + track (no path consistency)"
                         % (label, h, w, t, r, thres),
@@ -499,9 +550,134 @@ def secondary_track(ctx, h, w, t, r, seed, label, thres=THRES, n=10):
                                         "achieved": step_bytes / (us * 1e-6) / 1e9 if us > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": step_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else None, "avg_alive_tracks": A},
                          "flow_check_side_stream_ms": pr["flow_check"]["total_ms"], "finalize_ms": pr["finalize"]["total_ms"]},
-            "cpu_port_points_per_s": Rc.n_points / cpu_s, "cpu_port_sample": "whole sequence, %d thread(s), %.2f s" % (orc.num_threads(), cpu_s),
+            "cpu_port_points_per_s": cpu["threads_wide"]["points_per_s"], "cpu_port": cpu,
+            "cpu_port_sample": "whole sequence: %d threads %.2f s, %d threads %.2f s" % (cpu["threads_wide"]["threads"], cpu["threads_wide"]["seconds"],
+                                                                                        cpu["threads_8"]["threads"], cpu["threads_8"]["seconds"]),
             "parity": {"vs": "cpu oracle, whole sequence", "ids_lengths_equal": same,
                        "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None}}
+
+
+def secondary_batch(h, w, t, r, opt, thres, B, seed0, label, single, n=5):
+    """psfm_connect_batch on B sequences of one of the small BASELINE shapes (different seeds; sequence 0 is the one `single` was
+    measured on): ONE launch per frame for the whole batch, one checkpoint per window, one segmented finalize.  Time per sequence
+    against `single` (one psfm_connect per sequence), the batched frame launch from HIP events with its roofline, and every
+    sequence's result against its own single-sequence run (counts for all, bits for the first and the last)."""
+    import numpy as np
+    import torch
+    import psfm_synth
+    from point_trajectory import _hip
+    from point_trajectory.trajectory import run_connect, run_connect_batch, _result_to_host
+    data = [psfm_synth.synth_sequence_torch(t, h, w, seed=seed0 + k, sigma=0.05, n_occluders=2, stride2=opt, device="cuda") for k in range(B)]
+    seqs = [(d["flows_f"], d["flows_b"], d.get("flows_f2") if opt else None, d.get("flows_b2") if opt else None) for d in data]
+    for _ in range(2):
+        ctxs, infos = run_connect_batch(seqs, thres, r)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ctxs, infos = run_connect_batch(seqs, thres, r)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    pts = int(sum(int(i.n_points) for i in infos))
+    ctxs[0].set_profiling(1)
+    ctxs, infos = run_connect_batch(seqs, thres, r)
+    torch.cuda.synchronize()
+    pr = ctxs[0].profile()
+    ctxs[0].set_profiling(0)
+    kind = "solver" if opt else "chain_step"
+    us = 1e3 * pr[kind]["total_ms"] / max(pr[kind]["launches"], 1)
+    # parity of the batching: every sequence against ONE psfm_connect of its own on the same tensors
+    ctx1 = _hip.context()
+    counts_equal, bits = True, {}
+    keep = {0: _result_to_host(ctxs[0], infos[0]), B - 1: _result_to_host(ctxs[B - 1], infos[B - 1])}
+    got = [(int(i.n_traj), int(i.n_points), int(i.solver_iterations)) for i in infos]
+    for k in range(B):
+        i1 = run_connect(*seqs[k], thres, r, return_device=True)
+        if (int(i1.n_traj), int(i1.n_points), int(i1.solver_iterations)) != got[k]:
+            counts_equal = False
+        if k in keep:
+            R1 = _result_to_host(ctx1, i1)
+            Rb = keep[k]
+            same = bool(np.array_equal(R1.birth, Rb.birth) and np.array_equal(R1.length, Rb.length))
+            bits["sequence_%d" % k] = {"ids_lengths_equal": same, "max_abs_dxy_px": float(np.abs(R1.xy - Rb.xy).max()) if same else None}
+    single_ms = single.get("ms_per_sequence") if isinstance(single, dict) else None
+    out = {"workload": "%s x %d sequences (seeds %d..%d) through psfm_connect_batch: %dx%d x %d frames, sample_ratio=%d, %s"
+                       % (label, B, seed0, seed0 + B - 1, h, w, t, r, "flow_check x2 + track_optimize" if opt else "flow_check + track"),
+           "batch": B, "ms_per_batch": ms, "ms_per_sequence": ms / B, "trajectory_points_per_s": pts / (ms * 1e-3), "points": pts,
+           "single_sequence_ms": single_ms, "speedup_vs_one_psfm_connect_per_sequence": (single_ms / (ms / B)) if single_ms else None,
+           "modes": sorted(set(int(i.chain_mode) for i in infos)),
+           "frame_launch": {"kernel": "psfm_seq_batch_kernel<R, 4> (blockIdx.y = sequence: chain step + fused solve of every sequence's next frame)" if opt
+                                      else "psfm_chain_step_batch_kernel<R> (blockIdx.y = sequence)",
+                            "avg_launch_us": us, "launches": int(pr[kind]["launches"])},
+           "flow_check_enqueue_ms": pr["flow_check"]["total_ms"], "finalize_ms": pr["finalize"]["total_ms"],
+           "parity": {"vs": "one psfm_connect per sequence on the same tensors", "counts_equal_every_sequence": counts_equal, "bits": bits}}
+    try:
+        roof = single["roofline"]
+        if not opt:
+            cs = roof["chain_step"]
+            by = cs["bytes_per_step"] * B      # (every sequence has the same shape and flow statistics: sequence 0's bytes x B)
+            out["frame_launch"].update({"bound": "hbm", "bytes_per_launch": by, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                        "single_sequence_frac": cs.get("frac")})
+        else:
+            fk = roof["frame_kernel"]
+            wi = fk["valu_wave_instructions_per_launch"] * B * (t - 2) / max(pr[kind]["launches"], 1)     # (per batched launch, spare launches included)
+            out["frame_launch"].update({"bound": "valu-issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GWIPS,
+                                        "valu_wave_instructions_per_launch": wi, "achieved": wi / (us * 1e-6) / 1e9,
+                                        "frac": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS, "single_sequence_frac": fk.get("frac"),
+                                        "valu_source": "sequence 0's replayed figure (profiles/solver_valu.json) x %d sequences x %d solves / launches" % (B, t - 2)})
+    except Exception:      # noqa: BLE001  (the single-sequence figure failed or has no roofline)
+        pass
+    return out
+
+
+def end_to_end_batch(n_seq=16, h=480, w=854, t=50, r=4):
+    """SURVEY 8(d)(iii) for the shapes real data has: n_seq configs[0]-shaped sequences on tmpfs (.flo) -> track.npy each, through
+    point_trajectory.batch.connect_sequences -- one psfm_connect per sequence at 1 / 2 / 4 host threads, and psfm_connect_batch
+    (batch = 8 per worker) at 1 / 2 threads.  sequences/s; the phases of neighbours overlap only where the threads do."""
+    import shutil
+    import tempfile
+    import torch
+    import psfm_synth
+    from point_trajectory.utils import write_flo
+    from point_trajectory.batch import connect_sequences
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="psfm_e2eb_", dir=base)
+    try:
+        fdirs, tdirs = [], []
+        for k in range(n_seq):
+            d = psfm_synth.synth_sequence_torch(t, h, w, seed=200 + k, sigma=0.05, n_occluders=2, stride2=False)
+            fd = os.path.join(work, "seq%02d" % k, "flows")
+            for name, key in (("flow_f", "flows_f"), ("flow_b", "flows_b")):
+                os.makedirs(os.path.join(fd, name))
+                arr = d[key].cpu().numpy()
+                for i in range(t - 1):
+                    write_flo(os.path.join(fd, name, "%05d.flo" % i), arr[i])
+            fdirs.append(fd)
+            tdirs.append(os.path.join(work, "seq%02d" % k, "traj"))
+            del d
+        torch.cuda.empty_cache()
+        gb = n_seq * 2 * (t - 1) * h * w * 8 / 1e9
+        rows = []
+        for conc, batch in ((1, 1), (2, 1), (4, 1), (1, 8), (2, 8)):
+            for rep in range(2):      # (second pass: warm page cache and workspaces)
+                for td in tdirs:
+                    shutil.rmtree(td, ignore_errors=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                connect_sequences(fdirs, tdirs, sample_ratio=r, flow_check_thres=THRES, skip_path_consistency=True, concurrency=conc,
+                                  rank=0, world=1, layout="reference", batch=batch)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            rows.append({"host_threads": conc, "batch": batch, "total_s": dt, "sequences_per_s": n_seq / dt, "ms_per_sequence": 1e3 * dt / n_seq})
+        size = sum(os.path.getsize(os.path.join(td, "track.npy")) for td in tdirs)
+        return {"workload": "%d configs[0]-shaped sequences (%dx%d x %d frames, sample_ratio %d, track only) disk to disk on %s: %.2f GB of .flo -> "
+                            "%.2f GB of track.npy (reference pickle layout), warm second pass" % (n_seq, h, w, t, r, base, gb, size / 1e9),
+                "runs": rows,
+                "note": "batch = 1: one main_connect_point_trajectories per sequence on `host_threads` threads (ingest / compute / write of "
+                        "neighbouring sequences overlap only across threads; the GIL is released in file reads, copies and library calls); "
+                        "batch = 8: every thread ingests 8 sequences, runs ONE psfm_connect_batch, filters and writes them"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def end_to_end(frames=N_FRAMES, workdir=None):
@@ -694,11 +870,19 @@ def main():
     dt_max, total_points = psfm_dist.reduce_totals(dt, points, device=dev)   # max time, summed units over ranks
 
     # ---- ONE sequence over all ranks (exact track-sharded mode), outside the timed region ----
-    single, hung = None, False
+    single, single_hard, hung = None, None, False
     if not args.no_extras or world > 1:
         if world > 1:
             dist.barrier()
         single, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, args.single_seq_frames), 240)
+        # ... and on flows whose solves reject steps (psfm_synth.HARD, 100 frames: VERDICT r4 item 2) -- the redo path of the sharded engine
+        single_hard = None
+        if not hung:
+            if world > 1:
+                dist.barrier()
+            import psfm_synth as _ps
+            single_hard, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, 101, reps=1, dist=_ps.HARD,
+                                                                        label="headline shape, hard flows (sigma 0.3, 5 % occluders)"), 300)
 
     if rank == 0:
         # ---- roofline of the flow-chaining kernel (K2): algorithmic bytes per launch / avg duration ----
@@ -784,6 +968,8 @@ def main():
         out["config"]["source_sha16"] = source_sha16()
         if single is not None:
             out["single_sequence"] = single
+        if single_hard is not None:
+            out["single_sequence_hard"] = single_hard
         if world == 1 and not args.no_cpu:
             n_cpu = min(args.cpu_pairs, n_flows)
             cb, Rc = cpu_baseline(flows_f, flows_b, n_cpu)
@@ -814,6 +1000,11 @@ def main():
                 # takes interpolated dogleg steps, i.e. the launch chain instead of the speculated fused solve
                 out["secondary_hard"] = extra(secondary_track_optimize, ctx, H, W, n_frames, RATIO, seed=6, k=6, dist=psfm_synth.HARD,
                                               label="headline shape with path consistency, hard flows")
+                # the third distribution (psfm_synth.REALISTIC: layers with true (dis)occlusion, correlated flow error, outlier blobs) on the
+                # headline shape: which solver path real-looking flows take, and what it costs
+                out["secondary_realistic"] = extra(secondary_track_optimize, ctx, H, W, n_frames, RATIO, seed=7, k=6,
+                                                   dist=dict(psfm_synth.REALISTIC, realistic=True),
+                                                   label="headline shape with path consistency, realistic flows (layers, true disocclusion, correlated error, outliers)")
                 out["concurrent"] = extra(concurrent_sequences, 3, n_frames)
                 del flows_f
                 torch.cuda.empty_cache()
@@ -823,7 +1014,16 @@ def main():
                 out["secondary_scannet"] = extra(secondary_track_optimize, ctx, 480, 640, 1000, 1, seed=4, k=6, thres=3.0, n=2,
                                                  label="configs[4] shape (ScanNet, dense)")
                 torch.cuda.empty_cache()
+                # B sequences per launch on the shapes real data has (psfm_connect_batch)
+                out["secondary_davis_batch"] = extra(secondary_batch, 480, 854, 50, 4, False, THRES, 16, 2, "configs[0] shape (DAVIS snowboard)",
+                                                     out["secondary_davis"])
+                out["secondary_batch"] = extra(secondary_batch, 436, 1024, 50, 2, True, THRES, 16, 2, "configs[2] shape (Sintel alley_1)", out["secondary"])
+                torch.cuda.empty_cache()
+                out["secondary_scannet_batch"] = extra(secondary_batch, 480, 640, 1000, 1, True, 3.0, 4, 4, "configs[4] shape (ScanNet, dense)",
+                                                       out["secondary_scannet"], n=2)
+                torch.cuda.empty_cache()
                 out["end_to_end"] = extra(end_to_end, n_frames)
+                out["end_to_end_batch"] = extra(end_to_end_batch)
         print(json.dumps(out), flush=True)
     if hung:            # a rank is stuck in a collective of the extra mode: the line is out, leave without the barrier
         sys.stdout.flush()

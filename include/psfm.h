@@ -124,6 +124,12 @@ psfm_status psfm_ctx_set_solver(psfm_ctx* ctx, int mode, int k);
  * the chain, chain.  k_now: the adaptive iterations per fused launch after that sequence.  Any pointer may be NULL. */
 psfm_status psfm_solver_counters(psfm_ctx* ctx, int64_t* fused, int64_t* fused_redone, int64_t* chain, int32_t* k_now);
 
+/* Launches of the last psfm_track / psfm_connect / psfm_optimize_location on the context for the solves that did NOT go as the fused
+ * solve speculates: resident launches (one per solve: the trust-region loop with the tracks' state on chip -- needs the device to
+ * itself), how many of them gave up their hand-off, launches of ONE trust-region iteration each (the launch chain).  Which kernel a
+ * measured solver time belongs to.  Any pointer may be NULL. */
+psfm_status psfm_solver_launches(psfm_ctx* ctx, int64_t* resident, int64_t* giveups, int64_t* iterations);
+
 /* utils.py:94-105.  flows_f, flows_b: (n_pairs,H,W,2) f32 stacks in the .flo-native interleaved
  * layout.  occ_out: (n_pairs,H,W) u8 0/1.  err_out: (n_pairs,H,W) f32 or NULL (the reference
  * pipeline never consumes it).  Bit-exact with the reference's torch-CPU arithmetic. */

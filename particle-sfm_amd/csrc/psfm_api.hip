@@ -213,6 +213,15 @@ extern "C" psfm_status psfm_solver_counters(psfm_ctx* c, int64_t* fused, int64_t
     return PSFM_OK;
 }
 
+extern "C" psfm_status psfm_solver_launches(psfm_ctx* c, int64_t* resident, int64_t* giveups, int64_t* iterations)
+{
+    if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
+    if (resident) *resident = c->n_resident;
+    if (giveups) *giveups = c->pc_giveups;
+    if (iterations) *iterations = c->n_iter_launches;
+    return PSFM_OK;
+}
+
 extern "C" psfm_status psfm_ctx_set_profiling(psfm_ctx* c, int enable)
 {
     if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
@@ -276,6 +285,7 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
     PsfmGate gate(c->device, c->chain_mode == 1 ? 0 : 1);
     c->pc_persist_ok = gate.exclusive;
     c->pc_giveups = 0;
+    c->n_resident = c->n_iter_launches = 0;
     if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
         psfm_set_error("psfm_optimize_location: bad argument (n=%lld h=%d w=%d)", (long long)n, h, w);
         return PSFM_ERR_ARG;
@@ -488,6 +498,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // window (the frames between two checkpoints) whose solves rejected steps / left the Gauss-Newton path sends the next
     // window to the chain, a clean window brings the fused solve back; solve_K follows the accepted steps seen.
     c->n_fused_ok = c->n_fused_redone = c->n_chain = 0;
+    c->n_resident = c->n_iter_launches = 0;
     if (optimize && (st = psfm_solve_prepare(c, d)) != PSFM_OK) return st;
     // PSFM_MERGE_FRAME=0: chain step and fused solve as two launches (what the merged frame kernel is measured against);
     // PSFM_SEQ=0: host-paced frame kernels (one per frame, stall + redo when a solve needs more iterations than speculated)

@@ -117,6 +117,7 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             c->pc_persist_ok = false;
             c->pc_giveups = 0;
             c->n_fused_ok = c->n_fused_redone = c->n_chain = 0;
+            c->n_resident = c->n_iter_launches = 0;
             if (D[i].cap > cap_max) cap_max = D[i].cap;
             S[i].hstats.assign((size_t)n_flows[i] + 1, psfm_solve_stats());
             // a context told to use the launch chain for every solve has nothing to gain from the batch: it runs alone

@@ -165,6 +165,7 @@ struct psfm_ctx {
     int solve_mode = 0;     // 0 fused solve (one launch per frame), 1 launch chain (sequences whose solves reject steps)
     int solver_mode = 0, solver_K = 0;   // psfm_ctx_set_solver: 0 adaptive / 1 chain / 2 fused; K 0 = adaptive
     int64_t n_fused_ok = 0, n_fused_redone = 0, n_chain = 0;   // solves of the last psfm_track by how they ran
+    int64_t n_resident = 0, n_iter_launches = 0;               // launches of the last call: resident solves, single trust-region iterations
     PsfmTrackDims* shard_dims = nullptr;   // psfm_shard_begin .. psfm_shard_finish
     bool shard_optimize = false;
     int solve_unroll = 6;   // iterations enqueued per frame without polling (adapted at checkpoints)

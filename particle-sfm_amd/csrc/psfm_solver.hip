@@ -1663,6 +1663,7 @@ static psfm_status pc_finish_sync(psfm_ctx* c, PcParams& P, int n_blocks, double
         if (resident && launched == 0) c->pc_giveups += 1;
         if (launched > 2 * 200 + 64) { psfm_set_error("path-consistency solver did not terminate"); return PSFM_ERR_SOLVER; }
         for (int k = 0; k < chunk; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+        c->n_iter_launches += chunk;
         PSFM_HIP(hipGetLastError());
         launched += chunk;
         chunk = chunk < 32 ? chunk * 2 : 32;
@@ -1768,6 +1769,7 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
     if (ns == 1) hipLaunchKernelGGL(psfm_pc_resident_kernel<1>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
     else if (ns == 2) hipLaunchKernelGGL(psfm_pc_resident_kernel<2>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
     else hipLaunchKernelGGL(psfm_pc_resident_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
+    c->n_resident += 1;
     return true;
 }
 
@@ -1792,6 +1794,7 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
         hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
         if (!pc_persist_enqueue(c, P, n_blocks, nullptr, false, true, s)) {
             for (int k = 0; k < unroll; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+            c->n_iter_launches += unroll;
             // (the resident solve writes back, or raises the stall flag, itself)
             hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
         }
@@ -1837,8 +1840,10 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     // (the host polls behind this launch: a resident solve that gives up must leave the stall flag alone -- see pc_res_stall)
     bool resident = false;
-    if (chain_stalled || !(resident = pc_persist_enqueue(c, P, n_blocks, nullptr, false, false, s)))
+    if (chain_stalled || !(resident = pc_persist_enqueue(c, P, n_blocks, nullptr, false, false, s))) {
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+        c->n_iter_launches += 4;
+    }
     PSFM_HIP(hipGetLastError());
     return pc_finish_sync(c, P, n_blocks, nullptr, st, s, resident);
 }
@@ -2202,8 +2207,10 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     PSFM_HIP(hipMemcpyAsync(P.scale, scale, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     bool resident = false;
-    if (!(resident = pc_persist_enqueue(c, P, n_blocks, out, false, false, s)))
+    if (!(resident = pc_persist_enqueue(c, P, n_blocks, out, false, false, s))) {
         for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
+        c->n_iter_launches += 4;
+    }
     PSFM_HIP(hipGetLastError());
     rc = pc_finish_sync(c, P, n_blocks, out, st, s, resident);
     if (rc != PSFM_OK) return rc;

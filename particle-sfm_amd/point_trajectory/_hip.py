@@ -22,7 +22,7 @@ EXPORTS = [
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
-    "psfm_connect_batch",
+    "psfm_connect_batch", "psfm_solver_launches",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
     L.psfm_ctx_set_chain_mode.argtypes = [vp, i32]
     L.psfm_ctx_set_solver.argtypes = [vp, i32, i32]
     L.psfm_solver_counters.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    L.psfm_solver_launches.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.psfm_result_filter.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), vp]
     L.psfm_result_filtered_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.psfm_window_sample.argtypes = [vp, i32, i32, i32, i32, i64, ctypes.c_uint64, i32, i32, i32, i32, i64, vp, vp, vp, vp,
@@ -148,7 +149,11 @@ class Context:
     def solver_counters(self):
         a, b, c_, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
         check(lib().psfm_solver_counters(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c_), ctypes.byref(k)))
-        return {"fused": a.value, "fused_redone": b.value, "chain": c_.value, "k": k.value}
+        out = {"fused": a.value, "fused_redone": b.value, "chain": c_.value, "k": k.value}
+        r, g, it = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(lib().psfm_solver_launches(self._h, ctypes.byref(r), ctypes.byref(g), ctypes.byref(it)))
+        out.update({"resident_launches": r.value, "resident_giveups": g.value, "iteration_launches": it.value})
+        return out
 
     def set_profiling(self, enable):
         check(lib().psfm_ctx_set_profiling(self._h, int(enable)))   # 0 off, 1 every launch, N>1 every N-th chain_step
