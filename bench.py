@@ -207,7 +207,7 @@ def concurrent_sequences(n_seq, n_frames, reps=4):
             "trajectory_points_per_s": sum(pts) * reps / dt}
 
 
-def single_sequence_sharded(dev, rank, world, frames, reps=2, dist=None, label="configs[3] shape"):
+def single_sequence_sharded(dev, rank, world, frames, reps=2, flows_dist=None, label="configs[3] shape"):
     """BASELINE.json configs[3]: ONE 1080p sequence with the full path-consistency optimize over all ranks, exactly
     (psfm_dist.connect_sharded: flow_check by frame pair + all-gather, tracks by birth row band, one all-reduce(max) of
     the blocked map per frame, solver sums all-gathered per launch; RCCL when world > 1).  Every rank synthesises the same
@@ -221,7 +221,7 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2, dist=None, label="
     from point_trajectory.shard import HipShardEngine, flow_check_slice
     from point_trajectory.trajectory import run_connect
     torch.cuda.set_device(dev)
-    d = psfm_synth.synth_sequence_torch(frames, H, W, seed=1, stride2=True, device=dev, **(dist or dict(sigma=0.05, n_occluders=2)))
+    d = psfm_synth.synth_sequence_torch(frames, H, W, seed=1, stride2=True, device=dev, **(flows_dist or dict(sigma=0.05, n_occluders=2)))
     comm = psfm_dist.TorchComm()
     eng = HipShardEngine()
 
@@ -257,7 +257,7 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2, dist=None, label="
     out = {"mode": "single-sequence", "world_size": dist.get_world_size() if world > 1 else 1,
            "backend": (dist.get_backend() if world > 1 else None),
            "workload": "%s: synthetic %dx(1920x1080) flow pairs + stride-2 stacks, sample_ratio=2, flow_check x2 + "
-                       "track_optimize, ONE sequence over %d rank(s)" % (label, frames - 1, world), "flows": dict(dist or dict(sigma=0.05, n_occluders=2)),
+                       "track_optimize, ONE sequence over %d rank(s)" % (label, frames - 1, world), "flows": dict(flows_dist or dict(sigma=0.05, n_occluders=2)),
            "partition": "flow_check by frame pair (all-gather of bit-packed maps); tracks by birth row band; per frame one "
                         "all-reduce(max) of %d bytes; per fused solve one all-gather of k x 13 doubles" % (((W + RATIO - 1) // RATIO) * ((H + RATIO - 1) // RATIO) + 1),
            "ms_per_sequence": 1e3 * dt, "trajectory_points_per_s": pts / dt, "points": int(pts), "trajectories": int(part["n_traj"]),
@@ -585,6 +585,25 @@ def secondary_batch(h, w, t, r, opt, thres, B, seed0, label, single, n=5):
     ctxs[0].set_profiling(0)
     kind = "solver" if opt else "chain_step"
     us = 1e3 * pr[kind]["total_ms"] / max(pr[kind]["launches"], 1)
+    # the same launches with every occlusion map ready before the first frame (PSFM_BATCH_FC_CHUNK=0: flow_check up front on the
+    # launch stream instead of beside the frame loop on the side stream, whose bandwidth the frame launches above share)
+    os.environ["PSFM_BATCH_FC_CHUNK"] = "0"
+    try:
+        run_connect_batch(seqs, thres, r)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run_connect_batch(seqs, thres, r)
+        torch.cuda.synchronize()
+        ms_upfront = 1e3 * (time.perf_counter() - t0) / n
+        ctxs[0].set_profiling(1)
+        ctxs, infos = run_connect_batch(seqs, thres, r)
+        torch.cuda.synchronize()
+        pr0 = ctxs[0].profile()
+        ctxs[0].set_profiling(0)
+    finally:
+        os.environ.pop("PSFM_BATCH_FC_CHUNK", None)
+    us0 = 1e3 * pr0[kind]["total_ms"] / max(pr0[kind]["launches"], 1)
     # parity of the batching: every sequence against ONE psfm_connect of its own on the same tensors
     ctx1 = _hip.context()
     counts_equal, bits = True, {}
@@ -607,7 +626,8 @@ def secondary_batch(h, w, t, r, opt, thres, B, seed0, label, single, n=5):
            "modes": sorted(set(int(i.chain_mode) for i in infos)),
            "frame_launch": {"kernel": "psfm_seq_batch_kernel<R, 4> (blockIdx.y = sequence: chain step + fused solve of every sequence's next frame)" if opt
                                       else "psfm_chain_step_batch_kernel<R> (blockIdx.y = sequence)",
-                            "avg_launch_us": us, "launches": int(pr[kind]["launches"])},
+                            "avg_launch_us": us, "launches": int(pr[kind]["launches"]),
+                            "avg_launch_us_on_ready_maps": us0, "ms_per_sequence_with_flow_check_up_front": ms_upfront / B},
            "flow_check_enqueue_ms": pr["flow_check"]["total_ms"], "finalize_ms": pr["finalize"]["total_ms"],
            "parity": {"vs": "one psfm_connect per sequence on the same tensors", "counts_equal_every_sequence": counts_equal, "bits": bits}}
     try:
@@ -615,15 +635,20 @@ def secondary_batch(h, w, t, r, opt, thres, B, seed0, label, single, n=5):
         if not opt:
             cs = roof["chain_step"]
             by = cs["bytes_per_step"] * B      # (every sequence has the same shape and flow statistics: sequence 0's bytes x B)
-            out["frame_launch"].update({"bound": "hbm", "bytes_per_launch": by, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            out["frame_launch"].update({"bound": "hbm", "bytes_per_launch": by, "achieved": by / (us0 * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": by / (us0 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                        "frac_beside_the_side_streams_flow_check": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                        "note": "frac: the launch on ready maps (the chain step's own bytes / its own time); in the default run "
+                                                "flow_check streams 17 P bytes per pair through the same memory system meanwhile",
                                         "single_sequence_frac": cs.get("frac")})
         else:
             fk = roof["frame_kernel"]
             wi = fk["valu_wave_instructions_per_launch"] * B * (t - 2) / max(pr[kind]["launches"], 1)     # (per batched launch, spare launches included)
             out["frame_launch"].update({"bound": "valu-issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GWIPS,
-                                        "valu_wave_instructions_per_launch": wi, "achieved": wi / (us * 1e-6) / 1e9,
-                                        "frac": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS, "single_sequence_frac": fk.get("frac"),
+                                        "valu_wave_instructions_per_launch": wi, "achieved": wi / (us0 * 1e-6) / 1e9,
+                                        "frac": wi / (us0 * 1e-6) / 1e9 / VALU_PEAK_GWIPS,
+                                        "frac_beside_the_side_streams_flow_check": wi / (us * 1e-6) / 1e9 / VALU_PEAK_GWIPS,
+                                        "single_sequence_frac": fk.get("frac"),
                                         "valu_source": "sequence 0's replayed figure (profiles/solver_valu.json) x %d sequences x %d solves / launches" % (B, t - 2)})
     except Exception:      # noqa: BLE001  (the single-sequence figure failed or has no roofline)
         pass
@@ -881,7 +906,7 @@ def main():
             if world > 1:
                 dist.barrier()
             import psfm_synth as _ps
-            single_hard, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, 101, reps=1, dist=_ps.HARD,
+            single_hard, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, 101, reps=1, flows_dist=_ps.HARD,
                                                                         label="headline shape, hard flows (sigma 0.3, 5 % occluders)"), 300)
 
     if rank == 0:

@@ -124,6 +124,16 @@ psfm_status psfm_ctx_set_solver(psfm_ctx* ctx, int mode, int k);
  * the chain, chain.  k_now: the adaptive iterations per fused launch after that sequence.  Any pointer may be NULL. */
 psfm_status psfm_solver_counters(psfm_ctx* ctx, int64_t* fused, int64_t* fused_redone, int64_t* chain, int32_t* k_now);
 
+/* Solves that reject steps run their whole trust-region loop as ONE resident launch whose blocks must all be on the device at once
+ * (two 256-thread blocks per CU: psfm_resident_capacity, 512 on an MI355X).  By default a call only does that when it has the device
+ * to itself (the exclusive gate): sequences processed concurrently by several host threads fall back to one launch per trust-region
+ * iteration, 3-5x slower on such flows.  psfm_ctx_set_resident_budget(ctx, n) with n > 0 lets this context's resident solves use at
+ * most n blocks while OTHER contexts run theirs -- the caller guarantees that the budgets of all contexts in flight on the device add
+ * up to at most the capacity (e.g. 4 worker threads x 128).  A launch that does not become co-resident after all (other work holding
+ * the block slots) gives up at its spin limit and is redone with launches; results never depend on it.  n = 0: the default policy. */
+psfm_status psfm_ctx_set_resident_budget(psfm_ctx* ctx, int blocks);
+psfm_status psfm_resident_capacity(psfm_ctx* ctx, int32_t* blocks);
+
 /* Launches of the last psfm_track / psfm_connect / psfm_optimize_location on the context for the solves that did NOT go as the fused
  * solve speculates: resident launches (one per solve: the trust-region loop with the tracks' state on chip -- needs the device to
  * itself), how many of them gave up their hand-off, launches of ONE trust-region iteration each (the launch chain).  Which kernel a

@@ -32,8 +32,9 @@ static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int rati
 {
     if (c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;
     // track_optimize: no persistent frame loop, but solves that reject steps run their trust-region loop as one persistent
-    // launch (psfm_pc_persist_kernel) when the call has the device to itself -- take the gate if it is free
-    if (optimize) return 1;
+    // launch (psfm_pc_resident_kernel) when the call has the device to itself -- take the gate if it is free.  A context with a
+    // resident budget runs those launches on its share of the device's block slots beside other contexts': shared gate
+    if (optimize) return c->resident_budget > 0 ? 0 : 1;
     const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
     const int64_t P = (int64_t)h * w;
     const int maxb = psfm_persist_max_blocks(c);
@@ -132,6 +133,12 @@ void PsfmProfiler::destroy()
     pool.clear();
 }
 
+#define PSFM_CHECK_CTX(c)                                                     \
+    do {                                                                      \
+        if (!(c)) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }     \
+        PSFM_HIP(hipSetDevice((c)->device));                                  \
+    } while (0)
+
 extern "C" psfm_status psfm_ctx_create(int device, psfm_ctx** out)
 {
     if (!out) { psfm_set_error("psfm_ctx_create: out is NULL"); return PSFM_ERR_ARG; }
@@ -213,6 +220,20 @@ extern "C" psfm_status psfm_solver_counters(psfm_ctx* c, int64_t* fused, int64_t
     return PSFM_OK;
 }
 
+extern "C" psfm_status psfm_ctx_set_resident_budget(psfm_ctx* c, int blocks)
+{
+    if (!c || blocks < 0) { psfm_set_error("psfm_ctx_set_resident_budget: blocks must be >= 0"); return PSFM_ERR_ARG; }
+    c->resident_budget = blocks;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_resident_capacity(psfm_ctx* c, int32_t* blocks)
+{
+    PSFM_CHECK_CTX(c);
+    if (blocks) *blocks = psfm_resident_blocks(c);
+    return PSFM_OK;
+}
+
 extern "C" psfm_status psfm_solver_launches(psfm_ctx* c, int64_t* resident, int64_t* giveups, int64_t* iterations)
 {
     if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
@@ -240,12 +261,6 @@ extern "C" psfm_status psfm_profile_get(psfm_ctx* c, int kind, double* total_ms,
     if (launches) *launches = c->prof.launches[kind];
     return PSFM_OK;
 }
-
-#define PSFM_CHECK_CTX(c)                                                     \
-    do {                                                                      \
-        if (!(c)) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }     \
-        PSFM_HIP(hipSetDevice((c)->device));                                  \
-    } while (0)
 
 extern "C" psfm_status psfm_flow_check(psfm_ctx* c, const float* flows_f, const float* flows_b, int n_pairs, int h, int w,
                                        float thres, uint8_t* occ_out, float* err_out, void* stream)
@@ -282,8 +297,8 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
     PSFM_CHECK_CTX(c);
     // exclusive if no other psfm call is in flight: the solve may then run as ONE resident launch; psfm_ctx_set_chain_mode(ctx, 1)
     // -- what callers that overlap several solves from several host threads set -- keeps the gate shared and the solve on launches
-    PsfmGate gate(c->device, c->chain_mode == 1 ? 0 : 1);
-    c->pc_persist_ok = gate.exclusive;
+    PsfmGate gate(c->device, (c->chain_mode == 1 || c->resident_budget > 0) ? 0 : 1);
+    c->pc_persist_ok = gate.exclusive || c->resident_budget > 0;
     c->pc_giveups = 0;
     c->n_resident = c->n_iter_launches = 0;
     if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
@@ -397,7 +412,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;
     c->res_n_flows = n_flows;
-    c->pc_persist_ok = device_is_ours;
+    c->pc_persist_ok = device_is_ours || c->resident_budget > 0;
     c->pc_giveups = 0;
 
     // ---- track mode: the whole recurrence as ONE persistent launch when every lane can be resident at once ----
@@ -522,7 +537,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         // Nothing of this call is in flight now.  If other psfm calls of the process wait for the device (this sequence holds it
         // exclusively for its resident solves), let them in: the rest of the sequence runs its solves as launches, which overlap
         // with other sequences -- a late-comer waits for one window of frames at most, not for the whole sequence.
-        if (gate.yield_exclusive()) c->pc_persist_ok = false;
+        if (gate.yield_exclusive()) c->pc_persist_ok = c->resident_budget > 0;
         const int stalled = hc->stall ? hc->stall - 1 : -1;   // (the redo below reuses the pinned block `hc` points at)
         int last_ok = f_hi;
         if (seq) {      // frames below the device's program counter are complete (it may be in the middle of the next solve)

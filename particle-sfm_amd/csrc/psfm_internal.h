@@ -158,7 +158,8 @@ struct psfm_ctx {
     PsfmBuf sol_x, sol_state, sol_partials, sol_ctrl, sol_misc, sol_stats, sol_fused, sol_bar;
     PsfmBuf sol_list;              // launch chain / resident solve: per block, the lanes that take part in the solve (pc_build_list)
     int pc_persist_blocks[4] = {-1, -1, -1, -1};   // co-resident blocks of psfm_pc_resident_kernel<NS> on this device (-1: not queried yet)
-    bool pc_persist_ok = false;    // this call has the device to itself: the launch chain may run as one persistent launch
+    bool pc_persist_ok = false;    // this call has the device to itself (or a resident budget): the launch chain may run as one persistent launch
+    int resident_budget = 0;       // psfm_ctx_set_resident_budget: > 0 = resident solves of at most that many blocks under the SHARED gate
     unsigned pc_epoch = 0;         // resident solve: launch counter, part of every granule's tag (stale granules never match)
     int pc_giveups = 0;            // resident solves of this call whose hand-off timed out (two of them: launches from there on)
     int solve_K = 4;        // fused solve: trust-region iterations speculated per launch (adapted at checkpoints)
@@ -272,6 +273,7 @@ psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* fl
 psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d);   // every solver buffer of a sequence, up front
 int psfm_solve_kmax(void);
+int psfm_resident_blocks(psfm_ctx* c);     // co-resident blocks of the resident solve on the context's device
 // track-sharded runs (psfm_shard.hip)
 void psfm_shard_abandon(psfm_ctx* c);   // a run that was begun and never finished (context teardown)
 psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12, const float* flow02,

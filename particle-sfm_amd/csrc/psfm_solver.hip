@@ -1601,11 +1601,13 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_load_rows_kernel(const doubl
 // ------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------
-static int pc_blocks(int n_rows_upper)
+static int pc_blocks(const psfm_ctx* c, int n_rows_upper)
 {
-    // grid of the launch chain's grid-stride kernels; PSFM_PC_BLOCKS (<= PC_MAX_BLOCKS) overrides for measurements
+    // grid of the launch chain's grid-stride kernels; PSFM_PC_BLOCKS (<= PC_MAX_BLOCKS) overrides for measurements.  A context with a
+    // resident budget (psfm_ctx_set_resident_budget: its resident solves share the device with other contexts') stays inside it
     static const int limit_env = getenv("PSFM_PC_BLOCKS") ? atoi(getenv("PSFM_PC_BLOCKS")) : 0;
-    const int limit = limit_env >= 1 && limit_env <= PC_MAX_BLOCKS ? limit_env : PC_CHAIN_BLOCKS;
+    int limit = limit_env >= 1 && limit_env <= PC_MAX_BLOCKS ? limit_env : PC_CHAIN_BLOCKS;
+    if (c->resident_budget > 0 && c->resident_budget < limit) limit = c->resident_budget;
     int n_blocks = (n_rows_upper + PC_BLOCK - 1) / PC_BLOCK;
     if (n_blocks > limit) n_blocks = limit;
     return n_blocks < 1 ? 1 : n_blocks;
@@ -1624,7 +1626,7 @@ static psfm_status pc_setup(psfm_ctx* c, PcParams& P, hipStream_t s)
     P.ticket = (unsigned*)((char*)c->sol_ctrl.p + sizeof(PsfmSolveCtrl));
     if (!P.stall) P.stall = (int*)((char*)c->sol_ctrl.p + sizeof(PsfmSolveCtrl) + 16);
     // the blocks' lists (pc_build_list): block b of the chain's grid sees the lane chunks b, b + n_blocks, ...
-    const int n_blocks = pc_blocks(P.n_rows);
+    const int n_blocks = pc_blocks(c, P.n_rows);
     const int chunks = (P.n_rows + PC_BLOCK - 1) / PC_BLOCK;
     // (a banded block takes every (n_blocks / 8)-th chunk of a band of ceil(chunks / 8): at most one chunk more than in block order)
     P.list_pitch = ((chunks + n_blocks - 1) / n_blocks + 1) * PC_BLOCK;
@@ -1784,7 +1786,7 @@ psfm_status psfm_solve_frame_enqueue(psfm_ctx* c, const PsfmTrackDims& d, const 
     PcParams P;
     psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
     if (rc != PSFM_OK) return rc;
-    const int n_blocks = pc_blocks((int)d.cap);
+    const int n_blocks = pc_blocks(c, (int)d.cap);
     // iteration 0, then the loop and the write-back in one launch when possible (a loop that gave up on its barrier leaves the
     // control block "not done": the write-back kernel behind it then raises the stall flag and the host redoes the solve at its
     // checkpoint), else `unroll` launches of one iteration each + write-back
@@ -1836,7 +1838,7 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
         hipLaunchKernelGGL(psfm_pc_flush_kernel, dim3(nb_all), dim3(PC_BLOCK), 0, s, P);
         hipLaunchKernelGGL(psfm_pc_clear_sel_kernel, dim3(1), dim3(1), 0, s, P.sel, (const int*)P.stall);
     }
-    const int n_blocks = pc_blocks((int)d.cap);
+    const int n_blocks = pc_blocks(c, (int)d.cap);
     hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     // (the host polls behind this launch: a resident solve that gives up must leave the stall flag alone -- see pc_res_stall)
     bool resident = false;
@@ -1849,6 +1851,7 @@ psfm_status psfm_solve_frame_resume(psfm_ctx* c, const PsfmTrackDims& d, const f
 }
 
 int psfm_solve_kmax(void) { return PC_KMAX; }
+int psfm_resident_blocks(psfm_ctx* c) { return pc_resident_capacity<PC_RES_NS_MAX>(c); }
 
 // the chain steps of track_optimize capture the iterate-buffer pointer: allocate before the first one is enqueued
 psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d)
@@ -1913,7 +1916,7 @@ psfm_status psfm_solve_export(psfm_ctx* c, const PsfmTrackDims& d, const float* 
         P.K = K < 1 ? 1 : (K > PC_KMAX ? PC_KMAX : K);
         hipLaunchKernelGGL(psfm_pc_fused_kernel<4>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     } else {
-        const int n_blocks = pc_blocks((int)d.cap);
+        const int n_blocks = pc_blocks(c, (int)d.cap);
         if (kind == 1) hipLaunchKernelGGL(psfm_pc_init_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
         else hipLaunchKernelGGL(psfm_pc_iter_kernel, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P);
     }
@@ -1966,7 +1969,7 @@ psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame,
     PcParams P;
     psfm_status rc = pc_frame_params(c, d, nullptr, nullptr, nullptr, nullptr, frame, P, s);
     if (rc != PSFM_OK) return rc;
-    hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(pc_blocks((int)d.cap)), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
+    hipLaunchKernelGGL(psfm_pc_writeback_kernel, dim3(pc_blocks(c, (int)d.cap)), dim3(PC_BLOCK), 0, s, P, (double*)nullptr);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
@@ -2199,7 +2202,7 @@ psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1
     P.scale = (double*)(P.jscale + n);
     P.flow12 = (const float2*)flow12;
     if ((rc = pc_setup(c, P, s)) != PSFM_OK) return rc;
-    const int n_blocks = pc_blocks((int)n);
+    const int n_blocks = pc_blocks(c, (int)n);
     const unsigned nb = (unsigned)((n + PC_BLOCK - 1) / PC_BLOCK);
     hipLaunchKernelGGL(psfm_pc_load_rows_kernel, dim3(nb), dim3(PC_BLOCK), 0, s, uv12, n, P.x1a, P.x2a);
     PSFM_HIP(hipMemcpyAsync(P.ref1, ref1, sizeof(double2) * n, hipMemcpyDeviceToDevice, s));

@@ -22,7 +22,7 @@ EXPORTS = [
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
-    "psfm_connect_batch", "psfm_solver_launches",
+    "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity",
 ]
 
 
@@ -88,6 +88,8 @@ def lib():
     L.psfm_ctx_set_chain_mode.argtypes = [vp, i32]
     L.psfm_ctx_set_solver.argtypes = [vp, i32, i32]
     L.psfm_solver_counters.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_int32)]
+    L.psfm_ctx_set_resident_budget.argtypes = [vp, i32]
+    L.psfm_resident_capacity.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.psfm_solver_launches.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.psfm_result_filter.argtypes = [vp, i32, ctypes.POINTER(i64), ctypes.POINTER(i64), vp]
     L.psfm_result_filtered_copy.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -145,6 +147,17 @@ class Context:
         """track_optimize: 0 adaptive (fused solve, launch chain for windows whose solves reject steps), 1 launch chain,
         2 fused solve; k = trust-region iterations per fused launch (0: adaptive)."""
         check(lib().psfm_ctx_set_solver(self._h, int(mode), int(k)))
+
+    def set_resident_budget(self, blocks):
+        """> 0: this context's resident solves (flows whose solves reject steps) use at most `blocks` blocks and may run beside other
+        contexts' -- the budgets of all contexts in flight on the device must add up to at most resident_capacity(); 0: only with the
+        device to itself (default)."""
+        check(lib().psfm_ctx_set_resident_budget(self._h, int(blocks)))
+
+    def resident_capacity(self):
+        n = ctypes.c_int32()
+        check(lib().psfm_resident_capacity(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def solver_counters(self):
         a, b, c_, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()

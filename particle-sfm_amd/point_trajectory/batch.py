@@ -73,13 +73,15 @@ def connect_sequences(flow_dirs, traj_dirs, sample_ratio=2, flow_check_thres=1.0
         stream = torch.cuda.Stream(device=device)
         try:
             if n_threads > 1:
-                # several sequences in flight on this GPU: launches only -- the persistent forms (the frame loop of track mode,
-                # the trust-region loop of a solve that rejects steps) need the device to themselves and would take the
-                # device gate, i.e. serialise the sequences
-                _hip.context().set_chain_mode(1)
-                if batch > 1:
-                    for c in _hip.batch_contexts(batch):
-                        c.set_chain_mode(1)
+                # several sequences in flight on this GPU: no persistent frame loop (it needs the device to itself and would take the
+                # device gate, i.e. serialise the sequences).  Solves that reject steps keep their ONE-launch form: every worker's
+                # resident solves get an equal share of the device's co-resident block slots (psfm_ctx_set_resident_budget) and run
+                # beside the other workers' -- 3-5x the launch chain on such flows.
+                cs = _hip.batch_contexts(batch) if batch > 1 else [_hip.context()]
+                share = max(cs[0].resident_capacity() // n_threads, 1) if not skip_path_consistency else 0
+                for c in cs:
+                    c.set_chain_mode(1)
+                    c.set_resident_budget(share)
             with torch.cuda.stream(stream):
                 while True:
                     with lock:
