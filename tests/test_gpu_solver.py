@@ -451,6 +451,50 @@ def test_redo_of_a_fused_solve_survives_a_resident_launch_that_gives_up(pt, monk
     assert [s["termination"] for s in R.solve_stats] == [s["termination"] for s in O.solves]
 
 
+def test_resident_solves_of_several_threads_side_by_side(pt):
+    """psfm_ctx_set_resident_budget: four host threads, each with its own context and a quarter of the device's co-resident block
+    slots, run sequences whose solves reject steps at the same time -- every solve as ONE resident launch (shared gate) instead of
+    the launch chain.  Same results as the oracle; the counters say the resident form ran."""
+    import threading
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    H, W, r, n_thr = 120, 200, 2, 4
+    data, want = [], []
+    for k in range(n_thr):
+        d = psfm_synth.synth_sequence(8 + k, H, W, seed=85 + k, stride2=True, **psfm_synth.HARD)
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+        data.append((d, occ, occ2))
+        want.append(orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r))
+    res, err, cnts = {}, [], {}
+
+    def run(k):
+        import torch
+        try:
+            torch.cuda.set_device(0)
+            ctx = _hip.context()
+            ctx.set_chain_mode(1)
+            ctx.set_resident_budget(ctx.resident_capacity() // n_thr)
+            d, occ, occ2 = data[k]
+            for _ in range(2):
+                res[k] = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+            cnts[k] = ctx.solver_counters()
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+        finally:
+            _hip.release_thread_contexts()
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(n_thr)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not err, err
+    for k in range(n_thr):
+        R, O = res[k], want[k]
+        assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and float(np.abs(R.xy - O.xy).max()) <= TOL
+        assert [s["iterations"] for s in R.solve_stats] == [s["iterations"] for s in O.solves]
+        assert cnts[k]["resident_launches"] > 0 and cnts[k]["resident_giveups"] <= 1, cnts[k]
+
+
 def test_exclusive_sequence_lets_other_host_threads_in(pt):
     """A track_optimize call takes the device gate exclusively when it is free (its hard solves then run as resident launches);
     a psfm call of another host thread that arrives meanwhile announces itself and is let in at the sequence's next checkpoint
