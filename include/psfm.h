@@ -288,6 +288,11 @@ psfm_status psfm_shard_solve_control(psfm_ctx* ctx, int frame, int kind, int k, 
 psfm_status psfm_shard_solve_control_async(psfm_ctx* ctx, int frame, int k, const double* totals, void* stream);
 psfm_status psfm_shard_window_state(psfm_ctx* ctx, int f_lo, int f_hi, psfm_solve_stats* stats_host, int32_t* stalled_frame,
                                     void* stream);
+/* The redo of a stalled solve without a host round trip per trust-region iteration: psfm_shard_solve_control_chain_async enqueues the
+ * control step behind an export of kind 1 / 2 and returns; the caller enqueues a batch of rounds (export 2 -> exchange -> control)
+ * ahead and asks once per batch with psfm_shard_solve_poll (synchronises).  Rounds behind the one that ended the solve are no-ops. */
+psfm_status psfm_shard_solve_control_chain_async(psfm_ctx* ctx, int frame, int kind, const double* totals, void* stream);
+psfm_status psfm_shard_solve_poll(psfm_ctx* ctx, int32_t* done_host, psfm_solve_stats* stats_host, void* stream);
 /* the stall flag as of the last control step the device has completed, without synchronising (-1: none) */
 psfm_status psfm_shard_peek_stall(psfm_ctx* ctx, int32_t* stalled_frame);
 psfm_status psfm_shard_solve_restore(psfm_ctx* ctx, int frame, void* stream);

@@ -28,6 +28,12 @@ void psfm_gate_waiters_add(int device, int d) { g_dev_waiters[device & 15].fetch
 //   psfm_connect with flow_check fused in: 1080p r=2 0.94 -- 720p r=2 1.02, 1080p r=4 1.62, 4K r=4 1.20 (inside the loop
 //     flow_check costs its full bandwidth time, profiles/EXPERIMENTS.md 6.8; beside a short or flow_check-heavy step the
 //     side stream of the per-frame path is better)  ->  additionally >= 400 k grid points and at most 6 pixels per grid point.
+// What this policy cannot fix is the SIZE of a small sequence: below ~100 k grid points a frame is 8-13 us of dependent round trips
+// in either form on 5-40 % of the device's block slots (configs[0]: 96 blocks, 0.025 of the HBM peak).  The answer for those shapes is
+// not another way of running one sequence but several sequences per launch: psfm_connect_batch (psfm_batch.hip) -- blockIdx.y =
+// sequence in every frame launch, one checkpoint and one finalize for the batch: 4.3x the sequences per second at 16 DAVIS-sized
+// sequences (chain step 0.025 -> 0.17 of the HBM peak), 2.4x with path consistency at Sintel size (frame kernel 0.21 -> 0.38 of the
+// VALU-issue peak), 1.3x at ScanNet size (a dense 307 k grid already fills the block slots once) -- profiles/r05.
 static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int ratio, bool fused)
 {
     if (c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;

@@ -145,6 +145,34 @@ extern "C" psfm_status psfm_shard_solve_control_async(psfm_ctx* c, int frame, in
 #endif
 }
 
+// The redo of a solve that did not go as speculated, WITHOUT a host round trip per trust-region iteration: the control step behind
+// an export of kind 1 (iteration 0) / 2 (one iteration) is only enqueued; the caller enqueues a batch of rounds (export -> its
+// exchange -> this) ahead and asks once per batch (psfm_shard_solve_poll).  Rounds behind the one that terminated the solve find
+// the control block done: their export and their control step return at once (the exchange in between carries stale sums nobody
+// reads).  Every rank enqueues the same batches -- the decision is made from the same totals everywhere.
+extern "C" psfm_status psfm_shard_solve_control_chain_async(psfm_ctx* c, int frame, int kind, const double* totals, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    if (kind != 1 && kind != 2) { psfm_set_error("psfm_shard_solve_control_chain_async: kind must be 1 or 2"); return PSFM_ERR_ARG; }
+    return psfm_solve_control(c, *c->shard_dims, frame, kind, 1, totals, (hipStream_t)stream);
+}
+
+// Synchronises: is the solve the chain is working on done, and its statistics so far.
+extern "C" psfm_status psfm_shard_solve_poll(psfm_ctx* c, int32_t* done_host, psfm_solve_stats* stats_host, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    int done = 0, stall = 0;
+    psfm_solve_stats ss;
+    memset(&ss, 0, sizeof(ss));
+    psfm_status st = psfm_solve_state(c, &done, &stall, &ss, (hipStream_t)stream);
+    if (st != PSFM_OK) return st;
+    if (done_host) *done_host = done;
+    if (stats_host) *stats_host = ss;
+    return PSFM_OK;
+}
+
 // The stall flag as of the last control step the device has COMPLETED (no synchronisation: the value lags the queue by the
 // frames in flight): frame whose solve stalled, or -1.
 extern "C" psfm_status psfm_shard_peek_stall(psfm_ctx* c, int32_t* stalled_frame)

@@ -49,6 +49,7 @@
 #include "psfm_pc_control.h"
 
 #define PC_BLOCK 256
+#include "psfm_pc_resident.h"
 #include "psfm_pc_reduce.h"
 #ifndef PC_FUSED_PAIR
 #define PC_FUSED_PAIR false  // ... and the fused solve's: its lanes are neighbours in the image, and the frame kernel spills 7 VGPRs with them
@@ -177,19 +178,14 @@ __device__ __forceinline__ int pc_build_list(const PcParams& P, int n)
     __shared__ int s_wc[PC_BLOCK / PSFM_WAVE];
     int* lst = P.list + (int64_t)blockIdx.x * P.list_pitch;
     const int lane = threadIdx.x & (PSFM_WAVE - 1), w = threadIdx.x / PSFM_WAVE;
-    // Which chunks: by default XCD-BANDED -- blocks go to the eight XCDs round-robin, each XCD has a private L2, and lanes are
-    // (roughly) in image order: the blocks of XCD x = b % 8 share the x-th eighth of the chunks (block b takes chunks
-    // x * per + b / 8 + k * (blocks per XCD)), so the taps of an XCD's tracks come from one band of the flow field (2 MB of 16.6 at
-    // 1080p: it stays in that XCD's 4 MB L2 across the rounds of a solve) instead of from all of it.  P.list_banded == 0 or a
-    // grid that is not a multiple of 8: chunks b, b + gridDim.x, ...
-    const int nchunk = (n + PC_BLOCK - 1) / PC_BLOCK;
-    const bool banded = P.list_banded && (gridDim.x & 7u) == 0u && nchunk >= 64;
-    const int per = banded ? (nchunk + 7) / 8 : nchunk;                 // chunks of a band
-    const int first = banded ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // first chunk of this block inside its band
-    const int step = banded ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    const int band0 = banded ? (int)(blockIdx.x & 7u) * per : 0;
+    // Which chunks (pc_list_plan, psfm_pc_resident.h): by default XCD-BANDED -- the blocks of XCD x = b % 8 share the x-th eighth of the
+    // chunks, so the taps of an XCD's tracks come from one band of the flow field (2 MB of 16.6 at 1080p: it stays in that XCD's 4 MB
+    // L2 across the rounds of a solve) instead of from all of it.  P.list_banded == 0 or a grid that is not a multiple of 8: chunks b,
+    // b + gridDim.x, ...
+    const PcListPlan plan = pc_list_plan((int)blockIdx.x, (int)gridDim.x, n, P.list_banded);
+    const int first = plan.first, step = plan.step, band0 = plan.band0;
     int base = 0;
-    for (int q = first; q < per && band0 + q < nchunk; q += step) {
+    for (int q = first; pc_list_chunk_ok(plan, q); q += step) {
         const int i = (band0 + q) * PC_BLOCK + (int)threadIdx.x;
         const bool part = pc_participates(P, i, n);
         const unsigned long long m = __ballot(part);
@@ -419,8 +415,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_iter_kernel(PcParams P)
 // -- S_x is what ONE block of the resident solve (the "leader" x) adds up from its members' granules, the rest is what every
 // block adds up from the leaders' (pc_res_allreduce): two hops, a few loads per lane in each.  SUM_GMAX by max.
 // ------------------------------------------------------------------------------------------------
-#define PC_LEADERS 32
-__host__ __device__ inline int pc_tree_q(int n_blocks) { return ((n_blocks + PC_LEADERS - 1) / PC_LEADERS + 3) / 4; }
+// (PC_LEADERS, pc_tree_q and the same order as plain arithmetic on rows -- pc_tree_totals, what the host mirror adds up with: psfm_pc_resident.h)
 
 // Executed by the LAST block of pc_init / pc_iter to finish (detected with a ticket behind write-through partials; the loads
 // here bypass the caches -- cdna_hip_programming.md G16): the reduction above, then the scalar control step on thread 0.
@@ -679,23 +674,7 @@ __device__ __forceinline__ void pc_res_stall(const PcParams& P, int raise_stall)
     if (raise_stall && P.birth_frame && threadIdx.x == 0) *P.stall = P.frame + 1;
 }
 
-struct PcSlot {                    // (slot k of thread t holds entry k * PC_BLOCK + t of the block's list, if the list is that long)
-    double s, S0q, S1q;            // weight, squared Jacobi scaling of columns 0, 1
-    double x[4], u[4], d[4];       // the iterate, and the system's solution there for the mu in force
-};
-
-// the candidate x + a u + b d of a slot, as the launch chain forms it (pc_core_step<false, false>), and |x - x'|^2
-__device__ __forceinline__ double pc_slot_candidate(const PcSlot& T, double a, double b, double xp[4])
-{
-    double v[PC_NSUM], r0[6], j0[4];      // (r0, j0, the constants: not read in this form of the step)
-    PcSys y;
-    PcConst c;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { y.u[q] = T.u[q]; y.d[q] = T.d[q]; }
-    v[SUM_STEP2] = 0.0;
-    pc_core_step<false, false>(T.x, r0, j0, c, y, a, b, v, xp);
-    return v[SUM_STEP2];
-}
+// (PcSlot and what happens to a slot -- pc_slot_fill / _start / _round / _refresh / _accept / _candidate: psfm_pc_resident.h, host-compilable)
 
 template <int NS>
 __global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -732,17 +711,15 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
         for (int q = 0; q < PC_NSUM; ++q) acc[q] = 0.0;
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            if (k * PC_BLOCK + tid < cnt) {
+            if (pc_slot_entry(k, tid) < cnt) {
                 PcInit o;
-                pc_init_entry(P, lst[k * PC_BLOCK + tid], false, acc, o);
-                T[k].s = o.s; T[k].S0q = o.c.S0q; T[k].S1q = o.c.S1q;
+                pc_init_entry(P, lst[pc_slot_entry(k, tid)], false, acc, o);
+                pc_slot_fill(T[k], o.s, o.c, o.x, o.y);
                 s_ref[k][0][tid] = o.r1.x; s_ref[k][1][tid] = o.r1.y; s_ref[k][2][tid] = o.r2.x; s_ref[k][3][tid] = o.r2.y;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { T[k].x[q] = o.x[q]; T[k].u[q] = o.y.u[q]; T[k].d[q] = o.y.d[q]; }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        for (int p = NS * PC_BLOCK + tid; p < cnt; p += PC_BLOCK) {     // (streamed entries: their constants go to memory)
+        for (int p = pc_stream_first(NS, tid); p < cnt; p += PC_BLOCK) {     // (streamed entries: their constants go to memory)
             PcInit o;
             pc_init_entry(P, lst[p], true, acc, o);
         }
@@ -777,7 +754,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             PcTaps tp[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                const int i = k * PC_BLOCK + tid < cnt ? lst[k * PC_BLOCK + tid] : 0;
+                const int i = pc_slot_entry(k, tid) < cnt ? lst[pc_slot_entry(k, tid)] : 0;
                 const double2 r1 = P.ref1[i], r2 = P.ref2[i], js = P.jscale[i], p1 = P.x1a[i], p2 = P.x2a[i];
                 T[k].s = P.scale[i];
                 T[k].S0q = js.x; T[k].S1q = js.y;
@@ -787,17 +764,8 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
 #pragma unroll
             for (int k = 0; k < NS; ++k) tp[k] = pc_core_taps<PC_ITER_PAIR>(F12, P.H, P.W, T[k].x);
 #pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                double r[6], jac[4], unused[PC_NSUM];
-                PcSys y;
-#pragma unroll
-                for (int q = 0; q < PC_NSUM; ++q) unused[q] = 0.0;
-                const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
-                pc_core_eval_taps(tp[k], T[k].x, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
-                pc_core_system<false>(T[k].x, r, jac, c, s_R.mu, pc_core_iA22(c, s_R.mu), unused, y, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { T[k].u[q] = y.u[q]; T[k].d[q] = y.d[q]; }
-            }
+            for (int k = 0; k < NS; ++k)
+                pc_slot_start(T[k], tp[k], s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], s_R.mu);
         }
     }
     for (unsigned it = 0; it < (unsigned)max_rounds; ++it) {
@@ -829,16 +797,12 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 // (a lane without a track in this slot skips it; the sums receive ONE term per track, in list order, like the launches')
-                if (k * PC_BLOCK + tid < cnt) {
-                    double xe[4], r[6], jac[4];
-                    PcSys y;
-                    acc[SUM_STEP2] += pc_slot_candidate(T[k], a, b, xe);      // (recomputed: the same bits, 8 registers fewer across the gather)
-                    const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
-                    pc_core_eval_taps(tp[k], xe, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
-                    acc[SUM_COST] += pc_core_cost(r);
-                    pc_core_system<true>(xe, r, jac, c, mu_next, pc_core_iA22(c, mu_next), acc, y, CH_QUD, CH_QDD);
+                if (pc_slot_entry(k, tid) < cnt) {
+                    // (pc_slot_round recomputes the candidate: the same bits, 8 registers fewer across the gather)
+                    double nx[8];
+                    pc_slot_round(T[k], tp[k], s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], a, b, mu_next, acc, nx);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { s_next[k][q][tid] = y.u[q]; s_next[k][4 + q][tid] = y.d[q]; }
+                    for (int q = 0; q < 8; ++q) s_next[k][q][tid] = nx[q];
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (one slot at a time: interleaving them costs more registers than it hides)
             }
@@ -846,20 +810,13 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             // the system at x for the mu an invalid step has raised: (u, d) of the slots are replaced (rare)
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                if (k * PC_BLOCK + tid < cnt) {
-                    double r[6], jac[4];
-                    PcSys y;
-                    const PcConst c = pc_const_load(T[k].s, make_double2(T[k].S0q, T[k].S1q));
-                    pc_core_eval<PC_ITER_PAIR>(F12, P.H, P.W, T[k].x, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], T[k].s, r, jac);
-                    pc_core_system<true>(T[k].x, r, jac, c, mu, pc_core_iA22(c, mu), acc, y, CH_QUD, CH_QDD);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { T[k].u[q] = y.u[q]; T[k].d[q] = y.d[q]; }
-                }
+                if (pc_slot_entry(k, tid) < cnt)
+                    pc_slot_refresh<PC_ITER_PAIR>(T[k], F12, P.H, P.W, s_ref[k][0][tid], s_ref[k][1][tid], s_ref[k][2][tid], s_ref[k][3][tid], mu, acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         // entries beyond the slots: streamed, as the launches do it
-        if (cnt > NS * PC_BLOCK) pc_iter_tracks(P, NS * PC_BLOCK + tid, cur, mu, a, b, refresh, acc);
+        if (cnt > NS * PC_BLOCK) pc_iter_tracks(P, pc_stream_first(NS, tid), cur, mu, a, b, refresh, acc);
         PC_RTL(2);
         pc_block_sums<PC_RES_SUMS>(acc, s_blk);
         PC_RTL(3);
@@ -902,22 +859,22 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
             // x <- the candidate (the same operations: the same bits), (u, d) <- what was solved there
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                double xp[4];
-                (void)pc_slot_candidate(T[k], a, b, xp);
+                double nx[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { T[k].x[q] = xp[q]; T[k].u[q] = s_next[k][q][tid]; T[k].d[q] = s_next[k][4 + q][tid]; }
+                for (int q = 0; q < 8; ++q) nx[q] = s_next[k][q][tid];
+                pc_slot_accept(T[k], a, b, nx);
             }
         }
     }
     if (!s_R.done) { pc_res_stall(P, raise_stall); return; }            // (ran out of rounds)
     // ---- write-back (block 0 also: statistics, the control block) ----
     const PsfmSolveCtrl C = s_C;
-    const bool moved = C.cur != 0 && !C.failed;          // (a failed solve hands the parameters back as they came in)
+    const bool moved = pc_res_moved(C);                  // (a failed solve hands the parameters back as they came in)
     if (moved || out_rows) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            if (k * PC_BLOCK + tid >= cnt) continue;
-            const int i = lst[k * PC_BLOCK + tid];
+            if (pc_slot_entry(k, tid) >= cnt) continue;
+            const int i = lst[pc_slot_entry(k, tid)];
             double2 p1 = make_double2(T[k].x[0], T[k].x[1]), p2 = make_double2(T[k].x[2], T[k].x[3]);
             if (!moved) { p1 = P.x1a[i]; p2 = P.x2a[i]; }
             if (out_rows) {
@@ -927,10 +884,10 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
                 P.x1a[i] = p1; P.x2a[i] = p2;
             }
         }
-        const int src = moved ? C.cur : 0;
+        const int src = pc_res_stream_source(C);
         const double2* xc1 = pc_buf1(P, src);
         const double2* xc2 = pc_buf2(P, src);
-        for (int p = NS * PC_BLOCK + tid; p < cnt; p += PC_BLOCK) {
+        for (int p = pc_stream_first(NS, tid); p < cnt; p += PC_BLOCK) {
             const int i = lst[p];
             const double2 p1 = xc1[i], p2 = xc2[i];
             if (out_rows) {

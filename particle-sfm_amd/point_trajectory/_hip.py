@@ -22,7 +22,7 @@ EXPORTS = [
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
-    "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity",
+    "psfm_shard_solve_control_chain_async", "psfm_shard_solve_poll", "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity",
 ]
 
 
@@ -104,6 +104,8 @@ def lib():
     L.psfm_shard_solve_control.argtypes = [vp, i32, i32, i32, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
                                            ctypes.POINTER(SolveStats), vp]
     L.psfm_shard_solve_control_async.argtypes = [vp, i32, i32, vp, vp]
+    L.psfm_shard_solve_control_chain_async.argtypes = [vp, i32, i32, vp, vp]
+    L.psfm_shard_solve_poll.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(SolveStats), vp]
     L.psfm_shard_window_state.argtypes = [vp, i32, i32, ctypes.POINTER(SolveStats), ctypes.POINTER(ctypes.c_int32), vp]
     L.psfm_shard_peek_stall.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.psfm_shard_solve_restore.argtypes = [vp, i32, vp]

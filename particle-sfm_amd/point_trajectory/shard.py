@@ -127,16 +127,25 @@ class HipShardEngine:
             self.counters["fused_redone"] += 1
             _hip.check(L.psfm_shard_solve_restore(h, fs, self._sp()))
             mask = [(i % N_SUM) == SUM_GMAX for i in range(N_SUM)]
+            # The launch chain, a BATCH of trust-region rounds enqueued ahead (export -> sums over the ranks -> control, nothing read
+            # back in between) and ONE host synchronisation per batch: rounds behind the one that ends the solve find the control block
+            # done and return at once.  Every rank enqueues the same batches (8, 16, 32, 32, ...: the same totals, the same decision
+            # everywhere).  (Round 4: one synchronisation per iteration -- PSFM_SHARD_ROUNDS_AHEAD=1.)
+            ahead = max(1, int(os.environ.get("PSFM_SHARD_ROUNDS_AHEAD", "8")))
             kind, n = 1, 0
+            done, st = ctypes.c_int32(0), _hip.SolveStats()
             while True:
-                _hip.check(L.psfm_shard_solve_export(h, *p, fs, kind, 1, _hip.ptr(self.sums), self._sp()))
-                reduce(self.sums[:N_SUM], mask)
-                done, _, st = self._control(fs, kind, 1)
-                if done:
+                for _ in range(ahead):
+                    _hip.check(L.psfm_shard_solve_export(h, *p, fs, kind, 1, _hip.ptr(self.sums), self._sp()))
+                    reduce(self.sums[:N_SUM], mask)
+                    _hip.check(L.psfm_shard_solve_control_chain_async(h, fs, kind, _hip.ptr(self.sums), self._sp()))
+                    kind, n = 2, n + 1
+                _hip.check(L.psfm_shard_solve_poll(h, ctypes.byref(done), ctypes.byref(st), self._sp()))
+                if done.value:
                     break
-                kind, n = 2, n + 1
                 if n > 2 * 200 + 64:
                     raise RuntimeError("path-consistency solver did not terminate")
+                ahead = min(32, ahead * 2) if ahead > 1 else 1
             _hip.check(L.psfm_shard_solve_writeback(h, fs, ctypes.byref(st), self._sp()))
             self._adapt(st)
             redo = fs

@@ -15,7 +15,9 @@ import torch
 import bench
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 201
-out = bench.single_sequence_sharded(torch.device("cuda", 0), 0, 1, frames, reps=3)
+hard = len(sys.argv) > 2 and sys.argv[2] == "hard"       # psfm_synth.HARD: every solve rejects steps -> the engine's redo path
+import psfm_synth
+out = bench.single_sequence_sharded(torch.device("cuda", 0), 0, 1, frames, reps=1 if hard else 3, flows_dist=psfm_synth.HARD if hard else None)
 print(json.dumps({k: out[k] for k in ("ms_per_sequence", "one_gpu_psfm_connect_ms_per_sequence", "counts_equal_one_gpu",
                                       "solver_counters", "trust_region_iterations", "solves")} |
-                 {"frames": frames, "fused_waves": os.environ.get("PSFM_FUSED_WAVES", "3")}))
+                 {"frames": frames, "hard": hard, "rounds_ahead": os.environ.get("PSFM_SHARD_ROUNDS_AHEAD", "8")}))

@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def chain(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("pc_chain") / "libpc_chain_host.so")
     cmd = ["g++", "-O2", "-mfma", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off",
-           "-I", os.path.join(ROOT, "particle-sfm_amd", "csrc"), os.path.join(ROOT, "tests", "host", "pc_chain_host.cpp"), "-o", out]
+           "-I", os.path.join(ROOT, "particle-sfm_amd", "csrc"), os.path.join(ROOT, "tests", "host", "pc_chain_host.cpp"),
+           os.path.join(ROOT, "tests", "host", "pc_resident_host.cpp"), "-o", out]
     subprocess.run(cmd, check=True)
     L = ctypes.CDLL(out)
     dp, fp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
@@ -32,6 +33,9 @@ def chain(tmp_path_factory):
     L.pc_host_chain_solve_ex.restype = ctypes.c_int
     L.pc_host_fused_solve.argtypes = [ctypes.c_long, dp, dp, dp, dp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, dp]
     L.pc_host_fused_solve.restype = ctypes.c_int
+    ubp = ctypes.POINTER(ctypes.c_ubyte)
+    L.pc_host_resident_solve.argtypes = [ctypes.c_long, ubp, dp, dp, dp, dp, fp] + [ctypes.c_int] * 8 + [dp, ip, dp, ip]
+    L.pc_host_resident_solve.restype = ctypes.c_int
     return L
 
 
@@ -204,3 +208,137 @@ def test_device_fused_solve_on_the_host_finishes_exactly_the_clean_solves(chain)
             assert so["iterations"] > 3          # more than one launch's worth: the continuation ran
             _same_solve(got, sg, want, so, 1e-6)
     assert 3 <= done <= 9
+
+
+# ---- the RESIDENT solve's bookkeeping (csrc/psfm_pc_resident.h: lists, slots, the streamed tail, the accepted-step update, the
+#      block tree, the write-back, giving up) on the host ----
+def _resident(L, uv, ref1, ref2, scale, flow12, n_blocks, ns, banded=1, init_inside=1, part=None, quit=(-1, -1)):
+    dp, fp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 4)
+    n = len(uv)
+    r1 = np.ascontiguousarray(ref1, np.float64).reshape(-1, 2); r2 = np.ascontiguousarray(ref2, np.float64).reshape(-1, 2)
+    sc = np.ascontiguousarray(scale, np.float64).reshape(-1)
+    fl = np.ascontiguousarray(flow12, np.float32)
+    H, W = fl.shape[:2]
+    out = np.full((n, 4), -777.0); stats = np.zeros(7, np.int32); costs = np.zeros(2); info = np.zeros(4, np.int32)
+    pm = None if part is None else np.ascontiguousarray(part, np.uint8)
+    rc = L.pc_host_resident_solve(n, None if pm is None else pm.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), uv.ctypes.data_as(dp),
+                                  r1.ctypes.data_as(dp), r2.ctypes.data_as(dp), sc.ctypes.data_as(dp), fl.ctypes.data_as(fp), H, W,
+                                  int(n_blocks), int(ns), int(banded), int(init_inside), int(quit[0]), int(quit[1]),
+                                  out.ctypes.data_as(dp), stats.ctypes.data_as(ip), costs.ctypes.data_as(dp), info.ctypes.data_as(ip))
+    return out, {"iterations": int(stats[0]), "successful_steps": int(stats[1]), "termination": int(stats[2]),
+                 "dogleg_nonGN": int(stats[3]), "launches": int(stats[4]), "done": int(stats[5]), "failed": int(stats[6]),
+                 "initial_cost": float(costs[0]), "final_cost": float(costs[1])}, rc, \
+        {"longest_list": int(info[0]), "streamed": int(info[1]), "rounds": int(info[2]), "empty_blocks": int(info[3])}
+
+
+RESIDENT_SHAPES = [
+    # n_blocks, slots per thread, banded lists, iteration 0 inside the launch
+    (1, 1, 1, 1), (1, 3, 1, 1),            # one block holds everything: 256 / 768 tracks on chip, the rest streamed
+    (5, 2, 0, 1), (12, 1, 1, 0),           # (12 blocks: what a batch of 3000 tracks runs on; iteration 0 as its own launch)
+    (40, 3, 1, 1),                         # more blocks than leaders: the first level of the tree has members
+    (64, 2, 1, 1), (64, 1, 1, 0),          # a grid that is a multiple of 8: XCD-banded lists once there are >= 64 chunks
+    (100, 3, 1, 1),                        # more blocks than chunks: empty lists
+]
+
+
+@pytest.mark.parametrize("n_blocks,ns,banded,init_inside", RESIDENT_SHAPES)
+@pytest.mark.parametrize("H,W,n,seed,sigma,kink", [(60, 80, 3000, 2, 0.5, False), (45, 70, 5000, 3, 0.3, True), (270, 480, 20000, 4, 0.05, False),
+                                                   (33, 47, 1, 5, 0.1, False)])
+def test_resident_bookkeeping_on_the_host_is_the_launch_chain(chain, n_blocks, ns, banded, init_inside, H, W, n, seed, sigma, kink):
+    """psfm_pc_resident_kernel's slot / list / streamed-tail / write-back logic with the device's own functions
+    (csrc/psfm_pc_resident.h), for block counts and slot counts that put the tracks everywhere a launch can put them -- all on chip,
+    most of them streamed behind the slots, lists of different lengths, empty blocks: the same solve as the launch chain's (every
+    decision; positions to the rounding of another order of summation) and as the oracle's."""
+    from oracle import oracle as orc
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, seed, sigma, kink)
+    ch, sc, _ = _solve(chain, uv, ref1, ref2, scale, flow12, pair=1)
+    got, st, rc, info = _resident(chain, uv, ref1, ref2, scale, flow12, n_blocks, ns, banded, init_inside)
+    assert rc == 0 and st["done"] == 1
+    _same_solve(got, st, ch, sc, 1e-7)
+    want, st_o = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+    _same_solve(got, st, want, st_o, 1e-6)
+    if n_blocks == 1 and n > ns * 256:
+        assert info["streamed"] == n - ns * 256 and info["longest_list"] == n
+    if n_blocks == 100 and n <= 5000:
+        assert info["empty_blocks"] > 0
+
+
+def test_resident_bookkeeping_rows_that_do_not_take_part(chain):
+    """Frame mode's lists hold only the lanes whose track has three buffered points: a random 55 % of the rows take part; their solve
+    is the launch chain's on exactly those rows, the others are never touched."""
+    uv, ref1, ref2, scale, flow12 = solver_batch(60, 80, 6000, 12, 0.4, False)
+    rng = np.random.default_rng(5)
+    part = rng.uniform(size=len(uv)) < 0.55
+    ch, sc, _ = _solve(chain, uv[part], ref1[part], ref2[part], scale[part], flow12, pair=1)
+    for n_blocks, ns in ((7, 1), (24, 3)):
+        got, st, rc, info = _resident(chain, uv, ref1, ref2, scale, flow12, n_blocks, ns, part=part)
+        assert rc == 0
+        _same_solve(got[part], st, ch, sc, 1e-7)
+        assert np.all(got[~part] == -777.0)
+
+
+@pytest.mark.parametrize("quit", [(0, 0), (3, 1), (11, 4)])
+def test_resident_bookkeeping_giving_up_writes_nothing(chain, quit):
+    """A block that leaves in round r (its hand-off timed out: the grid was not co-resident) takes the solve with it -- and nothing
+    has been written: the caller's rows are as they were, the launches redo the solve from iteration 0."""
+    uv, ref1, ref2, scale, flow12 = solver_batch(60, 80, 3000, 2, 0.5, False)
+    got, st, rc, info = _resident(chain, uv, ref1, ref2, scale, flow12, 12, 3, quit=quit)
+    assert rc == 2 and np.all(got == -777.0)
+
+
+def test_resident_bookkeeping_failed_solve_hands_the_start_values_back(chain):
+    """Non-finite residuals at the start values (Ceres' FAILURE in IterationZero): slots and streamed entries alike keep the input."""
+    uv, ref1, ref2, scale, flow12 = solver_batch(40, 50, 900, 9, 0.1, False)
+    flow12 = flow12.copy(); flow12[10:14, 20:24] = np.nan
+    uv[:, 0] = np.clip(uv[:, 0], 20.2, 22.8); uv[:, 1] = np.clip(uv[:, 1], 10.2, 12.8)
+    got, st, rc, info = _resident(chain, uv, ref1, ref2, scale, flow12, 2, 1)
+    assert rc == 0 and st["failed"] == 1 and st["termination"] == 5 and info["streamed"] > 0
+    assert np.array_equal(got, np.ascontiguousarray(uv, np.float64).reshape(-1, 4))
+
+
+def test_block_tree_order_is_what_the_device_adds(chain):
+    """pc_tree_totals (the order every form of the chain adds the blocks' sums in: members -> 32 leaders -> four groups of eight)
+    against the same order written out with NumPy, for block counts on both sides of the leader count."""
+    import numpy as np
+    src = r"""
+    #include "psfm_pc_resident.h"
+    extern "C" void tree(const double* rows, int n_blocks, double* tot) { pc_tree_totals(rows, PC_NSUM, n_blocks, PC_NSUM, tot); }
+    """
+    import tempfile
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "t.cpp"), "w").write(src)
+    so = os.path.join(d, "t.so")
+    subprocess.run(["g++", "-O2", "-mfma", "-shared", "-fPIC", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "particle-sfm_amd", "csrc"),
+                    os.path.join(d, "t.cpp"), "-o", so], check=True)
+    T = ctypes.CDLL(so)
+    dp = ctypes.POINTER(ctypes.c_double)
+    T.tree.argtypes = [dp, ctypes.c_int, dp]
+    rng = np.random.default_rng(3)
+    for nb in (1, 2, 31, 32, 33, 100, 128, 129, 512, 1000):
+        rows = rng.standard_normal((nb, 13)) * 10.0 ** rng.integers(-6, 7, size=(nb, 13))
+        tot = np.zeros(13)
+        T.tree(np.ascontiguousarray(rows).ctypes.data_as(dp), nb, tot.ctypes.data_as(dp))
+        Lq, Q = min(32, nb), ((nb + 31) // 32 + 3) // 4
+        for k in range(13):
+            mx = k == 5
+            red = (lambda a, b: max(a, b)) if mx else (lambda a, b: a + b)
+            S = []
+            for x in range(Lq):
+                cnt = (nb - x + 31) // 32
+                sj = []
+                for j in range(4):
+                    v = 0.0
+                    for u in range(Q):
+                        m = j * Q + u
+                        if m < cnt:
+                            v = red(v, rows[x + 32 * m, k])
+                    sj.append(v)
+                S.append(red(red(red(sj[0], sj[1]), sj[2]), sj[3]))
+            t = []
+            for j in range(4):
+                v = 0.0
+                for x in range(8 * j, min(8 * j + 8, Lq)):
+                    v = red(v, S[x])
+                t.append(v)
+            assert tot[k] == red(red(red(t[0], t[1]), t[2]), t[3]), (nb, k)
