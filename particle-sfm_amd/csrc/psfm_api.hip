@@ -182,6 +182,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     psfm_shard_abandon(c);
     c->prof.destroy();
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->redo_stream) (void)hipStreamDestroy(c->redo_stream);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->host_seg) (void)hipHostFree(c->host_seg);
     if (c->host_batch) (void)hipHostFree(c->host_batch);

@@ -20,6 +20,8 @@
 // Results are those of psfm_connect, sequence by sequence (tests/test_gpu_batch.py: bit-identical to the oracle's).
 #include <string.h>
 #include <stdlib.h>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "psfm_internal.h"
@@ -284,6 +286,15 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                     for (int k = 0; k < win_max && lo[i] + k <= n_i; ++k) S[i].hstats[(size_t)(lo[i] + k)] = hw[k];
                     const int stalled = hc.stall ? hc.stall - 1 : -1;
                     int last_ok = (hc.pc_frame < n_i ? hc.pc_frame : n_i) - 1;     // frames below the device's program counter are complete
+                    if (stalled >= 0 && c->solver_mode != 2 && stalled - S[i].first_unchecked < 8) {
+                        // ... with fewer than eight solves of the window in front of it: whatever they were, the window counts as one whose
+                        // solves reject steps (one in eight is the bar below) and the sequence is about to leave the batch -- and to be run
+                        // again from its first frame by psfm_connect.  No point in redoing this solve with launches first.
+                        S[i].dropped = true; S[i].resync = true;
+                        c->solve_mode = 1;        // (what psfm_connect starts its first window with: the launch chain / the resident solve)
+                        progress = true;
+                        continue;
+                    }
                     if (stalled >= 0) {
                         // a solve that did not go as speculated (a rejected step, a dogleg interpolation, more iterations than the
                         // continuation launches cover): redone by the launch chain from the values it started with, as in psfm_track
@@ -367,11 +378,54 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             }
         }
     }
-    // ---- sequences that left the batch: alone, with everything psfm_connect has for them (the gate is released above) ----
-    for (int i : redo) {
-        st = psfm_connect(ctxs[i], flows_f[i], flows_b[i], optimize ? flows_f2[i] : nullptr, optimize ? flows_b2[i] : nullptr, n_flows[i], h, w, thres,
-                          ratio, nullptr, nullptr, infos ? &infos[i] : nullptr, stream);
-        if (st != PSFM_OK) return st;
+    // ---- sequences that left the batch (their solves reject steps): through psfm_connect, with everything it has for them -- the
+    // resident solve above all.  One sequence: the call as it is (it may take the device to itself).  Several: a few of them at a
+    // time on host threads of this call, every one with an equal share of the device's co-resident block slots for its resident
+    // solves (psfm_ctx_set_resident_budget: 1.6-1.8x one after the other on Sintel / DAVIS-sized realistic flows,
+    // profiles/r05/r05_f_resident_budget.txt); as many at a time as have room on chip for their tracks.  (The gate is released.) ----
+    if (redo.empty()) return PSFM_OK;
+    int n_thr = 1;
+    if (redo.size() >= 2 && optimize) {
+        const int capacity = psfm_resident_blocks(own);
+        const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
+        const int64_t need = (G * 6 / 10 + 767) / 768;            // blocks that hold ~60 % of the grid's tracks at three per thread
+        int fit = need > 0 ? (int)(capacity / need) : 4;
+        if (const char* e = getenv("PSFM_BATCH_REDO_THREADS")) fit = atoi(e);
+        n_thr = fit < 1 ? 1 : (fit > 4 ? 4 : fit);
+        if (n_thr > (int)redo.size()) n_thr = (int)redo.size();
+        if (capacity <= 0) n_thr = 1;
     }
+    if (n_thr == 1) {
+        for (int i : redo) {
+            st = psfm_connect(ctxs[i], flows_f[i], flows_b[i], optimize ? flows_f2[i] : nullptr, optimize ? flows_b2[i] : nullptr, n_flows[i], h, w, thres,
+                              ratio, nullptr, nullptr, infos ? &infos[i] : nullptr, stream);
+            if (st != PSFM_OK) return st;
+        }
+        return PSFM_OK;
+    }
+    const int share = psfm_resident_blocks(own) / n_thr;
+    std::vector<psfm_status> rc((size_t)n_thr, PSFM_OK);
+    std::vector<std::string> msg((size_t)n_thr);
+    std::vector<std::thread> workers;
+    for (int t = 0; t < n_thr; ++t)
+        workers.emplace_back([&, t]() {
+            for (size_t q = (size_t)t; q < redo.size(); q += (size_t)n_thr) {
+                const int i = redo[q];
+                psfm_ctx* c = ctxs[i];
+                if (hipSetDevice(c->device) != hipSuccess) { rc[(size_t)t] = PSFM_ERR_HIP; msg[(size_t)t] = "hipSetDevice failed"; return; }
+                if (!c->redo_stream && hipStreamCreateWithFlags(&c->redo_stream, hipStreamNonBlocking) != hipSuccess) {
+                    rc[(size_t)t] = PSFM_ERR_HIP; msg[(size_t)t] = "hipStreamCreateWithFlags failed"; return;
+                }
+                const int budget0 = c->resident_budget;
+                c->resident_budget = share;
+                const psfm_status r = psfm_connect(c, flows_f[i], flows_b[i], flows_f2[i], flows_b2[i], n_flows[i], h, w, thres, ratio, nullptr, nullptr,
+                                                   infos ? &infos[i] : nullptr, (void*)c->redo_stream);
+                c->resident_budget = budget0;
+                if (r != PSFM_OK) { rc[(size_t)t] = r; msg[(size_t)t] = psfm_last_error(); return; }      // (the error text is thread local)
+            }
+        });
+    for (auto& th : workers) th.join();
+    for (int t = 0; t < n_thr; ++t)
+        if (rc[(size_t)t] != PSFM_OK) { psfm_set_error("psfm_connect_batch: a sequence that left the batch failed: %s", msg[(size_t)t].c_str()); return rc[(size_t)t]; }
     return PSFM_OK;
 }

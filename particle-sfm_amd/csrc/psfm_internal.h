@@ -185,6 +185,7 @@ struct psfm_ctx {
     int64_t mt_n_kp = 0, mt_n_m = 0, mt_n_pairs = 0;
     int mt_n_img = 0;
     hipStream_t side_stream = nullptr;   // flow_check of psfm_connect runs here, ahead of the frame loop
+    hipStream_t redo_stream = nullptr;   // psfm_connect_batch: a sequence that left the batch runs here, beside the others that did
     std::vector<psfm_solve_stats> solve_stats;
     PsfmProfiler prof;
     void* host_pinned = nullptr;  // small pinned staging block

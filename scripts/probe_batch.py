@@ -14,13 +14,20 @@ from point_trajectory.trajectory import run_connect, run_connect_batch
 SHAPES = {"davis": ("configs[0] DAVIS 480x854 r4 track", 480, 854, 50, 4, False, 1.0, (1, 2, 4, 8, 16, 32)),
           "sintel": ("configs[2] Sintel 436x1024 r2 optimize", 436, 1024, 50, 2, True, 1.0, (1, 2, 4, 8, 16)),
           "scannet": ("configs[4] ScanNet 480x640 r1 optimize (200 frames)", 480, 640, 200, 1, True, 3.0, (1, 2, 4, 8)),
-          "sintel_track": ("Sintel 436x1024 r2 track", 436, 1024, 50, 2, False, 1.0, (1, 4, 16))}
+          "sintel_track": ("Sintel 436x1024 r2 track", 436, 1024, 50, 2, False, 1.0, (1, 4, 16)),
+          # psfm_synth.REALISTIC: every solve rejects steps -> the sequences leave the batch behind their first window and are run by
+          # psfm_connect, several at a time with shares of the resident block slots
+          "sintel_real": ("configs[2] Sintel 436x1024 r2 optimize, REALISTIC flows", 436, 1024, 50, 2, True, 1.0, (1, 2, 4, 8)),
+          "davis_real": ("DAVIS 480x854 r4 optimize, REALISTIC flows", 480, 854, 50, 4, True, 1.0, (1, 4, 8))}
 which = [a for a in sys.argv[2:]] or ["davis", "sintel", "scannet"]
 out = []
 for key in which:
     label, H, W, T, R, opt, thres, Bs = SHAPES[key]
     NMAX = max(Bs)
-    data = [psfm_synth.synth_sequence_torch(T, H, W, seed=100 + k, sigma=0.05, n_occluders=2, stride2=opt) for k in range(NMAX)]
+    if key.endswith("_real"):
+        data = [psfm_synth.synth_realistic_torch(T, H, W, seed=100 + k, stride2=opt, **psfm_synth.REALISTIC) for k in range(NMAX)]
+    else:
+        data = [psfm_synth.synth_sequence_torch(T, H, W, seed=100 + k, sigma=0.05, n_occluders=2, stride2=opt) for k in range(NMAX)]
     seqs = [(d["flows_f"], d["flows_b"], d.get("flows_f2") if opt else None, d.get("flows_b2") if opt else None) for d in data]
     # one psfm_connect per sequence (the default mode), one after the other
     ctx = _hip.context()
