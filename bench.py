@@ -557,7 +557,7 @@ def secondary_track(ctx, h, w, t, r, seed, label, thres=THRES, n=10):
                        "max_abs_dxy_px": float(np.abs(Rg.xy - Rc.xy).max()) if same else None}}
 
 
-def secondary_batch(h, w, t, r, opt, thres, B, seed0, label, single, n=5):
+def secondary_batch(h, w, t, r, opt, thres, B, seed0, label, single, n=5, pmc_key=None):
     """psfm_connect_batch on B sequences of one of the small BASELINE shapes (different seeds; sequence 0 is the one `single` was
     measured on): ONE launch per frame for the whole batch, one checkpoint per window, one segmented finalize.  Time per sequence
     against `single` (one psfm_connect per sequence), the batched frame launch from HIP events with its roofline, and every
@@ -652,6 +652,11 @@ def secondary_batch(h, w, t, r, opt, thres, B, seed0, label, single, n=5):
                                         "valu_source": "sequence 0's replayed figure (profiles/solver_valu.json) x %d sequences x %d solves / launches" % (B, t - 2)})
     except Exception:      # noqa: BLE001  (the single-sequence figure failed or has no roofline)
         pass
+    # the same launches under rocprofv3 (scripts/profile_round5.sh: PMC passes + kernel-trace durations of this shape and batch size),
+    # replayed with their provenance: measured wave-instructions / HBM bytes per launch instead of the scaled single-sequence figure
+    bp, prov = replayed(os.path.join(ROOT, "profiles", "batch_pmc.json"))
+    if bp and pmc_key and pmc_key in bp:
+        out["frame_launch"]["pmc"] = dict(bp[pmc_key], provenance=prov)
     return out
 
 
@@ -1041,8 +1046,9 @@ def main():
                 torch.cuda.empty_cache()
                 # B sequences per launch on the shapes real data has (psfm_connect_batch)
                 out["secondary_davis_batch"] = extra(secondary_batch, 480, 854, 50, 4, False, THRES, 16, 2, "configs[0] shape (DAVIS snowboard)",
-                                                     out["secondary_davis"])
-                out["secondary_batch"] = extra(secondary_batch, 436, 1024, 50, 2, True, THRES, 16, 2, "configs[2] shape (Sintel alley_1)", out["secondary"])
+                                                     out["secondary_davis"], pmc_key="davis_b16")
+                out["secondary_batch"] = extra(secondary_batch, 436, 1024, 50, 2, True, THRES, 16, 2, "configs[2] shape (Sintel alley_1)", out["secondary"],
+                                               pmc_key="sintel_b16")
                 torch.cuda.empty_cache()
                 out["secondary_scannet_batch"] = extra(secondary_batch, 480, 640, 1000, 1, True, 3.0, 4, 4, "configs[4] shape (ScanNet, dense)",
                                                        out["secondary_scannet"], n=2)

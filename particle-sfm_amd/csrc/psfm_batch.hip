@@ -59,6 +59,10 @@ static psfm_status batch_host_staging(psfm_ctx* own, size_t need)
     return PSFM_OK;
 }
 
+static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* const* flows_f, const float* const* flows_b,
+                             const float* const* flows_f2, const float* const* flows_b2, const int* n_flows, int h, int w,
+                             float thres, int ratio, psfm_track_info* infos, void* stream, bool trim, bool* grid_too_small);
+
 extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, const float* const* flows_f, const float* const* flows_b,
                                           const float* const* flows_f2, const float* const* flows_b2, const int* n_flows, int h, int w,
                                           float thres, int ratio, psfm_track_info* infos, void* stream)
@@ -77,6 +81,24 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             return PSFM_ERR_ARG;
         }
     }
+    // The frame launches cover the lanes a sequence can be expected to use (its grid + 1/8), not its whole lane table (2 x the grid by
+    // default): a block beyond the lanes in use leaves at once, but it still has to be dispatched -- half of the blocks of every launch
+    // (PSFM_BATCH_GRID_TRIM=0: the whole table).  A launch that finds more lanes in use than it covers says so (overflow bit 16) and the
+    // batch is run again with launches that cover the tables.
+    static const bool trim_env = !(getenv("PSFM_BATCH_GRID_TRIM") && atoi(getenv("PSFM_BATCH_GRID_TRIM")) == 0);
+    bool too_small = false;
+    psfm_status rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, trim_env, &too_small);
+    if (rc == PSFM_ERR_CAPACITY && too_small)
+        rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, false, &too_small);
+    return rc;
+}
+
+static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* const* flows_f, const float* const* flows_b,
+                             const float* const* flows_f2, const float* const* flows_b2, const int* n_flows, int h, int w,
+                             float thres, int ratio, psfm_track_info* infos, void* stream, bool trim, bool* grid_too_small)
+{
+    const bool optimize = flows_f2 != nullptr;
+    *grid_too_small = false;
     psfm_ctx* own = ctxs[0];
     PSFM_HIP(hipSetDevice(own->device));
     hipStream_t s = (hipStream_t)stream;
@@ -101,6 +123,7 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
         int tbits = 1;
         while ((1ll << tbits) < (long long)n_max + 2) ++tbits;
         int64_t cap_max = 0;
+        int64_t grid_lanes = 0;      // lanes the frame launches cover (<= cap_max); see below
         for (int i = 0; i < B; ++i) {
             psfm_ctx* c = ctxs[i];
             psfm_shard_abandon(c);
@@ -121,10 +144,13 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             c->n_fused_ok = c->n_fused_redone = c->n_chain = 0;
             c->n_resident = c->n_iter_launches = 0;
             if (D[i].cap > cap_max) cap_max = D[i].cap;
+            if (D[i].G + D[i].G / 8 + 2048 > grid_lanes) grid_lanes = D[i].G + D[i].G / 8 + 2048;
             S[i].hstats.assign((size_t)n_flows[i] + 1, psfm_solve_stats());
             // a context told to use the launch chain for every solve has nothing to gain from the batch: it runs alone
             if (optimize && c->solver_mode == 1 && n_flows[i] >= 2) S[i].dropped = true;
         }
+        if (trim && getenv("PSFM_BATCH_GRID_LANES")) grid_lanes = atoll(getenv("PSFM_BATCH_GRID_LANES"));      // (tests: launches that cover too little)
+        if (!trim || grid_lanes > cap_max || grid_lanes < 256) grid_lanes = cap_max;
         // ---- flow_check of every stack (utils.py:94-105) ----
         // Bandwidth-bound work beside a latency-bound frame loop: the maps are produced on the owner's side stream in chunks of
         // frame pairs -- ONE launch per chunk for all sequences (psfm_flow_check_x2v_batch_kernel) -- and the frame loop only waits
@@ -218,6 +244,9 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                 const float* f2 = n_flows[i] > 1 ? flows_f2[i] : flows_f[i];      // (a one-pair sequence has no stride-2 stack: never read)
                 if ((st = psfm_batch_fill_seq_opt(c, D[i], flows_f[i], c->occ_own.as<uint8_t>(), P, f2, c->occ2_own.as<uint8_t>(),
                                                   htabo + row_opt * (size_t)i, s)) != PSFM_OK) return st;
+                // a run whose launches covered too few lanes has left the fused solve's tickets mid-count (blocks they were waiting
+                // for never existed): the run that repeats it starts them from zero
+                if (!trim && c->sol_fused.p) PSFM_HIP(hipMemsetAsync(c->sol_fused.p, 0, 4096 * sizeof(unsigned), s));
             }
         }
         PSFM_HIP(hipMemcpyAsync(dtab, htab, tab_bytes + tabo_bytes, hipMemcpyHostToDevice, s));
@@ -229,12 +258,12 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             // ---- track.py:31-47: one launch per frame index for the whole batch ----
             for (int f = 0; f < n_max; ++f) {
                 if ((st = fc_need(f, false)) != PSFM_OK) return st;
-                if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, cap_max, f, false, s)) != PSFM_OK) return st;
+                if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, grid_lanes, f, false, s)) != PSFM_OK) return st;
             }
         } else {
             // ---- track_optimize.py:31-50: frame 0 is a plain chain step; from frame 1 on device-paced launches ----
             if ((st = fc_need(0, false)) != PSFM_OK) return st;
-            if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, cap_max, 0, true, s)) != PSFM_OK) return st;
+            if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, grid_lanes, 0, true, s)) != PSFM_OK) return st;
             int launch_id = 0;
             int v[PSFM_BATCH_MAX][4];
             for (int i = 0; i < B; ++i) {
@@ -268,7 +297,7 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                     if ((st = fc_need(f_hi, false)) != PSFM_OK) return st;
                     if ((st = fc_need(f_hi - 1, true)) != PSFM_OK) return st;
                 }
-                if ((st = psfm_launch_seq_batch(own, dtabo, B, ratio, cap_max, n_launch, launch_id, s)) != PSFM_OK) return st;
+                if ((st = psfm_launch_seq_batch(own, dtabo, B, ratio, grid_lanes, n_launch, launch_id, s)) != PSFM_OK) return st;
                 launch_id += n_launch;
                 // ---- ONE checkpoint for all sequences ----
                 int lo[PSFM_BATCH_MAX];
@@ -283,6 +312,11 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                     const PsfmCounters hc = *(const PsfmCounters*)(hpack + pack_row * (size_t)i);
                     const psfm_solve_stats* hw = (const psfm_solve_stats*)(hpack + pack_row * (size_t)i + sizeof(PsfmCounters));
                     const int n_i = n_flows[i];
+                    if (hc.overflow & 16) {      // a launch covered fewer lanes than the sequence had in use: once more, with launches that cover the tables
+                        *grid_too_small = true;
+                        psfm_set_error("psfm_connect_batch: sequence %d uses more lanes (%d) than the trimmed launches cover (%lld)", i, hc.n_lanes, (long long)grid_lanes);
+                        return PSFM_ERR_CAPACITY;
+                    }
                     for (int k = 0; k < win_max && lo[i] + k <= n_i; ++k) S[i].hstats[(size_t)(lo[i] + k)] = hw[k];
                     const int stalled = hc.stall ? hc.stall - 1 : -1;
                     int last_ok = (hc.pc_frame < n_i ? hc.pc_frame : n_i) - 1;     // frames below the device's program counter are complete
@@ -358,6 +392,8 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
             own->prof.begin(PSFM_PROF_FINALIZE, s);
             st = psfm_finalize_batch(own, kc.data(), kd.data(), (int)kc.size(), s);
             own->prof.end(s);
+            if (st == PSFM_ERR_CAPACITY)
+                for (psfm_ctx* c : kc) if (((PsfmCounters*)c->host_pinned)->overflow & 16) *grid_too_small = true;
             if (st != PSFM_OK) return st;
         }
         PSFM_HIP(hipStreamSynchronize(s));

@@ -73,7 +73,8 @@ struct PsfmBuf {
 struct PsfmCounters {
     int n_lanes;      // lanes ever handed out (high-water mark); chain_step scans [0, n_lanes)
     int overflow;     // bit0: lane table / free stack full, bit1: trajectory table full, bit2: more tracks than resident
-                      // lanes (persistent loop), bit3: barrier spin limit hit (persistent loop)
+                      // lanes (persistent loop), bit3: barrier spin limit hit (persistent loop), bit4: a batched frame launch
+                      // covered fewer lanes than the sequence had in use (psfm_batch.hip runs the batch again, untrimmed)
     int stall;        // != 0: solve of frame stall-1 ran out of unrolled iterations; later launches are no-ops
     int abort;        // persistent frame loop: a block gave up (spin limit); every block leaves at its next barrier
     int spill_cnt;    // persistent frame loop: records written to the shared tail behind the private segments

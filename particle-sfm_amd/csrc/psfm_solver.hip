@@ -1384,6 +1384,8 @@ __global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 void psfm_seq_batch_kernel(const PsfmBatchSeqOpt* __restrict__ seqs, int launch_id)
 {
     const PsfmBatchSeqOpt& q = seqs[blockIdx.y];
+    // (the launch may cover fewer lanes than the table has: say so if it is not enough -- psfm_batch.hip runs the batch again then)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && q.a.ctr->n_lanes > (int)(gridDim.x * PC_BLOCK)) atomicOr(&q.a.ctr->overflow, 16);
     psfm_seq_body<R>(q.a, q.P, q.st, q.occ2_stride, q.n_flows, launch_id);
 }
 

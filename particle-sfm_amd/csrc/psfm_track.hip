@@ -456,6 +456,8 @@ __global__ __launch_bounds__(PSFM_CHAIN_BLOCK) PSFM_CHAIN_WAVES void psfm_chain_
     const PsfmBatchSeq& q = seqs[blockIdx.y];
     if (frame >= q.n_flows) return;
     PsfmChainArgs a = q.a;
+    // (the launch may cover fewer lanes than the table has -- psfm_batch.hip: what the sequence can be expected to use --: say so if it is not enough)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.ctr->n_lanes > (int)(gridDim.x * PSFM_CHAIN_TILE)) atomicOr(&a.ctr->overflow, 16);
     psfm_chain_args_rebase(a, q.st, frame);
     PsfmChainOut o;
     (void)psfm_chain_step_body<R, OPT, false>(a, o);

@@ -148,6 +148,19 @@ def test_batch_of_one_and_consumers_on_a_member(pt):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
+@pytest.mark.parametrize("opt", [False, True])
+def test_batch_launches_that_cover_too_few_lanes_are_run_again(pt, monkeypatch, opt):
+    """The batched frame launches cover the lanes a sequence can be expected to use (grid + 1/8), not its whole lane table; a launch
+    that finds more lanes in use than it covers raises overflow bit 16 and the batch runs again with launches that cover the tables.
+    PSFM_BATCH_GRID_LANES=512 makes every launch too small for these grids (6000 points): same results as ever."""
+    H, W, r = 120, 200, 2
+    data = [psfm_synth.synth_sequence(7 + k, H, W, seed=111 + k, sigma=0.05, n_occluders=1 - k % 2, stride2=opt) for k in range(3)]
+    oracles = [_oracle(d, 1.0, r, opt) for d in data]
+    monkeypatch.setenv("PSFM_BATCH_GRID_LANES", "512")
+    ctxs, infos = pt.trajectory.run_connect_batch([_dev(pt, d, opt) for d in data], 1.0, r)
+    _check(pt, ctxs, infos, oracles, opt)
+
+
 def test_batch_rejects_bad_arguments(pt):
     import ctypes
     H, W = 40, 56
