@@ -120,30 +120,51 @@ def dump(fp, ts):
     R = len(rec)
     step = 1 << 18
     ids = np.asarray(ids, np.int64); birth = np.asarray(birth, np.int64); length = np.asarray(length, np.int64); off = np.asarray(off, np.int64)
-    chunks, failed = [], []
+    # ... handed over through a BOUNDED queue (a few chunks of 256 k records = 17 MB each in flight, whatever the number of
+    # trajectories) and written as they arrive once the point array is out; a writer that fails tells the builder to stop.
+    import queue
+    todo, failed, cancel = queue.Queue(maxsize=3), [], threading.Event()
 
     def build_records():
         try:
             for lo in range(0, n, step):
+                if cancel.is_set():
+                    return
                 hi = min(n, lo + step)
                 buf = np.tile(np.frombuffer(rec, np.uint8), hi - lo).reshape(hi - lo, R)
                 fields = {"id": ids[lo:hi], "b": birth[lo:hi], "bn": birth[lo:hi] + length[lo:hi], "s": off[lo:hi], "e": off[lo + 1:hi + 1],
                           "n": length[lo:hi]}
                 for name, v in fields.items():
                     buf[:, at[name]:at[name] + 4] = v.astype("<i4").view(np.uint8).reshape(-1, 4)
-                chunks.append(buf)
+                while not cancel.is_set():
+                    try:
+                        todo.put(buf, timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
         except BaseException as e:      # noqa: BLE001  (handed to the writing thread: a short record list must not reach the file)
             failed.append(e)
+        finally:
+            while not cancel.is_set():   # the end marker (behind a failure too: the writer must not wait for ever)
+                try:
+                    todo.put(None, timeout=0.1)
+                    break
+                except queue.Full:
+                    pass
     builder = threading.Thread(target=build_records)
     builder.start()
     try:
         xy_data, xy, rec_start = _write_front(fp, prefix, xy)
+        while True:
+            buf = todo.get()
+            if buf is None:
+                break
+            fp.write(memoryview(buf).cast("B"))
     finally:
+        cancel.set()
         builder.join()
     if failed:
         raise failed[0]
-    for buf in chunks:
-        fp.write(memoryview(buf).cast("B"))
     fp.write(b"u")
     fp.write(suffix)
     # footer: where the raw point bytes are

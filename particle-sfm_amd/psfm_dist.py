@@ -366,7 +366,9 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
         # enqueued behind a stall are no-ops, but each of them still costs its launches and exchanges -- on flows whose every solve
         # rejects steps a longer window would run each frame several times), doubled after every window without a stall, up to 32.
         fixed_window = int(os.environ.get("PSFM_SHARD_CHECK_EVERY", "0"))
-        engine.check_every = fixed_window or (max(16, n_flows) if world == 1 else 4)
+        # (one rank: at most 128 frames per window -- the engine keeps the tensors of every enqueued frame alive for a redo and FrameWindow
+        # keeps the frames since the last confirmed one: O(window), not O(sequence), for 1000-frame inputs)
+        engine.check_every = fixed_window or (min(max(16, n_flows), 128) if world == 1 else 4)
     confirmed = 0                  # frames below this are final
     since = 0                      # frames enqueued since the last checkpoint
     t = 0

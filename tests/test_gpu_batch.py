@@ -161,6 +161,20 @@ def test_batch_launches_that_cover_too_few_lanes_are_run_again(pt, monkeypatch, 
     _check(pt, ctxs, infos, oracles, opt)
 
 
+def test_batch_grows_its_tables_when_a_sequence_needs_more(pt):
+    """PSFM_ERR_CAPACITY from one sequence of the batch (here: trajectory-record tables sized 1 x the grid for sequences that kill and
+    respawn half of their tracks every frame): the mirror grows the tables of all contexts and runs the batch again."""
+    H, W, r = 150, 210, 1
+    data = [psfm_synth.synth_sequence(13, H, W, seed=121 + k, sigma=0.9, n_occluders=3, stride2=False) for k in range(3)]
+    oracles = [_oracle(d, 1.0, r, False) for d in data]
+    assert oracles[0].n_traj > 2.5 * H * W + 70000        # (more records than tables of 1.5 x + 1 x the grid + their head-room hold)
+    ctxs = pt.hip.batch_contexts(3)
+    ctxs[0]._capacity = {("batch", H, W, r, False): (1.0, 1.0)}
+    ctxs, infos = pt.trajectory.run_connect_batch([_dev(pt, d, False) for d in data], 1.0, r)
+    _check(pt, ctxs, infos, oracles, False)
+    assert ctxs[0]._capacity[("batch", H, W, r, False)][1] > 1.0
+
+
 def test_batch_rejects_bad_arguments(pt):
     import ctypes
     H, W = 40, 56
