@@ -51,6 +51,10 @@ def test_no_cpu_fallback():
         flow_check(f, f, 1.0)
     with pytest.raises(RuntimeError):
         track(f, [np.zeros((8, 8), bool)], 2)
+    from point_trajectory.trajectory import run_connect_batch
+    z = torch.zeros((3, 8, 8, 2))
+    with pytest.raises(RuntimeError):
+        run_connect_batch([(z, z, None, None), (z, z, None, None)], 1.0, 2)       # (a batch of sequences: no GPU, no result)
     # the product package never imports the oracle
     pkg = os.path.join(ROOT, "particle-sfm_amd")
     for dp, _, files in os.walk(pkg):

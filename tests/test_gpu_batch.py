@@ -175,6 +175,39 @@ def test_batch_grows_its_tables_when_a_sequence_needs_more(pt):
     assert ctxs[0]._capacity[("batch", H, W, r, False)][1] > 1.0
 
 
+@pytest.mark.parametrize("opt", [False, True])
+def test_connect_sequences_in_batches_writes_the_same_files(pt, tmp_path, opt):
+    """point_trajectory.batch.connect_sequences(batch=N): the reference driver's loop over a directory of sequences
+    (run_particlesfm.py:168-176) disk to disk -- .flo files in, one track.npy per sequence out -- through psfm_connect_batch on two
+    worker threads: every file holds what main_connect_point_trajectories writes for that sequence alone."""
+    import os
+    from point_trajectory.batch import connect_sequences
+    from point_trajectory.main_connect_point_trajectories import main_connect_point_trajectories
+    from point_trajectory.trajectory import load_track_npy
+    from point_trajectory.utils import write_flo
+    H, W, r = 60, 80, 2
+    fdirs, tdirs, sdirs = [], [], []
+    for k in range(5):
+        d = psfm_synth.synth_sequence(6 + k % 3, H, W, seed=131 + k, sigma=0.1, n_occluders=1, stride2=opt)
+        fd = tmp_path / ("seq%d" % k) / "flows"
+        for name, key in (("flow_f", "flows_f"), ("flow_b", "flows_b"), ("flow_f2", "flows_f2"), ("flow_b2", "flows_b2")):
+            if key not in d:
+                continue
+            os.makedirs(fd / name)
+            for i, a in enumerate(d[key]):
+                write_flo(str(fd / name / ("%05d.flo" % i)), a)
+        fdirs.append(str(fd)); tdirs.append(str(tmp_path / ("seq%d" % k) / "traj")); sdirs.append(str(tmp_path / ("seq%d" % k) / "single"))
+    connect_sequences(fdirs, tdirs, sample_ratio=r, skip_path_consistency=not opt, concurrency=2, rank=0, world=1, layout="reference", batch=3)
+    for fd, td, sd in zip(fdirs, tdirs, sdirs):
+        main_connect_point_trajectories(fd, sd, sample_ratio=r, skip_path_consistency=not opt)
+        a, b = load_track_npy(os.path.join(td, "track.npy")), load_track_npy(os.path.join(sd, "track.npy"))
+        for x, y in zip(a._to_csr()[:4], b._to_csr()[:4]):
+            if np.asarray(x).dtype == np.float64 and opt:
+                assert float(np.abs(np.asarray(x) - np.asarray(y)).max()) <= 1e-9
+            else:
+                assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
 def test_batch_rejects_bad_arguments(pt):
     import ctypes
     H, W = 40, 56
