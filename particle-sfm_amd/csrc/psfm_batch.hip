@@ -87,9 +87,14 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
     // batch is run again with launches that cover the tables.
     static const bool trim_env = !(getenv("PSFM_BATCH_GRID_TRIM") && atoi(getenv("PSFM_BATCH_GRID_TRIM")) == 0);
     bool too_small = false;
-    psfm_status rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, trim_env, &too_small);
-    if (rc == PSFM_ERR_CAPACITY && too_small)
+    psfm_ctx* own0 = ctxs[0];
+    const int64_t shape_key = ((int64_t)h << 40) ^ ((int64_t)w << 16) ^ (int64_t)ratio ^ (flows_f2 ? (1ll << 62) : 0);
+    const bool trim = trim_env && own0->batch_notrim_shape != shape_key;      // (a shape whose sequences outgrew the trimmed launches once: not again)
+    psfm_status rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, trim, &too_small);
+    if (rc == PSFM_ERR_CAPACITY && too_small) {
+        own0->batch_notrim_shape = shape_key;
         rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, false, &too_small);
+    }
     return rc;
 }
 
@@ -373,6 +378,18 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
                     if (c->solve_mode == 1 && c->solver_mode != 2 && S[i].f < n_i) { S[i].dropped = true; S[i].resync = true; }
                 }
                 if (!progress) { psfm_set_error("psfm_connect_batch: no sequence advanced in a window of launches"); return PSFM_ERR_SOLVER; }
+                if (trim) {
+                    // the next window's launches cover the lanes the sequences have in use NOW plus head-room for 18 frames of growth
+                    // (on a dense grid the high-water mark creeps up all through a long sequence: a death is a birth one frame later,
+                    // and not always on a lane of the same block)
+                    int64_t in_use = 0;
+                    for (int i = 0; i < B; ++i) {
+                        const PsfmCounters* hc = (const PsfmCounters*)(hpack + pack_row * (size_t)i);
+                        if (!S[i].dropped && hc->n_lanes > in_use) in_use = hc->n_lanes;
+                    }
+                    const int64_t want = in_use + in_use / 16 + 2048;
+                    if (want > grid_lanes) grid_lanes = want < cap_max ? want : cap_max;
+                }
             }
             if ((st = psfm_launch_flush_batch(dtabo, B, cap_max, s)) != PSFM_OK) return st;
         }

@@ -178,6 +178,7 @@ struct psfm_ctx {
     size_t host_batch_bytes = 0;
     void* host_batch2 = nullptr;
     size_t host_batch2_bytes = 0;
+    int64_t batch_notrim_shape = 0;      // (h, w, sample_ratio, mode) whose sequences once outgrew launches trimmed to the lanes in use
     PsfmBuf win_ws;                      // psfm_window_sample / psfm_result_filter workspace
     PsfmBuf flt_ids, flt_birth, flt_len, flt_off, flt_xy;   // psfm_result_filter: the saved set (length >= traj_min_len), CSR
     int64_t flt_n_traj = 0, flt_n_points = 0;
