@@ -5,6 +5,7 @@
  * This is the drop-in boundary.  Every entry point replaces one interface of the
  * reference (paths relative to the reference root, bytedance/particle-sfm):
  *
+ *   psfm_load_flo_stack     point_trajectory/utils.py:26-56         load_flows() / read_flo()
  *   psfm_flow_check         point_trajectory/utils.py:94-105        flow_check()
  *   psfm_grid_sample        point_trajectory/trajectory.py:25-37    grid_sample()
  *   psfm_optimize_location  point_trajectory/optimize/src/trajectory_optimize.cpp:30-96
@@ -145,6 +146,13 @@ psfm_status psfm_solver_launches(psfm_ctx* ctx, int64_t* resident, int64_t* give
  * pipeline never consumes it).  Bit-exact with the reference's torch-CPU arithmetic. */
 psfm_status psfm_flow_check(psfm_ctx* ctx, const float* flows_f, const float* flows_b, int n_pairs, int h,
                             int w, float thres, uint8_t* occ_out, float* err_out, void* stream);
+
+/* utils.py:26-56 (load_flows / read_flo) for a whole stack, straight into HBM: the n Middlebury .flo files `paths_host` (12-byte header
+ * {f32 202021.25, i32 w, i32 h} + h*w interleaved (u,v) f32 -- the layout the kernels read), all of frame size w x h, into
+ * dst (n,H,W,2) f32 on the device.  n_threads reader threads -> a ring of pinned staging buffers owned by the context -> asynchronous
+ * H2D copies; returns when the last copy has completed (`stream` is only used to order the copies behind what the caller enqueued).
+ * A missing / foreign / truncated file or a frame of another size is PSFM_ERR_ARG with the file named in psfm_last_error(). */
+psfm_status psfm_load_flo_stack(psfm_ctx* ctx, const char* const* paths_host, int n, int h, int w, float* dst, int n_threads, void* stream);
 
 /* trajectory.py:25-37 on an (H,W,C) f32 map, C in {1,2}; xy: (n,2) f64; out: (n,C) f32. */
 psfm_status psfm_grid_sample(psfm_ctx* ctx, const float* map_hwc, int c, int h, int w, const double* xy,

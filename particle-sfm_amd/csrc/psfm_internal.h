@@ -187,6 +187,10 @@ struct psfm_ctx {
     int64_t mt_n_kp = 0, mt_n_m = 0, mt_n_pairs = 0;
     int mt_n_img = 0;
     hipStream_t side_stream = nullptr;   // flow_check of psfm_connect runs here, ahead of the frame loop
+    hipStream_t copy_stream = nullptr;   // psfm_load_flo_stack: H2D copies out of the pinned ring
+    std::vector<void*> ingest_slots;     // ... the ring (pinned, ingest_slot_bytes each) and the event behind the last copy out of every slot
+    std::vector<hipEvent_t> ingest_events;
+    size_t ingest_slot_bytes = 0;
     hipStream_t redo_stream = nullptr;   // psfm_connect_batch: a sequence that left the batch runs here, beside the others that did
     std::vector<psfm_solve_stats> solve_stats;
     PsfmProfiler prof;

@@ -22,7 +22,7 @@ EXPORTS = [
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
-    "psfm_shard_solve_control_chain_async", "psfm_shard_solve_poll", "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity",
+    "psfm_shard_solve_control_chain_async", "psfm_shard_solve_poll", "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity", "psfm_load_flo_stack",
 ]
 
 
@@ -74,6 +74,7 @@ def lib():
     L.psfm_ctx_create.argtypes = [i32, ctypes.POINTER(vp)]
     L.psfm_ctx_destroy.argtypes = [vp]
     L.psfm_ctx_set_capacity.argtypes = [vp, f64, f64]
+    L.psfm_load_flo_stack.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, i32, i32, vp, i32, vp]
     L.psfm_flow_check.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp, vp]
     L.psfm_grid_sample.argtypes = [vp, vp, i32, i32, i32, vp, i64, vp, vp]
     L.psfm_optimize_location.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, ctypes.POINTER(SolveStats), vp]

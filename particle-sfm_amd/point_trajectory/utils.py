@@ -67,8 +67,11 @@ def load_flows_device(dir, device=None, n_staging=16, n_readers=8, _names=None, 
     """`load_flows` (utils.py:26-32) straight into HBM: the .flo files are read by a few reader threads into pinned
     host buffers (owned by the context, reused across calls) and copied to their slot of one (n,H,W,2) device tensor with
     asynchronous H2D copies on a side stream, so disk / page-cache reads and PCIe transfers overlap (at
-    cfg 4 the stacks are 26.5 GB, ingest bounds the end-to-end time once the kernels are fast).
+    cfg 4 the stacks are 26.5 GB, ingest bounds the end-to-end time once the kernels are fast).  The pipeline runs inside the
+    library (psfm_load_flo_stack: no interpreter work per file -- what a stack of SMALL frames is made of); PSFM_FLO_NATIVE=0
+    keeps the Python implementation of the same pipeline below (A/B runs).  A missing / foreign / truncated file raises.
     Returns a float32 device tensor (empty (0,0,0,2) if no files)."""
+    import ctypes
     import torch
     from concurrent.futures import ThreadPoolExecutor
     n_staging = int(os.environ.get("PSFM_FLO_STAGING", n_staging))      # (measurement knobs)
@@ -86,6 +89,11 @@ def load_flows_device(dir, device=None, n_staging=16, n_readers=8, _names=None, 
     with open(names[0], 'rb') as f:
         h, w = _flo_shape(f, names[0])
     out = torch.empty((len(names), h, w, 2), dtype=torch.float32, device=dev)
+    if os.environ.get("PSFM_FLO_NATIVE", "1") != "0":
+        arr = (ctypes.c_char_p * len(names))(*[os.fsencode(nm) for nm in names])
+        _hip.check(_hip.lib().psfm_load_flo_stack(ctx.handle, arr, len(names), h, w, _hip.ptr(out), int(n_readers),
+                                                  _hip.current_stream_ptr(ctx.device)))
+        return out
     n_staging = max(2, min(int(n_staging), len(names)))
     key = (h, w, n_staging)
     cache = getattr(ctx, "_flo_staging", None)

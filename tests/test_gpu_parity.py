@@ -241,6 +241,51 @@ def test_main_connect_end_to_end(pt, tmp_path):
         main_connect_point_trajectories(str(fd), str(out), sample_ratio=r, skip_path_consistency=skip, skip_exists=True)
 
 
+def test_flo_stack_ingest(pt, tmp_path, monkeypatch):
+    """utils.py:26-56 for a whole stack straight into HBM (psfm_load_flo_stack: reader threads -> pinned ring -> async H2D): the
+    bytes of the files, for more files than ring slots and for one file; the Python pipeline of the same design (PSFM_FLO_NATIVE=0)
+    gives the same tensor; a truncated file, a foreign file and a frame of another size are refused with the file named."""
+    from point_trajectory.utils import write_flo, load_flows_device
+    rng = np.random.default_rng(7)
+    H, W = 37, 53
+    frames = [rng.standard_normal((H, W, 2)).astype(np.float32) for _ in range(41)]
+    d = tmp_path / "stack"
+    d.mkdir()
+    for i, f in enumerate(frames):
+        write_flo(str(d / ("%05d.flo" % i)), f)
+    for readers in (1, 3, 8):
+        got = load_flows_device(str(d), n_readers=readers)
+        assert got.shape == (41, H, W, 2) and np.array_equal(got.cpu().numpy(), np.stack(frames))
+    monkeypatch.setenv("PSFM_FLO_NATIVE", "0")
+    assert np.array_equal(load_flows_device(str(d)).cpu().numpy(), np.stack(frames))
+    monkeypatch.delenv("PSFM_FLO_NATIVE")
+    one = tmp_path / "one"
+    one.mkdir()
+    write_flo(str(one / "00000.flo"), frames[0])
+    assert np.array_equal(load_flows_device(str(one)).cpu().numpy(), np.stack(frames[:1]))
+    assert load_flows_device(str(tmp_path / "nothing")).shape == (0, 0, 0, 2)
+    bad = tmp_path / "bad"
+    for kind in ("truncated", "foreign", "size"):
+        if bad.exists():
+            for q in bad.iterdir():
+                q.unlink()
+        else:
+            bad.mkdir()
+        for i in range(5):
+            write_flo(str(bad / ("%05d.flo" % i)), frames[i])
+        victim = bad / "00003.flo"
+        raw = victim.read_bytes()
+        if kind == "truncated":
+            victim.write_bytes(raw[:len(raw) // 2])
+        elif kind == "foreign":
+            victim.write_bytes(b"NOPE" + raw[4:])          # (the real tag reads "PIEH")
+        else:
+            write_flo(str(victim), rng.standard_normal((H + 1, W, 2)).astype(np.float32))
+        with pytest.raises(RuntimeError) as ei:
+            load_flows_device(str(bad))
+        assert "00003.flo" in str(ei.value)
+
+
 @pytest.mark.parametrize("H,W,T,r,seed,thres", [
     (41, 59, 6, 5, 91, 1.0),      # generic-ratio kernel instantiation (R = 0), H*W odd -> scalar flow_check kernel
     (30, 44, 5, 6, 92, 3.0),      # ratio 6, README's ScanNet threshold
