@@ -35,6 +35,17 @@ VALU_PEAK_GWIPS = 256 * 4 * 2.4 / 4.0
 REFERENCE_SOLVER_THREADS = 8     # solver_options.num_threads at trajectory_optimize.cpp:79 (what BASELINE.md specifies)
 
 
+def quiet_gc():
+    """Python's cyclic collector out of a timed region that drives many frames from Python: a full collection of a process that has
+    torch imported walks ~10^6 objects -- 30-35 ms on the GPU box's host, a whole 1080p sequence -- and lands wherever the allocation
+    counts put it (round 5 found it inside the first timed `single_sequence` run: profiles/r05/r05_v_gc.txt).  Collect now and move
+    everything alive out of the collector's reach; later collections walk only what the run allocates.  Skips no work of the measured
+    path (INTEGRATION.md section 4 recommends the same to Python hosts)."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def source_sha16():
     """Hash of the sources libpsfm_hip.so is built from (particle-sfm_amd/build.py::source_hash): what the PMC figures under
     profiles/ are stamped with.  Counters cannot be collected inside a timed run, so those figures are REPLAYED from the file --
@@ -248,6 +259,7 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2, flows_dist=None, l
 
     part = once()
     sync()
+    quiet_gc()
     t0 = time.perf_counter()
     for _ in range(reps):
         part = once()
@@ -263,6 +275,24 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2, flows_dist=None, l
            "ms_per_sequence": 1e3 * dt, "trajectory_points_per_s": pts / dt, "points": int(pts), "trajectories": int(part["n_traj"]),
            "solves": part["n_solves"], "trust_region_iterations": part["solver_iterations"],
            "solver_counters": dict(eng.counters), "local_trajectories_rank0": int(part["ids"].numel())}
+    lc = eng.ctx.solver_counters()
+    out["solver_launches"] = {k: lc[k] for k in ("resident_launches", "resident_giveups", "iteration_launches")}
+    if world == 1:
+        # one rank exchanges nothing: windows whose solves reject steps take the one-GPU call's forms (psfm_shard_solve_local: resident
+        # solves).  What several ranks pay for the same solves -- export -> exchange -> control per trust-region iteration, rounds
+        # enqueued ahead -- is this engine with PSFM_SHARD_LOCAL=0, timed beside it
+        out["rejecting_solves"] = "one rank: psfm_shard_solve_local / _redo_local (the one-GPU call's resident solves)"
+        if flows_dist is not None:
+            os.environ["PSFM_SHARD_LOCAL"] = "0"
+            try:
+                once()
+                sync()
+                t0 = time.perf_counter()
+                once()
+                sync()
+                out["ms_per_sequence_exchange_form"] = 1e3 * (time.perf_counter() - t0)
+            finally:
+                del os.environ["PSFM_SHARD_LOCAL"]
     out["flow_stacks_per_rank_GB"] = sum(int(v.numel()) * 4 for v in d.values()) / 1e9
     out["flow_ownership"] = "frame-pair slices + per-frame broadcast (psfm_dist.FrameWindow)" if world > 1 else "whole sequence (one rank)"
     if rank == 0 and world == 1:   # the one-GPU product call on the same tensors: time and counts
@@ -809,6 +839,9 @@ def main():
     from point_trajectory import _hip
     from point_trajectory.utils import flow_check_device
     from point_trajectory.trajectory import run_connect, run_track
+    import point_trajectory.shard, point_trajectory.batch, psfm_dist      # noqa: E401,F401  (everything imported before the freeze)
+
+    quiet_gc()
 
     n_frames = args.frames
     n_flows = n_frames - 1

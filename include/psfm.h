@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PSFM_VERSION 140   /* round 5: psfm_connect_batch */
+#define PSFM_VERSION 141   /* round 5: psfm_connect_batch */
 
 typedef enum psfm_status {
     PSFM_OK = 0,
@@ -301,6 +301,18 @@ psfm_status psfm_shard_window_state(psfm_ctx* ctx, int f_lo, int f_hi, psfm_solv
  * ahead and asks once per batch with psfm_shard_solve_poll (synchronises).  Rounds behind the one that ended the solve are no-ops. */
 psfm_status psfm_shard_solve_control_chain_async(psfm_ctx* ctx, int frame, int kind, const double* totals, void* stream);
 psfm_status psfm_shard_solve_poll(psfm_ctx* ctx, int32_t* done_host, psfm_solve_stats* stats_host, void* stream);
+/* A shard that is the WHOLE sequence (g0 = 0, g1 = every grid point: ONE rank, the windowed engine for one long sequence on one GPU;
+ * PSFM_ERR_ARG for a band): its solves need no exchange, so solves whose steps get rejected run like psfm_connect's
+ * (track_optimize.py:49-50 -> trajectory_optimize.cpp:74-82) instead of export -> exchange -> control once per trust-region
+ * iteration.  psfm_shard_solve_local ENQUEUES the solve of `frame` behind psfm_shard_step(frame): the resident solve -- ONE launch per
+ * solve, inside the context's resident budget (psfm_ctx_set_resident_budget; without one: `unroll` launches of one iteration each);
+ * a solve that is not done behind its launches raises the device-side stall flag (psfm_shard_window_state).
+ * psfm_shard_solve_redo_local redoes a stalled solve to termination and writes it back (synchronises; chain_stalled: the solve had
+ * been enqueued by psfm_shard_solve_local, not by a fused export).  Same sums in the same order as the exchange form: same positions. */
+psfm_status psfm_shard_solve_local(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02, const uint8_t* occ02,
+                                   int frame, int unroll, void* stream);
+psfm_status psfm_shard_solve_redo_local(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02,
+                                        const uint8_t* occ02, int frame, int chain_stalled, psfm_solve_stats* stats_host, void* stream);
 /* the stall flag as of the last control step the device has completed, without synchronising (-1: none) */
 psfm_status psfm_shard_peek_stall(psfm_ctx* ctx, int32_t* stalled_frame);
 psfm_status psfm_shard_solve_restore(psfm_ctx* ctx, int frame, void* stream);

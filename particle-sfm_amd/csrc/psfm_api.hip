@@ -344,7 +344,9 @@ psfm_status psfm_track_dims(psfm_ctx* c, int n_flows, int h, int w, int ratio, i
     // records are spread over PSFM_NSHARD slices by block index: give every slice head-room
     // trajectory records: traj_factor x G, but at least G x n_flows / 8 (one death in eight per frame and grid point)
     const double tf = c->traj_factor > (double)n_flows / 8.0 ? c->traj_factor : (double)n_flows / 8.0;
-    d.shard_cap = (int)(((int64_t)(tf * (double)Gown) + d.cap) / PSFM_NSHARD) + 1024;
+    // (a slice is filled by the blocks whose index it is modulo PSFM_NSHARD: a grid of fewer than PSFM_NSHARD blocks uses that many
+    // slices only -- round 5: a 736-point grid put 9 865 records into three slices sized for a 64th of them each)
+    d.shard_cap = (int)(((int64_t)(tf * (double)Gown) + d.cap) / d.nsh) + 1024;
     d.traj_cap = (int64_t)d.shard_cap * PSFM_NSHARD;
     if (d.cap > 0x7fffffff / 2 || d.traj_cap > 0x7fffffff / 2) { psfm_set_error("psfm_track: grid too large"); return PSFM_ERR_ARG; }
     d.shift_b = 1; while ((1ll << d.shift_b) < d.G) ++d.shift_b;

@@ -69,6 +69,11 @@ extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, 
     delete c->shard_dims;
     c->shard_dims = new PsfmTrackDims(d);
     c->shard_optimize = optimize != 0;
+    // (psfm_shard_solve_local / _redo_local: a resident launch only inside a budget -- the calls of a sharded run come and go under
+    // the shared gate, nothing holds the device for the sequence)
+    c->pc_persist_ok = c->resident_budget > 0;
+    c->pc_giveups = 0;
+    c->n_resident = c->n_iter_launches = 0;
     return psfm_launch_track_init(c, d, (hipStream_t)stream);
 }
 
@@ -169,6 +174,56 @@ extern "C" psfm_status psfm_shard_solve_poll(psfm_ctx* c, int32_t* done_host, ps
     psfm_status st = psfm_solve_state(c, &done, &stall, &ss, (hipStream_t)stream);
     if (st != PSFM_OK) return st;
     if (done_host) *done_host = done;
+    if (stats_host) *stats_host = ss;
+    return PSFM_OK;
+}
+
+// ---- a shard that is the WHOLE sequence (g0 = 0, g1 = G: one rank -- the windowed engine used for one long sequence on one GPU).
+// Nothing of its solves has to be exchanged, so a solve whose steps get rejected does not have to go round export -> exchange ->
+// control once per trust-region iteration: it runs like the one-GPU call's -- the resident solve (one launch per solve, the context's
+// resident budget permitting: psfm_ctx_set_resident_budget) or the launch chain with its own reduction, and the same write-back.  The
+// sums are added in the same order either way (psfm_pc_resident.h: pc_tree_totals), so the positions are the ones the exchange
+// form gives.  Refused for a band of the grid (PSFM_ERR_ARG): a band's totals are not the sequence's.
+static bool shard_is_whole(const PsfmTrackDims& d) { return d.g0 == 0 && d.Gband == d.G; }
+
+// ENQUEUES the solve of `frame` (behind psfm_shard_step(frame)) -- what psfm_connect does for a window whose solves reject steps; a
+// solve that is not done behind its launches raises the device-side stall flag like a fused one (psfm_shard_window_state reports it;
+// it does not reach psfm_shard_peek_stall, which follows the control steps of fused solves only)
+extern "C" psfm_status psfm_shard_solve_local(psfm_ctx* c, const float* flow01, const float* flow12, const float* flow02,
+                                              const uint8_t* occ02, int frame, int unroll, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    const PsfmTrackDims& d = *c->shard_dims;
+    if (!shard_is_whole(d) || !c->shard_optimize || !flow01 || !flow12 || !flow02 || !occ02 || frame < 1 || frame >= d.n_flows) {
+        psfm_set_error("psfm_shard_solve_local: frame %d of a shard [%lld, %lld) of %lld grid points (the whole grid only)", frame,
+                       (long long)d.g0, (long long)(d.g0 + d.Gband), (long long)d.G);
+        return PSFM_ERR_ARG;
+    }
+    return psfm_solve_frame_enqueue(c, d, flow01, flow12, flow02, occ02, frame, unroll < 1 ? 1 : (unroll > 64 ? 64 : unroll),
+                                    (hipStream_t)stream);
+}
+
+// The stalled solve of `frame` redone to termination and written back (synchronises).  chain_stalled: it had been enqueued by
+// psfm_shard_solve_local (its resident launch gave up / its launches did not suffice), not by a fused export
+extern "C" psfm_status psfm_shard_solve_redo_local(psfm_ctx* c, const float* flow01, const float* flow12, const float* flow02,
+                                                   const uint8_t* occ02, int frame, int chain_stalled, psfm_solve_stats* stats_host,
+                                                   void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    const PsfmTrackDims& d = *c->shard_dims;
+    if (!shard_is_whole(d) || !c->shard_optimize || !flow01 || !flow12 || !flow02 || !occ02 || frame < 1 || frame >= d.n_flows) {
+        psfm_set_error("psfm_shard_solve_redo_local: frame %d of a shard [%lld, %lld) of %lld grid points (the whole grid only)", frame,
+                       (long long)d.g0, (long long)(d.g0 + d.Gband), (long long)d.G);
+        return PSFM_ERR_ARG;
+    }
+    *(int32_t*)((char*)c->host_pinned + c->host_pinned_bytes - 64) = 0;     // (the caller has synchronised: nothing is in flight)
+    psfm_solve_stats ss;
+    memset(&ss, 0, sizeof(ss));
+    psfm_status st = psfm_solve_frame_resume(c, d, flow01, flow12, flow02, occ02, frame, &ss, 0, chain_stalled != 0, (hipStream_t)stream);
+    if (st != PSFM_OK) return st;
+    if (ss.termination >= 0) c->solve_stats.push_back(ss);
     if (stats_host) *stats_host = ss;
     return PSFM_OK;
 }

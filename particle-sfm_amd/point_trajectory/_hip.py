@@ -22,7 +22,7 @@ EXPORTS = [
     "psfm_shard_begin", "psfm_shard_step", "psfm_shard_solve_export", "psfm_shard_solve_control", "psfm_shard_solve_restore",
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
-    "psfm_shard_solve_control_chain_async", "psfm_shard_solve_poll", "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity", "psfm_load_flo_stack",
+    "psfm_shard_solve_control_chain_async", "psfm_shard_solve_poll", "psfm_shard_solve_local", "psfm_shard_solve_redo_local", "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity", "psfm_load_flo_stack",
 ]
 
 
@@ -107,6 +107,8 @@ def lib():
     L.psfm_shard_solve_control_async.argtypes = [vp, i32, i32, vp, vp]
     L.psfm_shard_solve_control_chain_async.argtypes = [vp, i32, i32, vp, vp]
     L.psfm_shard_solve_poll.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(SolveStats), vp]
+    L.psfm_shard_solve_local.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+    L.psfm_shard_solve_redo_local.argtypes = [vp, vp, vp, vp, vp, i32, i32, ctypes.POINTER(SolveStats), vp]
     L.psfm_shard_window_state.argtypes = [vp, i32, i32, ctypes.POINTER(SolveStats), ctypes.POINTER(ctypes.c_int32), vp]
     L.psfm_shard_peek_stall.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.psfm_shard_solve_restore.argtypes = [vp, i32, vp]
@@ -134,6 +136,7 @@ class Context:
         self._h = ctypes.c_void_p()
         check(lib().psfm_ctx_create(int(device), ctypes.byref(self._h)))
         self.device = int(device)
+        self.resident_budget = 0           # (what set_resident_budget was last given)
 
     @property
     def handle(self):
@@ -156,6 +159,7 @@ class Context:
         contexts' -- the budgets of all contexts in flight on the device must add up to at most resident_capacity(); 0: only with the
         device to itself (default)."""
         check(lib().psfm_ctx_set_resident_budget(self._h, int(blocks)))
+        self.resident_budget = int(blocks)
 
     def resident_capacity(self):
         n = ctypes.c_int32()

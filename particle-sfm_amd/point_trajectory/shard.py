@@ -24,6 +24,23 @@ class HipShardEngine:
         # iterations speculated beyond what the clean solves of the last 16 frames needed: an iteration more costs a few us per frame,
         # a solve that needed one more than speculated costs a redo through the launch chain and the frames behind it once again
         self.k_margin = int(os.environ.get("PSFM_SHARD_K_MARGIN", "0"))
+        # ONE rank (psfm_dist.connect_sharded at world size 1 -- the windowed engine for one long sequence on one GPU): the band is the
+        # whole grid, nothing of a solve is exchanged, so solves whose steps get rejected take the one-GPU call's forms
+        # (psfm_shard_solve_local / _redo_local: the resident solve, one launch per solve) instead of export -> exchange -> control once
+        # per trust-region iteration.  mode: 0 fused solves, 1 a window whose solves are expected to reject steps (psfm_connect's rule)
+        self.local = False
+        self._loc = False
+        self.mode = 0
+        self.unroll = 4
+        self._own_budget = False
+
+    def set_local(self, on):
+        self.local = bool(on) and os.environ.get("PSFM_SHARD_LOCAL", "1") != "0"
+
+    def _release_budget(self):
+        if self._own_budget:
+            self.ctx.set_resident_budget(0)
+            self._own_budget = False
 
     @property
     def device(self):
@@ -39,8 +56,16 @@ class HipShardEngine:
         # not terminate) must not hand its enqueued solves -- frame numbers and flow tensors of ANOTHER sequence -- to this one
         self._pending = []
         self._need = []
-        self.counters = {"fused": 0, "fused_redone": 0}
+        self.counters = {"fused": 0, "fused_redone": 0, "local": 0, "local_redone": 0}
         self.G = ((W + ratio - 1) // ratio) * ((H + ratio - 1) // ratio)
+        self.mode, self.unroll = 0, 4
+        self._release_budget()
+        self._loc = self.local and bool(optimize) and int(g0) == 0 and int(g1) == self.G      # (this run)
+        if self._loc and self.ctx.resident_budget == 0:
+            # the resident solves of this engine run inside a budget (the calls of a sharded run come and go under the shared gate: no
+            # call holds the device for the sequence) -- all of the device's slots unless the caller has set a share
+            self.ctx.set_resident_budget(self.ctx.resident_capacity())
+            self._own_budget = True
         self.pitch = (self.G + 1 + 255) // 256 * 256
         self.maps = torch.zeros(2 * self.pitch, dtype=torch.uint8, device=self.device)
         self.sums = torch.zeros(K_MAX * N_SUM, dtype=torch.float64, device=self.device)
@@ -70,13 +95,22 @@ class HipShardEngine:
         context is a no-op from then on); checkpoint() finds out, redoes it with the launch chain (one export / reduce / control
         per trust-region iteration) and tells the driver where to resume."""
         L, h = _hip.lib(), self.ctx.handle
+        if self._loc and self.mode == 1:
+            return self._solve_local(t, flow_prev, flow_cur, flow2_prev, occ2_prev)
         p = (_hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ2_prev))
         k = max(1, min(K_MAX, self.k))
         mask = [(i % N_SUM) == SUM_GMAX for i in range(k * N_SUM)]
         _hip.check(L.psfm_shard_solve_export(h, *p, int(t), 0, k, _hip.ptr(self.sums), self._sp()))
         reduce(self.sums[:k * N_SUM], mask)
         _hip.check(L.psfm_shard_solve_control_async(h, int(t), k, _hip.ptr(self.sums), self._sp()))
-        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev)))    # (keeps the frames alive for a redo)
+        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev), 0))    # (keeps the frames alive for a redo)
+
+    def _solve_local(self, t, flow_prev, flow_cur, flow2_prev, occ2_prev):
+        """one rank, a window whose solves reject steps: the solve of frame t enqueued the way the one-GPU call does it (the resident
+        solve -- iteration 0, every trust-region round and the write-back in ONE launch -- or `unroll` launches of one iteration)"""
+        _hip.check(_hip.lib().psfm_shard_solve_local(self.ctx.handle, _hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev),
+                                                     _hip.ptr(occ2_prev), int(t), int(self.unroll), self._sp()))
+        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev), 1))
 
     def frame(self, t, flow_prev, flow_cur, occ, flow2_prev, occ2_prev, reduce_first, reduce):
         """step(t) and the fused export of solve(t) as ONE launch (psfm_shard_frame): the solve of frame t needs this rank's own
@@ -85,6 +119,9 @@ class HipShardEngine:
         like solve()'s."""
         L, h = _hip.lib(), self.ctx.handle
         assert flow_cur.is_cuda and flow_cur.is_contiguous() and occ.is_contiguous()
+        if self._loc and self.mode == 1:       # (two launches: the chain step, then the solve of the frame's tracks)
+            reduce_first(self.step(t, flow_cur, occ))
+            return self._solve_local(t, flow_prev, flow_cur, flow2_prev, occ2_prev)
         k = max(1, min(K_MAX, self.k))
         mask = [(i % N_SUM) == SUM_GMAX for i in range(k * N_SUM)]
         _hip.check(L.psfm_shard_frame(h, _hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ),
@@ -93,7 +130,12 @@ class HipShardEngine:
         reduce_first(self.maps[o:o + self.G + 1])
         reduce(self.sums[:k * N_SUM], mask)
         _hip.check(L.psfm_shard_solve_control_async(h, int(t), k, _hip.ptr(self.sums), self._sp()))
-        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev)))
+        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev), 0))
+
+    def window_full(self):
+        """one rank: a window of solves enqueued as resident launches ends after 16 frames, like the one-GPU call's -- should the flows
+        have turned clean, the next window goes back to fused solves (a third of the time per solve)"""
+        return self._loc and self.mode == 1 and len(self._pending) >= 16
 
     def stalled(self):
         """True once the device has got to a solve that did not go as speculated (read from pinned memory, no synchronisation)."""
@@ -113,16 +155,35 @@ class HipShardEngine:
         _hip.check(L.psfm_shard_window_state(h, f_lo, f_hi, stats, ctypes.byref(stalled), self._sp()))
         fs = int(stalled.value)
         last_ok = f_hi if fs < 0 else fs - 1
-        for t, _ in self._pending:
+        seen = []                      # statistics of the window's completed solves (the redone one included)
+        for t, _, how in self._pending:
             if t > last_ok:
                 break
             st = stats[t - f_lo]
             _hip.check(L.psfm_shard_solve_record(h, ctypes.byref(st)))
-            self.counters["fused"] += 1
+            self.counters["local" if how else "fused"] += 1
             self._adapt(st)
+            seen.append(st)
         redo = None
-        if fs >= 0:
-            frames = dict(self._pending)
+        if fs >= 0 and self._loc:
+            frames = {t: (x, how) for t, x, how in self._pending}
+            x, how = frames[fs]
+            st = _hip.SolveStats()
+            self.counters["local_redone" if how else "fused_redone"] += 1
+            _hip.check(L.psfm_shard_solve_redo_local(h, *(_hip.ptr(q) for q in x), fs, int(how), ctypes.byref(st), self._sp()))
+            self._adapt(st)
+            seen.append(st)
+            redo = fs
+            if os.environ.get("PSFM_SHARD_TRACE"):
+                import sys
+                import time
+                import torch
+                torch.cuda.synchronize()
+                print("[shard] window %d..%d: solve %d (%s) redone locally: %d iterations, launches %s, t=%.3f" %
+                      (f_lo, f_hi, fs, "resident" if how else "fused", st.iterations, self.ctx.solver_counters(), time.perf_counter()),
+                      file=sys.stderr)
+        elif fs >= 0:
+            frames = {t: x for t, x, _ in self._pending}
             p = tuple(_hip.ptr(x) for x in frames[fs])
             self.counters["fused_redone"] += 1
             _hip.check(L.psfm_shard_solve_restore(h, fs, self._sp()))
@@ -149,13 +210,31 @@ class HipShardEngine:
             _hip.check(L.psfm_shard_solve_writeback(h, fs, ctypes.byref(st), self._sp()))
             self._adapt(st)
             redo = fs
+        if self._loc:
+            # psfm_connect's rule (csrc/psfm_api.hip): a window with more than one solve in eight off the Gauss-Newton path sends the
+            # next window to the resident solves, a clean one brings the fused solves back; launches per solve without a budget:
+            # what the slowest solve of the window needed, within [4, 64]
+            solved = [q for q in seen if q.termination >= 0]
+            if solved:
+                self.mode = 1 if 8 * sum(0 if self._clean(q) else 1 for q in solved) > len(solved) else 0
+                want = min(64, max(4, max(q.iterations for q in solved) + 1))
+                self.unroll = want if want > self.unroll else self.unroll - (self.unroll - want + 1) // 2
+            if os.environ.get("PSFM_SHARD_TRACE"):
+                import sys
+                import time
+                print("[shard] window %d..%d checked: %d solves, next mode %d, k %d, t=%.3f" % (f_lo, f_hi, len(solved), self.mode, self.k,
+                                                                                           time.perf_counter()), file=sys.stderr)
         self._pending = []
         return redo
 
+    @staticmethod
+    def _clean(st):
+        return st.dogleg_nonGN == 0 and st.termination != 5 and (st.iterations == st.successful_steps + 1 or
+                                                                 (st.termination == 2 and st.iterations == st.successful_steps))
+
     def _adapt(self, st):
         # the next solves speculate what the clean ones of the last 16 frames needed (same statistics, same choice on every rank)
-        clean = st.dogleg_nonGN == 0 and st.termination != 5 and (st.iterations == st.successful_steps + 1 or
-                                                                  (st.termination == 2 and st.iterations == st.successful_steps))
+        clean = self._clean(st)
         if st.termination >= 0 and clean:
             self._need = (self._need + [min(K_MAX, st.successful_steps + 1)])[-16:]
             self.k = min(K_MAX, max(self._need) + self.k_margin)
@@ -167,6 +246,7 @@ class HipShardEngine:
             raise RuntimeError("HipShardEngine.finish: solves enqueued since the last checkpoint()")
         info = _hip.TrackInfo()
         _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
+        self._release_budget()
         R = _result_to_host(self.ctx, info)
         return R.birth, R.length, R.off, R.xy, R.solve_stats
 
@@ -177,6 +257,7 @@ class HipShardEngine:
             raise RuntimeError("HipShardEngine.finish_device: solves enqueued since the last checkpoint()")
         info = _hip.TrackInfo()
         _hip.check(_hip.lib().psfm_shard_finish(self.ctx.handle, ctypes.byref(info), self._sp()))
+        self._release_budget()
         keys = torch.empty(int(info.n_traj), dtype=torch.int64, device=self.device)
         _hip.check(_hip.lib().psfm_result_keys(self.ctx.handle, int(ratio), int(width), _hip.ptr(keys), self._sp()))
         return info, keys

@@ -350,6 +350,8 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     wf = FrameWindow(flows_f, n_flows, comm) if owned else None
     w2 = FrameWindow(flows_f2, n2, comm) if owned and optimize and n2 > 0 else None
     g0, g1 = band_range(GH, GW, rank, world)
+    if hasattr(engine, "set_local"):     # one rank: nothing of a solve is exchanged -- rejecting solves take the one-GPU call's forms
+        engine.set_local(world == 1)
     engine.begin(n_flows, H, W, r, g0, g1, optimize)
     reduce = make_reduce(comm=comm)
     # Engines that only ENQUEUE a frame's solve (the HIP engine: no host round trip per solve) are asked every CHECK frames whether
@@ -390,7 +392,8 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
                 engine.solve(t, f_prev, f_t, f2_prev, occ2[t - 1], reduce)
         since += 1
         # (every 16 frames -- or as soon as the engine sees, without synchronising, that a solve of the window has stalled)
-        if has_ck and (since >= engine.check_every or t == n_flows - 1 or _any_stalled(engine, comm)):
+        if has_ck and (since >= engine.check_every or t == n_flows - 1 or _any_stalled(engine, comm) or
+                       (world == 1 and hasattr(engine, "window_full") and engine.window_full())):
             redone = engine.checkpoint(reduce)
             if redone is not None:
                 t = redone                   # frames redone + 1 .. are run again

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libpsfm_hip.so does not export %s" % n
     assert set(names) == set(_hip.EXPORTS)
-    assert L.psfm_version() == 140
+    assert L.psfm_version() == 141
 
 
 def test_no_cpu_fallback():

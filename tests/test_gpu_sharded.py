@@ -64,12 +64,90 @@ def test_connect_sharded_hip_engine(world, T, H, W, r, seed, sigma, nocc, optimi
         assert ((gidx >= g0) & (gidx < g1)).all()
         n_local += len(part["birth"])
         if optimize:
-            assert cnt["fused"] + cnt["fused_redone"] == len(O.solves)
+            assert cnt["fused"] + cnt["fused_redone"] + cnt["local"] + cnt["local_redone"] == len(O.solves)
+            assert world == 1 or cnt["local"] + cnt["local_redone"] == 0     # (several ranks: every solve goes through the exchange)
     assert n_local == O.n_traj
     if optimize and sigma <= 0.05:
         assert res[0][2]["fused"] >= len(O.solves) - 3          # clean sequence: (nearly) every solve in one launch
-    if optimize and sigma >= 0.4:
+    if optimize and sigma >= 0.4 and world > 1:
         assert res[0][2]["fused_redone"] >= len(O.solves) // 2  # noisy sequence: the chain protocol did the work
+    if optimize and sigma >= 0.4 and world == 1:
+        # one rank: the first stalled solve sends the windows behind it to the one-GPU call's forms (resident solves)
+        assert res[0][2]["local"] >= len(O.solves) - 3 and res[0][2]["fused_redone"] <= 2
+
+
+def _mixed_sequence(T, H, W, seed, hard_until):
+    """frames [0, hard_until) from the noisy distribution, the rest from the clean one (two synthetic sequences of one size spliced:
+    parity needs the same input on both sides, not a plausible video)"""
+    a = psfm_synth.synth_sequence(T, H, W, seed=seed, sigma=0.4, n_occluders=2, stride2=True)
+    b = psfm_synth.synth_sequence(T, H, W, seed=seed + 1, sigma=0.02, n_occluders=0, stride2=True)
+    d = {}
+    for k in ("flows_f", "flows_b"):
+        d[k] = [a[k][t] if t < hard_until else b[k][t] for t in range(len(a[k]))]
+    for k in ("flows_f2", "flows_b2"):
+        d[k] = [a[k][t] if t < hard_until else b[k][t] for t in range(len(a[k]))]
+    return d
+
+
+@pytest.mark.parametrize("variant", ["resident", "no-budget", "give-up", "two-launches"])
+def test_connect_sharded_one_rank_takes_the_one_gpu_solver_forms(variant, monkeypatch):
+    """World size 1 (the windowed engine for one long sequence on one GPU): windows whose solves reject steps run them as
+    psfm_connect does -- resident solves enqueued behind the chain steps (psfm_shard_solve_local), a stalled solve redone by
+    psfm_shard_solve_redo_local -- instead of export -> exchange -> control once per trust-region iteration; clean windows go back to
+    fused exports.  Same trajectories, BIT FOR BIT, as the exchange form (PSFM_SHARD_LOCAL=0: the sums are added in the same order),
+    decisions equal to the oracle's.  Variants: the caller's context has no say (default: the engine takes the whole resident budget
+    for the run and gives it back); a resident launch that gives up (PSFM_PC_SPIN=0: stall flag, redo with launches); no budget to
+    be had (PSFM_PC_PERSIST=0: `unroll` launches per solve); the two-launch frame form."""
+    import torch
+    import psfm_dist
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    from point_trajectory.shard import HipShardEngine, flow_check_slice
+    T, H, W, r = 60, 45, 63, 2
+    d = _mixed_sequence(T, H, W, 31, 20)      # (solves 1-19 reject steps, 20-58 are Gauss-Newton all the way)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stack = {k: torch.from_numpy(np.stack(d[k])).to(dev) for k in ("flows_f", "flows_b", "flows_f2", "flows_b2")}
+
+    def run(local):
+        with monkeypatch.context() as m:
+            m.setenv("PSFM_SHARD_LOCAL", "1" if local else "0")
+            if local and variant == "give-up":
+                m.setenv("PSFM_PC_SPIN", "0")
+            if local and variant == "no-budget":
+                m.setenv("PSFM_PC_PERSIST", "0")
+            if variant == "two-launches":
+                m.setenv("PSFM_SHARD_MERGED", "0")
+            eng = HipShardEngine(_hip.Context(dev.index or 0))
+            eng.ctx.set_capacity(2.0, 24.0)      # (the noisy part ends a track per grid point every other frame)
+            part = psfm_dist.connect_sharded(eng, stack["flows_f"], stack["flows_b"], stack["flows_f2"], stack["flows_b2"], 1.0, r,
+                                             flow_check_slice)
+            launches = eng.ctx.solver_counters()
+            assert eng.ctx.resident_budget == 0          # (the engine's own budget is given back)
+            return part, dict(eng.counters), launches
+
+    got, cnt, launches = run(True)
+    ref, cnt0, _ = run(False)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    for k in ("birth", "length", "off", "ids"):
+        assert np.array_equal(got[k], ref[k])
+    assert np.array_equal(got["xy"], ref["xy"])                          # bit for bit: same sums in the same order
+    order = np.argsort(got["ids"])
+    assert np.array_equal(got["birth"][order], O.birth) and np.array_equal(got["length"][order], O.length)
+    assert [s["iterations"] for s in got["solve_stats"]] == [s["iterations"] for s in O.solves]
+    assert [s["termination"] for s in got["solve_stats"]] == [s["termination"] for s in O.solves]
+    assert cnt0["local"] + cnt0["local_redone"] == 0
+    n = len(O.solves)
+    assert cnt["fused"] + cnt["fused_redone"] + cnt["local"] + cnt["local_redone"] == n
+    assert cnt["local"] + cnt["local_redone"] >= 16           # the noisy part: resident windows
+    assert cnt["fused"] >= 8                                  # the clean tail: back to fused exports
+    if variant == "resident" or variant == "two-launches":
+        assert launches["resident_launches"] >= 16 and launches["resident_giveups"] == 0
+    if variant == "give-up":
+        assert cnt["local_redone"] >= 1 and launches["resident_giveups"] >= 1 and launches["iteration_launches"] > 0
+    if variant == "no-budget":
+        assert launches["resident_launches"] == 0 and launches["iteration_launches"] > 0
 
 
 @pytest.mark.parametrize("case", [1, 2])
