@@ -283,7 +283,10 @@ psfm_status psfm_shard_solve_export(psfm_ctx* ctx, const float* flow01, const fl
                                     const uint8_t* occ02, int frame, int kind, int k, double* sums_out, void* stream);
 /* psfm_shard_step(frame) + psfm_shard_solve_export(frame, kind 0, k) as ONE launch (track_optimize.py:31-50 for the own tracks:
  * the chain step of the frame and the fused solve of its tracks, sums exported); frame >= 1, flow12 = the frame's own forward
- * flow, occ = its occlusion map.  The frame's marks are exchanged behind it like psfm_shard_step's. */
+ * flow, occ = its occlusion map.  The frame's marks are exchanged behind it like psfm_shard_step's.  sums_out NULL (a shard that is
+ * the whole sequence only, see psfm_shard_solve_local): nothing is exported, the launch runs the control step on its own totals
+ * and no psfm_shard_solve_control* call follows; a solve that did not go as speculated raises the device-side stall flag, which
+ * reaches psfm_shard_peek_stall with every 8th frame (and psfm_shard_window_state at once). */
 psfm_status psfm_shard_frame(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02, const uint8_t* occ,
                              const uint8_t* occ02, int frame, int k, double* sums_out, void* stream);
 psfm_status psfm_shard_solve_control(psfm_ctx* ctx, int frame, int kind, int k, const double* totals, int32_t* done_host,

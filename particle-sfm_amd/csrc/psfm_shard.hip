@@ -105,9 +105,25 @@ extern "C" psfm_status psfm_shard_frame(psfm_ctx* c, const float* flow01, const 
     PSFM_SHARD_CHECK(c);
     PsfmGate gate(c->device, 0);
     const PsfmTrackDims& d = *c->shard_dims;
-    if (!flow01 || !flow12 || !flow02 || !occ || !occ02 || !sums_out || frame < 1 || frame >= d.n_flows || !c->shard_optimize) {
+    if (!flow01 || !flow12 || !flow02 || !occ || !occ02 || frame < 1 || frame >= d.n_flows || !c->shard_optimize) {
         psfm_set_error("psfm_shard_frame: bad argument (frame %d)", frame);
         return PSFM_ERR_ARG;
+    }
+    if (!sums_out) {
+        // a shard that is the whole sequence: nothing to exchange, the launch runs the control step on its own totals (the frame
+        // kernel as psfm_connect's host-paced windows launch it) -- no export, no control launch behind every frame.  A solve that
+        // does not go as speculated raises the device-side stall flag; every 8th frame carries it to where psfm_shard_peek_stall looks
+        if (d.g0 != 0 || d.Gband != d.G) {
+            psfm_set_error("psfm_shard_frame: sums_out is NULL for a band [%lld, %lld) of %lld grid points (the whole grid only)",
+                           (long long)d.g0, (long long)(d.g0 + d.Gband), (long long)d.G);
+            return PSFM_ERR_ARG;
+        }
+        psfm_status st = psfm_launch_frame(c, d, flow01, flow12, flow02, occ, occ02, frame, k, (hipStream_t)stream, nullptr);
+        if (st != PSFM_OK) return st;
+        if ((frame & 7) == 7 || frame == d.n_flows - 1)
+            PSFM_HIP(hipMemcpyAsync((char*)c->host_pinned + c->host_pinned_bytes - 64, &c->counters.as<PsfmCounters>()->stall, sizeof(int32_t),
+                                    hipMemcpyDeviceToHost, (hipStream_t)stream));
+        return PSFM_OK;
     }
     return psfm_launch_frame(c, d, flow01, flow12, flow02, occ, occ02, frame, k, (hipStream_t)stream, sums_out);
 }

@@ -123,6 +123,14 @@ class HipShardEngine:
             reduce_first(self.step(t, flow_cur, occ))
             return self._solve_local(t, flow_prev, flow_cur, flow2_prev, occ2_prev)
         k = max(1, min(K_MAX, self.k))
+        if self._loc and os.environ.get("PSFM_SHARD_LOCAL_CONTROL", "1") != "0":
+            # one rank: the launch runs the control step on its own totals -- no export, no exchange, no control launch per frame
+            _hip.check(L.psfm_shard_frame(h, _hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ),
+                                          _hip.ptr(occ2_prev), int(t), k, None, self._sp()))
+            o = (int(t) & 1) * self.pitch
+            reduce_first(self.maps[o:o + self.G + 1])
+            self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev), 0))
+            return
         mask = [(i % N_SUM) == SUM_GMAX for i in range(k * N_SUM)]
         _hip.check(L.psfm_shard_frame(h, _hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ),
                                       _hip.ptr(occ2_prev), int(t), k, _hip.ptr(self.sums), self._sp()))

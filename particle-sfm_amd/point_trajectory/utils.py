@@ -144,12 +144,14 @@ def load_flows_device(dir, device=None, n_staging=16, n_readers=8, _names=None, 
     return out
 
 
-def flow_check_device(flows, flows_b, thres, want_error=False):
-    """flow_check on device tensors: (n,H,W,2) float32 stacks -> (err (n,H,W) f32 | None, occ (n,H,W) uint8)."""
+def flow_check_device(flows, flows_b, thres, want_error=False, out=None):
+    """flow_check on device tensors: (n,H,W,2) float32 stacks -> (err (n,H,W) f32 | None, occ (n,H,W) uint8; `out` if given)."""
     import torch
     ctx = _hip.context()
     n, H, W = int(flows.shape[0]), int(flows.shape[1]), int(flows.shape[2])
-    occ = torch.empty((n, H, W), dtype=torch.uint8, device=flows.device)
+    if out is not None and (tuple(out.shape) != (n, H, W) or out.dtype != torch.uint8 or not out.is_contiguous()):
+        raise ValueError("flow_check_device: out must be a contiguous (n,H,W) uint8 tensor")
+    occ = out if out is not None else torch.empty((n, H, W), dtype=torch.uint8, device=flows.device)
     err = torch.empty((n, H, W), dtype=torch.float32, device=flows.device) if want_error else None
     _hip.check(_hip.lib().psfm_flow_check(ctx.handle, _hip.ptr(flows), _hip.ptr(flows_b), n, H, W, float(thres),
                                           _hip.ptr(occ), _hip.ptr(err), _hip.current_stream_ptr(ctx.device)))

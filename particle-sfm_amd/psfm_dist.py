@@ -343,7 +343,8 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     occ2 = (flow_check_sharded(flows_f2, flows_b2, thres, check_fn, comm=comm, n_total=n2 if owned else None)
             if optimize and n2 > 0 else None)
     # (Stage A stays up front also at world size 1: in chunks on a side stream, a chunk ahead of the recurrence -- the way the one-GPU call
-    # hides two thirds of its flow_check -- ONE sequence of configs[3] took 40.3-41.9 ms instead of 38.1-38.3: profiles/EXPERIMENTS.md 6.6)
+    # hides two thirds of its flow_check -- ONE sequence of configs[3] took 40.3-41.9 ms instead of 38.1-38.3: profiles/EXPERIMENTS.md 6.6;
+    # round 5, with one launch per frame and no control launch behind it: 37.6-38.6 ms in chunks of 8 / 16 / 32 pairs, 37.5-37.9 up front: 7.8)
     # ---- Stage B: the recurrence, tracks split by birth row band ----
     # n_flows_total given: the four stacks are owned by Stage A's frame-pair shards (every rank passed its slice only); the
     # forward stacks reach the other ranks frame by frame, broadcast from their owner two frames ahead of the recurrence

@@ -89,7 +89,7 @@ def _mixed_sequence(T, H, W, seed, hard_until):
     return d
 
 
-@pytest.mark.parametrize("variant", ["resident", "no-budget", "give-up", "two-launches"])
+@pytest.mark.parametrize("variant", ["resident", "no-budget", "give-up", "two-launches", "control-launch"])
 def test_connect_sharded_one_rank_takes_the_one_gpu_solver_forms(variant, monkeypatch):
     """World size 1 (the windowed engine for one long sequence on one GPU): windows whose solves reject steps run them as
     psfm_connect does -- resident solves enqueued behind the chain steps (psfm_shard_solve_local), a stalled solve redone by
@@ -97,7 +97,8 @@ def test_connect_sharded_one_rank_takes_the_one_gpu_solver_forms(variant, monkey
     fused exports.  Same trajectories, BIT FOR BIT, as the exchange form (PSFM_SHARD_LOCAL=0: the sums are added in the same order),
     decisions equal to the oracle's.  Variants: the caller's context has no say (default: the engine takes the whole resident budget
     for the run and gives it back); a resident launch that gives up (PSFM_PC_SPIN=0: stall flag, redo with launches); no budget to
-    be had (PSFM_PC_PERSIST=0: `unroll` launches per solve); the two-launch frame form."""
+    be had (PSFM_PC_PERSIST=0: `unroll` launches per solve); the two-launch frame form; fused frames with the export + control launch
+    of the exchange form (default on one rank: the frame launch runs the control step itself, psfm_shard_frame with sums_out NULL)."""
     import torch
     import psfm_dist
     from oracle import oracle as orc
@@ -117,6 +118,8 @@ def test_connect_sharded_one_rank_takes_the_one_gpu_solver_forms(variant, monkey
                 m.setenv("PSFM_PC_PERSIST", "0")
             if variant == "two-launches":
                 m.setenv("PSFM_SHARD_MERGED", "0")
+            if variant == "control-launch":       # (fused frames export their sums and a control launch follows, as on several ranks)
+                m.setenv("PSFM_SHARD_LOCAL_CONTROL", "0")
             eng = HipShardEngine(_hip.Context(dev.index or 0))
             eng.ctx.set_capacity(2.0, 24.0)      # (the noisy part ends a track per grid point every other frame)
             part = psfm_dist.connect_sharded(eng, stack["flows_f"], stack["flows_b"], stack["flows_f2"], stack["flows_b2"], 1.0, r,
@@ -142,7 +145,7 @@ def test_connect_sharded_one_rank_takes_the_one_gpu_solver_forms(variant, monkey
     assert cnt["fused"] + cnt["fused_redone"] + cnt["local"] + cnt["local_redone"] == n
     assert cnt["local"] + cnt["local_redone"] >= 16           # the noisy part: resident windows
     assert cnt["fused"] >= 8                                  # the clean tail: back to fused exports
-    if variant == "resident" or variant == "two-launches":
+    if variant in ("resident", "two-launches", "control-launch"):
         assert launches["resident_launches"] >= 16 and launches["resident_giveups"] == 0
     if variant == "give-up":
         assert cnt["local_redone"] >= 1 and launches["resident_giveups"] >= 1 and launches["iteration_launches"] > 0
