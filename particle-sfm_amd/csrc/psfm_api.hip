@@ -533,6 +533,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     const bool seq_env = !(getenv("PSFM_SEQ") && atoi(getenv("PSFM_SEQ")) == 0);
     bool seq_ok = optimize && merge && seq_env && unroll_fixed == 0;
     int launch_id = 0;            // device-paced windows: id of the next psfm_seq_kernel launch (== PsfmCounters::pc_owner)
+    int idle_windows = 0;         // ... consecutive windows in which no frame completed (the device inside one long solve)
     bool pc_in_step = true;       // the device's program counter is where the host thinks it is (track_init: frame 1, launch 0)
     int* hpc = (int*)((char*)c->host_pinned + 320);     // pinned staging for {pc_frame, pc_phase, pc_owner, solve_K}
     PsfmCounters* dctr = c->counters.as<PsfmCounters>();
@@ -645,7 +646,16 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
             launch_id += n_launch;
             const int f_before = f;
             if ((st = checkpoint(f_hi, true, true, &f)) != PSFM_OK) return st;
-            if (f == f_before) { seq_ok = false; pc_in_step = false; }   // (no frame completed: never expected -- host-paced from here)
+            if (f == f_before) {
+                // No frame completed and no solve stalled: the device is INSIDE the solve of frame f -- every iteration so far accepted,
+                // none terminating, the window's launches used up (a sequence's last frame has three: K + 2 + 2 iterations).  Its chain
+                // step has run: the next window's launches go on with the solve (at PC_KMAX accepted iterations it stalls and is redone
+                // above).  Running the frame from the top here -- what rounds 2-4 did, "never expected" -- gave birth to the frame's
+                // newborns twice (found by scripts/stress_batch.py in round 5: a two-flow sequence whose one solve takes 8 iterations).
+                if (++idle_windows > 8) { psfm_set_error("psfm_track: the device-paced sequence made no progress in 8 windows (frame %d)", f); return PSFM_ERR_SOLVER; }
+            } else {
+                idle_windows = 0;
+            }
             continue;
         }
         pc_in_step = false;         // a host-paced frame: the device-side counter is not maintained

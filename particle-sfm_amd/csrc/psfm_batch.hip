@@ -269,7 +269,7 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
             // ---- track_optimize.py:31-50: frame 0 is a plain chain step; from frame 1 on device-paced launches ----
             if ((st = fc_need(0, false)) != PSFM_OK) return st;
             if ((st = psfm_launch_chain_step_batch(own, dtab, B, ratio, grid_lanes, 0, true, s)) != PSFM_OK) return st;
-            int launch_id = 0;
+            int launch_id = 0, idle_windows = 0;
             int v[PSFM_BATCH_MAX][4];
             for (int i = 0; i < B; ++i) {
                 S[i].f = 1;
@@ -377,7 +377,10 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
                     // batch and runs alone behind it (psfm_ctx_set_solver(ctx, 2, k) keeps it in)
                     if (c->solve_mode == 1 && c->solver_mode != 2 && S[i].f < n_i) { S[i].dropped = true; S[i].resync = true; }
                 }
-                if (!progress) { psfm_set_error("psfm_connect_batch: no sequence advanced in a window of launches"); return PSFM_ERR_SOLVER; }
+                // (no frame completed anywhere and nothing stalled: every sequence still running is inside one long solve -- all iterations
+                // accepted, none terminating -- which the next window's launches continue; psfm_track_impl has the same case)
+                idle_windows = progress ? 0 : idle_windows + 1;
+                if (idle_windows > 8) { psfm_set_error("psfm_connect_batch: no sequence advanced in 8 windows of launches"); return PSFM_ERR_SOLVER; }
                 if (trim) {
                     // the next window's launches cover the lanes the sequences have in use NOW plus head-room for 18 frames of growth
                     // (on a dense grid the high-water mark creeps up all through a long sequence: a death is a birth one frame later,

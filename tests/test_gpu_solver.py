@@ -267,6 +267,39 @@ def test_track_optimize_two_flows_only(pt, solver_mode):
     assert np.array_equal(R1.birth, O1.birth) and np.array_equal(R1.xy, O1.xy)
 
 
+@pytest.mark.parametrize("mode,k", [(0, 1), (0, 2), (0, 3), (2, 2), (0, 0)])
+@pytest.mark.parametrize("batch", [False, True])
+def test_solve_that_outlasts_the_launches_of_its_window(pt, mode, k, batch):
+    """A device-paced window has (frames left + 2) launches; a sequence's LAST frame therefore has three -- K + 2 + 2 iterations --
+    and a solve whose every step is accepted without terminating for longer than that leaves the window with no frame completed and
+    nothing stalled.  The next window's launches must go on with that solve (rounds 2-4 ran the frame again from the top: its newborn
+    tracks came out twice -- found by scripts/stress_batch.py, seed 3 batch 86).  The sequence: two flows, one solve of 8 iterations with
+    7 accepted steps; also as the tail of a longer sequence and as a batch of one."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    import torch
+    d = psfm_synth.synth_sequence(3, 57, 26, seed=410372702, sigma=0.4, n_occluders=2, stride2=True)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+    assert [(s["iterations"], s["successful_steps"]) for s in O.solves] == [(8, 7)]
+    dev = {k2: torch.from_numpy(np.stack(d[k2])).cuda() for k2 in ("flows_f", "flows_b", "flows_f2", "flows_b2")}
+    ctx = _hip.batch_contexts(1)[0] if batch else _hip.context()
+    ctx.set_solver(mode, k)
+    try:
+        if batch:
+            ctxs, infos = pt.trajectory.run_connect_batch([(dev["flows_f"], dev["flows_b"], dev["flows_f2"], dev["flows_b2"])], 1.0, 2)
+            R = pt.trajectory._result_to_host(ctxs[0], infos[0])
+        else:
+            R = pt.trajectory.run_connect(dev["flows_f"], dev["flows_b"], dev["flows_f2"], dev["flows_b2"], 1.0, 2)
+    finally:
+        ctx.set_solver(0, 0)
+    assert len(R.birth) == O.n_traj == 488 and np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+    assert float(np.abs(R.xy - O.xy).max()) <= TOL
+    assert [(s["iterations"], s["successful_steps"], s["termination"]) for s in R.solve_stats] == \
+           [(s["iterations"], s["successful_steps"], s["termination"]) for s in O.solves]
+
+
 def test_track_optimize_full_size_properties(pt):
     """configs[3]/[4] shapes with fewer frames: 1080p r=2 and 480x640 r=1 (dense), full path-consistency optimise.
     Size-independent invariants + the first frames against the oracle."""
