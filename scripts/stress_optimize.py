@@ -21,13 +21,18 @@ worst = 0.0
 t0 = time.time()
 for k in range(n_cases):
     H, W = int(rng.integers(40, 200)), int(rng.integers(40, 240))
-    T, r = int(rng.integers(4, 14)), int(rng.integers(1, 5))
+    # (3 frames = two flows = ONE solve in a window of three launches; 18-20 frames end one frame behind a 16-frame window: round 5's
+    # stress found a solve that outlasts such a window run its frame twice)
+    T, r = int(rng.choice([3, 3, 4, 5, 6, 8, 10, 13, 18, 19, 20, 34])), int(rng.integers(1, 5))
     if big:
         H, W, T, r = int(rng.integers(300, 540)), int(rng.integers(400, 960)), int(rng.integers(4, 8)), int(rng.integers(1, 3))
     sigma, nocc = float(rng.uniform(0.02, 0.6)), int(rng.integers(0, 4))
     drift = (float(rng.uniform(-11, 11)), float(rng.uniform(-4, 4))) if rng.uniform() < 0.33 else (0.0, 0.0)
-    d = psfm_synth.synth_sequence(T, H, W, seed=int(rng.integers(1 << 30)), sigma=sigma, n_occluders=nocc, stride2=True,
-                                  amp=float(rng.uniform(1.0, 3.0)), drift=drift, warp_b=drift != (0.0, 0.0))
+    if not big and rng.uniform() < 0.2:
+        d = psfm_synth.synth_realistic(T, H, W, seed=int(rng.integers(1 << 30)), stride2=True, **psfm_synth.REALISTIC)
+    else:
+        d = psfm_synth.synth_sequence(T, H, W, seed=int(rng.integers(1 << 30)), sigma=sigma, n_occluders=nocc, stride2=True,
+                                      amp=float(rng.uniform(1.0, 3.0)), drift=drift, warp_b=drift != (0.0, 0.0))
     _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
     _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
     O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
