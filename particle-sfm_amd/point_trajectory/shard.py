@@ -37,6 +37,11 @@ class HipShardEngine:
     def set_local(self, on):
         self.local = bool(on) and os.environ.get("PSFM_SHARD_LOCAL", "1") != "0"
 
+    def abort(self):
+        """a run that ended in an exception: nothing of it is handed to the next one"""
+        self._pending = []
+        self._release_budget()
+
     def _release_budget(self):
         if self._own_budget:
             self.ctx.set_resident_budget(0)

@@ -354,6 +354,17 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     if hasattr(engine, "set_local"):     # one rank: nothing of a solve is exchanged -- rejecting solves take the one-GPU call's forms
         engine.set_local(world == 1)
     engine.begin(n_flows, H, W, r, g0, g1, optimize)
+    try:
+        return _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, GW, optimize, owned, wf, w2, g0, g1, keep_on_device)
+    except BaseException:
+        if hasattr(engine, "abort"):         # (gives back what the engine took for the run: enqueued solves, its resident budget)
+            engine.abort()
+        raise
+
+
+def _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, GW, optimize, owned, wf, w2, g0, g1, keep_on_device):
+    """Stage B of connect_sharded: the recurrence, tracks split by birth row band (engine.begin() has run)."""
+    world = comm.world
     reduce = make_reduce(comm=comm)
     # Engines that only ENQUEUE a frame's solve (the HIP engine: no host round trip per solve) are asked every CHECK frames whether
     # one of them did not go as speculated; they redo it there and the frames behind it -- no-ops on the device since -- run again.
