@@ -36,6 +36,8 @@ for b in range(n_batches):
     r = int(rng.choice([1, 2, 2, 3, 4]))
     opt = bool(rng.random() < 0.65)
     B = int(rng.integers(1, 13))
+    if os.environ.get("PSFM_STRESS_B"):      # (e.g. 64: the largest batch the entry point takes)
+        B = int(os.environ["PSFM_STRESS_B"])
     thres = float(rng.choice([1.0, 1.0, 3.0]))
     kinds, seqs, data = [], [], []
     for k in range(B):
