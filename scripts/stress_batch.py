@@ -33,6 +33,8 @@ n_seq_total = n_left = 0
 worst = 0.0
 for b in range(n_batches):
     H, W = int(rng.integers(24, 140)), int(rng.integers(24, 180))
+    if os.environ.get("PSFM_STRESS_BIG"):      # (DAVIS / Sintel-sized frames: launches of several hundred blocks, trimmed grids)
+        H, W = int(rng.integers(200, 480)), int(rng.integers(300, 860))
     r = int(rng.choice([1, 2, 2, 3, 4]))
     opt = bool(rng.random() < 0.65)
     B = int(rng.integers(1, 13))

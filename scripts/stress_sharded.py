@@ -32,6 +32,8 @@ worst = 0.0
 forms = {"local": 0, "local_redone": 0, "fused": 0, "fused_redone": 0}
 for case in range(n_cases):
     H, W = int(rng.integers(30, 120)), int(rng.integers(30, 150))
+    if os.environ.get("PSFM_STRESS_BIG"):
+        H, W = int(rng.integers(200, 480)), int(rng.integers(300, 860))
     r = int(rng.choice([1, 2, 2, 3, 4]))
     T = int(rng.choice([3, 3, 4, 6, 9, 13, 18, 19, 26, 34, 40]))
     opt = bool(rng.random() < 0.75)
