@@ -160,3 +160,55 @@ def test_frame_window_serves_every_frame_from_its_owner(seed, world, n):
         if world > 1:
             assert all(lo <= k < hi for k in touched)
             assert buffers <= n                                    # buffers are recycled, never one per request
+
+
+class _RecordingEngine:
+    """the engine protocol of connect_sharded with nothing behind it: records the calls, raises where it is told to"""
+
+    def __init__(self, G, fail_at=None):
+        self.G, self.fail_at, self.calls, self.local = G, fail_at, [], None
+
+    def set_local(self, on):
+        self.local = bool(on)
+
+    def begin(self, *a):
+        self.calls.append("begin")
+
+    def step(self, t, flow, occ):
+        if t == self.fail_at:
+            raise RuntimeError("frame %d failed" % t)
+        self.calls.append("step%d" % t)
+        return torch.zeros(self.G + 1, dtype=torch.uint8)
+
+    def after_exchange(self, t, x):
+        pass
+
+    def abort(self):
+        self.calls.append("abort")
+
+    def finish(self):
+        self.calls.append("finish")
+        return (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros((0, 2)), [])
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_connect_sharded_tells_the_engine_whether_it_is_alone_and_aborts_it_on_an_exception(world):
+    """connect_sharded's contract with an engine beyond the frame calls: set_local(world == 1) before begin() (one rank exchanges nothing:
+    the GPU engine then takes the one-GPU call's solver forms) and abort() when the run ends in an exception -- on every rank, before the
+    exception leaves the call (the GPU engine gives back its resident budget and drops the solves it had enqueued)."""
+    T, H, W, r = 5, 12, 16, 2
+    flows = torch.zeros((T, H, W, 2), dtype=torch.float32)
+    check = lambda f, b, thres: torch.zeros(f.shape[:3], dtype=torch.uint8)
+    G = ((W + r - 1) // r) * ((H + r - 1) // r)
+
+    def rank_fn(comm):
+        ok = _RecordingEngine(G)
+        psfm_dist.connect_sharded(ok, flows, flows, None, None, 1.0, r, check, comm=comm)
+        bad = _RecordingEngine(G, fail_at=2)
+        with pytest.raises(RuntimeError, match="frame 2 failed"):
+            psfm_dist.connect_sharded(bad, flows, flows, None, None, 1.0, r, check, comm=comm)
+        return ok, bad
+
+    for ok, bad in run_ranks(world, rank_fn):
+        assert ok.local is (world == 1) and ok.calls == ["begin"] + ["step%d" % t for t in range(T)] + ["finish"]
+        assert bad.local is (world == 1) and bad.calls == ["begin", "step0", "step1", "abort"]
