@@ -526,7 +526,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // window to the chain, a clean window brings the fused solve back; solve_K follows the accepted steps seen.
     c->n_fused_ok = c->n_fused_redone = c->n_chain = 0;
     c->n_resident = c->n_iter_launches = 0;
-    if (optimize && (st = psfm_solve_prepare(c, d)) != PSFM_OK) return st;
+    if (optimize && (st = psfm_solve_prepare(c, d, s)) != PSFM_OK) return st;
     // PSFM_MERGE_FRAME=0: chain step and fused solve as two launches (what the merged frame kernel is measured against);
     // PSFM_SEQ=0: host-paced frame kernels (one per frame, stall + redo when a solve needs more iterations than speculated)
     static const bool merge = !(getenv("PSFM_MERGE_FRAME") && atoi(getenv("PSFM_MERGE_FRAME")) == 0);
@@ -551,6 +551,14 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
         // exclusively for its resident solves), let them in: the rest of the sequence runs its solves as launches, which overlap
         // with other sequences -- a late-comer waits for one window of frames at most, not for the whole sequence.
         if (gate.yield_exclusive()) c->pc_persist_ok = c->resident_budget > 0;
+        // A full table ends the sequence here: a launch behind that point counts on blocks the grid does not have (its solve never
+        // sees its last arrival: no stall flag, no progress), and finalize would refuse the result anyway.  The caller raises the
+        // capacity and runs the sequence again (the Python mirror does: trajectory.run_connect).
+        if ((hc->overflow & 7) != 0 || hc->n_lanes > d.cap) {
+            psfm_set_error("capacity exceeded: lanes used %d of %lld, overflow bits %d (frame %d of %d); raise psfm_ctx_set_capacity",
+                           hc->n_lanes, (long long)d.cap, hc->overflow, hc->pc_frame, n_flows);
+            return PSFM_ERR_CAPACITY;
+        }
         const int stalled = hc->stall ? hc->stall - 1 : -1;   // (the redo below reuses the pinned block `hc` points at)
         int last_ok = f_hi;
         if (seq) {      // frames below the device's program counter are complete (it may be in the middle of the next solve)
@@ -652,6 +660,15 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
                 // step has run: the next window's launches go on with the solve (at PC_KMAX accepted iterations it stalls and is redone
                 // above).  Running the frame from the top here -- what rounds 2-4 did, "never expected" -- gave birth to the frame's
                 // newborns twice (found by scripts/stress_batch.py in round 5: a two-flow sequence whose one solve takes 8 iterations).
+                if (getenv("PSFM_TRACE")) {
+                    const PsfmCounters* hc = (const PsfmCounters*)c->host_pinned;
+                    unsigned tk[8] = {0};
+                    if (c->sol_fused.p) (void)hipMemcpy(tk, c->sol_fused.p, sizeof(tk), hipMemcpyDeviceToHost);
+                    fprintf(stderr, "[psfm %p] device-paced window without a completed frame: host frame %d, next launch %d; device pc {frame %d, phase %d, "
+                            "owner %d, K %d}, lanes %d (snapshots %d %d), stall %d, overflow %d, tickets %u %u %u %u\n", (void*)c, f, launch_id,
+                            hc->pc_frame, hc->pc_phase, hc->pc_owner, hc->solve_K, hc->n_lanes, hc->n_lanes_snap[0], hc->n_lanes_snap[1], hc->stall,
+                            hc->overflow, tk[0], tk[1], tk[2], tk[3]);
+                }
                 if (++idle_windows > 8) { psfm_set_error("psfm_track: the device-paced sequence made no progress in 8 windows (frame %d)", f); return PSFM_ERR_SOLVER; }
             } else {
                 idle_windows = 0;

@@ -139,7 +139,7 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
             if ((st = c->occ_own.ensure((size_t)P * (size_t)n_flows[i])) != PSFM_OK) return st;
             if (optimize) {
                 if ((st = c->occ2_own.ensure((size_t)P * (size_t)(n_flows[i] > 1 ? n_flows[i] - 1 : 1))) != PSFM_OK) return st;
-                if ((st = psfm_solve_prepare(c, D[i])) != PSFM_OK) return st;
+                if ((st = psfm_solve_prepare(c, D[i], s)) != PSFM_OK) return st;
             }
             c->solve_stats.clear();
             c->res_n_traj = c->res_n_points = 0;
@@ -317,6 +317,11 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
                     const PsfmCounters hc = *(const PsfmCounters*)(hpack + pack_row * (size_t)i);
                     const psfm_solve_stats* hw = (const psfm_solve_stats*)(hpack + pack_row * (size_t)i + sizeof(PsfmCounters));
                     const int n_i = n_flows[i];
+                    if ((hc.overflow & 7) != 0 || hc.n_lanes > D[i].cap) {      // (as psfm_track_impl's checkpoint: a full table ends the run here)
+                        psfm_set_error("capacity exceeded (sequence %d of the batch): lanes used %d of %lld, overflow bits %d; raise psfm_ctx_set_capacity",
+                                       i, hc.n_lanes, (long long)D[i].cap, hc.overflow);
+                        return PSFM_ERR_CAPACITY;
+                    }
                     if (hc.overflow & 16) {      // a launch covered fewer lanes than the sequence had in use: once more, with launches that cover the tables
                         *grid_too_small = true;
                         psfm_set_error("psfm_connect_batch: sequence %d uses more lanes (%d) than the trimmed launches cover (%lld)", i, hc.n_lanes, (long long)grid_lanes);

@@ -278,7 +278,7 @@ psfm_status psfm_launch_frame(psfm_ctx* c, const PsfmTrackDims& d, const float* 
 psfm_status psfm_launch_seq(psfm_ctx* c, const PsfmTrackDims& d, const float* flows, const uint8_t* occ, int64_t occ_pitch,
                             const float* flows_f2, const uint8_t* occ_s2, int n_launches, int launch_id0, hipStream_t s);
 psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
-psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d);   // every solver buffer of a sequence, up front
+psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);   // every solver buffer of a sequence, up front
 int psfm_solve_kmax(void);
 int psfm_resident_blocks(psfm_ctx* c);     // co-resident blocks of the resident solve on the context's device
 // track-sharded runs (psfm_shard.hip)

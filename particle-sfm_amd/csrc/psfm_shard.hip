@@ -61,7 +61,7 @@ extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, 
     if ((st = psfm_track_dims(c, n_flows, h, w, ratio, g1 - g0, d)) != PSFM_OK) return st;
     d.g0 = g0; d.Gband = g1 - g0; d.shard_maps = maps; d.shard_pitch = map_pitch;
     if ((st = psfm_track_alloc(c, d)) != PSFM_OK) return st;
-    if (optimize && (st = psfm_solve_prepare(c, d)) != PSFM_OK) return st;
+    if (optimize && (st = psfm_solve_prepare(c, d, (hipStream_t)stream)) != PSFM_OK) return st;
     c->solve_stats.clear();
     c->res_n_traj = c->res_n_points = 0;
     c->res_n_flows = n_flows;

@@ -1813,11 +1813,21 @@ int psfm_solve_kmax(void) { return PC_KMAX; }
 int psfm_resident_blocks(psfm_ctx* c) { return pc_resident_capacity<PC_RES_NS_MAX>(c); }
 
 // the chain steps of track_optimize capture the iterate-buffer pointer: allocate before the first one is enqueued
-psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d)
+psfm_status psfm_solve_prepare(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
 {
     psfm_status rc;
     if ((rc = pc_workspace(c, d.cap, PC_KMAX)) != PSFM_OK) return rc;
-    return c->sol_stats.ensure(sizeof(psfm_solve_stats) * (size_t)(d.n_flows + 1));
+    if ((rc = c->sol_stats.ensure(sizeof(psfm_solve_stats) * (size_t)(d.n_flows + 1))) != PSFM_OK) return rc;
+    // The fused solve's tickets, zero at the start of every sequence.  Every launch leaves them at zero -- unless a sequence runs into
+    // its lane capacity: its launches then count on more blocks than the grid has, never see their last arrival, and the tickets would
+    // stay mid-count for every later sequence of this context (round 5's stress: a capacity retry that made "no progress").
+    const int n_blocks = (int)((d.cap + PC_BLOCK - 1) / PC_BLOCK);
+    const int n_groups = (n_blocks + PC_GROUP - 1) / PC_GROUP;
+    const size_t tbytes = 4096 * sizeof(unsigned), gbytes = sizeof(double) * (size_t)n_groups * PC_KMAX * PC_NSUM;
+    if (n_groups + 1 > 4096) { psfm_set_error("psfm_track: lane table too large for the fused solve"); return PSFM_ERR_ARG; }
+    if ((rc = c->sol_fused.ensure(tbytes + gbytes)) != PSFM_OK) return rc;
+    PSFM_HIP(hipMemsetAsync(c->sol_fused.p, 0, tbytes, s));
+    return PSFM_OK;
 }
 
 // One frame's solve as ONE launch that speculates K Gauss-Newton iterations (psfm_pc_fused_kernel).  No host

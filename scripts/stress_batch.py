@@ -119,7 +119,23 @@ for b in range(n_batches):
                     print("      behind sequence %d (%s; its counters %s): %d / %d   %s" % (prev, kinds[prev], c0, len(R2.birth), len(R2.xy),
                                                                                          ctx.solver_counters()), flush=True)
     for k in range(B):
-        R = run_connect(*seqs[k], thres, r)
+        try:
+            R = run_connect(*seqs[k], thres, r)
+        except Exception as e:      # noqa: BLE001  (say which sequence, and whether the call fails again / in its other forms)
+            print("EXCEPTION: batch %d sequence %d (%s) %dx%d r=%d opt=%s thres=%.1f kinds=%s modes=%s: %s" % (b, k, kinds[k], H, W, r, opt, thres, kinds, modes, e))
+            ctx = _hip.context()
+            print("   counters", ctx.solver_counters())
+            for label, env in (("again", {}), ("host-paced frames", {"PSFM_SEQ": "0"}), ("again", {}), ("window of 4 frames", {"PSFM_CHECK_FRAMES": "4"})):
+                os.environ.update(env)
+                try:
+                    R2 = run_connect(*seqs[k], thres, r)
+                    print("   %-20s ok: %d / %d %s, equal to the batch's: %s" % (label, len(R2.birth), len(R2.xy), ctx.solver_counters(),
+                                                                               np.array_equal(R2.birth, got[k].birth) and np.array_equal(R2.length, got[k].length)))
+                except Exception as e2:      # noqa: BLE001
+                    print("   %-20s fails: %s" % (label, e2))
+                for q in env:
+                    del os.environ[q]
+            sys.exit(1)
         G = got[k]
         ok = np.array_equal(R.birth, G.birth) and np.array_equal(R.length, G.length) and np.array_equal(R.off, G.off)
         if ok and not opt:

@@ -43,8 +43,9 @@ def one_thread(tid, rounds, seed):
             readers = int(rng.integers(1, 17))
             damage = rng.random() < 0.15 and n >= 2
             if damage:
-                victim = os.path.join(d, "%05d.flo" % int(rng.integers(0, n)))
                 kind = int(rng.integers(0, 3))
+                # (a frame of another size: not the first file -- the stack's size IS the first file's, the refusal would name the second)
+                victim = os.path.join(d, "%05d.flo" % int(rng.integers(1 if kind == 2 else 0, n)))
                 raw = open(victim, "rb").read()
                 if kind == 0:
                     open(victim, "wb").write(raw[:max(12, len(raw) // 2)])

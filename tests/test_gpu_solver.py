@@ -300,6 +300,35 @@ def test_solve_that_outlasts_the_launches_of_its_window(pt, mode, k, batch):
            [(s["iterations"], s["successful_steps"], s["termination"]) for s in O.solves]
 
 
+def test_lane_table_full_inside_a_device_paced_window(pt):
+    """A sequence that outgrows its lane table (a 17 x 15 grid whose lanes creep past twice the grid in 24 frames) inside a device-paced
+    window: the fused launch behind that point counts on blocks the grid does not have -- it never sees its last arrival, raises no stall
+    flag and left its tickets mid-count for every later sequence of the context (found by scripts/stress_batch.py, seed 54).  The
+    checkpoint now ends such a run with PSFM_ERR_CAPACITY (run_connect raises the capacity and runs it again) and every sequence starts
+    with its tickets at zero: the sequence equals the oracle, and so does the next one on the same context."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    import ctypes
+    import torch
+    ctx = _hip.context()
+    for seed, T in ((88003367, 25), (494952463, 7)):
+        d = psfm_synth.synth_sequence(T, 34, 30, seed=seed, sigma=0.03, n_occluders=0, stride2=True)
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 3.0)
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 3.0)
+        O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, 2)
+        dev = {k2: torch.from_numpy(np.stack(d[k2])).cuda() for k2 in ("flows_f", "flows_b", "flows_f2", "flows_b2")}
+        if T == 25:      # the call itself, with the default tables: a capacity error, not a solver error and not a wrong result
+            ctx.set_capacity(2.0, 8.0)
+            info = _hip.TrackInfo()
+            st = _hip.lib().psfm_connect(ctx.handle, _hip.ptr(dev["flows_f"]), _hip.ptr(dev["flows_b"]), _hip.ptr(dev["flows_f2"]),
+                                         _hip.ptr(dev["flows_b2"]), T - 1, 34, 30, 3.0, 2, None, None, ctypes.byref(info),
+                                         _hip.current_stream_ptr(ctx.device))
+            assert st == _hip.PSFM_ERR_CAPACITY, (st, _hip.lib().psfm_last_error())
+        R = pt.trajectory.run_connect(dev["flows_f"], dev["flows_b"], dev["flows_f2"], dev["flows_b2"], 3.0, 2)
+        assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length) and float(np.abs(R.xy - O.xy).max()) <= TOL
+        assert [(q["iterations"], q["termination"]) for q in R.solve_stats] == [(q["iterations"], q["termination"]) for q in O.solves]
+
+
 def test_track_optimize_full_size_properties(pt):
     """configs[3]/[4] shapes with fewer frames: 1080p r=2 and 480x640 r=1 (dense), full path-consistency optimise.
     Size-independent invariants + the first frames against the oracle."""
