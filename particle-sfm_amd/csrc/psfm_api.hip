@@ -36,7 +36,7 @@ void psfm_gate_waiters_add(int device, int d) { g_dev_waiters[device & 15].fetch
 // VALU-issue peak), 1.3x at ScanNet size (a dense 307 k grid already fills the block slots once) -- profiles/r05.
 static int psfm_wants_persist(psfm_ctx* c, bool optimize, int h, int w, int ratio, bool fused)
 {
-    if (c->chain_mode == 1 || ratio < 1 || h < 2 || w < 2) return 0;
+    if (c->chain_mode == 1 || ratio < 1 || !psfm_frame_ok(h, w)) return 0;
     // track_optimize: no persistent frame loop, but solves that reject steps run their trust-region loop as one persistent
     // launch (psfm_pc_resident_kernel) when the call has the device to itself -- take the gate if it is free.  A context with a
     // resident budget runs those launches on its share of the device's block slots beside other contexts': shared gate
@@ -277,7 +277,7 @@ extern "C" psfm_status psfm_flow_check(psfm_ctx* c, const float* flows_f, const 
 {
     PSFM_CHECK_CTX(c);
     PsfmGate gate(c->device, 0);
-    if (n_pairs < 0 || h < 2 || w < 2 || (n_pairs > 0 && (!flows_f || !flows_b || !occ_out))) {
+    if (n_pairs < 0 || !psfm_frame_ok(h, w) || (n_pairs > 0 && (!flows_f || !flows_b || !occ_out))) {
         psfm_set_error("psfm_flow_check: bad argument (n_pairs=%d h=%d w=%d)", n_pairs, h, w);
         return PSFM_ERR_ARG;
     }
@@ -293,7 +293,7 @@ extern "C" psfm_status psfm_grid_sample(psfm_ctx* c, const float* map_hwc, int c
 {
     PSFM_CHECK_CTX(c);
     PsfmGate gate(c->device, 0);
-    if ((ch != 1 && ch != 2) || h < 2 || w < 2 || n < 0 || (n > 0 && (!map_hwc || !xy || !out))) {
+    if ((ch != 1 && ch != 2) || !psfm_frame_ok(h, w) || n < 0 || (n > 0 && (!map_hwc || !xy || !out))) {
         psfm_set_error("psfm_grid_sample: bad argument (c=%d h=%d w=%d n=%lld)", ch, h, w, (long long)n);
         return PSFM_ERR_ARG;
     }
@@ -311,7 +311,7 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
     c->pc_persist_ok = gate.exclusive || c->resident_budget > 0;
     c->pc_giveups = 0;
     c->n_resident = c->n_iter_launches = 0;
-    if (n < 0 || h < 2 || w < 2 || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
+    if (n < 0 || !psfm_frame_ok(h, w) || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || !out))) {
         psfm_set_error("psfm_optimize_location: bad argument (n=%lld h=%d w=%d)", (long long)n, h, w);
         return PSFM_ERR_ARG;
     }
@@ -409,7 +409,7 @@ static psfm_status psfm_track_impl(psfm_ctx* c, const float* flows, const uint8_
     // psfm_shard_* call on the context reports "no sharded run in progress" instead of stepping foreign state)
     psfm_shard_abandon(c);
     const bool optimize = flows_f2 != nullptr;
-    if (n_flows < 1 || h < 2 || w < 2 || ratio < 1 || !flows || !occ || (optimize && !occ_s2 && n_flows > 1)) {
+    if (n_flows < 1 || !psfm_frame_ok(h, w) || ratio < 1 || !flows || !occ || (optimize && !occ_s2 && n_flows > 1)) {
         psfm_set_error("psfm_track: bad argument (n_flows=%d h=%d w=%d ratio=%d)", n_flows, h, w, ratio);
         return PSFM_ERR_ARG;
     }
@@ -752,7 +752,7 @@ extern "C" psfm_status psfm_connect(psfm_ctx* c, const float* flows_f, const flo
     PSFM_CHECK_CTX(c);
     const bool optimize = flows_f2 != nullptr;
     PsfmGate gate(c->device, psfm_wants_persist(c, optimize, h, w, ratio, true));
-    if (n_flows < 1 || h < 2 || w < 2 || !flows_f || !flows_b || (optimize && n_flows > 1 && !flows_b2)) {
+    if (n_flows < 1 || !psfm_frame_ok(h, w) || !flows_f || !flows_b || (optimize && n_flows > 1 && !flows_b2)) {
         psfm_set_error("psfm_connect: bad argument (n_flows=%d h=%d w=%d)", n_flows, h, w);
         return PSFM_ERR_ARG;
     }

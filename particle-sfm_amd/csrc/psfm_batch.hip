@@ -67,7 +67,7 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
                                           const float* const* flows_f2, const float* const* flows_b2, const int* n_flows, int h, int w,
                                           float thres, int ratio, psfm_track_info* infos, void* stream)
 {
-    if (!ctxs || n_seq < 1 || n_seq > PSFM_BATCH_MAX || !flows_f || !flows_b || !n_flows || h < 2 || w < 2 || ratio < 1 || ratio > 64 ||
+    if (!ctxs || n_seq < 1 || n_seq > PSFM_BATCH_MAX || !flows_f || !flows_b || !n_flows || !psfm_frame_ok(h, w) || ratio < 1 || ratio > 64 ||
         ((flows_f2 == nullptr) != (flows_b2 == nullptr))) {
         psfm_set_error("psfm_connect_batch: bad argument (n_seq=%d of at most %d, h=%d w=%d sample_ratio=%d)", n_seq, PSFM_BATCH_MAX, h, w, ratio);
         return PSFM_ERR_ARG;

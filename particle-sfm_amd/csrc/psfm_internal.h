@@ -19,6 +19,11 @@ void psfm_set_error(const char* fmt, ...);
         }                                                                                       \
     } while (0)
 
+// A frame size every kernel can address: the samplers reach a map as base + a 32-bit BYTE offset (psfm_device.h: "every map / table
+// here is < 4 GB"), so the largest per-frame map -- (H,W,2) f32 = 8 H W bytes -- must stay below 2^32 (H W < 2^29: 23170 x 23170;
+// a 1080p frame is 2^21).  Every entry point that takes h, w checks this first (PSFM_ERR_ARG), none wraps silently.
+static inline bool psfm_frame_ok(int h, int w) { return h >= 2 && w >= 2 && (int64_t)h * (int64_t)w * 8 < ((int64_t)1 << 32); }
+
 // Per device and process: every entry point that launches kernels or copies holds this gate SHARED; the persistent frame
 // loop needs it EXCLUSIVE.  All blocks of that kernel must be resident at once, and with another queue feeding the device
 // they may never be (measured: a second host thread running psfm_connect alongside stalls the loop until its spin limit)

@@ -38,7 +38,7 @@ extern "C" psfm_status psfm_shard_begin(psfm_ctx* c, int n_flows, int h, int w, 
     if (!c) { psfm_set_error("ctx is NULL"); return PSFM_ERR_ARG; }
     PSFM_HIP(hipSetDevice(c->device));
     PsfmGate gate(c->device, 0);
-    if (n_flows < 1 || h < 2 || w < 2 || ratio < 1 || ratio > 64 || !maps) {
+    if (n_flows < 1 || !psfm_frame_ok(h, w) || ratio < 1 || ratio > 64 || !maps) {
         psfm_set_error("psfm_shard_begin: bad argument (n_flows=%d h=%d w=%d ratio=%d)", n_flows, h, w, ratio);
         return PSFM_ERR_ARG;
     }

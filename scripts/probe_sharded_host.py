@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
     sys.path.insert(0, p)
 import torch
-import bench
+import bench_common as bench
+import bench_extras
 import psfm_dist
 import psfm_synth
 from point_trajectory.shard import HipShardEngine, flow_check_slice

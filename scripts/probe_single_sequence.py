@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "particle-sfm_amd")):
     sys.path.insert(0, p)
 import torch
-import bench
+import bench_common as bench
+import bench_extras
 
 import gc
 if os.environ.get("PSFM_PROBE_GC") == "freeze":      # everything imported so far out of the collector's way (what bench.py does)
@@ -30,7 +31,7 @@ elif os.environ.get("PSFM_PROBE_GC") == "log":
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 201
 hard = len(sys.argv) > 2 and sys.argv[2] == "hard"       # psfm_synth.HARD: every solve rejects steps -> the engine's redo path
 import psfm_synth
-out = bench.single_sequence_sharded(torch.device("cuda", 0), 0, 1, frames, reps=1 if hard else 3, flows_dist=psfm_synth.HARD if hard else None)
+out = bench_extras.single_sequence_sharded(torch.device("cuda", 0), 0, 1, frames, reps=1 if hard else 3, flows_dist=psfm_synth.HARD if hard else None)
 print(json.dumps({k: out.get(k) for k in ("ms_per_sequence", "one_gpu_psfm_connect_ms_per_sequence", "counts_equal_one_gpu",
                                           "solver_counters", "solver_launches", "ms_per_sequence_exchange_form",
                                           "trust_region_iterations", "solves")} |

@@ -288,9 +288,13 @@ def test_bench_multi_rank_control_flow_dry_run_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "11",
                         "--single-seq-frames", "13"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert r.stdout.strip().splitlines()[-1].startswith("{") and len(r.stdout.strip().splitlines()[-1]) < 4096
+    line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "dryrun" in line and line["value"] > 0
-    ranks = line["config"]["ranks"]
+    assert line["config"]["world_size"] == 2 and line["config"]["backend"] == "gloo" and len(line["config"]["points_per_rank"]) == 2
+    assert line["extras"]["one_seq_400f_opt"]["world"] == 2 and line["extras"]["one_seq_400f_opt"]["ms"] > 0
+    full = json.load(open(os.path.join(ROOT, line["extras_file"])))          # the full record: beside bench.py, never in the line
+    ranks = full["ranks"]
     assert ranks["world_size"] == 2 and ranks["backend"] == "gloo" and [q["rank"] for q in ranks["per_rank"]] == [0, 1]
-    ss = line["single_sequence"]
+    ss = full["single_sequence"]
     assert ss["world_size"] == 2 and ss["trajectories"] > 0 and 0 < ss["local_trajectories_rank0"] < ss["trajectories"]
