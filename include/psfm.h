@@ -165,6 +165,15 @@ psfm_status psfm_optimize_location(psfm_ctx* ctx, const double* uv12, const doub
                                    const double* scale, const float* flow12, int64_t n, int w, int h,
                                    double* out, psfm_solve_stats* stats_host, void* stream);
 
+/* optimize/src/path_consistency_cost.h:42-59 + linear_interpolation.h:97-123 (over ceres::Grid2D's clamp-to-edge GetValue): what
+ * ceres::AutoDiffCostFunction<PathConsistencyError, 6, 4>::Evaluate returns for each of the n residual blocks of
+ * trajectory_optimize.cpp:56-65 at uv12 -- residuals (n,6) and jacobians (n,6,4) row-major, f64; either may be NULL.  The arithmetic is
+ * the one the solver kernels run (csrc/psfm_pc_core.h); exported so that it can be checked without a solve around it.  Asynchronous on
+ * `stream`. */
+psfm_status psfm_path_consistency_eval(psfm_ctx* ctx, const double* uv12, const double* ref1, const double* ref2,
+                                       const double* scale, const float* flow12, int64_t n, int w, int h,
+                                       double* residuals, double* jacobians, void* stream);
+
 /* track.py:24-50 when flows_f2 == NULL, track_optimize.py:24-53 otherwise.
  *   flows    (n_flows,H,W,2) f32      occ     (n_flows,H,W) u8
  *   flows_f2 (n_flows-1,H,W,2) f32    occ_s2  (n_flows-1,H,W) u8        (stride-2 stacks)

@@ -161,6 +161,23 @@ def optimize_location(uv12, ref1, ref2, scale, flow12_map, total_num=None, width
     return (out, st.as_dict()) if return_stats else out
 
 
+def path_consistency_eval(uv12, ref1, ref2, scale, flow12_map):
+    """path_consistency_cost.h:42-59 as AutoDiffCostFunction<.., 6, 4> evaluates it: residuals (n,6), Jacobians (n,6,4)."""
+    uv12 = np.ascontiguousarray(uv12, np.float64).reshape(-1, 4)
+    n = uv12.shape[0]
+    ref1 = np.ascontiguousarray(ref1, np.float64).reshape(n, 2)
+    ref2 = np.ascontiguousarray(ref2, np.float64).reshape(n, 2)
+    scale = np.ascontiguousarray(scale, np.float64).reshape(n)
+    fm = _f32(flow12_map)
+    H, W = fm.shape[:2]
+    res, jac = np.empty((n, 6), np.float64), np.empty((n, 6, 4), np.float64)
+    L = lib()
+    L.orc_path_consistency_eval.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_path_consistency_eval.restype = None
+    L.orc_path_consistency_eval(_ptr(uv12), _ptr(ref1), _ptr(ref2), _ptr(scale), _ptr(fm), n, W, H, _ptr(res), _ptr(jac))
+    return res, jac
+
+
 class TrackResult:
     """All trajectories in full_trajs order (index == saved id) as CSR arrays."""
 

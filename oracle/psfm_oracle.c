@@ -291,6 +291,25 @@ static inline void orc_build_js(const double* jac, double s, const double* S, or
     J->a[5][0] = jac[2] * S[0]; J->a[5][1] = jac[3] * S[1]; J->a[5][3] = 1.0 * S[3];
 }
 
+/* The residual blocks of trajectory_optimize.cpp:56-65 evaluated at uv12 the way AutoDiffCostFunction<PathConsistencyError, 6, 4>
+ * hands them to Ceres: residuals (n,6), jacobians (n,6,4) row-major.  For tests that hold orc_pc_eval against an independent
+ * differentiation of the functor (tests/test_pc_eval_autograd.py). */
+ORC_API void orc_path_consistency_eval(const double* uv12, const double* ref1, const double* ref2, const double* scale,
+                                       const float* flow12, int64_t n, int W, int H, double* res, double* jac)
+{
+    orc_grid_t g = { flow12, H, W };
+    for (int64_t i = 0; i < n; ++i) {
+        double r[6], j[4];
+        orc_pc_eval(&g, uv12 + 4 * i, ref1 + 2 * i, ref2 + 2 * i, scale[i], r, j);
+        for (int k = 0; k < 6; ++k) res[6 * i + k] = r[k];
+        double* J = jac + 24 * i;
+        for (int k = 0; k < 24; ++k) J[k] = 0.0;
+        J[0] = 1.0; J[5] = 1.0; J[10] = scale[i]; J[15] = scale[i];
+        J[16] = j[0]; J[17] = j[1]; J[18] = 1.0;
+        J[20] = j[2]; J[21] = j[3]; J[23] = 1.0;
+    }
+}
+
 #define ORC_CHUNK 2048   /* tracks per summation chunk (see orc_optimize_location) */
 
 /* Track-sharded runs (tests of psfm_dist.connect_sharded: the tracks of ONE sequence split over several processes):

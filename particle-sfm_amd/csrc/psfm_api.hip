@@ -325,6 +325,19 @@ extern "C" psfm_status psfm_optimize_location(psfm_ctx* c, const double* uv12, c
     return rc;
 }
 
+extern "C" psfm_status psfm_path_consistency_eval(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
+                                                  const double* scale, const float* flow12, int64_t n, int w, int h,
+                                                  double* residuals, double* jacobians, void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    PsfmGate gate(c->device, 0);
+    if (n < 0 || n > 0x3fffffff || !psfm_frame_ok(h, w) || (n > 0 && (!uv12 || !ref1 || !ref2 || !scale || !flow12 || (!residuals && !jacobians)))) {
+        psfm_set_error("psfm_path_consistency_eval: bad argument (n=%lld h=%d w=%d)", (long long)n, h, w);
+        return PSFM_ERR_ARG;
+    }
+    return psfm_launch_pc_eval(uv12, ref1, ref2, scale, flow12, n, w, h, residuals, jacobians, (hipStream_t)stream);
+}
+
 // Sizes of one run of the frame recurrence.  g_own < 0: the whole stride-r grid; otherwise the number of grid points whose
 // births this process owns (track-sharded runs): lane / record tables are sized for those, keys for the whole grid.
 psfm_status psfm_track_dims(psfm_ctx* c, int n_flows, int h, int w, int ratio, int64_t g_own, PsfmTrackDims& d)

@@ -296,6 +296,8 @@ psfm_status psfm_solve_state(psfm_ctx* c, int* done, int* stall, psfm_solve_stat
 psfm_status psfm_solve_restore(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 // Batch API form (psfm_optimize_location).
+psfm_status psfm_launch_pc_eval(const double* uv12, const double* ref1, const double* ref2, const double* scale, const float* flow12,
+                                int64_t n, int w, int h, double* res, double* jac, hipStream_t s);
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
                              const double* scale, const float* flow12, int64_t n, int w, int h, double* out,
                              psfm_solve_stats* st, hipStream_t s);

@@ -2148,6 +2148,42 @@ psfm_status psfm_solve_flush(psfm_ctx* c, const PsfmTrackDims& d, int frame, hip
     return PSFM_OK;
 }
 
+// path_consistency_cost.h:42-59 as ceres::AutoDiffCostFunction<PathConsistencyError, 6, 4>::Evaluate sees it, one residual block per
+// thread: the six residuals and the 6 x 4 Jacobian (row-major, like Ceres' jacobians[0]) at uv12 -- through the SAME pc_core_eval the
+// solver kernels call, written out in full so that a test can hold it against the functor differentiated by an independent mechanism
+// (tests/test_pc_eval_autograd.py: f64 torch.autograd of the reference's formulas as written).
+__global__ void __launch_bounds__(PC_BLOCK) psfm_pc_eval_kernel(const double* __restrict__ uv12, const double* __restrict__ ref1,
+                                                                const double* __restrict__ ref2, const double* __restrict__ scale,
+                                                                const float2* __restrict__ flow12, long long n, int W, int H,
+                                                                double* __restrict__ res, double* __restrict__ jac)
+{
+    const long long i = (long long)blockIdx.x * PC_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double x[4] = {uv12[4 * i], uv12[4 * i + 1], uv12[4 * i + 2], uv12[4 * i + 3]};
+    const double s = scale[i];
+    double r[6], j[4];
+    pc_core_eval<true>((const PcF2*)flow12, H, W, x, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+    if (res) for (int k = 0; k < 6; ++k) res[6 * i + k] = r[k];
+    if (jac) {
+        double* J = jac + 24 * i;
+        for (int k = 0; k < 24; ++k) J[k] = 0.0;
+        J[0] = 1.0; J[5] = 1.0; J[10] = s; J[15] = s;              // d r0 / d x0, d r1 / d x1, d r2 / d x2, d r3 / d x3
+        J[16] = j[0]; J[17] = j[1]; J[18] = 1.0;                   // r4 = (x2 - x0) - F12.x(row = x1, col = x0)
+        J[20] = j[2]; J[21] = j[3]; J[23] = 1.0;                   // r5 = (x3 - x1) - F12.y
+    }
+}
+
+psfm_status psfm_launch_pc_eval(const double* uv12, const double* ref1, const double* ref2, const double* scale, const float* flow12,
+                                int64_t n, int w, int h, double* res, double* jac, hipStream_t s)
+{
+    if (n == 0) return PSFM_OK;
+    const unsigned nb = (unsigned)((n + PC_BLOCK - 1) / PC_BLOCK);
+    hipLaunchKernelGGL(psfm_pc_eval_kernel, dim3(nb), dim3(PC_BLOCK), 0, s, uv12, ref1, ref2, scale, (const float2*)flow12,
+                       (long long)n, w, h, res, jac);
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
+}
+
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,
                              const double* scale, const float* flow12, int64_t n, int w, int h, double* out,
                              psfm_solve_stats* st, hipStream_t s)

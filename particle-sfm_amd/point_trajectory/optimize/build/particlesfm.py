@@ -50,6 +50,28 @@ def optimize_location(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map, total_num,
     return out.cpu().numpy()
 
 
+def path_consistency_eval(uv12, uv_ref1, uv_ref2, ref2_scale, flow12_map):
+    """path_consistency_cost.h:42-59: residuals (N,6) and Jacobians (N,6,4) of the N residual blocks trajectory_optimize.cpp:56-65
+    adds, at uv12 -- psfm_path_consistency_eval (the solver kernels' own arithmetic, without a solve around it).  Not part of the
+    reference's module; there for verification."""
+    import torch
+    from ... import _hip
+    ctx = _hip.context()
+    dev = torch.device("cuda", ctx.device)
+    uv = torch.from_numpy(np.ascontiguousarray(np.asarray(uv12, np.float64).reshape(-1, 4))).to(dev)
+    n = uv.shape[0]
+    r1 = torch.from_numpy(np.ascontiguousarray(np.asarray(uv_ref1, np.float64).reshape(n, 2))).to(dev)
+    r2 = torch.from_numpy(np.ascontiguousarray(np.asarray(uv_ref2, np.float64).reshape(n, 2))).to(dev)
+    sc = torch.from_numpy(np.ascontiguousarray(np.asarray(ref2_scale, np.float64).reshape(n))).to(dev)
+    fm = torch.from_numpy(np.ascontiguousarray(np.asarray(flow12_map, np.float32))).to(dev)
+    H, W = int(fm.shape[0]), int(fm.shape[1])
+    res = torch.empty((n, 6), dtype=torch.float64, device=dev)
+    jac = torch.empty((n, 6, 4), dtype=torch.float64, device=dev)
+    _hip.check(_hip.lib().psfm_path_consistency_eval(ctx.handle, _hip.ptr(uv), _hip.ptr(r1), _hip.ptr(r2), _hip.ptr(sc), _hip.ptr(fm),
+                                                     n, W, H, _hip.ptr(res), _hip.ptr(jac), _hip.current_stream_ptr(ctx.device)))
+    return res.cpu().numpy(), jac.cpu().numpy()
+
+
 class Trajectory:
     """optimize/src/trajectory_base.h:35-60.  Constructors (bindings.cc:34-37):
     Trajectory(time, point, *, buffer_size=0) | Trajectory(times, xys, *, labels=[]) | Trajectory(dict)."""

@@ -53,3 +53,23 @@ extern "C" void pc_host_taps(long n, const double* x, const float* flow, int H, 
         o[4] = t.p10.x; o[5] = t.p10.y; o[6] = t.p11.x; o[7] = t.p11.y;
     }
 }
+
+// residuals (n,6) and Jacobians (n,6,4) of the residual blocks at x, through pc_core_eval (PAIR taps when pair != 0): what
+// psfm_pc_eval_kernel writes on the device (tests/test_pc_eval_autograd.py)
+extern "C" void pc_host_eval(long n, const double* x, const double* ref1, const double* ref2, const double* scale, const float* flow,
+                             int H, int W, int pair, double* res, double* jac)
+{
+    const PcF2* F = (const PcF2*)flow;
+    for (long i = 0; i < n; ++i) {
+        double r[6], j[4];
+        const double s = scale[i];
+        if (pair) pc_core_eval<true>(F, H, W, x + 4 * i, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+        else pc_core_eval<false>(F, H, W, x + 4 * i, ref1[2 * i], ref1[2 * i + 1], ref2[2 * i], ref2[2 * i + 1], s, r, j);
+        for (int k = 0; k < 6; ++k) res[6 * i + k] = r[k];
+        double* J = jac + 24 * i;
+        for (int k = 0; k < 24; ++k) J[k] = 0.0;
+        J[0] = 1.0; J[5] = 1.0; J[10] = s; J[15] = s;
+        J[16] = j[0]; J[17] = j[1]; J[18] = 1.0;
+        J[20] = j[2]; J[21] = j[3]; J[23] = 1.0;
+    }
+}

@@ -18,6 +18,10 @@ from _common import solver_batch, SOLVER_BATCHES
 import psfm_synth
 
 SO = os.environ.get("PSFM_REF_PARTICLESFM_SO", "")
+if not SO:      # a module dropped into oracle/_ref/ (BUILD.md step 3) is found without the variable
+    import glob
+    _found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "particlesfm*.so")))
+    SO = _found[0] if _found else ""
 pytestmark = pytest.mark.skipif(not (SO and os.path.isfile(SO)),
                                 reason="real reference module not available (set PSFM_REF_PARTICLESFM_SO, see oracle/_ref/BUILD.md)")
 TOL = 1e-4
@@ -42,6 +46,25 @@ def test_real_ceres_vs_both_restatements(H, W, n, seed, sigma, kink):
     out_n, _ = ct.optimize_location(uv, ref1, ref2, scale, flow12, n, W, H)
     assert float(np.abs(out_r - out_c).max()) <= TOL
     assert float(np.abs(out_r - out_n).max()) <= TOL
+
+
+def test_real_ceres_on_the_hand_derived_cases():
+    """tests/test_ceres_hand_cases.py's three solves through the real module: the derived positions (the summary is not returned by
+    trajectory_optimize.cpp:84-95, so iterations / termination cannot be read -- the positions after 2 / 5 / 0 iterations can)."""
+    import test_ceres_hand_cases as hc
+    real = _real_module()
+
+    def engine(uv12, ref1, ref2, scale, flow):
+        n = len(uv12)
+        out = np.asarray(real.optimize_location(uv12, ref1, ref2, scale, flow.astype(np.float64), n, flow.shape[1], flow.shape[0]))
+        _, st = hc.run_numpy(uv12, ref1, ref2, scale, flow)      # (decisions: from the restatement, positions: from real Ceres)
+        return out, st
+
+    for near in (False, True):
+        hc.test_linear_problem_one_gauss_newton_step_then_a_tolerance(engine, near)
+    for n in (1, 4):
+        hc.test_radius_binds_three_times_then_gauss_newton(engine, n)
+    hc.test_zero_gradient_start_ends_at_iteration_zero(engine)
 
 
 def test_which_reading_of_ceres_the_real_module_agrees_with(capsys):
