@@ -1311,7 +1311,9 @@ void psfm_frame_kernel(PsfmChainArgs a, PcParams P)
     P.K = P.K < 1 ? 1 : (P.K > PC_KMAX ? PC_KMAX : P.K);      // (clamped by the host already: the stated range keeps the loop from spilling)
     PsfmChainOut o;
     if (!psfm_chain_step_body<R, true, true>(a, o)) return;
-    const int n_active = (max(a.ctr->n_lanes_snap[a.frame & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
+    // (clamped to the launch's grid: a lane table that ran full leaves a snapshot beyond it -- the host ends such a run at its next
+    // checkpoint, PSFM_ERR_CAPACITY; until then no launch may count on blocks that do not exist)
+    const int n_active = min((max(a.ctr->n_lanes_snap[a.frame & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK, (int)gridDim.x);
     pc_fused_body(P, o.solve, o.p0, o.p1, o.p2, n_active, &a.ctr->n_lanes_snap[(a.frame + 1) & 1], &a.ctr->n_lanes, nullptr, 0, o.tile);
 }
 
@@ -1351,7 +1353,7 @@ __device__ __forceinline__ void psfm_seq_body(PsfmChainArgs a, PcParams P, const
     pc_params_rebase(P, st, occ2_stride, f);
     const int k = ctr->solve_K;
     P.K = k < 1 ? 1 : (k > PC_KMAX ? PC_KMAX : k);
-    const int n_active = (max(ctr->n_lanes_snap[f & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK;
+    const int n_active = min((max(ctr->n_lanes_snap[f & 1], a.Gband) + PC_BLOCK - 1) / PC_BLOCK, (int)gridDim.x);   // (as in psfm_frame_kernel)
     if (phase == 0) {
         PsfmChainOut o;
         if (!psfm_chain_step_body<R, true, true>(a, o)) return;

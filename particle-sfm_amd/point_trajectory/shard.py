@@ -42,6 +42,12 @@ class HipShardEngine:
         self._pending = []
         self._release_budget()
 
+    def grow_tables(self):
+        """psfm_dist.connect_sharded, after some rank reported PSFM_ERR_CAPACITY: the next run of this engine gets twice the lanes and
+        four times the trajectory records (the factors run_connect uses for the one-GPU call); kept for the engine's later sequences"""
+        self._lane_f, self._traj_f = getattr(self, "_lane_f", 2.0) * 2.0, getattr(self, "_traj_f", 8.0) * 4.0
+        self.ctx.set_capacity(self._lane_f, self._traj_f)
+
     def _release_budget(self):
         if self._own_budget:
             self.ctx.set_resident_budget(0)

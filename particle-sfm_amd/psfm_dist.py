@@ -348,18 +348,47 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
     # ---- Stage B: the recurrence, tracks split by birth row band ----
     # n_flows_total given: the four stacks are owned by Stage A's frame-pair shards (every rank passed its slice only); the
     # forward stacks reach the other ranks frame by frame, broadcast from their owner two frames ahead of the recurrence
-    wf = FrameWindow(flows_f, n_flows, comm) if owned else None
-    w2 = FrameWindow(flows_f2, n2, comm) if owned and optimize and n2 > 0 else None
     g0, g1 = band_range(GH, GW, rank, world)
     if hasattr(engine, "set_local"):     # one rank: nothing of a solve is exchanged -- rejecting solves take the one-GPU call's forms
         engine.set_local(world == 1)
-    engine.begin(n_flows, H, W, r, g0, g1, optimize)
+    # A rank whose lane / record tables run full learns it when it finalizes (PSFM_ERR_CAPACITY from psfm_shard_finish: the launches behind
+    # an overflow are harmless by themselves, csrc/psfm_solver.hip clamps what they count on).  That is behind the last collective of the
+    # recurrence, so the ranks can agree on it: every rank reports, and if ANY table was too small ALL of them run Stage B again with
+    # the tables doubled / quadrupled -- what run_connect does for the one-GPU call (trajectory.py), collectively.
+    for attempt in range(6):
+        wf = FrameWindow(flows_f, n_flows, comm) if owned else None
+        w2 = FrameWindow(flows_f2, n2, comm) if owned and optimize and n2 > 0 else None
+        engine.begin(n_flows, H, W, r, g0, g1, optimize)
+        try:
+            return _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, GW, optimize, owned, wf, w2, g0, g1, keep_on_device)
+        except _CapacityRetry:
+            if hasattr(engine, "abort"):
+                engine.abort()
+            if attempt == 5 or not hasattr(engine, "grow_tables"):
+                raise RuntimeError("connect_sharded: lane / trajectory tables still too small after %d enlargements" % attempt)
+            engine.grow_tables()
+        except BaseException:
+            if hasattr(engine, "abort"):         # (gives back what the engine took for the run: enqueued solves, its resident budget)
+                engine.abort()
+            raise
+
+
+class _CapacityRetry(Exception):
+    """some rank's tables ran full: every rank leaves Stage B with this and runs it again with larger ones"""
+
+
+def _finish_agreed(engine, comm, fn):
+    """fn() = the engine's finalize on this rank; PSFM_ERR_CAPACITY there is shared with the other ranks before anybody goes on"""
+    out, full = None, 0
     try:
-        return _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, GW, optimize, owned, wf, w2, g0, g1, keep_on_device)
-    except BaseException:
-        if hasattr(engine, "abort"):         # (gives back what the engine took for the run: enqueued solves, its resident budget)
-            engine.abort()
-        raise
+        out = fn()
+    except RuntimeError as e:
+        if getattr(e, "status", None) != 3:      # (_hip.PSFM_ERR_CAPACITY; the CPU engines of the gloo tests have no tables to overflow)
+            raise
+        full = 1
+    if any(comm.all_gather_object(full)) if comm.world > 1 else full:
+        raise _CapacityRetry()
+    return out
 
 
 def _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, GW, optimize, owned, wf, w2, g0, g1, keep_on_device):
@@ -422,12 +451,12 @@ def _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, G
                 w2.release_below(keep)
         t += 1
     if keep_on_device:      # the trajectories stay in the engine's HBM (psfm_result_device); only their ids are formed
-        info, keys = engine.finish_device(r, W)
+        info, keys = _finish_agreed(engine, comm, lambda: engine.finish_device(r, W))
         ids, n_traj = global_ids_device(keys, comm)
         return {"info": info, "ids": ids, "n_traj": n_traj, "n_points_local": int(info.n_points), "n_solves": int(info.n_solves),
                 "solver_iterations": int(info.solver_iterations), "occ": occ, "occ2": occ2, "band": (g0, g1),
                 "frames_read_from_own_slice": (sorted(wf.touched) if owned else None)}
-    birth, length, off, xy, stats = engine.finish()
+    birth, length, off, xy, stats = _finish_agreed(engine, comm, engine.finish)
     first = xy[off[:-1]] if len(birth) else np.zeros((0, 2))
     ids, n_traj = global_ids(birth, length, first, n_flows, r, GW, comm=comm)
     return {"birth": birth, "length": length, "off": off, "xy": xy, "ids": ids, "n_traj": n_traj, "solve_stats": stats,

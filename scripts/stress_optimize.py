@@ -53,3 +53,4 @@ for k in range(n_cases):
                           "rejected_steps": rejected, "seconds": round(time.time() - t0, 1)}), flush=True)
 print(json.dumps({"cases": n_cases, "mismatches": bad, "bit_equal": exact, "max_abs_dxy_px": worst, "trust_region_iterations": iters,
                   "rejected_steps": rejected, "seconds": round(time.time() - t0, 1)}))
+sys.exit(1 if bad else 0)

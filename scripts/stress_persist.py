@@ -44,3 +44,4 @@ for i in range(n_cases):
                 i, key, T, H, W, r, sigma, nocc, seed, len(A), len(B), out[("c", 1)][1], out[key][1]))
 ctx.set_chain_mode(0)
 print("%d cases, %d mismatches, %.1f s" % (n_cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)

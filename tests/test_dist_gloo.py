@@ -128,6 +128,39 @@ def _sharded_worker(rank, world, port, ret):
         Bd, Ld, Od, XYd = psfm_dist.gather_result({"birth": b_, "length": l_, "off": o_, "xy": xy_, "ids": ids, "n_traj": n})
         O = orc.track(d["flows_f"], occ, r)
         out["alldie"] = bool(n == O.n_traj and np.array_equal(Bd, O.birth) and np.array_equal(Ld, O.length) and np.array_equal(XYd, O.xy))
+        # a rank whose tables run full (PSFM_ERR_CAPACITY when it finalizes): ALL ranks run Stage B again with larger tables
+        class FullOnce(orc.ShardEngine):
+            def __init__(self, full_on_rank):
+                super().__init__()
+                self.full, self.grown, self.begun = (rank == full_on_rank), 0, 0
+
+            def begin(self, *a):
+                self.begun += 1
+                return super().begin(*a)
+
+            def grow_tables(self):
+                self.grown += 1
+
+            def finish(self):
+                if self.full:
+                    self.full = False
+                    super().finish()
+                    e = RuntimeError("libpsfm_hip status 3: lane table full")
+                    e.status = 3
+                    raise e
+                return super().finish()
+
+        T, H, W, r = 7, 38, 52, 2
+        d = psfm_synth.synth_sequence(T, H, W, seed=11, sigma=0.3, n_occluders=2, stride2=True)
+        tf = lambda k: torch.from_numpy(np.stack(d[k]))
+        eng = FullOnce(world - 1)
+        part = psfm_dist.connect_sharded(eng, tf("flows_f"), tf("flows_b"), tf("flows_f2"), tf("flows_b2"), 1.0, r, check)
+        birth, length, off, xy = psfm_dist.gather_result(part)
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+        O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        out["capacity_retry"] = bool(eng.grown == 1 and eng.begun == 2 and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
+                                     and float(np.abs(xy - O.xy).max()) <= 1e-9)
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -287,6 +320,7 @@ def test_connect_sharded_gloo(world):
             assert same_ids and err == 0.0 and stats_ok and own_band, (r, ci, out[ci])
             assert 0 < n_local < n_total
         assert out["alldie"], (r, "alldie")
+        assert out["capacity_retry"], (r, "capacity retry: every rank reruns Stage B once, result equal to the oracle")
 
 
 def test_world2_gloo():

@@ -298,3 +298,47 @@ def test_bench_multi_rank_control_flow_dry_run_on_one_gpu():
     assert ranks["world_size"] == 2 and ranks["backend"] == "gloo" and [q["rank"] for q in ranks["per_rank"]] == [0, 1]
     ss = full["single_sequence"]
     assert ss["world_size"] == 2 and ss["trajectories"] > 0 and 0 < ss["local_trajectories_rank0"] < ss["trajectories"]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_connect_sharded_grows_tables_that_run_full(world):
+    """A rank whose trajectory-record table is too small learns it when it finalizes (PSFM_ERR_CAPACITY); the ranks agree on it behind
+    the recurrence's last collective and ALL run Stage B again with larger tables (psfm_dist.connect_sharded -> HipShardEngine.grow_tables),
+    as run_connect does for the one-GPU call.  Result equal to the oracle's; the run in between left nothing behind."""
+    import torch
+    import psfm_dist
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    from point_trajectory.shard import HipShardEngine, flow_check_slice
+    T, H, W, r = 14, 58, 76, 2
+    d = psfm_synth.synth_sequence(T, H, W, seed=41, sigma=0.5, n_occluders=3, stride2=True)     # noisy: many short trajectories
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stack = {k: torch.from_numpy(np.stack(d[k])).to(dev) for k in ("flows_f", "flows_b", "flows_f2", "flows_b2")}
+    torch.cuda.synchronize()
+    grown = []
+
+    def rank_fn(comm):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            try:
+                eng = HipShardEngine(_hip.Context(dev.index or 0))
+                eng.ctx.set_capacity(2.0, 0.25)           # a quarter of a record per grid point: far too few
+                calls = []
+                grow = eng.grow_tables
+                eng.grow_tables = lambda: (calls.append(1), grow())
+                part = psfm_dist.connect_sharded(eng, stack["flows_f"], stack["flows_b"], stack["flows_f2"], stack["flows_b2"], 1.0, r,
+                                                 flow_check_slice, comm=comm)
+                grown.append(len(calls))
+                return psfm_dist.gather_result(part, comm=comm), part
+            finally:
+                _hip.release_thread_contexts()
+
+    res = run_ranks(world, rank_fn)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    assert len(grown) == world and min(grown) >= 1 and len(set(grown)) == 1      # every rank grew, the same number of times
+    for (birth, length, off, xy), part in res:
+        assert len(birth) == O.n_traj and np.array_equal(birth, O.birth) and np.array_equal(length, O.length)
+        assert float(np.abs(xy - O.xy).max()) <= 1e-4
+        assert [s["iterations"] for s in part["solve_stats"]] == [s["iterations"] for s in O.solves]
