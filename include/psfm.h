@@ -131,7 +131,12 @@ psfm_status psfm_solver_counters(psfm_ctx* ctx, int64_t* fused, int64_t* fused_r
  * iteration, 3-5x slower on such flows.  psfm_ctx_set_resident_budget(ctx, n) with n > 0 lets this context's resident solves use at
  * most n blocks while OTHER contexts run theirs -- the caller guarantees that the budgets of all contexts in flight on the device add
  * up to at most the capacity (e.g. 4 worker threads x 128).  A launch that does not become co-resident after all (other work holding
- * the block slots) gives up at its spin limit and is redone with launches; results never depend on it.  n = 0: the default policy. */
+ * the block slots) gives up at its spin limit and is redone with launches.  n = 0: the default policy.
+ * What a budget may change: a budget below the solve's own block count (lane capacity / 256) makes the solver's launches smaller, and
+ * the f64 sums over the tracks (cost, step norms, the dogleg's inner products) are then added in another grouping.  Every DECISION of
+ * the trust-region loop has been the same with and without a budget on all tests (iterations, accepted steps, terminations: tested
+ * against the unbudgeted run and the oracle, tests/test_gpu_solver.py::test_budget_below_the_solves_block_count); positions agree to
+ * rounding (<= 1e-9 px), not bit for bit.  Ids and lengths never depend on it. */
 psfm_status psfm_ctx_set_resident_budget(psfm_ctx* ctx, int blocks);
 psfm_status psfm_resident_capacity(psfm_ctx* ctx, int32_t* blocks);
 
@@ -211,7 +216,9 @@ psfm_status psfm_connect(psfm_ctx* ctx, const float* flows_f, const float* flows
  *   infos_host   n_seq entries or NULL
  * track_optimize: a sequence whose solves reject steps has them redone by the launch chain at the checkpoint, like psfm_track; when
  * a whole window of it is like that (or its context is set to the launch chain, psfm_ctx_set_solver mode 1) it leaves the batch
- * and is run alone by psfm_connect behind it.  Results do not depend on the batching.  n_seq <= 64.  Synchronises `stream`. */
+ * and is run alone by psfm_connect behind it.  Ids, lengths and every solver decision do not depend on the batching; track-mode positions are bit-identical, path-consistency
+ * positions agree to rounding (<= 1e-9 px: a sequence that leaves the batch solves on a share of the block slots, see
+ * psfm_ctx_set_resident_budget).  n_seq <= 64.  Synchronises `stream`. */
 psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, const float* const* flows_f, const float* const* flows_b,
                                const float* const* flows_f2, const float* const* flows_b2, const int* n_flows, int h, int w,
                                float thres, int sample_ratio, psfm_track_info* infos_host, void* stream);

@@ -20,6 +20,7 @@
 // Results are those of psfm_connect, sequence by sequence (tests/test_gpu_batch.py: bit-identical to the oracle's).
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -90,10 +91,28 @@ extern "C" psfm_status psfm_connect_batch(psfm_ctx* const* ctxs, int n_seq, cons
     psfm_ctx* own0 = ctxs[0];
     const int64_t shape_key = ((int64_t)h << 40) ^ ((int64_t)w << 16) ^ (int64_t)ratio ^ (flows_f2 ? (1ll << 62) : 0);
     const bool trim = trim_env && own0->batch_notrim_shape != shape_key;      // (a shape whose sequences outgrew the trimmed launches once: not again)
-    psfm_status rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, trim, &too_small);
-    if (rc == PSFM_ERR_CAPACITY && too_small) {
-        own0->batch_notrim_shape = shape_key;
-        rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, false, &too_small);
+    // (the counters a failed finalize reads the "grid too small" bit from are the ones THIS call refreshes: none left over from an earlier one)
+    for (int i = 0; i < n_seq; ++i) if (ctxs[i]->host_pinned) ((PsfmCounters*)ctxs[i]->host_pinned)->overflow = 0;
+    // A failed run leaves nothing in flight that still reads the caller's flow stacks or writes the maps: the side stream's flow_check
+    // launches are drained before the error goes back (the caller may free or reuse the tensors), and before the untrimmed rerun.
+    auto quiesce = [&]() {
+        if (hipSetDevice(own0->device) != hipSuccess) return;
+        if (own0->side_stream) (void)hipStreamSynchronize(own0->side_stream);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+    };
+    psfm_status rc = PSFM_ERR_HIP;
+    try {
+        rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, trim, &too_small);
+        if (rc != PSFM_OK) quiesce();
+        if (rc == PSFM_ERR_CAPACITY && too_small) {
+            own0->batch_notrim_shape = shape_key;
+            rc = batch_run(ctxs, n_seq, flows_f, flows_b, flows_f2, flows_b2, n_flows, h, w, thres, ratio, infos, stream, false, &too_small);
+            if (rc != PSFM_OK) quiesce();
+        }
+    } catch (const std::exception& e) {      // (std::thread / std::vector: nothing may unwind through the extern "C" boundary)
+        quiesce();
+        psfm_set_error("psfm_connect_batch: %s", e.what());
+        rc = PSFM_ERR_HIP;
     }
     return rc;
 }
@@ -446,8 +465,12 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
     // profiles/r05/r05_f_resident_budget.txt); as many at a time as have room on chip for their tracks.  (The gate is released.) ----
     if (redo.empty()) return PSFM_OK;
     int n_thr = 1;
+    // what the redo threads may share: the CALLER's budget when it set one (psfm.h: the budgets of all contexts in flight on the device
+    // add up to at most the capacity -- connect_sequences gives every worker capacity / n_threads, and two workers' batches may redo at
+    // the same time), else the device's co-resident block slots
+    const int room = own->resident_budget > 0 ? std::min(own->resident_budget, psfm_resident_blocks(own)) : psfm_resident_blocks(own);
     if (redo.size() >= 2 && optimize) {
-        const int capacity = psfm_resident_blocks(own);
+        const int capacity = room;
         const int64_t G = (int64_t)((w + ratio - 1) / ratio) * ((h + ratio - 1) / ratio);
         const int64_t need = (G * 6 / 10 + 767) / 768;            // blocks that hold ~60 % of the grid's tracks at three per thread
         int fit = need > 0 ? (int)(capacity / need) : 4;
@@ -464,12 +487,11 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
         }
         return PSFM_OK;
     }
-    const int share = psfm_resident_blocks(own) / n_thr;
+    const int share = std::max(room / n_thr, 1);
     std::vector<psfm_status> rc((size_t)n_thr, PSFM_OK);
     std::vector<std::string> msg((size_t)n_thr);
     std::vector<std::thread> workers;
-    for (int t = 0; t < n_thr; ++t)
-        workers.emplace_back([&, t]() {
+    auto body = [&](int t) {
             for (size_t q = (size_t)t; q < redo.size(); q += (size_t)n_thr) {
                 const int i = redo[q];
                 psfm_ctx* c = ctxs[i];
@@ -484,7 +506,12 @@ static psfm_status batch_run(psfm_ctx* const* ctxs, int n_seq, const float* cons
                 c->resident_budget = budget0;
                 if (r != PSFM_OK) { rc[(size_t)t] = r; msg[(size_t)t] = psfm_last_error(); return; }      // (the error text is thread local)
             }
-        });
+        };
+    std::vector<int> inline_shares;      // shares whose thread could not be created (std::system_error): run here, behind the others
+    for (int t = 0; t < n_thr; ++t) {
+        try { workers.emplace_back(body, t); } catch (const std::exception&) { inline_shares.push_back(t); }
+    }
+    for (int t : inline_shares) body(t);
     for (auto& th : workers) th.join();
     for (int t = 0; t < n_thr; ++t)
         if (rc[(size_t)t] != PSFM_OK) { psfm_set_error("psfm_connect_batch: a sequence that left the batch failed: %s", msg[(size_t)t].c_str()); return rc[(size_t)t]; }

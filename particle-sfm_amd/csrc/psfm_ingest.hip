@@ -126,7 +126,12 @@ extern "C" psfm_status psfm_load_flo_stack(psfm_ctx* c, const char* const* paths
         }
     };
     std::vector<std::thread> ths;
-    for (int t = 0; t < n_threads; ++t) ths.emplace_back(worker);
+    // (a thread that cannot be created -- std::system_error -- must not unwind through the extern "C" entry point with joinable threads
+    // behind it: the workers pull frames from one queue, so the ones that did start, or this thread, read everything)
+    for (int t = 0; t < n_threads; ++t) {
+        try { ths.emplace_back(worker); } catch (const std::exception&) { break; }
+    }
+    if (ths.empty()) worker();
     for (auto& t : ths) t.join();
     // the staging buffers belong to the context: nothing may still read them when the call returns; `stream` continues behind the copies
     hipError_t e1 = hipStreamSynchronize(cs);

@@ -19,30 +19,51 @@ from . import _hip
 from .main_connect_point_trajectories import main_connect_point_trajectories
 
 
+BATCH_MAX = 64                 # PSFM_BATCH_MAX of csrc/psfm_batch.hip: sequences per psfm_connect_batch call
+BATCH_BYTES = 48 << 30         # flow stacks of one group resident in HBM before its compute starts (of 288 GB)
+
+
 def _connect_batch_to_disk(flow_dirs, traj_dirs, sample_ratio, flow_check_thres, traj_min_len, skip_path_consistency, skip_exists, layout):
     """main_connect_point_trajectories.py:27-62 for a group of sequences through psfm_connect_batch: ingest all, ONE batched
     compute call per frame size, then filter + save each from its own context."""
     import os
     from .utils import load_flows_device
     from .trajectory import run_connect_batch, result_to_trajectory_set, save_track_npy
-    todo = []
+    import glob
+    from .main_connect_point_trajectories import main_connect_point_trajectories
+
+    def flush(group):
+        ctxs, infos = run_connect_batch([sq for _, sq in group], flow_check_thres, sample_ratio)
+        for (td, _), ctx, info in zip(group, ctxs, infos):
+            ts = result_to_trajectory_set(ctx, info, traj_min_len, reuse_pinned=True)
+            save_track_npy(os.path.join(td, "track.npy"), ts, layout=layout)
+
+    # Groups of one frame size go through psfm_connect_batch as they fill up: at most PSFM_BATCH_MAX (64) sequences and BATCH_BYTES of
+    # flow stacks in HBM at a time (a group is ingested whole before its compute starts).  A directory without flows, or one whose
+    # frames cannot be read here, goes through the one-sequence entry point, which reports / handles it by itself -- it must not take
+    # the other sequences of the call with it.
+    by_shape, held = {}, {}
     for fd, td in zip(flow_dirs, traj_dirs):
         os.makedirs(td, exist_ok=True)
         if skip_exists and os.path.exists(os.path.join(td, "track.npy")):
+            continue
+        if not glob.glob(os.path.join(fd, "flow_f", "*.flo")):
+            main_connect_point_trajectories(fd, td, sample_ratio=sample_ratio, flow_check_thres=flow_check_thres, traj_min_len=traj_min_len,
+                                            skip_path_consistency=skip_path_consistency, skip_exists=skip_exists, layout=layout)
             continue
         f, b = load_flows_device(os.path.join(fd, "flow_f")), load_flows_device(os.path.join(fd, "flow_b"))
         f2 = b2 = None
         if not skip_path_consistency:
             f2, b2 = load_flows_device(os.path.join(fd, "flow_f2")), load_flows_device(os.path.join(fd, "flow_b2"))
-        todo.append((td, (f, b, f2, b2)))
-    by_shape = {}
-    for td, sq in todo:
-        by_shape.setdefault((int(sq[0].shape[1]), int(sq[0].shape[2])), []).append((td, sq))
+        key = (int(f.shape[1]), int(f.shape[2]))
+        by_shape.setdefault(key, []).append((td, (f, b, f2, b2)))
+        held[key] = held.get(key, 0) + sum(int(t.numel()) * 4 for t in (f, b, f2, b2) if t is not None)
+        if len(by_shape[key]) >= BATCH_MAX or held[key] >= BATCH_BYTES:
+            flush(by_shape.pop(key))
+            held.pop(key)
+        del f, b, f2, b2
     for group in by_shape.values():
-        ctxs, infos = run_connect_batch([sq for _, sq in group], flow_check_thres, sample_ratio)
-        for (td, _), ctx, info in zip(group, ctxs, infos):
-            ts = result_to_trajectory_set(ctx, info, traj_min_len, reuse_pinned=True)
-            save_track_npy(os.path.join(td, "track.npy"), ts, layout=layout)
+        flush(group)
 
 
 def connect_sequences(flow_dirs, traj_dirs, sample_ratio=2, flow_check_thres=1.0, traj_min_len=3,

@@ -300,8 +300,9 @@ def test_bench_multi_rank_control_flow_dry_run_on_one_gpu():
     assert ss["world_size"] == 2 and ss["trajectories"] > 0 and 0 < ss["local_trajectories_rank0"] < ss["trajectories"]
 
 
+@pytest.mark.parametrize("lane_f", [2.0, 1.0], ids=["records-full", "lanes-and-records-full"])
 @pytest.mark.parametrize("world", [1, 2])
-def test_connect_sharded_grows_tables_that_run_full(world):
+def test_connect_sharded_grows_tables_that_run_full(world, lane_f):
     """A rank whose trajectory-record table is too small learns it when it finalizes (PSFM_ERR_CAPACITY); the ranks agree on it behind
     the recurrence's last collective and ALL run Stage B again with larger tables (psfm_dist.connect_sharded -> HipShardEngine.grow_tables),
     as run_connect does for the one-GPU call.  Result equal to the oracle's; the run in between left nothing behind."""
@@ -322,7 +323,7 @@ def test_connect_sharded_grows_tables_that_run_full(world):
         with torch.cuda.stream(torch.cuda.Stream(device=dev)):
             try:
                 eng = HipShardEngine(_hip.Context(dev.index or 0))
-                eng.ctx.set_capacity(2.0, 0.25)           # a quarter of a record per grid point: far too few
+                eng.ctx.set_capacity(lane_f, 1.0)         # 1.6 records per grid point (max(1, n_flows / 8)) where the sequence ends 5.4; lanes: 1 or 2
                 calls = []
                 grow = eng.grow_tables
                 eng.grow_tables = lambda: (calls.append(1), grow())

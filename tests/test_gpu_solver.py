@@ -606,3 +606,35 @@ def test_exclusive_sequence_lets_other_host_threads_in(pt):
         for B in res["b"]:
             assert np.array_equal(B.birth, alone_b.birth) and np.array_equal(B.xy, alone_b.xy)
 
+
+
+def test_budget_below_the_solves_block_count(pt):
+    """psfm_ctx_set_resident_budget with a budget BELOW the solve's own block count (lane capacity / 256: ~870 blocks at 436 x 1024,
+    sample_ratio 2): the solver's launches shrink to the budget, so the f64 sums over the tracks are grouped by other blocks than in
+    the unbudgeted run (psfm.h used to promise identical results).  What holds, against the unbudgeted run AND the oracle:
+    ids, lengths and every decision of every solve (iterations, accepted steps, terminations) equal; positions to rounding."""
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    H, W, r, T = 436, 1024, 2, 7
+    d = psfm_synth.synth_sequence(T, H, W, seed=91, stride2=True, **psfm_synth.HARD)
+    _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+    _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+    O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+    ctx = _hip.context()
+    runs = {}
+    try:
+        for budget in (0, 128, 48):
+            ctx.set_resident_budget(budget)
+            R = pt.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+            runs[budget] = (R, ctx.solver_counters())
+    finally:
+        ctx.set_resident_budget(0)
+    assert ((W + r - 1) // r) * ((H + r - 1) // r) * 2 // 256 > 128          # the budgets really are below the block count
+    R0 = runs[0][0]
+    for budget, (R, cnt) in runs.items():
+        assert np.array_equal(R.birth, O.birth) and np.array_equal(R.length, O.length)
+        for key in ("iterations", "successful_steps", "termination", "dogleg_nonGN"):
+            assert [s[key] for s in R.solve_stats] == [s[key] for s in O.solves], (budget, key)
+        assert float(np.abs(R.xy - O.xy).max()) <= TOL
+        assert float(np.abs(R.xy - R0.xy).max()) <= 1e-9, budget
+        assert cnt["resident_launches"] > 0, (budget, cnt)
