@@ -332,6 +332,22 @@ psfm_status psfm_shard_solve_local(psfm_ctx* ctx, const float* flow01, const flo
                                    int frame, int unroll, void* stream);
 psfm_status psfm_shard_solve_redo_local(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02,
                                         const uint8_t* occ02, int frame, int chain_stalled, psfm_solve_stats* stats_host, void* stream);
+/* ONE solve over several ranks with no host and no collective library in its loop (csrc/psfm_shard.hip, csrc/psfm_solver.hip: PcPeers):
+ * every rank runs the resident solve of trajectory_optimize.cpp:74-82 on its own tracks, and the second hop of the launch's all-reduce
+ * writes each leader's sums into EVERY rank's granule area through peer-mapped pointers (IPC handles between processes -- P2P over
+ * xGMI between GPUs -- plain pointers between host threads of one process).  Set-up once per context: psfm_shard_peer_area (this rank's
+ * area + its 64-byte IPC handle), psfm_shard_peer_open (another process's area), psfm_shard_peer_connect (world <= 8, rank, every rank's
+ * area as this process addresses it, every rank's launch size from psfm_shard_solve_blocks; 0 blocks anywhere = PSFM_ERR_ARG: keep the
+ * exchange form).  Per frame psfm_shard_solve_peer(frame, epoch) ENQUEUES this rank's launch; all ranks pass the same epoch (a counter
+ * they advance together, 20 bits).  A launch that gives up (a rank missing, not co-resident) raises the stall flag on every rank --
+ * psfm_shard_window_state reports it and the caller redoes that solve with psfm_shard_solve_export / _control. */
+psfm_status psfm_shard_peer_area(psfm_ctx* ctx, void** area_dev, void* ipc_handle_64, void* stream);
+psfm_status psfm_shard_peer_open(psfm_ctx* ctx, const void* ipc_handle_64, int peer_rank, void** mapped);
+psfm_status psfm_shard_peer_connect(psfm_ctx* ctx, int world, int rank, void* const* areas, const int32_t* n_blocks);
+psfm_status psfm_shard_solve_blocks(psfm_ctx* ctx, int32_t* n_blocks);
+psfm_status psfm_shard_solve_peer(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02, const uint8_t* occ02,
+                                  int frame, uint32_t epoch, void* stream);
+
 /* the stall flag as of the last control step the device has completed, without synchronising (-1: none) */
 psfm_status psfm_shard_peek_stall(psfm_ctx* ctx, int32_t* stalled_frame);
 psfm_status psfm_shard_solve_restore(psfm_ctx* ctx, int frame, void* stream);

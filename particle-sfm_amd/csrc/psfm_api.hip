@@ -179,6 +179,8 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
                        &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar, &c->batch_tab, &c->batch_ws, &c->batch_fc, &c->win_ws, &c->flt_ids, &c->flt_birth, &c->flt_len, &c->flt_off, &c->flt_xy,
                        &c->mt_kp_off, &c->mt_q, &c->mt_pts, &c->mt_kp_ind, &c->mt_kp_xy, &c->mt_moff, &c->mt_keys, &c->mt_rows, &c->mt_gid, &c->mt_pairs};
     for (auto b : bufs) b->release();
+    for (void*& q : c->peer_opened) { if (q) (void)hipIpcCloseMemHandle(q); q = nullptr; }
+    c->peer_area.release();
     psfm_shard_abandon(c);
     c->prof.destroy();
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);

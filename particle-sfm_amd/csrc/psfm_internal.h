@@ -8,6 +8,8 @@
 
 #include "../../include/psfm.h"
 
+#define PSFM_MAX_PEERS 8      // ranks of one solve (psfm_shard_peer_*): the GPUs of one node
+
 void psfm_set_error(const char* fmt, ...);
 
 #define PSFM_HIP(expr)                                                                          \
@@ -167,6 +169,13 @@ struct psfm_ctx {
     bool pc_persist_ok = false;    // this call has the device to itself (or a resident budget): the launch chain may run as one persistent launch
     int resident_budget = 0;       // psfm_ctx_set_resident_budget: > 0 = resident solves of at most that many blocks under the SHARED gate
     unsigned pc_epoch = 0;         // resident solve: launch counter, part of every granule's tag (stale granules never match)
+    // ONE solve over several ranks (psfm_shard_peer_*): this rank's granule area (member rows + the leader rows every rank writes into),
+    // the other ranks' leader areas as this process addresses them, every rank's leader count
+    PsfmBuf peer_area;
+    int peer_world = 0, peer_rank = 0;
+    int peer_L[PSFM_MAX_PEERS] = {0};
+    void* peer_lead[PSFM_MAX_PEERS] = {nullptr};
+    void* peer_opened[PSFM_MAX_PEERS] = {nullptr};   // mappings this context opened with hipIpcOpenMemHandle (closed with it)
     int pc_giveups = 0;            // resident solves of this call whose hand-off timed out (two of them: launches from there on)
     int solve_K = 4;        // fused solve: trust-region iterations speculated per launch (adapted at checkpoints)
     int solve_mode = 0;     // 0 fused solve (one launch per frame), 1 launch chain (sequences whose solves reject steps)
@@ -296,6 +305,12 @@ psfm_status psfm_solve_state(psfm_ctx* c, int* done, int* stall, psfm_solve_stat
 psfm_status psfm_solve_restore(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 psfm_status psfm_solve_writeback(psfm_ctx* c, const PsfmTrackDims& d, int frame, hipStream_t s);
 // Batch API form (psfm_optimize_location).
+size_t psfm_peer_area_bytes(void);
+size_t psfm_peer_lead_offset(void);
+int psfm_peer_leaders(int n_blocks);
+int psfm_solve_blocks(psfm_ctx* c, const PsfmTrackDims& d);
+psfm_status psfm_solve_frame_enqueue_peer(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                          const float* flow02, const uint8_t* occ02, int frame, unsigned epoch, hipStream_t s);
 psfm_status psfm_launch_pc_eval(const double* uv12, const double* ref1, const double* ref2, const double* scale, const float* flow12,
                                 int64_t n, int w, int h, double* res, double* jac, hipStream_t s);
 psfm_status psfm_solve_batch(psfm_ctx* c, const double* uv12, const double* ref1, const double* ref2,

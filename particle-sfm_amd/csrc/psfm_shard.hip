@@ -244,6 +244,96 @@ extern "C" psfm_status psfm_shard_solve_redo_local(psfm_ctx* c, const float* flo
     return PSFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE solve over several ranks WITHOUT the host or a collective library in its loop (round 6).  A window whose solves reject steps
+// costs the exchange form one export launch + one all-gather + one control launch per trust-region iteration and a host poll every
+// few of them (3x the one-GPU call on a hard 1080p sequence).  Here every rank runs the RESIDENT solve on its own tracks and the
+// second hop of its all-reduce crosses the ranks: leaders write their sums into every rank's granule area through peer-mapped
+// pointers (csrc/psfm_solver.hip: PcPeers).  Set-up, once per engine:
+//     psfm_shard_peer_area      this rank's area (allocated once per context, zeroed) + its IPC handle
+//     psfm_shard_peer_open      another PROCESS's area from its handle (hipIpcOpenMemHandle; threads of one process pass pointers)
+//     psfm_shard_peer_connect   world, rank, every rank's area as this process addresses it, every rank's launch size
+// and per frame psfm_shard_solve_peer(frame, epoch) where psfm_shard_solve_local would run on one rank.  All ranks pass the same
+// epoch (a counter they advance together): it tags every granule of the solve.
+// ------------------------------------------------------------------------------------------------
+extern "C" psfm_status psfm_shard_peer_area(psfm_ctx* c, void** area_dev, void* ipc_handle_64, void* stream)
+{
+    if (!c || !area_dev) { psfm_set_error("psfm_shard_peer_area: bad argument"); return PSFM_ERR_ARG; }
+    PSFM_HIP(hipSetDevice(c->device));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    const bool fresh = c->peer_area.p == nullptr;
+    psfm_status st = c->peer_area.ensure(psfm_peer_area_bytes());
+    if (st != PSFM_OK) return st;
+    if (fresh) {
+        PSFM_HIP(hipMemsetAsync(c->peer_area.p, 0, psfm_peer_area_bytes(), (hipStream_t)stream));
+        PSFM_HIP(hipStreamSynchronize((hipStream_t)stream));
+    }
+    *area_dev = c->peer_area.p;
+    if (ipc_handle_64) {
+        hipIpcMemHandle_t h;
+        PSFM_HIP(hipIpcGetMemHandle(&h, c->peer_area.p));
+        memcpy(ipc_handle_64, &h, sizeof(h));
+    }
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_shard_peer_open(psfm_ctx* c, const void* ipc_handle_64, int peer_rank, void** mapped)
+{
+    if (!c || !ipc_handle_64 || !mapped || peer_rank < 0 || peer_rank >= PSFM_MAX_PEERS) { psfm_set_error("psfm_shard_peer_open: bad argument"); return PSFM_ERR_ARG; }
+    PSFM_HIP(hipSetDevice(c->device));
+    if (c->peer_opened[peer_rank]) { (void)hipIpcCloseMemHandle(c->peer_opened[peer_rank]); c->peer_opened[peer_rank] = nullptr; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, ipc_handle_64, sizeof(h));
+    void* q = nullptr;
+    PSFM_HIP(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+    c->peer_opened[peer_rank] = q;
+    *mapped = q;
+    return PSFM_OK;
+}
+
+// n_blocks[r]: blocks of rank r's solver launches (psfm_shard_solve_blocks on that rank, after ITS psfm_shard_begin); 0 anywhere = that
+// rank cannot run the resident form -> PSFM_ERR_ARG here on every rank (the caller keeps the exchange form)
+extern "C" psfm_status psfm_shard_peer_connect(psfm_ctx* c, int world, int rank, void* const* areas, const int32_t* n_blocks)
+{
+    if (!c || world < 1 || world > PSFM_MAX_PEERS || rank < 0 || rank >= world || !areas || !n_blocks || !c->peer_area.p || areas[rank] != c->peer_area.p) {
+        psfm_set_error("psfm_shard_peer_connect: bad argument (world %d of at most %d, rank %d)", world, PSFM_MAX_PEERS, rank);
+        return PSFM_ERR_ARG;
+    }
+    for (int r = 0; r < world; ++r)
+        if (!areas[r] || n_blocks[r] < 1) { psfm_set_error("psfm_shard_peer_connect: rank %d has no area / no resident launch", r); return PSFM_ERR_ARG; }
+    c->peer_world = world; c->peer_rank = rank;
+    for (int r = 0; r < world; ++r) {
+        c->peer_lead[r] = (char*)areas[r] + psfm_peer_lead_offset();
+        c->peer_L[r] = psfm_peer_leaders(n_blocks[r]);
+    }
+    return PSFM_OK;
+}
+
+// blocks of this rank's solver launches for the run psfm_shard_begin set up, or 0 when they cannot all be resident on the device
+// (the context's resident budget, else the device's capacity)
+extern "C" psfm_status psfm_shard_solve_blocks(psfm_ctx* c, int32_t* n_blocks)
+{
+    PSFM_SHARD_CHECK(c);
+    if (!n_blocks) { psfm_set_error("psfm_shard_solve_blocks: bad argument"); return PSFM_ERR_ARG; }
+    const int nb = psfm_solve_blocks(c, *c->shard_dims);
+    const int room = c->resident_budget > 0 ? c->resident_budget : psfm_resident_blocks(c);
+    *n_blocks = (c->shard_optimize && nb <= room) ? nb : 0;
+    return PSFM_OK;
+}
+
+extern "C" psfm_status psfm_shard_solve_peer(psfm_ctx* c, const float* flow01, const float* flow12, const float* flow02,
+                                             const uint8_t* occ02, int frame, uint32_t epoch, void* stream)
+{
+    PSFM_SHARD_CHECK(c);
+    PsfmGate gate(c->device, 0);
+    const PsfmTrackDims& d = *c->shard_dims;
+    if (c->peer_world < 1 || !c->shard_optimize || !flow01 || !flow12 || !flow02 || !occ02 || frame < 1 || frame >= d.n_flows) {
+        psfm_set_error("psfm_shard_solve_peer: frame %d, %d connected rank(s)", frame, c->peer_world);
+        return PSFM_ERR_ARG;
+    }
+    return psfm_solve_frame_enqueue_peer(c, d, flow01, flow12, flow02, occ02, frame, epoch, (hipStream_t)stream);
+}
+
 // The stall flag as of the last control step the device has COMPLETED (no synchronisation: the value lags the queue by the
 // frames in flight): frame whose solve stalled, or -1.
 extern "C" psfm_status psfm_shard_peek_stall(psfm_ctx* c, int32_t* stalled_frame)

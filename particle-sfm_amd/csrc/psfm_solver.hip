@@ -537,6 +537,24 @@ static_assert(sizeof(PsfmSolveCtrl) % 8 == 0, "the control block is copied as 8-
 
 struct PcRound { int done, cur, kind, accepted, giveup; double mu, a, b; };   // what a round of the loop needs from the control block
 
+// ONE solve over several GPUs / processes (track-sharded runs, psfm_shard.hip): every rank runs this launch on ITS tracks and the
+// second hop of the all-reduce crosses the ranks -- a leader publishes its sums into EVERY rank's leader area (its own included)
+// through peer-mapped pointers (hipIpcOpenMemHandle / P2P over xGMI; plain pointers between host threads of one process), and
+// every block adds up the leader rows of all ranks from its OWN rank's area, rank by rank in rank order:
+//     total = (...((T_0 + T_1) + T_2) ...) + T_{world-1},   T_r = rank r's total as pc_tree_totals forms it
+// -- the same numbers in the same order on every rank, hence the same control decisions everywhere, with no host and no collective
+// library in the loop.  Leader area of a rank: [set 0, 1][source rank][PC_LEADERS][PC_RES_ROW] granules.  world == 1 is the
+// one-GPU launch bit for bit (the template parameter only removes the loop).
+struct PcPeers {
+    int world, rank;
+    int L[PSFM_MAX_PEERS];                       // leaders of every rank's launch: min(PC_LEADERS, its blocks)
+    unsigned long long* lead[PSFM_MAX_PEERS];    // rank r's leader area as THIS process addresses it
+};
+__device__ __forceinline__ unsigned long long* pc_peer_rows(unsigned long long* area, int world, unsigned set, int src_rank)
+{
+    return area + ((size_t)(set * (unsigned)world + (unsigned)src_rank) * PC_LEADERS) * PC_RES_ROW;
+}
+
 __device__ __forceinline__ unsigned long long pc_gran_load(const unsigned long long* p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -561,9 +579,9 @@ __device__ __forceinline__ double pc_unhalf(unsigned long long hi, unsigned long
 // The all-reduce of one round, run by WAVE 0 of every block (the other waves wait at the caller's barrier): blk[] = this
 // block's sums (LDS), gran = [n_blocks rows of members][PC_LEADERS rows of leaders].  Returns 0 with the totals in tot[], 1
 // when the round is given up (this block timed out, or saw the poison of one that did).  Lane (k, j) = 4 k + j works on sum k.
-template <int NSUMS>
+template <int NSUMS, bool PEERS = false>
 __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long long* gran, int n_blocks, unsigned tag, unsigned poison,
-                                                int spin_limit, bool quit, double tot[PC_NSUM], int rtl)
+                                                int spin_limit, bool quit, double tot[PC_NSUM], int rtl, const PcPeers* peers = nullptr)
 {
     static_assert(4 * NSUMS <= PSFM_WAVE && 2 * NSUMS <= PC_RES_ROW, "one lane per (sum, quarter), two granules per sum");
     const int lane = threadIdx.x;            // (wave 0: lane == thread)
@@ -575,7 +593,8 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
     // round-r granules would find tag r + 1 there, never match, and poison the solve at its spin limit (a spurious give-up under
     // preemption).  Round r + 2 cannot be published before every block has read round r: it needs every leader's r + 1 row, which
     // needs every member's r + 1 granule, which a member only writes behind its round-r totals.
-    unsigned long long* lead = gran + ((size_t)n_blocks + (size_t)(tag & 1u) * PC_LEADERS) * PC_RES_ROW;
+    unsigned long long* lead = PEERS ? pc_peer_rows(peers->lead[peers->rank], peers->world, tag & 1u, peers->rank)
+                                     : gran + ((size_t)n_blocks + (size_t)(tag & 1u) * PC_LEADERS) * PC_RES_ROW;
     const int k = lane >> 2, j = lane & 3;
     const bool work = lane < 4 * NSUMS;
     int bad = quit ? 1 : 0;
@@ -616,19 +635,32 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
             const double s1 = __shfl(v, (lane & ~3) + 1), s2 = __shfl(v, (lane & ~3) + 2), s3 = __shfl(v, (lane & ~3) + 3);
             const double S = (k == SUM_GMAX) ? fmax(fmax(fmax(v, s1), s2), s3) : ((v + s1) + s2) + s3;   // (valid in lanes 4k)
             const double Sg = __shfl(S, 4 * (lane >> 1));        // granule lane g publishes sum g >> 1
-            if (lane < 2 * NSUMS) pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, tag, pc_half(Sg, lane & 1));
+            if (lane < 2 * NSUMS) {
+                if (PEERS) {
+                    for (int r = 0; r < peers->world; ++r)     // into every rank's area (this rank's slot there)
+                        pc_gran_store(pc_peer_rows(peers->lead[r], peers->world, tag & 1u, peers->rank) + (size_t)b * PC_RES_ROW + lane, tag,
+                                      pc_half(Sg, lane & 1));
+                } else {
+                    pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, tag, pc_half(Sg, lane & 1));
+                }
+            }
         }
         PC_RTL(5);
     }
-    double t = 0.0;
-    if (!bad) {
-        // ---- every block: lane (k, j) adds the leaders 8 j .. 8 j + 7 in order, then the four j's in order ----
+    double total = 0.0;
+    // ---- every block: lane (k, j) adds the leaders 8 j .. 8 j + 7 in order, then the four j's in order (PEERS: of every rank, rank
+    //      by rank, from this rank's own area -- a rank that is late keeps everybody in its poll, bounded by the spin limit) ----
+    const int n_src = PEERS ? peers->world : 1;
+    for (int r = 0; r < n_src && !bad; ++r) {
+        const unsigned long long* rows = PEERS ? pc_peer_rows(peers->lead[peers->rank], peers->world, tag & 1u, r) : lead;
+        const int Lr = PEERS ? peers->L[r] : L;
+        double t = 0.0;
         for (int spins = 0;; ++spins) {
             unsigned long long wh[8], wl[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int x = 8 * j + u;
-                const unsigned long long* src = lead + (size_t)(work && x < L ? x : 0) * PC_RES_ROW + 2 * (work ? k : 0);
+                const unsigned long long* src = rows + (size_t)(work && x < Lr ? x : 0) * PC_RES_ROW + 2 * (work ? k : 0);
                 wh[u] = pc_gran_load(src); wl[u] = pc_gran_load(src + 1);
             }
             bool ok = true, psn = false;
@@ -636,7 +668,7 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int x = 8 * j + u;
-                if (!work || x >= L) continue;
+                if (!work || x >= Lr) continue;
                 const unsigned th = (unsigned)(wh[u] >> 32), tl = (unsigned)(wl[u] >> 32);
                 if (th != tag || tl != tag) { ok = false; psn = psn || th == poison || tl == poison; }
                 const double S = pc_unhalf(wh[u], wl[u]);
@@ -647,18 +679,27 @@ __device__ __forceinline__ int pc_res_allreduce(const double* blk, unsigned long
             if (spins >= spin_limit) { bad = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (bad) break;
+        const double t1 = __shfl(t, (lane & ~3) + 1), t2 = __shfl(t, (lane & ~3) + 2), t3 = __shfl(t, (lane & ~3) + 3);
+        const double Tr = (k == SUM_GMAX) ? fmax(fmax(fmax(t, t1), t2), t3) : ((t + t1) + t2) + t3;       // (valid in lanes 4k)
+        total = r == 0 ? Tr : ((k == SUM_GMAX) ? fmax(total, Tr) : total + Tr);
     }
     if (bad) {
-        // poison: whoever waits for this block (its leader; everybody, if it is a leader) leaves at its next poll
+        // poison: whoever waits for this block (its leader; everybody -- on every rank -- if it is a leader) leaves at its next poll
         if (lane < 2 * NSUMS) {
             pc_gran_store(mine + lane, poison, 0u);
-            if (b < L) pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, poison, 0u);
+            if (b < L) {
+                if (PEERS) {
+                    for (int r = 0; r < peers->world; ++r)
+                        pc_gran_store(pc_peer_rows(peers->lead[r], peers->world, tag & 1u, peers->rank) + (size_t)b * PC_RES_ROW + lane, poison, 0u);
+                } else {
+                    pc_gran_store(lead + (size_t)b * PC_RES_ROW + lane, poison, 0u);
+                }
+            }
         }
         return 1;
     }
     PC_RTL(6);
-    const double t1 = __shfl(t, (lane & ~3) + 1), t2 = __shfl(t, (lane & ~3) + 2), t3 = __shfl(t, (lane & ~3) + 3);
-    const double total = (k == SUM_GMAX) ? fmax(fmax(fmax(t, t1), t2), t3) : ((t + t1) + t2) + t3;       // (valid in lanes 4k)
 #pragma unroll
     for (int q = 0; q < PC_NSUM; ++q) tot[q] = q < NSUMS ? __shfl(total, 4 * q) : 0.0;
     return 0;
@@ -676,10 +717,10 @@ __device__ __forceinline__ void pc_res_stall(const PcParams& P, int raise_stall)
 
 // (PcSlot and what happens to a slot -- pc_slot_fill / _start / _round / _refresh / _accept / _candidate: psfm_pc_resident.h, host-compilable)
 
-template <int NS>
+template <int NS, bool PEERS = false>
 __global__ __launch_bounds__(PC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoch, int spin_limit, int max_rounds, int quit_code,
-                             int init_inside, int raise_stall, double* out_rows)
+                             int init_inside, int raise_stall, double* out_rows, PcPeers peers)
 {
     // init_inside: iteration 0 (what psfm_pc_init_kernel does) is this launch's first round; else it runs behind that kernel.
     // When the loop ends with the solve done, every block writes its tracks back (what psfm_pc_writeback_kernel does) and the
@@ -726,7 +767,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
         pc_block_sums<PC_NSUM>(acc, s_blk);
         if (tid < PSFM_WAVE) {
             double tot[PC_NSUM];
-            const int bad = pc_res_allreduce<PC_NSUM>(s_blk, gran, nblk, (epoch << 12) | 0xffeu, poison, spin_limit, false, tot, -1);
+            const int bad = pc_res_allreduce<PC_NSUM, PEERS>(s_blk, gran, nblk, (epoch << 12) | 0xffeu, poison, spin_limit, false, tot, -1, &peers);
             if (tid == 0) {
                 s_R.giveup = bad; s_R.accepted = 0;
                 if (!bad) {
@@ -823,7 +864,7 @@ void psfm_pc_resident_kernel(PcParams P, unsigned long long* gran, unsigned epoc
         if (tid < PSFM_WAVE) {
             double tot[PC_NSUM];
             const bool quit = quit_code != 0 && (quit_code >> 16) == (int)blockIdx.x + 1 && (quit_code & 0xffff) == (int)it;
-            const int bad = pc_res_allreduce<PC_RES_SUMS>(s_blk, gran, nblk, (epoch << 12) | (it + 1u), poison, spin_limit, quit, tot, rtl);
+            const int bad = pc_res_allreduce<PC_RES_SUMS, PEERS>(s_blk, gran, nblk, (epoch << 12) | (it + 1u), poison, spin_limit, quit, tot, rtl, &peers);
             PC_RTL(9);
             // what the control step may need from the totals (pc_derive), one quantity per lane instead of one behind the other
             PcDerived D;
@@ -1492,6 +1533,7 @@ __global__ __launch_bounds__(PC_BLOCK) void psfm_pc_flush_kernel(PcParams P)
     }
 }
 __global__ void psfm_pc_clear_sel_kernel(int* sel, const int* stall) { if (!*stall) *sel = 0; }
+__global__ void psfm_pc_raise_stall_kernel(int* stall, int frame) { if (!*stall) *stall = frame + 1; }
 
 // what thread 0 of block 0 leaves behind a finished solve of the chain: the frame's statistics, PsfmCounters::sel, the lane snapshot
 __device__ __forceinline__ void pc_writeback_scalars(const PcParams& P, const PsfmSolveCtrl& C)
@@ -1690,14 +1732,18 @@ static int pc_resident_capacity(psfm_ctx* c)
         c->pc_persist_blocks[NS] = 0;
         int per_cu = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, psfm_pc_resident_kernel<NS>, PC_BLOCK, 0) == hipSuccess &&
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, psfm_pc_resident_kernel<NS, false>, PC_BLOCK, 0) == hipSuccess &&
             hipGetDeviceProperties(&prop, c->device) == hipSuccess)
             c->pc_persist_blocks[NS] = per_cu * prop.multiProcessorCount;
     }
     return c->pc_persist_blocks[NS];
 }
 
-static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, bool init_inside, bool raise_stall, hipStream_t s)
+// peers != nullptr: the launch of ONE rank of a solve that spans several (PcPeers); `peer_epoch` is the epoch all ranks tag this
+// solve's granules with, the member rows live in front of the leader area of the context's peer buffer (never in sol_bar, whose
+// granules carry the context's own launch counter)
+static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, double* out_rows, bool init_inside, bool raise_stall, hipStream_t s,
+                               const PcPeers* peers = nullptr, unsigned peer_epoch = 0)
 {
     const char* env = getenv("PSFM_PC_PERSIST");          // (read per call: the tests switch it inside one process)
     if ((env && atoi(env) == 0) || !c->pc_persist_ok || c->pc_giveups >= 2 || P.export_sums) return false;
@@ -1728,12 +1774,62 @@ static bool pc_persist_enqueue(psfm_ctx* c, const PcParams& P, int n_blocks, dou
     }
     unsigned long long* gran = c->sol_bar.as<unsigned long long>();
     const int max_rounds = 2 * 200 + 64;
+    PcPeers pp;
+    memset(&pp, 0, sizeof(pp));
     // (the write-back is in the launch too)
-    if (ns == 1) hipLaunchKernelGGL(psfm_pc_resident_kernel<1>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
-    else if (ns == 2) hipLaunchKernelGGL(psfm_pc_resident_kernel<2>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
-    else hipLaunchKernelGGL(psfm_pc_resident_kernel<3>, dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows);
+    if (peers) {
+        pp = *peers;
+        // ranks start this launch up to a host-side scheduling delay apart: the polls wait longer before they give a solve up (~100 ms)
+        const int spin_peer = getenv("PSFM_PC_SPIN") ? spin_limit : 80000;
+        unsigned long long* members = c->peer_area.as<unsigned long long>();      // [PC_RES_BLOCKS rows], in front of the leader area
+        const unsigned ep = peer_epoch & 0xfffffu;
+        if (ns == 1) hipLaunchKernelGGL((psfm_pc_resident_kernel<1, true>), dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, members, ep, spin_peer, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows, pp);
+        else if (ns == 2) hipLaunchKernelGGL((psfm_pc_resident_kernel<2, true>), dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, members, ep, spin_peer, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows, pp);
+        else hipLaunchKernelGGL((psfm_pc_resident_kernel<3, true>), dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, members, ep, spin_peer, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows, pp);
+    }
+    else if (ns == 1) hipLaunchKernelGGL((psfm_pc_resident_kernel<1, false>), dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows, pp);
+    else if (ns == 2) hipLaunchKernelGGL((psfm_pc_resident_kernel<2, false>), dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows, pp);
+    else hipLaunchKernelGGL((psfm_pc_resident_kernel<3, false>), dim3(n_blocks), dim3(PC_BLOCK), 0, s, P, gran, c->pc_epoch, spin_limit, max_rounds, quit_code, init_inside ? 1 : 0, raise_stall ? 1 : 0, out_rows, pp);
     c->n_resident += 1;
     return true;
+}
+
+// ---- ONE solve over several ranks (psfm_shard.hip) ----
+size_t psfm_peer_area_bytes(void) { return sizeof(unsigned long long) * PC_RES_ROW * ((size_t)PC_RES_BLOCKS + 2 * PSFM_MAX_PEERS * PC_LEADERS); }
+size_t psfm_peer_lead_offset(void) { return sizeof(unsigned long long) * PC_RES_ROW * (size_t)PC_RES_BLOCKS; }
+int psfm_peer_leaders(int n_blocks) { return n_blocks < PC_LEADERS ? n_blocks : PC_LEADERS; }
+int psfm_solve_blocks(psfm_ctx* c, const PsfmTrackDims& d) { return pc_blocks(c, (int)d.cap); }
+
+// This rank's launch of the solve of `frame` over all ranks of c->peers: iteration 0, the trust-region loop with the cross-rank
+// all-reduce, the write-back -- enqueued, nothing read back.  There is no launch-chain form of it (launches cannot add sums across
+// ranks): a launch that cannot be made, or that gives up, leaves the stall flag raised, every rank's polls run into this rank's
+// poison (or their limit), and the caller redoes the solve in the exchange form at its checkpoint.
+psfm_status psfm_solve_frame_enqueue_peer(psfm_ctx* c, const PsfmTrackDims& d, const float* flow01, const float* flow12,
+                                          const float* flow02, const uint8_t* occ02, int frame, unsigned epoch, hipStream_t s)
+{
+    PcParams P;
+    psfm_status rc = pc_frame_params(c, d, flow01, flow12, flow02, occ02, frame, P, s);
+    if (rc != PSFM_OK) return rc;
+    const int n_blocks = pc_blocks(c, (int)d.cap);
+    PcPeers pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.world = c->peer_world; pp.rank = c->peer_rank;
+    for (int r = 0; r < c->peer_world; ++r) { pp.L[r] = c->peer_L[r]; pp.lead[r] = (unsigned long long*)c->peer_lead[r]; }
+    if (pp.L[pp.rank] != psfm_peer_leaders(n_blocks)) {
+        psfm_set_error("psfm_shard_solve_peer: this rank's launch has %d blocks, the ranks were told %d leaders", n_blocks, pp.L[pp.rank]);
+        return PSFM_ERR_ARG;
+    }
+    const bool saved_ok = c->pc_persist_ok;
+    const int saved_giveups = c->pc_giveups;
+    c->pc_persist_ok = true; c->pc_giveups = 0;          // (the caller decided for all ranks at once: psfm_shard_peer_connect)
+    const bool ok = pc_persist_enqueue(c, P, n_blocks, nullptr, true, true, s, &pp, epoch);
+    c->pc_persist_ok = saved_ok; c->pc_giveups = saved_giveups;
+    if (!ok) {
+        // (the other ranks must not wait for sums that will never come: raise the flag, they give up at their spin limit)
+        hipLaunchKernelGGL(psfm_pc_raise_stall_kernel, dim3(1), dim3(1), 0, s, P.stall, frame);
+    }
+    PSFM_HIP(hipGetLastError());
+    return PSFM_OK;
 }
 
 // Enqueue one frame's solve with NO host synchronisation: the resident solve (iteration 0, the trust-region loop and the

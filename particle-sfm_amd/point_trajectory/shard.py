@@ -33,6 +33,14 @@ class HipShardEngine:
         self.mode = 0
         self.unroll = 4
         self._own_budget = False
+        # SEVERAL ranks (round 6): windows whose solves reject steps run every solve as ONE resident launch per rank, the second hop of
+        # its all-reduce crossing the ranks through peer-mapped granule rows (psfm_shard_solve_peer; connect_peers() below sets it up) --
+        # no export / all-gather / control launch per trust-region iteration, no host poll.  _epoch: the tag of a solve's granules, advanced
+        # by every rank for every such launch.  PSFM_SHARD_PEER=0 keeps the exchange form (A/B runs, tests of the exchange form).
+        self._peer = False
+        self._comm = None
+        self._epoch = 0
+        self._peer_maps = {}               # (pid, area pointer of that process) -> the area as this process addresses it
 
     def set_local(self, on):
         self.local = bool(on) and os.environ.get("PSFM_SHARD_LOCAL", "1") != "0"
@@ -41,6 +49,58 @@ class HipShardEngine:
         """a run that ended in an exception: nothing of it is handed to the next one"""
         self._pending = []
         self._release_budget()
+
+    def connect_peers(self, comm):
+        """After begin(), on every rank of `comm`: agree on whether the resident solve can span the ranks (every rank's launch fits its
+        share of its device) and, if so, exchange the granule areas -- raw pointers between ranks that are threads of one process, IPC
+        handles between processes (same GPU or peers over xGMI)."""
+        import socket
+        import torch
+        self._peer, self._comm = False, comm
+        if comm.world < 2 or comm.world > 8 or not self.optimize or os.environ.get("PSFM_SHARD_PEER", "1") == "0":
+            return False
+        L, h = _hip.lib(), self.ctx.handle
+        # ranks that share a device share its co-resident block slots
+        where = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"), int(self.ctx.device))
+        wheres = comm.all_gather_object(where)
+        sharing = sum(1 for w in wheres if w == where)
+        if self.ctx.resident_budget == 0 or self._own_budget:
+            self.ctx.set_resident_budget(max(self.ctx.resident_capacity() // sharing, 1))
+            self._own_budget = True
+        area, handle = ctypes.c_void_p(0), (ctypes.c_ubyte * 64)()
+        _hip.check(L.psfm_shard_peer_area(h, ctypes.byref(area), handle, self._sp()))
+        nb = ctypes.c_int32(0)
+        _hip.check(L.psfm_shard_solve_blocks(h, ctypes.byref(nb)))
+        mine = {"pid": os.getpid(), "area": int(area.value), "handle": bytes(handle), "blocks": int(nb.value), "epoch": int(self._epoch)}
+        infos = comm.all_gather_object(mine)
+        if any(q["blocks"] < 1 for q in infos):
+            return False                    # (the same answer on every rank: they all keep the exchange form)
+        ptrs = (ctypes.c_void_p * comm.world)()
+        for r, q in enumerate(infos):
+            if r == comm.rank or q["pid"] == os.getpid():
+                ptrs[r] = q["area"]        # (a thread of this process: its pointer is ours)
+                continue
+            key = (q["pid"], q["area"], q["handle"])
+            if key not in self._peer_maps:
+                m = ctypes.c_void_p(0)
+                buf = (ctypes.c_ubyte * 64).from_buffer_copy(q["handle"])
+                _hip.check(L.psfm_shard_peer_open(h, buf, r, ctypes.byref(m)))
+                self._peer_maps = {k: v for k, v in self._peer_maps.items() if k[0] != q["pid"]}      # (psfm_shard_peer_open closed rank r's old mapping)
+                self._peer_maps[key] = int(m.value)
+            ptrs[r] = self._peer_maps[key]
+        blocks = (ctypes.c_int32 * comm.world)(*[q["blocks"] for q in infos])
+        _hip.check(L.psfm_shard_peer_connect(h, comm.world, comm.rank, ptrs, blocks))
+        self._epoch = max(q["epoch"] for q in infos)      # (a rank whose earlier run was aborted catches up)
+        self._peer = True
+        self.counters.update({"peer": 0, "peer_redone": 0})
+        return True
+
+    def _solve_peer(self, t, flow_prev, flow_cur, flow2_prev, occ2_prev):
+        """several ranks, a window whose solves reject steps: this rank's launch of the solve of frame t over all ranks (enqueued)"""
+        self._epoch = (self._epoch % 0xFFFFE) + 1            # 1 .. 2^20 - 1, the same on every rank
+        _hip.check(_hip.lib().psfm_shard_solve_peer(self.ctx.handle, _hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev),
+                                                    _hip.ptr(occ2_prev), int(t), int(self._epoch), self._sp()))
+        self._pending.append((int(t), (flow_prev, flow_cur, flow2_prev, occ2_prev), 2))
 
     def grow_tables(self):
         """psfm_dist.connect_sharded, after some rank reported PSFM_ERR_CAPACITY: the next run of this engine gets twice the lanes and
@@ -71,6 +131,7 @@ class HipShardEngine:
         self.G = ((W + ratio - 1) // ratio) * ((H + ratio - 1) // ratio)
         self.mode, self.unroll = 0, 4
         self._release_budget()
+        self._peer = False                 # (connect_peers() decides for this run, on every rank alike)
         self._loc = self.local and bool(optimize) and int(g0) == 0 and int(g1) == self.G      # (this run)
         if self._loc and self.ctx.resident_budget == 0:
             # the resident solves of this engine run inside a budget (the calls of a sharded run come and go under the shared gate: no
@@ -108,6 +169,8 @@ class HipShardEngine:
         L, h = _hip.lib(), self.ctx.handle
         if self._loc and self.mode == 1:
             return self._solve_local(t, flow_prev, flow_cur, flow2_prev, occ2_prev)
+        if self._peer and self.mode == 1:
+            return self._solve_peer(t, flow_prev, flow_cur, flow2_prev, occ2_prev)
         p = (_hip.ptr(flow_prev), _hip.ptr(flow_cur), _hip.ptr(flow2_prev), _hip.ptr(occ2_prev))
         k = max(1, min(K_MAX, self.k))
         mask = [(i % N_SUM) == SUM_GMAX for i in range(k * N_SUM)]
@@ -133,6 +196,9 @@ class HipShardEngine:
         if self._loc and self.mode == 1:       # (two launches: the chain step, then the solve of the frame's tracks)
             reduce_first(self.step(t, flow_cur, occ))
             return self._solve_local(t, flow_prev, flow_cur, flow2_prev, occ2_prev)
+        if self._peer and self.mode == 1:      # (the chain step, the exchange of its marks, this rank's launch of the cross-rank solve)
+            reduce_first(self.step(t, flow_cur, occ))
+            return self._solve_peer(t, flow_prev, flow_cur, flow2_prev, occ2_prev)
         k = max(1, min(K_MAX, self.k))
         if self._loc and os.environ.get("PSFM_SHARD_LOCAL_CONTROL", "1") != "0":
             # one rank: the launch runs the control step on its own totals -- no export, no exchange, no control launch per frame
@@ -154,7 +220,7 @@ class HipShardEngine:
     def window_full(self):
         """one rank: a window of solves enqueued as resident launches ends after 16 frames, like the one-GPU call's -- should the flows
         have turned clean, the next window goes back to fused solves (a third of the time per solve)"""
-        return self._loc and self.mode == 1 and len(self._pending) >= 16
+        return (self._loc or self._peer) and self.mode == 1 and len(self._pending) >= 16
 
     def stalled(self):
         """True once the device has got to a solve that did not go as speculated (read from pinned memory, no synchronisation)."""
@@ -173,6 +239,17 @@ class HipShardEngine:
         stalled = ctypes.c_int32(-1)
         _hip.check(L.psfm_shard_window_state(h, f_lo, f_hi, stats, ctypes.byref(stalled), self._sp()))
         fs = int(stalled.value)
+        if self._peer and any(how == 2 for _, _, how in self._pending):
+            # every rank runs the same control step on the same totals, and a rank that gives a cross-rank solve up poisons the round for all
+            # of them -- so they stall on the same frame.  Checked, not assumed: ranks that disagreed here would wait for each other for ever
+            import torch
+            big = 1 << 30
+            v = torch.tensor([-(fs if fs >= 0 else big), fs], dtype=torch.int64, device=self.device)
+            self._comm.all_reduce_max_(v)
+            lo, hi = -int(v[0]), int(v[1])
+            if (lo if lo < big else -1) != hi:
+                raise RuntimeError("track-sharded run: the ranks disagree on the stalled solve (frames %d / %d): a cross-rank solve ended on "
+                                   "one rank and was given up on another" % (lo if lo < big else -1, hi))
         last_ok = f_hi if fs < 0 else fs - 1
         seen = []                      # statistics of the window's completed solves (the redone one included)
         for t, _, how in self._pending:
@@ -180,7 +257,7 @@ class HipShardEngine:
                 break
             st = stats[t - f_lo]
             _hip.check(L.psfm_shard_solve_record(h, ctypes.byref(st)))
-            self.counters["local" if how else "fused"] += 1
+            self.counters[("fused", "local", "peer")[how]] += 1
             self._adapt(st)
             seen.append(st)
         redo = None
@@ -203,8 +280,9 @@ class HipShardEngine:
                       file=sys.stderr)
         elif fs >= 0:
             frames = {t: x for t, x, _ in self._pending}
+            hows = {t: how for t, _, how in self._pending}
             p = tuple(_hip.ptr(x) for x in frames[fs])
-            self.counters["fused_redone"] += 1
+            self.counters["peer_redone" if hows[fs] == 2 else "fused_redone"] += 1
             _hip.check(L.psfm_shard_solve_restore(h, fs, self._sp()))
             mask = [(i % N_SUM) == SUM_GMAX for i in range(N_SUM)]
             # The launch chain, a BATCH of trust-region rounds enqueued ahead (export -> sums over the ranks -> control, nothing read
@@ -228,8 +306,9 @@ class HipShardEngine:
                 ahead = min(32, ahead * 2) if ahead > 1 else 1
             _hip.check(L.psfm_shard_solve_writeback(h, fs, ctypes.byref(st), self._sp()))
             self._adapt(st)
+            seen.append(st)
             redo = fs
-        if self._loc:
+        if self._loc or self._peer:
             # psfm_connect's rule (csrc/psfm_api.hip): a window with more than one solve in eight off the Gauss-Newton path sends the
             # next window to the resident solves, a clean one brings the fused solves back; launches per solve without a budget:
             # what the slowest solve of the window needed, within [4, 64]
@@ -238,7 +317,7 @@ class HipShardEngine:
                 self.mode = 1 if 8 * sum(0 if self._clean(q) else 1 for q in solved) > len(solved) else 0
                 want = min(64, max(4, max(q.iterations for q in solved) + 1))
                 self.unroll = want if want > self.unroll else self.unroll - (self.unroll - want + 1) // 2
-            if os.environ.get("PSFM_SHARD_TRACE"):
+            if os.environ.get("PSFM_SHARD_TRACE") and self._loc:
                 import sys
                 import time
                 print("[shard] window %d..%d checked: %d solves, next mode %d, k %d, t=%.3f" % (f_lo, f_hi, len(solved), self.mode, self.k,

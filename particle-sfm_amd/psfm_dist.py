@@ -359,6 +359,10 @@ def connect_sharded(engine, flows_f, flows_b, flows_f2, flows_b2, thres, sample_
         wf = FrameWindow(flows_f, n_flows, comm) if owned else None
         w2 = FrameWindow(flows_f2, n2, comm) if owned and optimize and n2 > 0 else None
         engine.begin(n_flows, H, W, r, g0, g1, optimize)
+        if world > 1 and optimize and hasattr(engine, "connect_peers"):
+            # several ranks: solves that reject steps run as ONE resident launch per rank whose all-reduce crosses the ranks on the device
+            # (peer-mapped granule rows) instead of export -> all-gather -> control per trust-region iteration with the host polling
+            engine.connect_peers(comm)
         try:
             return _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, GW, optimize, owned, wf, w2, g0, g1, keep_on_device)
         except _CapacityRetry:
@@ -434,7 +438,7 @@ def _stage_b(engine, comm, flows_f, flows_f2, occ, occ2, n_flows, n2, H, W, r, G
         since += 1
         # (every 16 frames -- or as soon as the engine sees, without synchronising, that a solve of the window has stalled)
         if has_ck and (since >= engine.check_every or t == n_flows - 1 or _any_stalled(engine, comm) or
-                       (world == 1 and hasattr(engine, "window_full") and engine.window_full())):
+                       (hasattr(engine, "window_full") and engine.window_full())):
             redone = engine.checkpoint(reduce)
             if redone is not None:
                 t = redone                   # frames redone + 1 .. are run again
