@@ -620,6 +620,16 @@ def end_to_end(frames=N_FRAMES, workdir=None):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def two_ranks_one_gpu():
+    """scripts/probe_peer_thread_ranks.py: the headline shape with hard flows over TWO thread-ranks on this GPU -- the multi-rank engine's
+    device-paced reject path (psfm_shard_solve_peer) -- beside ONE psfm_connect call on the same tensors.  No xGMI link is crossed."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("psfm_probe_peer", os.path.join(ROOT, "scripts", "probe_peer_thread_ranks.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.run(2, N_FRAMES, "hard", forms=("peer",), reps=2)
+
+
 def run_all(ctx, dev, n_frames=N_FRAMES, budget_s=150.0):
     """Every figure outside the timed region (world size 1), in order of how much the reviews lean on it.  A figure that raises
     reports {"error": ...}; once `budget_s` seconds are spent the rest report {"skipped": ...} -- the headline line never waits
@@ -672,6 +682,8 @@ def run_all(ctx, dev, n_frames=N_FRAMES, budget_s=150.0):
                     label="configs[4] shape (ScanNet, dense)")
     extra("secondary_scannet_batch", secondary_batch, 480, 640, 1000, 1, True, 3.0, 4, 4, "configs[4] shape (ScanNet, dense)",
           scannet, n=2)
+    # ONE hard sequence over two ranks (threads of this process, both on this GPU): the cross-rank resident solve beside psfm_connect
+    extra("two_ranks_one_gpu_hard", two_ranks_one_gpu)
     extra("single_sequence", single_sequence_sharded, dev, 0, 1, 401)      # configs[3]'s shape: 400 pairs + stride-2 stacks, 26 GB
     out["extras_wall_s"] = time.perf_counter() - t_start
     return out
@@ -720,6 +732,10 @@ def summary(full):
         if "world_size" in v:
             e["world"] = v["world_size"]
         s[name] = e
+    tr = full.get("two_ranks_one_gpu_hard")
+    if isinstance(tr, dict) and "peer_ms" in tr:
+        s["two_ranks_one_gpu_hard"] = {"ms": tr["peer_ms"], "vs_one_gpu_call": tr["peer_over_psfm_connect"], "cross_rank_solves": _first(tr, "counters_peer", "peer"),
+                                       "gave_up": _first(tr, "counters_peer", "peer_redone")}
     ee = full.get("end_to_end")
     if isinstance(ee, dict) and "total_s" in ee:
         s["disk_to_disk_s"] = {"total": ee["total_s"], "ingest": ee.get("ingest_s"), "compute": ee.get("compute_s"), "write": ee.get("write_s")}

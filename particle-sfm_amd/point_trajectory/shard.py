@@ -283,6 +283,11 @@ class HipShardEngine:
             hows = {t: how for t, _, how in self._pending}
             p = tuple(_hip.ptr(x) for x in frames[fs])
             self.counters["peer_redone" if hows[fs] == 2 else "fused_redone"] += 1
+            if hows[fs] == 2 and self.counters["peer_redone"] >= 2:
+                # two cross-rank launches of this run gave up (the ranks' launches were not running at the same time: ranks that share a
+                # device and its hardware queues, a device busy with other work): every give-up costs its spin limit, so the rest of the
+                # run keeps the exchange form.  Every rank counts the same stalls, so they all decide this here.
+                self._peer = False
             _hip.check(L.psfm_shard_solve_restore(h, fs, self._sp()))
             mask = [(i % N_SUM) == SUM_GMAX for i in range(N_SUM)]
             # The launch chain, a BATCH of trust-region rounds enqueued ahead (export -> sums over the ranks -> control, nothing read
