@@ -186,6 +186,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->redo_stream) (void)hipStreamDestroy(c->redo_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream2) (void)hipStreamDestroy(c->copy_stream2);
     for (void* p : c->ingest_slots) (void)hipHostFree(p);
     for (hipEvent_t e : c->ingest_events) (void)hipEventDestroy(e);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);

@@ -57,12 +57,19 @@ extern "C" psfm_status psfm_load_flo_stack(psfm_ctx* c, const char* const* paths
         PSFM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->ingest_events.push_back(e);
     }
+    // two copy streams, the slots alternating between them: the runtime gives streams their own SDMA engine, and one engine moves
+    // ~35 GB/s of a PCIe Gen5 x16 link's ~55 (PSFM_FLO_COPY_STREAMS=1: one stream, as in round 5)
+    static const int n_copy_env = getenv("PSFM_FLO_COPY_STREAMS") ? atoi(getenv("PSFM_FLO_COPY_STREAMS")) : 2;
+    const bool two = n_copy_env >= 2;
+    if (two && !c->copy_stream2) PSFM_HIP(hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking));
     hipStream_t cs = c->copy_stream;
+    hipStream_t cs2 = two ? c->copy_stream2 : c->copy_stream;
     hipStream_t s = (hipStream_t)stream;
     {   // the copies start behind whatever the caller has enqueued on `stream` (e.g. the allocation of dst on that stream)
         hipEvent_t e = c->prof.get();
         PSFM_HIP(hipEventRecord(e, s));
         PSFM_HIP(hipStreamWaitEvent(cs, e, 0));
+        if (two) PSFM_HIP(hipStreamWaitEvent(cs2, e, 0));
         c->prof.pool.push_back(e);
     }
     // ---- the readers ----
@@ -114,8 +121,9 @@ extern "C" psfm_status psfm_load_flo_stack(psfm_ctx* c, const char* const* paths
             if (have != bytes) { fail(std::string(path) + ": truncated (" + std::to_string(have) + " of " + std::to_string(bytes) + " data bytes)"); return; }
             {   // copies are enqueued in any order (each waits only for its own slot); the event tells when the slot is free again
                 std::lock_guard<std::mutex> lk(mu);
-                if (hipMemcpyAsync((char*)dst_dev + (size_t)i * bytes, dst, bytes, hipMemcpyHostToDevice, cs) != hipSuccess ||
-                    hipEventRecord(c->ingest_events[(size_t)k], cs) != hipSuccess) {
+                hipStream_t q = (k & 1) ? cs2 : cs;
+                if (hipMemcpyAsync((char*)dst_dev + (size_t)i * bytes, dst, bytes, hipMemcpyHostToDevice, q) != hipSuccess ||
+                    hipEventRecord(c->ingest_events[(size_t)k], q) != hipSuccess) {
                     if (!failed.exchange(true)) err = "hipMemcpyAsync / hipEventRecord failed";
                     cv.notify_all();
                     return;
@@ -135,6 +143,7 @@ extern "C" psfm_status psfm_load_flo_stack(psfm_ctx* c, const char* const* paths
     for (auto& t : ths) t.join();
     // the staging buffers belong to the context: nothing may still read them when the call returns; `stream` continues behind the copies
     hipError_t e1 = hipStreamSynchronize(cs);
+    if (two) { const hipError_t e2 = hipStreamSynchronize(cs2); if (e1 == hipSuccess) e1 = e2; }
     if (failed.load()) { psfm_set_error("psfm_load_flo_stack: %s", err.c_str()); return PSFM_ERR_ARG; }
     PSFM_HIP(e1);
     return PSFM_OK;

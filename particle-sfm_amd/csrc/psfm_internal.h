@@ -202,6 +202,7 @@ struct psfm_ctx {
     int mt_n_img = 0;
     hipStream_t side_stream = nullptr;   // flow_check of psfm_connect runs here, ahead of the frame loop
     hipStream_t copy_stream = nullptr;   // psfm_load_flo_stack: H2D copies out of the pinned ring
+    hipStream_t copy_stream2 = nullptr;  // ... every second slot's copies (two SDMA engines; PSFM_FLO_COPY_STREAMS=1: one)
     std::vector<void*> ingest_slots;     // ... the ring (pinned, ingest_slot_bytes each) and the event behind the last copy out of every slot
     std::vector<hipEvent_t> ingest_events;
     size_t ingest_slot_bytes = 0;
