@@ -63,7 +63,7 @@ def load_flows_device_slice(dir, rank, world, device=None, **kw):
     return load_flows_device(dir, device=device, _names=names[lo:hi], _probe=names[:1], **kw), len(names)
 
 
-def load_flows_device(dir, device=None, n_staging=16, n_readers=8, _names=None, _probe=None):
+def load_flows_device(dir, device=None, n_staging=32, n_readers=16, _names=None, _probe=None):
     """`load_flows` (utils.py:26-32) straight into HBM: the .flo files are read by a few reader threads into pinned
     host buffers (owned by the context, reused across calls) and copied to their slot of one (n,H,W,2) device tensor with
     asynchronous H2D copies on a side stream, so disk / page-cache reads and PCIe transfers overlap (at

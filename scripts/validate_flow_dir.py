@@ -70,6 +70,8 @@ def main(argv=None):
             names = names[:n]
         return [np.ascontiguousarray(read_flo(f), np.float32) for f in names]
 
+    # (small maps: the oracle's OpenMP loops crawl when spread over every core of a 256-core host)
+    orc.set_num_threads(min(int(os.environ.get("PSFM_CPU_THREADS", "0")) or 32, os.cpu_count() or 1))
     n = args.frames or None
     ff, fb = stack("flow_f", n), stack("flow_b", n)
     if not ff or len(ff) != len(fb):

@@ -64,13 +64,19 @@ def test_connect_sharded_hip_engine(world, T, H, W, r, seed, sigma, nocc, optimi
         assert ((gidx >= g0) & (gidx < g1)).all()
         n_local += len(part["birth"])
         if optimize:
-            assert cnt["fused"] + cnt["fused_redone"] + cnt["local"] + cnt["local_redone"] == len(O.solves)
-            assert world == 1 or cnt["local"] + cnt["local_redone"] == 0     # (several ranks: every solve goes through the exchange)
+            assert sum(cnt.values()) == len(O.solves)                         # every solve went exactly one way
+            assert world == 1 or cnt["local"] + cnt["local_redone"] == 0     # (several ranks: the exchange form or the cross-rank launch)
+            assert world > 1 or "peer" not in cnt
     assert n_local == O.n_traj
     if optimize and sigma <= 0.05:
-        assert res[0][2]["fused"] >= len(O.solves) - 3          # clean sequence: (nearly) every solve in one launch
+        # clean sequence: (nearly) every solve in one launch -- the fused frame launch, or, in the window behind a solve that left the
+        # Gauss-Newton path, this rank's launch of the cross-rank solve
+        assert res[0][2]["fused"] + res[0][2].get("peer", 0) >= len(O.solves) - 3
     if optimize and sigma >= 0.4 and world > 1:
-        assert res[0][2]["fused_redone"] >= len(O.solves) // 2  # noisy sequence: the chain protocol did the work
+        # noisy sequence: the first solve is redone by the chain protocol, the windows behind it run cross-rank resident launches (or,
+        # where those give up -- eight thread-ranks share the process's hardware queues -- the chain protocol again)
+        c0 = res[0][2]
+        assert c0["fused_redone"] >= 1 and c0["fused_redone"] + c0.get("peer", 0) + c0.get("peer_redone", 0) >= len(O.solves) // 2
     if optimize and sigma >= 0.4 and world == 1:
         # one rank: the first stalled solve sends the windows behind it to the one-GPU call's forms (resident solves)
         assert res[0][2]["local"] >= len(O.solves) - 3 and res[0][2]["fused_redone"] <= 2
