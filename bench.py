@@ -235,7 +235,7 @@ def main():
     single, single_hard, hung = None, None, False
     if world > 1:      # (world size 1: bench_extras.run_all times the same two figures, inside its budget)
         dist.barrier()
-        single, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, args.single_seq_frames), 240)
+        single, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, args.single_seq_frames), 150)
         # ... and on flows whose solves reject steps (psfm_synth.HARD, 100 frames: VERDICT r4 item 2) -- the redo path of the sharded engine
         single_hard = None
         if not hung:
@@ -243,7 +243,7 @@ def main():
                 dist.barrier()
             import psfm_synth as _ps
             single_hard, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, 101, reps=1, flows_dist=_ps.HARD,
-                                                                        label="headline shape, hard flows (sigma 0.3, 5 % occluders)"), 300)
+                                                                        label="headline shape, hard flows (sigma 0.3, 5 % occluders)"), 150)
 
 
     if rank == 0:

@@ -116,6 +116,9 @@ def single_sequence_sharded(dev, rank, world, frames, reps=2, flows_dist=None, l
            "ms_per_sequence": 1e3 * dt, "trajectory_points_per_s": pts / dt, "points": int(pts), "trajectories": int(part["n_traj"]),
            "solves": part["n_solves"], "trust_region_iterations": part["solver_iterations"],
            "solver_counters": dict(eng.counters), "local_trajectories_rank0": int(part["ids"].numel())}
+    if world > 1:     # how the solves that reject steps ran across the ranks: cross-rank resident launches (psfm_shard_solve_peer) or the exchange form
+        out["cross_rank_solve"] = {"launches": int(eng.counters.get("peer", 0)), "gave_up": int(eng.counters.get("peer_redone", 0)),
+                                   "refused": getattr(eng, "peer_refused", None)}
     lc = eng.ctx.solver_counters()
     out["solver_launches"] = {k: lc[k] for k in ("resident_launches", "resident_giveups", "iteration_launches")}
     if world == 1:
@@ -731,6 +734,9 @@ def summary(full):
             e["ms_exchange_form"] = v["ms_per_sequence_exchange_form"]
         if "world_size" in v:
             e["world"] = v["world_size"]
+        if isinstance(v.get("cross_rank_solve"), dict):
+            e["cross_rank_launches"] = v["cross_rank_solve"]["launches"]
+            e["cross_rank_gave_up"] = v["cross_rank_solve"]["gave_up"]
         s[name] = e
     tr = full.get("two_ranks_one_gpu_hard")
     if isinstance(tr, dict) and "peer_ms" in tr:

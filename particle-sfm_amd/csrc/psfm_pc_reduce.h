@@ -82,11 +82,19 @@ __device__ __forceinline__ void pc_block_sums(const double* acc, double* out)
     const double g = pc_row_tree<NS_>(acc, slot);
     s_row[tid >> 4][slot] = g;
     __syncthreads();
-    if (tid < NS_) {
+    // the 16 row totals of a slot, in row order: the added slots by the first lanes of wave 0, the maximum by the first lane of wave 1 --
+    // one wave adds, another takes maxima (round 6: one loop that formed BOTH for every row and selected was 105 instructions on the
+    // critical path of every launch / round; the order of the additions is unchanged)
+    if (tid < NS_ && tid != SUM_GMAX) {
         double v = s_row[0][tid];
 #pragma unroll
-        for (int q = 1; q < 4 * (PC_BLOCK / PSFM_WAVE); ++q) v = (tid == SUM_GMAX) ? fmax(v, s_row[q][tid]) : v + s_row[q][tid];
+        for (int q = 1; q < 4 * (PC_BLOCK / PSFM_WAVE); ++q) v = v + s_row[q][tid];
         out[tid] = v;
+    } else if (tid == PSFM_WAVE && SUM_GMAX < NS_) {
+        double v = s_row[0][SUM_GMAX];
+#pragma unroll
+        for (int q = 1; q < 4 * (PC_BLOCK / PSFM_WAVE); ++q) v = fmax(v, s_row[q][SUM_GMAX]);
+        out[SUM_GMAX] = v;
     }
     __syncthreads();
 }

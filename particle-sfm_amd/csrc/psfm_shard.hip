@@ -13,6 +13,7 @@
 //   psfm_shard_finish          write-backs pending, finalize: the own trajectories as the usual CSR result, sorted by the
 //                              key (last valid time, birth frame, birth grid index) -- global ids follow from the keys
 // No collective is issued from here: the caller owns the process group (RCCL over xGMI, or gloo in tests).
+#include <stdlib.h>
 #include <string.h>
 
 #include "psfm_internal.h"
@@ -262,6 +263,20 @@ extern "C" psfm_status psfm_shard_peer_area(psfm_ctx* c, void** area_dev, void* 
     PSFM_HIP(hipSetDevice(c->device));
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
     const bool fresh = c->peer_area.p == nullptr;
+    if (fresh) {
+        // FINE-GRAINED device memory: other GPUs write into this area over xGMI while this GPU's launch polls it.  Coarse-grained memory
+        // is only guaranteed coherent across agents at kernel boundaries; fine-grained allocations are not held in the L2s.  (Within one
+        // device the granules work on either kind -- the one-GPU launch keeps its rows in a plain allocation.)  PSFM_PEER_COARSE=1: plain
+        // hipMalloc (A/B runs); also the fall-back where the extension is refused.
+        void* q = nullptr;
+        const bool coarse = getenv("PSFM_PEER_COARSE") && atoi(getenv("PSFM_PEER_COARSE")) != 0;
+        if (!coarse && hipExtMallocWithFlags(&q, psfm_peer_area_bytes(), hipDeviceMallocFinegrained) == hipSuccess && q) {
+            c->peer_area.p = q;
+            c->peer_area.bytes = psfm_peer_area_bytes();
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     psfm_status st = c->peer_area.ensure(psfm_peer_area_bytes());
     if (st != PSFM_OK) return st;
     if (fresh) {

@@ -41,6 +41,7 @@ class HipShardEngine:
         self._comm = None
         self._epoch = 0
         self._peer_maps = {}               # (pid, area pointer of that process) -> the area as this process addresses it
+        self.peer_refused = None           # why the last connect_peers() kept the exchange form (a peer's area could not be mapped), if it did
 
     def set_local(self, on):
         self.local = bool(on) and os.environ.get("PSFM_SHARD_LOCAL", "1") != "0"
@@ -76,20 +77,29 @@ class HipShardEngine:
         if any(q["blocks"] < 1 for q in infos):
             return False                    # (the same answer on every rank: they all keep the exchange form)
         ptrs = (ctypes.c_void_p * comm.world)()
-        for r, q in enumerate(infos):
-            if r == comm.rank or q["pid"] == os.getpid():
-                ptrs[r] = q["area"]        # (a thread of this process: its pointer is ours)
-                continue
-            key = (q["pid"], q["area"], q["handle"])
-            if key not in self._peer_maps:
-                m = ctypes.c_void_p(0)
-                buf = (ctypes.c_ubyte * 64).from_buffer_copy(q["handle"])
-                _hip.check(L.psfm_shard_peer_open(h, buf, r, ctypes.byref(m)))
-                self._peer_maps = {k: v for k, v in self._peer_maps.items() if k[0] != q["pid"]}      # (psfm_shard_peer_open closed rank r's old mapping)
-                self._peer_maps[key] = int(m.value)
-            ptrs[r] = self._peer_maps[key]
-        blocks = (ctypes.c_int32 * comm.world)(*[q["blocks"] for q in infos])
-        _hip.check(L.psfm_shard_peer_connect(h, comm.world, comm.rank, ptrs, blocks))
+        failure = None
+        try:
+            for r, q in enumerate(infos):
+                if r == comm.rank or q["pid"] == os.getpid():
+                    ptrs[r] = q["area"]        # (a thread of this process: its pointer is ours)
+                    continue
+                key = (q["pid"], q["area"], q["handle"])
+                if key not in self._peer_maps:
+                    m = ctypes.c_void_p(0)
+                    buf = (ctypes.c_ubyte * 64).from_buffer_copy(q["handle"])
+                    _hip.check(L.psfm_shard_peer_open(h, buf, r, ctypes.byref(m)))
+                    self._peer_maps = {k: v for k, v in self._peer_maps.items() if k[0] != q["pid"]}      # (psfm_shard_peer_open closed rank r's old mapping)
+                    self._peer_maps[key] = int(m.value)
+                ptrs[r] = self._peer_maps[key]
+            blocks = (ctypes.c_int32 * comm.world)(*[q["blocks"] for q in infos])
+            _hip.check(L.psfm_shard_peer_connect(h, comm.world, comm.rank, ptrs, blocks))
+        except RuntimeError as e:              # (no peer access between two devices, IPC refused by the driver, ...)
+            failure = str(e)
+        # a rank that could not map a peer must not leave the others waiting for its launches: all of them, or none
+        failures = comm.all_gather_object(failure)
+        if any(f is not None for f in failures):
+            self.peer_refused = [f for f in failures if f is not None][0]
+            return False
         self._epoch = max(q["epoch"] for q in infos)      # (a rank whose earlier run was aborted catches up)
         self._peer = True
         self.counters.update({"peer": 0, "peer_redone": 0})
