@@ -159,6 +159,21 @@ PC_HD void pc_tree_totals(const double* rows, int pitch, int n_blocks, int n_sum
     }
 }
 
+// ---- ONE solve over several ranks (PcPeers in psfm_solver.hip): every rank forms its total T_r with the tree above over ITS blocks'
+// rows, and every block of every rank adds the ranks' totals in rank order,
+//     total = (...((T_0 + T_1) + T_2) ...) + T_{world-1}            (SUM_GMAX by max)
+// -- the same numbers in the same order everywhere.  rows: rank r's block rows start at rows + (n_blocks[0] + ... + n_blocks[r-1]) * pitch.
+PC_HD void pc_peer_totals(const double* rows, int pitch, const int* n_blocks, int world, int n_sums, double tot[PC_NSUM])
+{
+    double Tr[PC_NSUM];
+    long start = 0;
+    for (int r = 0; r < world; ++r) {
+        pc_tree_totals(rows + start * pitch, pitch, n_blocks[r], n_sums, Tr);
+        for (int k = 0; k < PC_NSUM; ++k) tot[k] = r == 0 ? Tr[k] : (k == SUM_GMAX ? fmax(tot[k], Tr[k]) : tot[k] + Tr[k]);
+        start += n_blocks[r];
+    }
+}
+
 // ---- the end of a solve: which buffer the positions of the solve come from.  A failed solve hands the parameters back as they
 // came in (buffer 0, which no form of the chain writes before its write-back); otherwise a slot writes its own x, a streamed
 // entry is copied from the iterate buffer the control block names ----

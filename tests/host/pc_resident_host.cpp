@@ -14,22 +14,49 @@
 #include "psfm_pc_resident.h"
 
 // returns 0: done (x_out, stats, costs filled); 1: ran out of rounds; 2: gave up (a block quit: nothing written, x_out untouched)
+// world > 1 (owner[i] = the rank row i belongs to): the same solve spread over `world` ranks the way psfm_shard_solve_peer runs it -- every
+// rank its own launch of n_blocks blocks over the rows it owns, every rank's tree total, the totals added in rank order (pc_peer_totals),
+// every block of every rank running the same control step.  quit_block counts through the ranks' blocks (rank * n_blocks + block).
+static int pc_host_resident_solve_ranks(long n, const unsigned char* part, const unsigned char* owner, int world, const double* x0,
+                                        const double* ref1, const double* ref2, const double* scale, const float* flow, int H, int W,
+                                        int n_blocks_per_rank, int NS, int banded, int init_inside, int quit_block, int quit_round,
+                                        double* x_out, int* stats, double* costs, int* info);
+
 extern "C" int pc_host_resident_solve(long n, const unsigned char* part, const double* x0, const double* ref1, const double* ref2,
                                       const double* scale, const float* flow, int H, int W, int n_blocks, int NS, int banded,
                                       int init_inside, int quit_block, int quit_round, double* x_out, int* stats, double* costs,
                                       int* info /* [0] longest list, [1] streamed entries, [2] rounds, [3] empty blocks */)
 {
+    return pc_host_resident_solve_ranks(n, part, nullptr, 1, x0, ref1, ref2, scale, flow, H, W, n_blocks, NS, banded, init_inside, quit_block,
+                                        quit_round, x_out, stats, costs, info);
+}
+
+extern "C" int pc_host_peer_solve(long n, const unsigned char* part, const unsigned char* owner, int world, const double* x0, const double* ref1,
+                                  const double* ref2, const double* scale, const float* flow, int H, int W, int n_blocks_per_rank, int NS,
+                                  int banded, int init_inside, int quit_block, int quit_round, double* x_out, int* stats, double* costs, int* info)
+{
+    return pc_host_resident_solve_ranks(n, part, owner, world, x0, ref1, ref2, scale, flow, H, W, n_blocks_per_rank, NS, banded, init_inside,
+                                        quit_block, quit_round, x_out, stats, costs, info);
+}
+
+static int pc_host_resident_solve_ranks(long n, const unsigned char* part, const unsigned char* owner, int world, const double* x0,
+                                        const double* ref1, const double* ref2, const double* scale, const float* flow, int H, int W,
+                                        int n_blocks_per_rank, int NS, int banded, int init_inside, int quit_block, int quit_round,
+                                        double* x_out, int* stats, double* costs, int* info)
+{
+    const int n_blocks = world * n_blocks_per_rank;       // all ranks' blocks, rank-major: block lb = rank * n_blocks_per_rank + b
     const PcF2* F = (const PcF2*)flow;
     if (NS < 1) NS = 1;
     if (NS > 3) NS = 3;
     // ---- the blocks' lists (pc_build_list: chunks of the plan, the participating lanes of a chunk in lane order) ----
     std::vector<std::vector<long>> lists((size_t)n_blocks);
     for (int b = 0; b < n_blocks; ++b) {
-        const PcListPlan plan = pc_list_plan(b, n_blocks, (int)n, banded);
+        const int rank = b / n_blocks_per_rank;
+        const PcListPlan plan = pc_list_plan(b % n_blocks_per_rank, n_blocks_per_rank, (int)n, banded);
         for (int q = plan.first; pc_list_chunk_ok(plan, q); q += plan.step)
             for (int t = 0; t < PC_BLOCK; ++t) {
                 const long i = (long)(plan.band0 + q) * PC_BLOCK + t;
-                if (i < n && (!part || part[i])) lists[(size_t)b].push_back(i);
+                if (i < n && (!part || part[i]) && (!owner || owner[i] == rank)) lists[(size_t)b].push_back(i);
             }
     }
     {   // (every participating row is in exactly one list)
@@ -79,7 +106,7 @@ extern "C" int pc_host_resident_solve(long n, const unsigned char* part, const d
             for (long p = pc_stream_first(NS, t); p < cnt; p += PC_BLOCK) init_entry(lst[(size_t)p], nullptr);
         }
     }
-    pc_tree_totals(rows.data(), PC_NSUM, n_blocks, PC_NSUM, tot);
+    { std::vector<int> nb((size_t)world, n_blocks_per_rank); pc_peer_totals(rows.data(), PC_NSUM, nb.data(), world, PC_NSUM, tot); }
     pc_chain_control(C, tot, 0);
     C.launches = 1;
     if (!init_inside && !C.done) {
@@ -152,7 +179,7 @@ extern "C" int pc_host_resident_solve(long n, const unsigned char* part, const d
             }
         }
         ++rounds;
-        pc_tree_totals(rows.data(), PC_NSUM, n_blocks, PC_NSUM, tot);
+        { std::vector<int> nb((size_t)world, n_blocks_per_rank); pc_peer_totals(rows.data(), PC_NSUM, nb.data(), world, PC_NSUM, tot); }
         const int cur0 = C.cur;
         pc_chain_control(C, tot, 1);
         C.launches += 1;

@@ -36,6 +36,8 @@ def chain(tmp_path_factory):
     ubp = ctypes.POINTER(ctypes.c_ubyte)
     L.pc_host_resident_solve.argtypes = [ctypes.c_long, ubp, dp, dp, dp, dp, fp] + [ctypes.c_int] * 8 + [dp, ip, dp, ip]
     L.pc_host_resident_solve.restype = ctypes.c_int
+    L.pc_host_peer_solve.argtypes = [ctypes.c_long, ubp, ubp, ctypes.c_int, dp, dp, dp, dp, fp] + [ctypes.c_int] * 8 + [dp, ip, dp, ip]
+    L.pc_host_peer_solve.restype = ctypes.c_int
     return L
 
 
@@ -342,3 +344,48 @@ def test_block_tree_order_is_what_the_device_adds(chain):
                     v = red(v, S[x])
                 t.append(v)
             assert tot[k] == red(red(red(t[0], t[1]), t[2]), t[3]), (nb, k)
+
+
+def _peer(L, uv, ref1, ref2, scale, flow12, owner, world, n_blocks, ns, banded=1, init_inside=1, quit=(-1, -1)):
+    dp, fp, ip, ubp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ubyte)
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 4)
+    n = len(uv)
+    r1 = np.ascontiguousarray(ref1, np.float64).reshape(-1, 2); r2 = np.ascontiguousarray(ref2, np.float64).reshape(-1, 2)
+    sc = np.ascontiguousarray(scale, np.float64).reshape(-1)
+    fl = np.ascontiguousarray(flow12, np.float32)
+    H, W = fl.shape[:2]
+    ow = np.ascontiguousarray(owner, np.uint8)
+    out = np.full((n, 4), -777.0); stats = np.zeros(7, np.int32); costs = np.zeros(2); info = np.zeros(4, np.int32)
+    rc = L.pc_host_peer_solve(n, None, ow.ctypes.data_as(ubp), int(world), uv.ctypes.data_as(dp), r1.ctypes.data_as(dp), r2.ctypes.data_as(dp),
+                              sc.ctypes.data_as(dp), fl.ctypes.data_as(fp), H, W, int(n_blocks), int(ns), int(banded), int(init_inside),
+                              int(quit[0]), int(quit[1]), out.ctypes.data_as(dp), stats.ctypes.data_as(ip), costs.ctypes.data_as(dp),
+                              info.ctypes.data_as(ip))
+    return out, {"iterations": int(stats[0]), "successful_steps": int(stats[1]), "termination": int(stats[2]), "dogleg_nonGN": int(stats[3]),
+                 "done": int(stats[5]), "failed": int(stats[6]), "initial_cost": float(costs[0]), "final_cost": float(costs[1])}, rc
+
+
+@pytest.mark.parametrize("world,n_blocks,ns", [(2, 5, 2), (3, 12, 1), (8, 4, 3), (4, 40, 3)])
+@pytest.mark.parametrize("H,W,n,seed,sigma,kink", [(60, 80, 3000, 2, 0.5, False), (45, 70, 5000, 3, 0.3, True)])
+def test_cross_rank_bookkeeping_on_the_host(chain, world, n_blocks, ns, H, W, n, seed, sigma, kink):
+    """psfm_shard_solve_peer's arithmetic without a GPU: the tracks of ONE solve dealt to `world` ranks (bands of rows, as connect_sharded
+    deals them), every rank the resident launch's bookkeeping over its own rows (csrc/psfm_pc_resident.h), every rank's tree total, the
+    totals added in RANK ORDER (pc_peer_totals: what every block of every rank does with the leader rows in its area), one control
+    step on them -- same decisions as one rank and as the oracle, positions to the rounding of another grouping of the sums; a rank
+    whose block gives up takes every rank's solve with it."""
+    from oracle import oracle as orc
+    uv, ref1, ref2, scale, flow12 = solver_batch(H, W, n, seed, sigma, kink)
+    owner = (np.arange(n) * world // n).astype(np.uint8)            # contiguous bands of rows
+    one, st1, rc1, _ = _resident(chain, uv, ref1, ref2, scale, flow12, n_blocks, ns)
+    got, st, rc = _peer(chain, uv, ref1, ref2, scale, flow12, owner, world, n_blocks, ns)
+    assert rc == 0 and rc1 == 0 and st["done"] == 1
+    for key in ("iterations", "successful_steps", "termination", "dogleg_nonGN"):
+        assert st[key] == st1[key], key
+    assert float(np.abs(got - one).max()) <= 1e-9
+    want, st_o = orc.optimize_location(uv, ref1, ref2, scale, flow12, return_stats=True)
+    _same_solve(got, st, want, st_o, 1e-6)
+    # ... and with ONE rank it is the one-GPU bookkeeping bit for bit
+    same, st_s, rc_s = _peer(chain, uv, ref1, ref2, scale, flow12, np.zeros(n, np.uint8), 1, n_blocks, ns)
+    assert rc_s == 0 and np.array_equal(same, one) and st_s["iterations"] == st1["iterations"]
+    # a block of the LAST rank leaves in round 2: nothing is written anywhere
+    out, _, rc_q = _peer(chain, uv, ref1, ref2, scale, flow12, owner, world, n_blocks, ns, quit=(world * n_blocks - 1, 2))
+    assert rc_q == 2 and (out == -777.0).all()
