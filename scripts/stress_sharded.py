@@ -29,7 +29,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = torch.device("cuda", 0)
 t0 = time.time()
 worst = 0.0
-forms = {"local": 0, "local_redone": 0, "fused": 0, "fused_redone": 0}
+forms = {"local": 0, "local_redone": 0, "fused": 0, "fused_redone": 0, "peer": 0, "peer_redone": 0}
 for case in range(n_cases):
     H, W = int(rng.integers(30, 120)), int(rng.integers(30, 150))
     if os.environ.get("PSFM_STRESS_BIG"):
