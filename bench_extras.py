@@ -630,7 +630,7 @@ def two_ranks_one_gpu():
     spec = importlib.util.spec_from_file_location("psfm_probe_peer", os.path.join(ROOT, "scripts", "probe_peer_thread_ranks.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.run(2, N_FRAMES, "hard", forms=("peer",), reps=2)
+    return mod.run(2, N_FRAMES, "hard", forms=("peer",), reps=3)
 
 
 def run_all(ctx, dev, n_frames=N_FRAMES, budget_s=150.0):
