@@ -68,13 +68,19 @@ class HipShardEngine:
         if self.ctx.resident_budget == 0 or self._own_budget:
             self.ctx.set_resident_budget(max(self.ctx.resident_capacity() // sharing, 1))
             self._own_budget = True
-        area, handle = ctypes.c_void_p(0), (ctypes.c_ubyte * 64)()
-        _hip.check(L.psfm_shard_peer_area(h, ctypes.byref(area), handle, self._sp()))
-        nb = ctypes.c_int32(0)
-        _hip.check(L.psfm_shard_solve_blocks(h, ctypes.byref(nb)))
-        mine = {"pid": os.getpid(), "area": int(area.value), "handle": bytes(handle), "blocks": int(nb.value), "epoch": int(self._epoch)}
+        # (whatever fails on ONE rank -- the allocation, the IPC handle -- is shared with the others before anybody decides: a rank that
+        # raised here would leave the rest waiting in the next collective)
+        try:
+            area, handle = ctypes.c_void_p(0), (ctypes.c_ubyte * 64)()
+            _hip.check(L.psfm_shard_peer_area(h, ctypes.byref(area), handle, self._sp()))
+            nb = ctypes.c_int32(0)
+            _hip.check(L.psfm_shard_solve_blocks(h, ctypes.byref(nb)))
+            mine = {"pid": os.getpid(), "area": int(area.value), "handle": bytes(handle), "blocks": int(nb.value), "epoch": int(self._epoch)}
+        except Exception as e:                  # noqa: BLE001
+            mine = {"pid": os.getpid(), "area": 0, "handle": b"", "blocks": 0, "epoch": int(self._epoch), "error": "%s: %s" % (type(e).__name__, e)}
         infos = comm.all_gather_object(mine)
         if any(q["blocks"] < 1 for q in infos):
+            self.peer_refused = next((q["error"] for q in infos if "error" in q), "a rank's resident launch does not fit its share of its device")
             return False                    # (the same answer on every rank: they all keep the exchange form)
         ptrs = (ctypes.c_void_p * comm.world)()
         failure = None
@@ -93,8 +99,8 @@ class HipShardEngine:
                 ptrs[r] = self._peer_maps[key]
             blocks = (ctypes.c_int32 * comm.world)(*[q["blocks"] for q in infos])
             _hip.check(L.psfm_shard_peer_connect(h, comm.world, comm.rank, ptrs, blocks))
-        except RuntimeError as e:              # (no peer access between two devices, IPC refused by the driver, ...)
-            failure = str(e)
+        except Exception as e:                 # noqa: BLE001  (no peer access between two devices, IPC refused by the driver, ...)
+            failure = "%s: %s" % (type(e).__name__, e)
         # a rank that could not map a peer must not leave the others waiting for its launches: all of them, or none
         failures = comm.all_gather_object(failure)
         if any(f is not None for f in failures):
