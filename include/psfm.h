@@ -339,10 +339,14 @@ psfm_status psfm_shard_solve_redo_local(psfm_ctx* ctx, const float* flow01, cons
  * area + its 64-byte IPC handle), psfm_shard_peer_open (another process's area), psfm_shard_peer_connect (world <= 8, rank, every rank's
  * area as this process addresses it, every rank's launch size from psfm_shard_solve_blocks; 0 blocks anywhere = PSFM_ERR_ARG: keep the
  * exchange form).  Per frame psfm_shard_solve_peer(frame, epoch) ENQUEUES this rank's launch; all ranks pass the same epoch (a counter
- * they advance together, 20 bits).  A launch that gives up (a rank missing, not co-resident) raises the stall flag on every rank --
+ * they advance together, 1 .. 2^20 - 1, never reused on an area: psfm_shard_peer_epoch).  A launch that gives up (a rank missing, not co-resident) raises the stall flag on every rank --
  * psfm_shard_window_state reports it and the caller redoes that solve with psfm_shard_solve_export / _control. */
 psfm_status psfm_shard_peer_area(psfm_ctx* ctx, void** area_dev, void* ipc_handle_64, void* stream);
 psfm_status psfm_shard_peer_open(psfm_ctx* ctx, const void* ipc_handle_64, int peer_rank, void** mapped);
+/* The last epoch a launch of this context tagged its area's granules with.  A driver starts a run from the maximum over the ranks (an
+ * area outlives the engine object that drove it: starting over would let stale granules match) and resets every rank's area
+ * (reset != 0, between two collectives) before the 20-bit count wraps. */
+psfm_status psfm_shard_peer_epoch(psfm_ctx* ctx, uint32_t* last_epoch, int reset, void* stream);
 psfm_status psfm_shard_peer_connect(psfm_ctx* ctx, int world, int rank, void* const* areas, const int32_t* n_blocks);
 psfm_status psfm_shard_solve_blocks(psfm_ctx* ctx, int32_t* n_blocks);
 psfm_status psfm_shard_solve_peer(psfm_ctx* ctx, const float* flow01, const float* flow12, const float* flow02, const uint8_t* occ02,

@@ -172,6 +172,8 @@ struct psfm_ctx {
     // ONE solve over several ranks (psfm_shard_peer_*): this rank's granule area (member rows + the leader rows every rank writes into),
     // the other ranks' leader areas as this process addresses them, every rank's leader count
     PsfmBuf peer_area;
+    unsigned peer_epoch = 0;         // the last epoch a launch of this context tagged granules of the area with: a new engine on the same
+                                     // context (same area) must go on from here, never start over (stale granules would match)
     int peer_world = 0, peer_rank = 0;
     int peer_L[PSFM_MAX_PEERS] = {0};
     void* peer_lead[PSFM_MAX_PEERS] = {nullptr};

@@ -292,6 +292,23 @@ extern "C" psfm_status psfm_shard_peer_area(psfm_ctx* c, void** area_dev, void* 
     return PSFM_OK;
 }
 
+// The last epoch this context's area has seen (every launch of psfm_shard_solve_peer records its epoch).  Engines take the maximum
+// over the ranks and go on from there; reset != 0 (every rank, between two collectives, nothing in flight: the epochs are about to
+// wrap around their 20 bits): the area is zeroed and the count starts over.
+extern "C" psfm_status psfm_shard_peer_epoch(psfm_ctx* c, uint32_t* last_epoch, int reset, void* stream)
+{
+    if (!c || !last_epoch) { psfm_set_error("psfm_shard_peer_epoch: bad argument"); return PSFM_ERR_ARG; }
+    if (reset && c->peer_area.p) {
+        PSFM_HIP(hipSetDevice(c->device));
+        PSFM_HIP(hipStreamSynchronize((hipStream_t)stream));
+        PSFM_HIP(hipMemsetAsync(c->peer_area.p, 0, psfm_peer_area_bytes(), (hipStream_t)stream));
+        PSFM_HIP(hipStreamSynchronize((hipStream_t)stream));
+        c->peer_epoch = 0;
+    }
+    *last_epoch = c->peer_epoch;
+    return PSFM_OK;
+}
+
 extern "C" psfm_status psfm_shard_peer_open(psfm_ctx* c, const void* ipc_handle_64, int peer_rank, void** mapped)
 {
     if (!c || !ipc_handle_64 || !mapped || peer_rank < 0 || peer_rank >= PSFM_MAX_PEERS) { psfm_set_error("psfm_shard_peer_open: bad argument"); return PSFM_ERR_ARG; }
@@ -346,6 +363,8 @@ extern "C" psfm_status psfm_shard_solve_peer(psfm_ctx* c, const float* flow01, c
         psfm_set_error("psfm_shard_solve_peer: frame %d, %d connected rank(s)", frame, c->peer_world);
         return PSFM_ERR_ARG;
     }
+    if (epoch == 0 || epoch > 0xfffffu) { psfm_set_error("psfm_shard_solve_peer: epoch %u outside 1 .. 2^20 - 1", epoch); return PSFM_ERR_ARG; }
+    c->peer_epoch = epoch;
     return psfm_solve_frame_enqueue_peer(c, d, flow01, flow12, flow02, occ02, frame, epoch, (hipStream_t)stream);
 }
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
     "psfm_shard_solve_control_chain_async", "psfm_shard_solve_poll", "psfm_shard_solve_local", "psfm_shard_solve_redo_local", "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity", "psfm_load_flo_stack",
     "psfm_path_consistency_eval",
-    "psfm_shard_peer_area", "psfm_shard_peer_open", "psfm_shard_peer_connect", "psfm_shard_solve_blocks", "psfm_shard_solve_peer",
+    "psfm_shard_peer_area", "psfm_shard_peer_epoch", "psfm_shard_peer_open", "psfm_shard_peer_connect", "psfm_shard_solve_blocks", "psfm_shard_solve_peer",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
     L.psfm_shard_solve_local.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
     L.psfm_shard_peer_area.argtypes = [vp, ctypes.POINTER(vp), vp, vp]
     L.psfm_shard_peer_open.argtypes = [vp, vp, i32, ctypes.POINTER(vp)]
+    L.psfm_shard_peer_epoch.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), i32, vp]
     L.psfm_shard_peer_connect.argtypes = [vp, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)]
     L.psfm_shard_solve_blocks.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     L.psfm_shard_solve_peer.argtypes = [vp, vp, vp, vp, vp, i32, ctypes.c_uint32, vp]

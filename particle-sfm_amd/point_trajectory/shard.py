@@ -75,6 +75,10 @@ class HipShardEngine:
             _hip.check(L.psfm_shard_peer_area(h, ctypes.byref(area), handle, self._sp()))
             nb = ctypes.c_int32(0)
             _hip.check(L.psfm_shard_solve_blocks(h, ctypes.byref(nb)))
+            # the area belongs to the CONTEXT and outlives this engine object: go on from the last epoch its granules were tagged with
+            last = ctypes.c_uint32(0)
+            _hip.check(L.psfm_shard_peer_epoch(h, ctypes.byref(last), 0, self._sp()))
+            self._epoch = max(int(self._epoch), int(last.value))
             mine = {"pid": os.getpid(), "area": int(area.value), "handle": bytes(handle), "blocks": int(nb.value), "epoch": int(self._epoch)}
         except Exception as e:                  # noqa: BLE001
             mine = {"pid": os.getpid(), "area": 0, "handle": b"", "blocks": 0, "epoch": int(self._epoch), "error": "%s: %s" % (type(e).__name__, e)}
@@ -106,7 +110,14 @@ class HipShardEngine:
         if any(f is not None for f in failures):
             self.peer_refused = [f for f in failures if f is not None][0]
             return False
-        self._epoch = max(q["epoch"] for q in infos)      # (a rank whose earlier run was aborted catches up)
+        self._epoch = max(q["epoch"] for q in infos)      # (a rank whose earlier run was aborted, or whose context is new, catches up)
+        if self._epoch > 0xFFFFF - 70000:
+            # a run enqueues at most 65 535 solves: before the 20-bit count can wrap inside one, every rank zeroes its area -- nothing is
+            # in flight here, and the all-gathers in front of and behind this keep a rank from launching into an area not yet cleared
+            last = ctypes.c_uint32(0)
+            _hip.check(L.psfm_shard_peer_epoch(h, ctypes.byref(last), 1, self._sp()))
+            comm.all_gather_object(0)
+            self._epoch = 0
         self._peer = True
         self.counters.update({"peer": 0, "peer_redone": 0})
         return True

@@ -469,3 +469,46 @@ def test_cross_rank_resident_solve_two_processes_one_gpu():
         # redone in the exchange form, which is still correct; say which
         assert cnt["peer"] + cnt["peer_redone"] >= len(O.solves) // 2, cnt
         print("rank %d counters: %s" % (rank, cnt))
+
+
+def test_cross_rank_solve_new_engine_on_a_used_context():
+    """The granule area belongs to the CONTEXT and outlives the engine object that drove it: a second run with a NEW engine on the same
+    contexts must go on from the area's last epoch (psfm_shard_peer_epoch) -- starting over at epoch 1 would find the first run's granules
+    under the same tags and add THEIR sums.  Two different hard sequences one after the other on the same two contexts, new engines."""
+    import torch
+    import psfm_dist
+    from oracle import oracle as orc
+    from point_trajectory import _hip
+    from point_trajectory.shard import HipShardEngine, flow_check_slice
+    world, H, W, r = 2, 58, 76, 2
+    seqs = [_hard_sequence(24, H, W, 71), _hard_sequence(24, H, W, 72)]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stacks = [{k: torch.from_numpy(np.stack(d[k])).to(dev) for k in ("flows_f", "flows_b", "flows_f2", "flows_b2")} for d in seqs]
+    torch.cuda.synchronize()
+
+    def rank_fn(comm):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            try:
+                ctx = _hip.Context(dev.index or 0)
+                ctx.set_capacity(2.0, 24.0)
+                out = []
+                for st in stacks:
+                    eng = HipShardEngine(ctx)                 # a NEW engine (epoch counter at zero) on the USED context
+                    part = psfm_dist.connect_sharded(eng, st["flows_f"], st["flows_b"], st["flows_f2"], st["flows_b2"], 1.0, r, flow_check_slice, comm=comm)
+                    out.append((psfm_dist.gather_result(part, comm=comm), part["solve_stats"], dict(eng.counters), int(eng._epoch)))
+                return out
+            finally:
+                _hip.release_thread_contexts()
+
+    res = run_ranks(world, rank_fn)
+    for k, d in enumerate(seqs):
+        _, occ = orc.flow_check(d["flows_f"], d["flows_b"], 1.0)
+        _, occ2 = orc.flow_check(d["flows_f2"], d["flows_b2"], 1.0)
+        O = orc.track_optimize(d["flows_f"], d["flows_f2"], occ, occ2, r)
+        for rank in range(world):
+            (birth, length, off, xy), stats, cnt, epoch = res[rank][k]
+            assert np.array_equal(birth, O.birth) and np.array_equal(length, O.length) and float(np.abs(xy - O.xy).max()) <= 1e-4
+            assert [s["iterations"] for s in stats] == [s["iterations"] for s in O.solves]
+            assert cnt["peer"] >= 10 and cnt["peer_redone"] == 0, cnt
+    assert res[0][1][3] > res[0][0][3] >= 10          # the second run's epochs continue behind the first run's
