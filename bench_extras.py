@@ -624,13 +624,16 @@ def end_to_end(frames=N_FRAMES, workdir=None):
 
 
 def two_ranks_one_gpu():
-    """scripts/probe_peer_thread_ranks.py: the headline shape with hard flows over TWO thread-ranks on this GPU -- the multi-rank engine's
-    device-paced reject path (psfm_shard_solve_peer) -- beside ONE psfm_connect call on the same tensors.  No xGMI link is crossed."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("psfm_probe_peer", os.path.join(ROOT, "scripts", "probe_peer_thread_ranks.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod.run(2, N_FRAMES, "hard", forms=("peer",), reps=3)
+    """scripts/probe_peer_thread_ranks.py in a process of its own (the two rank streams then get hardware queues of their own; inside this
+    process they share the four default queues with every stream the other figures created): the headline shape with hard flows over TWO
+    thread-ranks on this GPU -- the multi-rank engine's device-paced reject path (psfm_shard_solve_peer) -- beside ONE psfm_connect call on
+    the same tensors.  No xGMI link is crossed."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_peer_thread_ranks.py"), "2", str(N_FRAMES), "hard", "peer"],
+                       capture_output=True, text=True, timeout=200)
+    if r.returncode != 0:
+        raise RuntimeError((r.stdout + r.stderr)[-300:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def run_all(ctx, dev, n_frames=N_FRAMES, budget_s=150.0):

@@ -6,7 +6,7 @@ driver (marks of a frame, the exchange form's sums) are done ON THE DEVICE throu
 host, like RCCL on real ranks.  Times: the cross-rank resident solve (psfm_shard_solve_peer), the exchange form (PSFM_SHARD_PEER=0),
 ONE psfm_connect call on the same tensors.  One JSON line.
 
-    python scripts/probe_peer_thread_ranks.py [world=2] [frames=101] [dist=hard|clean]
+    python scripts/probe_peer_thread_ranks.py [world=2] [frames=101] [dist=hard|clean] [forms=peer,exchange]
 
 All ranks share one device's CUs, L2s and HBM: the figure prices the hand-off protocol, it is not a multi-GPU speed-up."""
 import json
@@ -156,4 +156,5 @@ def run(world=2, frames=101, dist_name="hard", forms=("peer", "exchange"), reps=
 
 if __name__ == "__main__":
     print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 2, int(sys.argv[2]) if len(sys.argv) > 2 else 101,
-                         sys.argv[3] if len(sys.argv) > 3 else "hard")))
+                         sys.argv[3] if len(sys.argv) > 3 else "hard",
+                         forms=tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("peer", "exchange"))))
