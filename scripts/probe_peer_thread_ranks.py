@@ -51,13 +51,13 @@ class EventComm:
         self._publish("b", None)
 
     def all_reduce_max_(self, t):
+        # in place and without a second rendezvous: a rank that reads another's buffer while that one is already folding the maximum in
+        # sees, element by element, either the old value or the maximum -- the same result either way; the engine's maps are double-buffered
+        # by frame parity and every frame's exchange orders the streams, so a buffer is not rewritten before everybody has read it
         vals = self._publish("a", t)
-        tmp = t.clone()
         for q, v in enumerate(vals):
             if q != self.rank:
-                torch.maximum(tmp, v, out=tmp)
-        self._done_reading()
-        t.copy_(tmp)
+                torch.maximum(t, v, out=t)
         return t
 
     def all_gather_flat(self, t):
