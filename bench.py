@@ -338,7 +338,9 @@ def main():
             full["cpu_baseline"] = cb
             refc = cb.get("reference_python_build_container") or {}
             out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                   "host_cores": cb["host_cores"], "sample": cb["sample"][:160],
+                                   "host_cores": cb["host_cores"],
+                                   "sample": "%d of %d frame pairs of this workload (flow_check + track + id order), C restatement of the reference path, "
+                                             "%d OpenMP threads" % (n_cpu, n_flows, cb["cores"]),
                                    "value_8_threads": cb["port_8_threads"]["value"],
                                    # the unmodified reference Python: timed in the build container only (it cannot travel to this box)
                                    "reference_python_points_per_s_build_container": refc.get("track_points_per_s")}
