@@ -17,7 +17,7 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def recorded():
     """The round-5 record (33 KB as one line) as the `full` dict bench.py now keeps out of the line."""
-    return json.load(open(os.path.join(ROOT, "profiles", "r05_zn_bench.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", "r05", "r05_zn_bench.json")))
 
 
 def headline_like(full):
