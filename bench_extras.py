@@ -677,6 +677,8 @@ def run_all(ctx, dev, n_frames=N_FRAMES, budget_s=150.0):
           davis, pmc_key="davis_b16")
     extra("secondary_batch", secondary_batch, 436, 1024, 50, 2, True, THRES, 16, 2, "configs[2] shape (Sintel alley_1)", sintel,
           pmc_key="sintel_b16")
+    # ... and the largest batch the entry point takes (64): what a directory of small sequences amortises a frame's latency to
+    extra("secondary_davis_batch64", secondary_batch, 480, 854, 50, 4, False, THRES, 64, 2, "configs[0] shape (DAVIS snowboard)", davis, n=3)
     # ONE sequence through the multi-rank engine at world size 1 (what sharding costs before a byte crosses xGMI), hard flows
     extra("single_sequence_hard", single_sequence_sharded, dev, 0, 1, 101, reps=1, flows_dist=psfm_synth.HARD,
           label="headline shape, hard flows (sigma 0.3, 5 % occluders)")
@@ -709,7 +711,7 @@ def summary(full):
     s = {}
     short = {"secondary": "sintel_opt", "secondary_1080p": "1080p_opt", "secondary_hard": "1080p_opt_hard",
              "secondary_realistic": "1080p_opt_realistic", "secondary_davis": "davis", "secondary_scannet": "scannet_opt",
-             "secondary_davis_batch": "davis_x16", "secondary_batch": "sintel_opt_x16", "secondary_scannet_batch": "scannet_opt_x4",
+             "secondary_davis_batch": "davis_x16", "secondary_davis_batch64": "davis_x64", "secondary_batch": "sintel_opt_x16", "secondary_scannet_batch": "scannet_opt_x4",
              "single_sequence": "one_seq_400f_opt", "single_sequence_hard": "one_seq_100f_opt_hard"}
     for key, name in short.items():
         v = full.get(key)
