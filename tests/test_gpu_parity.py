@@ -343,6 +343,23 @@ def test_bad_arguments_are_rejected(pt):
     assert len(L.psfm_last_error()) > 0
     with pytest.raises(ValueError):
         pt.track([], [], 2)
+    # frames whose (H,W,2) f32 map does not fit 32-bit byte offsets (8 H W >= 2^32) are refused by every entry point that takes h, w --
+    # before a single byte of the (here far too small) buffers is touched
+    import torch
+    t = torch.zeros(64, dtype=torch.float32, device="cuda")
+    o = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    d64 = torch.zeros(64, dtype=torch.float64, device="cuda")
+    P, sp = hip.ptr, hip.current_stream_ptr()
+    info = hip.TrackInfo()
+    for h, w in ((32768, 16384), (23171, 23171), (2, 1 << 28)):
+        assert 8 * h * w >= 1 << 32
+        assert L.psfm_flow_check(ctx.handle, P(t), P(t), 1, h, w, 1.0, P(o), None, sp) == hip.PSFM_ERR_ARG
+        assert L.psfm_grid_sample(ctx.handle, P(t), 2, h, w, P(d64), 1, P(t), sp) == hip.PSFM_ERR_ARG
+        assert L.psfm_optimize_location(ctx.handle, P(d64), P(d64), P(d64), P(d64), P(t), 1, w, h, P(d64), None, sp) == hip.PSFM_ERR_ARG
+        assert L.psfm_path_consistency_eval(ctx.handle, P(d64), P(d64), P(d64), P(d64), P(t), 1, w, h, P(d64), P(d64), sp) == hip.PSFM_ERR_ARG
+        assert L.psfm_track(ctx.handle, P(t), P(o), None, None, 1, h, w, 2, ctypes.byref(info), sp) == hip.PSFM_ERR_ARG
+        assert L.psfm_connect(ctx.handle, P(t), P(t), None, None, 1, h, w, 1.0, 2, None, None, ctypes.byref(info), sp) == hip.PSFM_ERR_ARG
+    assert L.psfm_flow_check(ctx.handle, P(t), P(t), 0, 23170, 23170, 1.0, P(o), None, sp) == hip.PSFM_OK      # (the largest square frame: 8 H W < 2^32)
 
 
 def test_connect_sequences_concurrently(pt, tmp_path):
