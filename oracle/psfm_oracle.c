@@ -26,6 +26,14 @@
  *     (trust_region_minimizer.cc, dogleg_strategy.cc,
  *     trust_region_step_evaluator.cc, cubic_interpolation.h Grid2D) as
  *     configured at point_trajectory/optimize/src/trajectory_optimize.cpp:74-79.
+ *     What IS checked without Ceres: the cost functor's residuals and
+ *     Jacobians (orc_path_consistency_eval) against torch autograd through an
+ *     independent float64 restatement of the Catmull-Rom interpolator
+ *     (tests/test_pc_eval_autograd.py), and the step rule on linear problems
+ *     whose every iterate is derived by hand (tests/test_ceres_hand_cases.py).
+ *     What stays unpinned is Ceres' own stopping iterate on real inputs; the
+ *     day oracle/_ref builds against a Ceres install, tests/test_ref_ceres.py
+ *     runs the same cases through the reference's pybind module.
  *
  * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -- no fused ops except
  * the explicit fmaf() chains that restate ATen's vectorised kernel).
