@@ -138,7 +138,7 @@ def main():
     from point_trajectory.utils import flow_check_device
     from point_trajectory.trajectory import run_connect, run_track
     import point_trajectory.shard, point_trajectory.batch, psfm_dist      # noqa: E401,F401  (everything imported before the freeze)
-    from bench_extras import guarded, single_sequence_sharded
+    from bench_extras import guarded, sharded_children
 
     quiet_gc()
 
@@ -234,17 +234,11 @@ def main():
     # ---- ONE sequence over all ranks (exact track-sharded mode), outside the timed region ----
     single, single_hard, hung = None, None, False
     if world > 1:      # (world size 1: bench_extras.run_all times the same two figures, inside its budget)
+        # configs[3], and the headline shape on flows whose solves reject steps (psfm_synth.HARD: the redo path of the sharded engine) --
+        # each rank's share in a child process: a device fault in a cross-GPU form must not take the headline figure with it
         dist.barrier()
-        single, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, args.single_seq_frames), 150)
-        # ... and on flows whose solves reject steps (psfm_synth.HARD, 100 frames: VERDICT r4 item 2) -- the redo path of the sharded engine
-        single_hard = None
-        if not hung:
-            if world > 1:
-                dist.barrier()
-            import psfm_synth as _ps
-            single_hard, hung = guarded(lambda: single_sequence_sharded(dev, rank, world, 101, reps=1, flows_dist=_ps.HARD,
-                                                                        label="headline shape, hard flows (sigma 0.3, 5 % occluders)"), 150)
-
+        res, hung = guarded(lambda: sharded_children(rank, world, args.single_seq_frames), 600)
+        single, single_hard = res if isinstance(res, tuple) else (res, None)      # (a dict = guarded()'s own error record)
 
     if rank == 0:
         # ---- roofline of the flow-chaining kernel (K2): algorithmic bytes per launch / avg duration ----

@@ -171,6 +171,88 @@ def guarded(fn, timeout_s):
     return box["r"], False
 
 
+HARD_LABEL = "headline shape, hard flows (sigma 0.3, 5 % occluders)"
+
+
+def sharded_children(rank, world, frames, timeout_s=None):
+    """`single_sequence_sharded` twice (BASELINE configs[3]; the headline shape on hard flows) over all ranks, each rank's share in a CHILD
+    process of that rank (this file run with --sharded-child; the children form a process group of their own on a fresh port).  The
+    cross-GPU forms of the sharded engine -- RCCL exchanges, and granules written into other ranks' memory through IPC mappings -- have
+    only run on one-GPU proxies; a device fault there ends the process it happens in, and that must be a child, never the process that
+    holds the headline figure.  Returns (single, single_hard): rank 0's child's record, or {"error": ...}."""
+    import socket
+    import subprocess
+    import torch.distributed as dist
+    timeout_s = timeout_s or int(os.environ.get("PSFM_BENCH_CHILD_TIMEOUT", "240"))
+    out = []
+    for hard in (False, True):
+        port = [None]
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port[0] = sk.getsockname()[1]
+        dist.broadcast_object_list(port, src=0)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}    # the children's rank 0 hosts their store itself
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--frames", str(101 if hard else frames)] + (["--hard"] if hard else [])
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                res = {"error": "rank %d's child left with code %d: %s" % (rank, r.returncode, (r.stderr or r.stdout)[-300:])}
+            elif rank == 0:
+                res = json.loads(r.stdout.strip().splitlines()[-1])
+                res["ran_in"] = "one child process per rank (a process group of their own)"
+            else:
+                res = {}
+        except subprocess.TimeoutExpired:
+            res = {"error": "rank %d's child: no result after %d s" % (rank, timeout_s)}
+        except Exception as e:     # noqa: BLE001
+            res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        every = [None] * world
+        dist.all_gather_object(every, res.get("error"))
+        bad = [e for e in every if e]
+        if bad and "error" not in res:
+            res = {"error": bad[0]}
+        out.append(res)
+        if bad:                     # the second run would meet the same end
+            out.append({"error": "skipped: " + bad[0]})
+            break
+    return out[0], out[1]
+
+
+def _sharded_child_main(argv):
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sharded-child", action="store_true")
+    ap.add_argument("--frames", type=int, default=401)
+    ap.add_argument("--hard", action="store_true")
+    a = ap.parse_args(argv)
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = (int(os.environ[k]) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"))
+    dryrun = os.environ.get("PSFM_BENCH_DRYRUN_ONE_GPU", "0") == "1"      # as in bench.py: every rank on cuda:0, gloo
+    if dryrun:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dryrun:
+        dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    if os.environ.get("PSFM_BENCH_CHILD_ABORT") == str(rank):     # tests: this rank's child dies the way a device fault ends a process
+        os.abort()
+    if a.hard:
+        import psfm_synth
+        rec = single_sequence_sharded(dev, rank, world, a.frames, reps=1, flows_dist=psfm_synth.HARD, label=HARD_LABEL)
+    else:
+        rec = single_sequence_sharded(dev, rank, world, a.frames)
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    _, stuck = guarded(lambda: (dist.barrier(), torch.cuda.synchronize(), dist.destroy_process_group()), 60)
+    sys.stdout.flush()
+    os._exit(0)
+
+
 def solver_roofline(R, prof, cnt, h, w, n_flows, ratio=RATIO):
     """SURVEY 8(d) algorithmic bytes of the track_optimize kernels / their HIP-event launch time / 8 TB/s.
     Per solve of frame f (N3 = tracks with three buffered points, k = trust-region iterations of that solve, P = H*W):
@@ -759,3 +841,10 @@ def summary(full):
     if "extras_wall_s" in full:
         s["wall_s"] = full["extras_wall_s"]
     return s
+
+
+if __name__ == "__main__":
+    if "--sharded-child" in sys.argv:
+        _sharded_child_main(sys.argv[1:])
+    else:
+        sys.exit("bench_extras.py is bench.py's library; its only command line is the --sharded-child mode bench.py starts itself")

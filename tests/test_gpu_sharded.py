@@ -306,6 +306,26 @@ def test_bench_multi_rank_control_flow_dry_run_on_one_gpu():
     assert ss["world_size"] == 2 and ss["trajectories"] > 0 and 0 < ss["local_trajectories_rank0"] < ss["trajectories"]
 
 
+def test_bench_headline_survives_a_rank_dying_in_the_one_sequence_mode():
+    """The one-sequence-over-all-ranks figures run in child processes (bench_extras.sharded_children): a child that dies the way a device
+    fault ends a process (SIGABRT) costs those figures, named as such in the line, and nothing else -- the headline line is printed and
+    bench.py leaves with code 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(PSFM_BENCH_DRYRUN_ONE_GPU="1", PSFM_BENCH_CHILD_ABORT="1", PSFM_BENCH_CHILD_TIMEOUT="120")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "11",
+                        "--single-seq-frames", "13"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "roofline" in line
+    assert "error" in line["extras"]["one_seq_400f_opt"] and "child" in line["extras"]["one_seq_400f_opt"]["error"]
+    assert "error" in line["extras"]["one_seq_100f_opt_hard"]
+
+
 @pytest.mark.parametrize("lane_f", [2.0, 1.0], ids=["records-full", "lanes-and-records-full"])
 @pytest.mark.parametrize("world", [1, 2])
 def test_connect_sharded_grows_tables_that_run_full(world, lane_f):
