@@ -179,6 +179,12 @@ psfm_status psfm_path_consistency_eval(psfm_ctx* ctx, const double* uv12, const 
                                        const double* scale, const float* flow12, int64_t n, int w, int h,
                                        double* residuals, double* jacobians, void* stream);
 
+/* The record sort of the id assignment (the reference's trajectory ids are the rank of a track by (death step, birth
+ * frame, birth grid index), the order trajectory.py:129-158 appends to full_trajs in): n (key, value) pairs on the device, keys sorted
+ * ascending by their bits [0, end_bit), 1 <= end_bit <= 32, STABLE; in place.  The kernels are the ones psfm_track / psfm_connect run
+ * on their records (csrc/psfm_sort.hip); exported so that the sort can be checked on its own.  n < 2^31.  Asynchronous on `stream`. */
+psfm_status psfm_sort_records(psfm_ctx* ctx, uint32_t* keys, int32_t* values, int64_t n, int end_bit, void* stream);
+
 /* track.py:24-50 when flows_f2 == NULL, track_optimize.py:24-53 otherwise.
  *   flows    (n_flows,H,W,2) f32      occ     (n_flows,H,W) u8
  *   flows_f2 (n_flows-1,H,W,2) f32    occ_s2  (n_flows-1,H,W) u8        (stride-2 stacks)

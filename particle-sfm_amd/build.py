@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpsfm_hip.so")
-SOURCES = ["psfm_api.hip", "psfm_track.hip", "psfm_persist.hip", "psfm_finalize.hip", "psfm_solver.hip", "psfm_window.hip", "psfm_matches.hip", "psfm_shard.hip", "psfm_batch.hip", "psfm_ingest.hip"]
+SOURCES = ["psfm_api.hip", "psfm_track.hip", "psfm_persist.hip", "psfm_finalize.hip", "psfm_sort.hip", "psfm_solver.hip", "psfm_window.hip", "psfm_matches.hip", "psfm_shard.hip", "psfm_batch.hip", "psfm_ingest.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result",

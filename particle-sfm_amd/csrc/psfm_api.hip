@@ -174,7 +174,7 @@ extern "C" psfm_status psfm_ctx_destroy(psfm_ctx* c)
     (void)hipSetDevice(c->device);
     PsfmBuf* bufs[] = {&c->log, &c->birth_frame, &c->birth_idx, &c->free_stack, &c->fin_keys, &c->fin_lanes,
                        &c->occupied, &c->counters, &c->shards, &c->survivors, &c->sort_keys, &c->sort_lanes, &c->sort_tmp,
-                       &c->scan_tmp, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
+                       &c->scan_tmp, &c->fin_marks, &c->res_birth, &c->res_len, &c->res_off, &c->res_xy, &c->sol_x, &c->sol_state,
                        &c->sol_partials, &c->sol_ctrl, &c->sol_misc, &c->sol_stats, &c->sol_fused, &c->sol_bar, &c->sol_list, &c->occ_own, &c->occ2_own,
                        &c->handoff, &c->seg_info, &c->seg_table, &c->persist_bar, &c->batch_tab, &c->batch_ws, &c->batch_fc, &c->win_ws, &c->flt_ids, &c->flt_birth, &c->flt_len, &c->flt_off, &c->flt_xy,
                        &c->mt_kp_off, &c->mt_q, &c->mt_pts, &c->mt_kp_ind, &c->mt_kp_xy, &c->mt_moff, &c->mt_keys, &c->mt_rows, &c->mt_gid, &c->mt_pairs};
@@ -339,6 +339,31 @@ extern "C" psfm_status psfm_path_consistency_eval(psfm_ctx* c, const double* uv1
         return PSFM_ERR_ARG;
     }
     return psfm_launch_pc_eval(uv12, ref1, ref2, scale, flow12, n, w, h, residuals, jacobians, (hipStream_t)stream);
+}
+
+extern "C" psfm_status psfm_sort_records(psfm_ctx* c, uint32_t* keys, int32_t* values, int64_t n, int end_bit, void* stream)
+{
+    PSFM_CHECK_CTX(c);
+    PsfmGate gate(c->device, 0);
+    if (n < 0 || n >= (1ll << 31) || end_bit < 1 || end_bit > 32 || (n > 0 && (!keys || !values))) {
+        psfm_set_error("psfm_sort_records: bad argument (n=%lld end_bit=%d)", (long long)n, end_bit);
+        return PSFM_ERR_ARG;
+    }
+    if (n == 0) return PSFM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    psfm_status st;
+    // the sort ping-pongs between two halves and ends in the first: stage through the context's sort buffers
+    if ((st = c->sort_keys.ensure(sizeof(unsigned long long) * (size_t)n * 2)) != PSFM_OK) return st;
+    if ((st = c->sort_lanes.ensure(sizeof(int) * (size_t)n * 2)) != PSFM_OK) return st;
+    const int64_t half = psfm_sort_pairs32_passes((unsigned)end_bit) % 2 == 0 ? 0 : n;
+    unsigned* k0 = c->sort_keys.as<unsigned>();
+    int* v0 = c->sort_lanes.as<int>();
+    PSFM_HIP(hipMemcpyAsync(k0 + half, keys, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    PSFM_HIP(hipMemcpyAsync(v0 + half, values, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    if ((st = psfm_sort_pairs32(c, k0, v0, k0 + n, v0 + n, n, (unsigned)end_bit, s)) != PSFM_OK) return st;
+    PSFM_HIP(hipMemcpyAsync(keys, k0, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    PSFM_HIP(hipMemcpyAsync(values, v0, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    return PSFM_OK;
 }
 
 // Sizes of one run of the frame recurrence.  g_own < 0: the whole stride-r grid; otherwise the number of grid points whose

@@ -136,6 +136,151 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_decode32_kernel(const unsigne
     len64[i] = (int64_t)(l - b + 1);
 }
 
+// ---- offsets without a scan over the trajectories ----
+// Sorted records with the same (last, birth) -- a GROUP, numbered g = last (last + 1) / 2 + birth, the order of the sort -- have the same
+// length, so the CSR offset of trajectory id is  goff[g] + (id - gstart[g]) * len(g):  one pass over the sorted keys marks where every
+// group starts, ONE block turns the (n_flows + 2)(n_flows + 3) / 2 starts into counts and offsets, and the gather computes birth /
+// length / offset of its 64 trajectories from their keys (and stores them for psfm_result_*).  That replaces the decode kernel and a
+// three-kernel scan over n + 1 int64 (2 M entries at the headline shape: 45 us of launches for what 5 253 groups say).  Sequences
+// with more groups than the plan block holds in LDS (n_flows > 178) keep the decode + scan form.
+#define PSFM_PLAN_MAX_GROUPS 16384
+#define PSFM_PLAN_BLOCK 1024
+struct PsfmPlan {
+    const int* gstart; const int64_t* goff;      // gstart == nullptr: birth / len / off are read from the arrays below instead
+    const void* keys; int use32, shift_b, shift_d;
+    int* birth_w; int* len_w; int64_t* off_w;    // where the gather stores what it computed (the result arrays)
+};
+__device__ __forceinline__ void psfm_tri_invert(unsigned tri, int* last, int* birth)
+{
+    // last = the largest l with l*(l+1)/2 <= tri
+    int l = (int)((sqrtf(8.0f * (float)tri + 1.0f) - 1.0f) * 0.5f);
+    while (l > 0 && (unsigned)l * (unsigned)(l + 1) / 2u > tri) --l;
+    while ((unsigned)(l + 1) * (unsigned)(l + 2) / 2u <= tri) ++l;
+    *last = l;
+    *birth = (int)(tri - (unsigned)l * (unsigned)(l + 1) / 2u);
+}
+__device__ __forceinline__ void psfm_key_fields(const void* keys, int64_t id, int use32, int shift_b, int shift_d, int* last, int* birth, int* idx)
+{
+    if (use32) {
+        const unsigned k = ((const unsigned*)keys)[id];
+        psfm_tri_invert(k >> shift_b, last, birth);
+        *idx = (int)(k & ((1u << shift_b) - 1u));
+    } else {
+        const unsigned long long k = ((const unsigned long long*)keys)[id];
+        *last = (int)(k >> shift_d);
+        *birth = (int)((k >> shift_b) & ((1ull << (shift_d - shift_b)) - 1ull));
+        *idx = (int)(k & ((1ull << shift_b) - 1ull));
+    }
+}
+__device__ __forceinline__ int psfm_key_group(const void* keys, int64_t id, int use32, int shift_b, int shift_d)
+{
+    if (use32) return (int)(((const unsigned*)keys)[id] >> shift_b);      // the 32-bit key carries the group number itself
+    const unsigned long long k = ((const unsigned long long*)keys)[id];
+    const unsigned last = (unsigned)(k >> shift_d);
+    const unsigned birth = (unsigned)((k >> shift_b) & ((1ull << (shift_d - shift_b)) - 1ull));
+    return (int)(last * (last + 1u) / 2u + birth);
+}
+
+// marks[g] = the first sorted record of group g (the array arrives filled with -1: groups nobody marks are empty)
+__global__ __launch_bounds__(PSFM_BLOCK) void psfm_group_bounds_kernel(const void* __restrict__ keys, int64_t n, int use32, int shift_b,
+                                                                       int shift_d, int* __restrict__ gstart)
+{
+    const int64_t i = (int64_t)blockIdx.x * PSFM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int g = psfm_key_group(keys, i, use32, shift_b, shift_d);
+    const int gp = i > 0 ? psfm_key_group(keys, i - 1, use32, shift_b, shift_d) : -1;
+    if (g != gp) gstart[g] = (int)i;
+}
+
+// ONE block: marks -> counts (the next non-empty group's start, or n, ends a group) -> goff[g] = points of all groups before g.
+// The marks go back to -1 on the way (what the next call's bounds kernel expects); the gather reads the starts from gstart.
+__global__ __launch_bounds__(PSFM_PLAN_BLOCK) void psfm_group_plan_kernel(int* __restrict__ marks, int* __restrict__ gstart,
+                                                                          int64_t* __restrict__ goff, int ng, int64_t n,
+                                                                          int64_t* __restrict__ off_n)
+{
+    __shared__ int s_g[PSFM_PLAN_MAX_GROUPS];          // starts, then counts
+    __shared__ int s_wmin[PSFM_PLAN_BLOCK / PSFM_WAVE];
+    __shared__ long long s_wsum[PSFM_PLAN_BLOCK / PSFM_WAVE];
+    constexpr int NW = PSFM_PLAN_BLOCK / PSFM_WAVE;
+    constexpr int INF = 0x7fffffff;
+    const int tid = threadIdx.x, lane = tid & (PSFM_WAVE - 1), wave = tid / PSFM_WAVE;
+    for (int k = tid; k < ng; k += PSFM_PLAN_BLOCK) {
+        const int v = marks[k];
+        s_g[k] = v;
+        gstart[k] = v;
+        if (v >= 0) marks[k] = -1;
+    }
+    __syncthreads();
+    const int per = (ng + PSFM_PLAN_BLOCK - 1) / PSFM_PLAN_BLOCK;
+    const int g0 = min(tid * per, ng), g1 = min(g0 + per, ng);
+    int first = INF;
+    for (int g = g1 - 1; g >= g0; --g) if (s_g[g] >= 0) first = s_g[g];
+    // the next non-empty start BEHIND this thread's groups: a suffix minimum (starts grow with g), wave by wave
+    int sm = first;
+#pragma unroll
+    for (int o = 1; o < PSFM_WAVE; o <<= 1) {
+        const int v = __shfl_down(sm, o);
+        if (lane + o < PSFM_WAVE && v < sm) sm = v;
+    }
+    if (lane == 0) s_wmin[wave] = sm;
+    int nxt = __shfl_down(sm, 1);
+    if (lane == PSFM_WAVE - 1) nxt = INF;
+    __syncthreads();
+    for (int w = wave + 1; w < NW; ++w) nxt = min(nxt, s_wmin[w]);
+    if (nxt == INF) nxt = (int)n;
+    int last = 0, birth = 0;
+    if (g0 < g1) psfm_tri_invert((unsigned)g0, &last, &birth);
+    // counts (walking back), then this thread's points (walking forward with (last, birth) of every group)
+    for (int g = g1 - 1; g >= g0; --g) {
+        const int st = s_g[g];
+        if (st >= 0) { s_g[g] = nxt - st; nxt = st; } else s_g[g] = 0;
+    }
+    long long pts = 0;
+    {
+        int l = last, b = birth;
+        for (int g = g0; g < g1; ++g) {
+            pts += (long long)s_g[g] * (long long)(l - b + 1);
+            if (++b > l) { ++l; b = 0; }
+        }
+    }
+    long long inc = pts;                                  // inclusive prefix sum over the threads, wave by wave
+#pragma unroll
+    for (int o = 1; o < PSFM_WAVE; o <<= 1) {
+        const long long v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == PSFM_WAVE - 1) s_wsum[wave] = inc;
+    __syncthreads();
+    long long base = 0, total = 0;
+    for (int w = 0; w < NW; ++w) { const long long v = s_wsum[w]; if (w < wave) base += v; total += v; }
+    long long run = base + inc - pts;
+    {
+        int l = last, b = birth;
+        for (int g = g0; g < g1; ++g) {
+            goff[g] = run;
+            run += (long long)s_g[g] * (long long)(l - b + 1);
+            if (++b > l) { ++l; b = 0; }
+        }
+    }
+    if (tid == 0) *off_n = total;      // off[n] = all points
+}
+
+// what the gather knows of its track `id`: from the plan (and stored), or from the decoded arrays
+__device__ __forceinline__ void psfm_track_header(const PsfmPlan& pl, const int* __restrict__ birth, const int* __restrict__ len,
+                                                  const int64_t* __restrict__ off, int64_t id, int* b, int* l, int64_t* o, int* idx)
+{
+    if (pl.gstart) {
+        int last;
+        psfm_key_fields(pl.keys, id, pl.use32, pl.shift_b, pl.shift_d, &last, b, idx);
+        const int g = last * (last + 1) / 2 + *b;
+        *l = last - *b + 1;
+        *o = pl.goff[g] + (id - (int64_t)pl.gstart[g]) * (int64_t)*l;
+        pl.birth_w[id] = *b; pl.len_w[id] = *l; pl.off_w[id] = *o;
+    } else {
+        *b = birth[id]; *l = len[id]; *o = off[id]; *idx = -1;
+    }
+}
+
 // Transpose gather: a block owns TILE_J consecutive ids and walks time in chunks of TILE_K steps.
 #ifndef TILE_J
 #define TILE_J 64
@@ -148,7 +293,7 @@ __device__ __forceinline__ void psfm_gather_body(const double2* __restrict__ log
                                                                  const int* __restrict__ birth,
                                                                  const int* __restrict__ len,
                                                                  const int64_t* __restrict__ off, int64_t n,
-                                                                 double2* __restrict__ out)
+                                                                 double2* __restrict__ out, const PsfmPlan& pl)
 {
     __shared__ double2 tile[TILE_J][TILE_K + 1];
     __shared__ int s_lane[TILE_J], s_birth[TILE_J], s_len[TILE_J];
@@ -161,11 +306,14 @@ __device__ __forceinline__ void psfm_gather_body(const double2* __restrict__ log
     if (tid < TILE_J) {
         const int64_t id = id0 + tid;
         const bool ok = id < n;
-        s_lane[tid] = ok ? lanes[id] : 0;
-        s_birth[tid] = ok ? birth[id] : 0;
-        s_len[tid] = ok ? len[id] : 0;
-        s_off[tid] = ok ? off[id] : 0;
-        if (ok) atomicMax(&s_maxlen, s_len[tid]);
+        int b = 0, l = 0, idx; int64_t o = 0;
+        const int my_lane = ok ? lanes[id] : 0;       // (in flight while the header's dependent loads run)
+        if (ok) psfm_track_header(pl, birth, len, off, id, &b, &l, &o, &idx);
+        s_lane[tid] = my_lane;
+        s_birth[tid] = b;
+        s_len[tid] = l;
+        s_off[tid] = o;
+        if (ok) atomicMax(&s_maxlen, l);
     }
     __syncthreads();
     const int maxlen = s_maxlen;
@@ -209,9 +357,9 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_kernel(const double2* 
                                                                  const int* __restrict__ birth,
                                                                  const int* __restrict__ len,
                                                                  const int64_t* __restrict__ off, int64_t n,
-                                                                 double2* __restrict__ out)
+                                                                 double2* __restrict__ out, PsfmPlan pl)
 {
-    psfm_gather_body(log, cap, lanes, birth, len, off, n, out);
+    psfm_gather_body(log, cap, lanes, birth, len, off, n, out, pl);
 }
 
 // The persistent loop logs the sampled flow of every survived step instead of positions (half the bytes, written once,
@@ -224,7 +372,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_delta_kernel(const flo
                                                                        const int* __restrict__ len,
                                                                        const int64_t* __restrict__ off, int64_t n,
                                                                        const void* __restrict__ keys, int use32, int shift_b,
-                                                                       int GW, int ratio, double2* __restrict__ out)
+                                                                       int GW, int ratio, double2* __restrict__ out, PsfmPlan pl)
 {
     __shared__ float2 dtile[TILE_J][TILE_K + 1];
     __shared__ double2 tile[TILE_J][TILE_K + 1];
@@ -239,14 +387,19 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_delta_kernel(const flo
     if (tid < TILE_J) {
         const int64_t id = id0 + tid;
         const bool ok = id < n;
-        s_lane[tid] = ok ? lanes[id] : 0;
-        s_birth[tid] = ok ? birth[id] : 0;
-        s_len[tid] = ok ? len[id] : 0;
-        s_off[tid] = ok ? off[id] : 0;
+        int b = 0, l = 0, idx = -1; int64_t o = 0;
+        const int my_lane = ok ? lanes[id] : 0;       // (in flight while the header's dependent loads run)
+        if (ok) psfm_track_header(pl, birth, len, off, id, &b, &l, &o, &idx);
+        s_lane[tid] = my_lane;
+        s_birth[tid] = b;
+        s_len[tid] = l;
+        s_off[tid] = o;
         if (ok) {
-            atomicMax(&s_maxlen, s_len[tid]);
-            const unsigned long long mask = (1ull << shift_b) - 1ull;
-            const int idx = (int)((use32 ? (unsigned long long)((const unsigned*)keys)[id] : ((const unsigned long long*)keys)[id]) & mask);
+            atomicMax(&s_maxlen, l);
+            if (idx < 0) {
+                const unsigned long long mask = (1ull << shift_b) - 1ull;
+                idx = (int)((use32 ? (unsigned long long)((const unsigned*)keys)[id] : ((const unsigned long long*)keys)[id]) & mask);
+            }
             const int gy = idx / GW, gx = idx - gy * GW;
             s_pos[tid] = make_double2((double)(gx * ratio), (double)(gy * ratio));   // trajectory.py:110-115
         }
@@ -320,8 +473,22 @@ static PsfmKeyFmt psfm_key_fmt(const PsfmTrackDims& d, unsigned* end_bit)
     return f;
 }
 
-// common tail: (key, lane) records already compacted into the SECOND halves of sort_keys / sort_lanes (keys in the
-// format psfm_key_fmt() chose: n 8-byte or n 4-byte entries behind the first n entries of the same width)
+// Which half of sort_keys / sort_lanes the compaction fills: the second (rocPRIM sorts second half -> first half), unless this file's
+// own sort runs an even number of passes -- it ping-pongs between the halves and has to END in the first.
+static bool psfm_own_sort(const PsfmKeyFmt& fmt, int64_t n)
+{
+    static const int on = getenv("PSFM_FIN_SORT") ? atoi(getenv("PSFM_FIN_SORT")) : 1;      // 0: rocPRIM's device sort (A/B, tests)
+    return on && fmt.use32 && n < (1ll << 31);
+}
+static bool psfm_records_in_first_half(const PsfmTrackDims& d, int64_t n)
+{
+    unsigned end_bit = 0;
+    const PsfmKeyFmt fmt = psfm_key_fmt(d, &end_bit);
+    return psfm_own_sort(fmt, n) && (psfm_sort_pairs32_passes(end_bit) % 2 == 0);
+}
+
+// common tail: (key, lane) records already compacted into the halves of sort_keys / sort_lanes psfm_records_in_first_half() names
+// (keys in the format psfm_key_fmt() chose: 8-byte or 4-byte entries, a half = n entries of that width)
 static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int64_t n, int64_t npts, bool delta_log, hipStream_t s)
 {
     psfm_status st;
@@ -332,7 +499,10 @@ static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int
     size_t tmp_bytes = 0, scan_bytes = 0;
     PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0,
                                      (size_t)(n + 1), rocprim::plus<int64_t>(), s));
-    if (fmt.use32) {
+    if (psfm_own_sort(fmt, n)) {
+        if ((st = c->sort_tmp.ensure(scan_bytes)) != PSFM_OK) return st;      // (before the sort's launches: growing the buffer frees it)
+        if ((st = psfm_sort_pairs32(c, c->sort_keys.as<unsigned>(), l_out, c->sort_keys.as<unsigned>() + n, l_in, n, end_bit, s)) != PSFM_OK) return st;
+    } else if (fmt.use32) {
         unsigned* k_in = c->sort_keys.as<unsigned>() + n;
         unsigned* k_out = c->sort_keys.as<unsigned>();
         PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
@@ -345,22 +515,48 @@ static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int
         if ((st = c->sort_tmp.ensure(tmp_bytes > scan_bytes ? tmp_bytes : scan_bytes)) != PSFM_OK) return st;
         PSFM_HIP(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)n, 0u, end_bit, s));
     }
-    // decode + offsets
+    // birth / length / offset of every trajectory: from the group plan (few groups), else decode + scan over the trajectories
     if ((st = c->res_birth.ensure(sizeof(int) * n)) != PSFM_OK) return st;
     if ((st = c->res_len.ensure(sizeof(int) * n)) != PSFM_OK) return st;
     if ((st = c->res_off.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
-    if ((st = c->scan_tmp.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
-    if (fmt.use32)
-        hipLaunchKernelGGL(psfm_decode32_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
-                           c->sort_keys.as<unsigned>(), n, d.shift_b, c->res_birth.as<int>(), c->res_len.as<int>(),
-                           c->scan_tmp.as<int64_t>());
-    else
-        hipLaunchKernelGGL(psfm_decode_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
-                           c->sort_keys.as<unsigned long long>(), n, d.shift_b, d.shift_d, c->res_birth.as<int>(),
-                           c->res_len.as<int>(), c->scan_tmp.as<int64_t>());
-    PSFM_HIP(hipGetLastError());
-    PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->res_off.as<int64_t>(),
-                                     (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+    static const int plan_on = getenv("PSFM_FIN_PLAN") ? atoi(getenv("PSFM_FIN_PLAN")) : 1;      // 0: decode + scan always (A/B, tests)
+    const long long lmax = (long long)d.n_flows + 1;
+    const long long ng = lmax * (lmax + 1) / 2 + lmax + 1;      // group numbers last (last + 1) / 2 + birth, birth <= last <= lmax
+    PsfmPlan pl;
+    pl.gstart = nullptr; pl.goff = nullptr; pl.keys = (const void*)c->sort_keys.p; pl.use32 = fmt.use32; pl.shift_b = d.shift_b; pl.shift_d = d.shift_d;
+    pl.birth_w = c->res_birth.as<int>(); pl.len_w = c->res_len.as<int>(); pl.off_w = c->res_off.as<int64_t>();
+    if (plan_on && ng <= PSFM_PLAN_MAX_GROUPS && n < (1ll << 31)) {
+        if ((st = c->scan_tmp.ensure((sizeof(int64_t) + sizeof(int)) * (size_t)ng)) != PSFM_OK) return st;
+        int64_t* goff = c->scan_tmp.as<int64_t>();
+        int* gstart = (int*)(goff + ng);
+        // the marks: -1 everywhere between two calls (the plan kernel puts back what the bounds kernel marked); filled here only
+        // the first time, after a call that did not get as far, or when the buffer is new
+        const void* had = c->fin_marks.p;
+        if ((st = c->fin_marks.ensure(sizeof(int) * (size_t)PSFM_PLAN_MAX_GROUPS)) != PSFM_OK) return st;
+        if (!c->fin_marks_clean || had != c->fin_marks.p)
+            PSFM_HIP(hipMemsetAsync(c->fin_marks.p, 0xff, sizeof(int) * (size_t)PSFM_PLAN_MAX_GROUPS, s));
+        c->fin_marks_clean = false;
+        hipLaunchKernelGGL(psfm_group_bounds_kernel, dim3((unsigned)((n + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
+                           (const void*)c->sort_keys.p, n, fmt.use32, d.shift_b, d.shift_d, c->fin_marks.as<int>());
+        hipLaunchKernelGGL(psfm_group_plan_kernel, dim3(1), dim3(PSFM_PLAN_BLOCK), 0, s, c->fin_marks.as<int>(), gstart, goff, (int)ng, n,
+                           c->res_off.as<int64_t>() + n);
+        PSFM_HIP(hipGetLastError());
+        c->fin_marks_clean = true;
+        pl.gstart = gstart; pl.goff = goff;
+    } else {
+        if ((st = c->scan_tmp.ensure(sizeof(int64_t) * (n + 1))) != PSFM_OK) return st;
+        if (fmt.use32)
+            hipLaunchKernelGGL(psfm_decode32_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
+                               c->sort_keys.as<unsigned>(), n, d.shift_b, c->res_birth.as<int>(), c->res_len.as<int>(),
+                               c->scan_tmp.as<int64_t>());
+        else
+            hipLaunchKernelGGL(psfm_decode_kernel, dim3((unsigned)((n + 1 + PSFM_BLOCK - 1) / PSFM_BLOCK)), dim3(PSFM_BLOCK), 0, s,
+                               c->sort_keys.as<unsigned long long>(), n, d.shift_b, d.shift_d, c->res_birth.as<int>(),
+                               c->res_len.as<int>(), c->scan_tmp.as<int64_t>());
+        PSFM_HIP(hipGetLastError());
+        PSFM_HIP(rocprim::exclusive_scan(c->sort_tmp.p, scan_bytes, c->scan_tmp.as<int64_t>(), c->res_off.as<int64_t>(),
+                                         (int64_t)0, (size_t)(n + 1), rocprim::plus<int64_t>(), s));
+    }
     c->res_n_points = npts;
     // transpose the frame-major log into the id-ordered CSR
     if ((st = c->res_xy.ensure(sizeof(double2) * (size_t)(npts > 0 ? npts : 1))) != PSFM_OK) return st;
@@ -368,11 +564,11 @@ static psfm_status psfm_finalize_sorted(psfm_ctx* c, const PsfmTrackDims& d, int
         hipLaunchKernelGGL(psfm_gather_delta_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
                            c->log.as<float2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
                            c->res_len.as<int>(), c->res_off.as<int64_t>(), n, (const void*)c->sort_keys.p, fmt.use32,
-                           d.shift_b, d.GW, d.ratio, c->res_xy.as<double2>());
+                           d.shift_b, d.GW, d.ratio, c->res_xy.as<double2>(), pl);
     else
         hipLaunchKernelGGL(psfm_gather_kernel, dim3((unsigned)((n + TILE_J - 1) / TILE_J)), dim3(PSFM_BLOCK), 0, s,
                            c->log.as<double2>(), d.cap, c->sort_lanes.as<int>(), c->res_birth.as<int>(),
-                           c->res_len.as<int>(), c->res_off.as<int64_t>(), n, c->res_xy.as<double2>());
+                           c->res_len.as<int>(), c->res_off.as<int64_t>(), n, c->res_xy.as<double2>(), pl);
     PSFM_HIP(hipGetLastError());
     return PSFM_OK;
 }
@@ -417,24 +613,38 @@ psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s)
     if ((st = c->sort_lanes.ensure(sizeof(int) * n * 2)) != PSFM_OK) return st;
     unsigned end_bit_unused = 0;
     const PsfmKeyFmt fmt = psfm_key_fmt(d, &end_bit_unused);
-    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(c->sort_keys.as<unsigned>() + n) : c->sort_keys.as<unsigned long long>() + n;
+    const int64_t half = psfm_records_in_first_half(d, n) ? 0 : n;
+    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(c->sort_keys.as<unsigned>() + half) : c->sort_keys.as<unsigned long long>() + half;
     hipLaunchKernelGGL(psfm_compact_shards_kernel, dim3(64, PSFM_NSHARD), dim3(PSFM_BLOCK), 0, s,
                        c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), d.shard_cap, so,
-                       kdst, c->sort_lanes.as<int>() + n, fmt);
+                       kdst, c->sort_lanes.as<int>() + half, fmt);
     PSFM_HIP(hipGetLastError());
     return psfm_finalize_sorted(c, d, n, npts, false, s);
 }
 
 // ---- persistent frame loop: records sit in one private segment per block (+ a shared tail) ----
-struct PsfmSegRow { long long src; long long dst; int count; int pad; };
+// Block b of the copy = segment b of the loop (b == nblk: the shared tail); where it goes in the sort's input is the sum of the counts
+// in front of it, which every block adds up for itself from seg_info (a few KB out of the L2s) -- no table from the host.
 __global__ __launch_bounds__(PSFM_BLOCK) void psfm_compact_segments_kernel(
-    const unsigned long long* __restrict__ fin_keys, const int* __restrict__ fin_lanes,
-    const PsfmSegRow* __restrict__ rows, unsigned long long* __restrict__ keys, int* __restrict__ lanes, PsfmKeyFmt fmt)
+    const unsigned long long* __restrict__ fin_keys, const int* __restrict__ fin_lanes, const int2* __restrict__ seg_info, int nblk,
+    int seg_cap, const PsfmCounters* __restrict__ ctr, int spill_cap, unsigned long long* __restrict__ keys, int* __restrict__ lanes,
+    PsfmKeyFmt fmt)
 {
-    const PsfmSegRow r = rows[blockIdx.x];
-    for (int i = threadIdx.x; i < r.count; i += PSFM_BLOCK) {
-        psfm_put_key(keys, r.dst + i, fin_keys[r.src + i], fmt);
-        lanes[r.dst + i] = fin_lanes[r.src + i];
+    __shared__ long long s_part[PSFM_BLOCK / PSFM_WAVE];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    long long mine = 0;
+    for (int k = tid; k < b; k += PSFM_BLOCK) mine += seg_info[k].x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((tid & (PSFM_WAVE - 1)) == 0) s_part[tid / PSFM_WAVE] = mine;
+    __syncthreads();
+    long long dst = 0;
+    for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) dst += s_part[w];
+    const int count = b < nblk ? seg_info[b].x : min(ctr->spill_cnt, spill_cap);
+    const long long src = (long long)b * seg_cap;
+    for (int i = tid; i < count; i += PSFM_BLOCK) {
+        psfm_put_key(keys, dst + i, fin_keys[src + i], fmt);
+        lanes[dst + i] = fin_lanes[src + i];
     }
 }
 
@@ -442,7 +652,7 @@ psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fal
 {
     *fallback = false;
     const int nseg = d.nblk + 1;
-    const size_t need = sizeof(int2) * (size_t)d.nblk + sizeof(PsfmSegRow) * (size_t)nseg;
+    const size_t need = sizeof(int2) * (size_t)d.nblk;
     if (c->host_seg_bytes < need) {
         if (c->host_seg) (void)hipHostFree(c->host_seg);
         c->host_seg = nullptr; c->host_seg_bytes = 0;
@@ -450,7 +660,6 @@ psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fal
         c->host_seg_bytes = need;
     }
     int2* hinfo = (int2*)c->host_seg;
-    PsfmSegRow* hrows = (PsfmSegRow*)((char*)c->host_seg + sizeof(int2) * (size_t)d.nblk);
     PsfmCounters* hc = (PsfmCounters*)c->host_pinned;
     PSFM_HIP(hipMemcpyAsync(hc, c->counters.p, sizeof(PsfmCounters), hipMemcpyDeviceToHost, s));
     PSFM_HIP(hipMemcpyAsync(hinfo, c->seg_info.p, sizeof(int2) * (size_t)d.nblk, hipMemcpyDeviceToHost, s));
@@ -462,12 +671,10 @@ psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fal
     }
     int64_t n = 0, npts = 0;
     for (int b = 0; b < d.nblk; ++b) {
-        hrows[b].src = (long long)b * d.seg_cap; hrows[b].dst = n; hrows[b].count = hinfo[b].x; hrows[b].pad = 0;
         n += hinfo[b].x;
         npts += hinfo[b].y;
     }
     const int spilled = hc->spill_cnt < d.spill_cap ? hc->spill_cnt : d.spill_cap;
-    hrows[d.nblk].src = (long long)d.nblk * d.seg_cap; hrows[d.nblk].dst = n; hrows[d.nblk].count = spilled; hrows[d.nblk].pad = 0;
     n += spilled;
     if (hc->overflow != 0) {
         psfm_set_error("capacity exceeded (persistent loop): overflow bits %d, trajectory records %lld (%d spilled of %d); "
@@ -480,14 +687,13 @@ psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fal
     psfm_status st;
     if ((st = c->sort_keys.ensure(sizeof(unsigned long long) * n * 2)) != PSFM_OK) return st;
     if ((st = c->sort_lanes.ensure(sizeof(int) * n * 2)) != PSFM_OK) return st;
-    if ((st = c->seg_table.ensure(sizeof(PsfmSegRow) * (size_t)nseg)) != PSFM_OK) return st;
-    PSFM_HIP(hipMemcpyAsync(c->seg_table.p, hrows, sizeof(PsfmSegRow) * (size_t)nseg, hipMemcpyHostToDevice, s));
     unsigned end_bit_unused = 0;
     const PsfmKeyFmt fmt = psfm_key_fmt(d, &end_bit_unused);
-    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(c->sort_keys.as<unsigned>() + n) : c->sort_keys.as<unsigned long long>() + n;
+    const int64_t half = psfm_records_in_first_half(d, n) ? 0 : n;
+    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(c->sort_keys.as<unsigned>() + half) : c->sort_keys.as<unsigned long long>() + half;
     hipLaunchKernelGGL(psfm_compact_segments_kernel, dim3((unsigned)nseg), dim3(PSFM_BLOCK), 0, s,
-                       c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), c->seg_table.as<PsfmSegRow>(),
-                       kdst, c->sort_lanes.as<int>() + n, fmt);
+                       c->fin_keys.as<unsigned long long>(), c->fin_lanes.as<int>(), (const int2*)c->seg_info.as<int2>(), d.nblk, d.seg_cap,
+                       (const PsfmCounters*)c->counters.as<PsfmCounters>(), d.spill_cap, kdst, c->sort_lanes.as<int>() + half, fmt);
     PSFM_HIP(hipGetLastError());
     return psfm_finalize_sorted(c, d, n, npts, true, s);   // the persistent loop logs flows, not positions
 }
@@ -602,7 +808,8 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_batch_kernel(const Psf
 {
     const PsfmFinSeq& q = T[blockIdx.y];
     if ((int64_t)blockIdx.x * TILE_J >= q.n) return;
-    psfm_gather_body(q.log, q.cap, lanes + q.rec_start, q.res_birth, q.res_len, q.res_off, q.n, q.res_xy);
+    PsfmPlan none; none.gstart = nullptr;
+    psfm_gather_body(q.log, q.cap, lanes + q.rec_start, q.res_birth, q.res_len, q.res_off, q.n, q.res_xy, none);
 }
 
 psfm_status psfm_finalize_batch(psfm_ctx* own, psfm_ctx* const* ctxs, const PsfmTrackDims* dims, int n_seq, hipStream_t s)
@@ -692,16 +899,22 @@ psfm_status psfm_finalize_batch(psfm_ctx* own, psfm_ctx* const* ctxs, const Psfm
     if ((st = own->sort_keys.ensure(sizeof(unsigned long long) * (size_t)N * 2)) != PSFM_OK) return st;
     if ((st = own->sort_lanes.ensure(sizeof(int) * (size_t)N * 2)) != PSFM_OK) return st;
     if ((st = own->scan_tmp.ensure(sizeof(int64_t) * (size_t)(N + 1) * 2)) != PSFM_OK) return st;
-    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(own->sort_keys.as<unsigned>() + N) : own->sort_keys.as<unsigned long long>() + N;
+    // (this file's sort ends in the first half whatever its pass count: with an even count the records start there)
+    const bool own_sort = psfm_own_sort(fmt, N);
+    const int64_t half = (own_sort && psfm_sort_pairs32_passes(sort_end) % 2 == 0) ? 0 : N;
+    unsigned long long* kdst = fmt.use32 ? (unsigned long long*)(own->sort_keys.as<unsigned>() + half) : own->sort_keys.as<unsigned long long>() + half;
     hipLaunchKernelGGL(psfm_compact_shards_batch_kernel, dim3(8, PSFM_NSHARD, (unsigned)n_seq), dim3(PSFM_BLOCK), 0, s, dT, kdst,
-                       own->sort_lanes.as<int>() + N, fmt, seq_shift);
+                       own->sort_lanes.as<int>() + half, fmt, seq_shift);
     PSFM_HIP(hipGetLastError());
     int* l_in = own->sort_lanes.as<int>() + N;
     int* l_out = own->sort_lanes.as<int>();
     size_t tmp_bytes = 0, scan_bytes = 0;
     PSFM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(N + 1),
                                      rocprim::plus<int64_t>(), s));
-    if (fmt.use32) {
+    if (own_sort) {
+        if ((st = own->sort_tmp.ensure(scan_bytes)) != PSFM_OK) return st;      // (before the sort's launches: growing the buffer frees it)
+        if ((st = psfm_sort_pairs32(own, own->sort_keys.as<unsigned>(), l_out, own->sort_keys.as<unsigned>() + N, l_in, N, sort_end, s)) != PSFM_OK) return st;
+    } else if (fmt.use32) {
         unsigned* k_in = own->sort_keys.as<unsigned>() + N;
         unsigned* k_out = own->sort_keys.as<unsigned>();
         PSFM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, l_in, l_out, (size_t)N, 0u, sort_end, s));

@@ -159,6 +159,8 @@ struct psfm_ctx {
     size_t host_seg_bytes = 0;
     // finalize workspace + result
     PsfmBuf sort_keys, sort_lanes, sort_tmp, scan_tmp;
+    PsfmBuf fin_marks;            // finalize: first sorted record of every (last, birth) group; all -1 between two calls (fin_marks_clean)
+    bool fin_marks_clean = false;
     PsfmBuf res_birth, res_len, res_off, res_xy;
     int64_t res_n_traj = 0, res_n_points = 0;
     int res_n_flows = 0;           // flows of the sequence the result came from (psfm_result_keys checks its packed key)
@@ -277,6 +279,9 @@ psfm_status psfm_launch_chain_persist(psfm_ctx* c, const PsfmTrackDims& d, const
 
 // ---- finalize (psfm_finalize.hip) -----------------------------------------------------------
 psfm_status psfm_finalize(psfm_ctx* c, const PsfmTrackDims& d, hipStream_t s);
+// psfm_sort.hip: stable LSD radix sort of (32-bit key, int) pairs for the finalize (input in half0 when the pass count is even, else half1; result in half0)
+int psfm_sort_pairs32_passes(unsigned end_bit);
+psfm_status psfm_sort_pairs32(psfm_ctx* c, unsigned* k_half0, int* v_half0, unsigned* k_half1, int* v_half1, int64_t n, unsigned end_bit, hipStream_t s);
 // after psfm_launch_chain_persist; *fallback = true (and PSFM_OK): the loop gave up, rerun with per-frame launches
 psfm_status psfm_finalize_persist(psfm_ctx* c, const PsfmTrackDims& d, bool* fallback, hipStream_t s);
 

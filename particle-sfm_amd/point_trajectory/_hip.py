@@ -23,7 +23,7 @@ EXPORTS = [
     "psfm_shard_solve_writeback", "psfm_shard_solve_record", "psfm_shard_finish", "psfm_result_keys",
     "psfm_shard_solve_control_async", "psfm_shard_window_state", "psfm_shard_peek_stall", "psfm_shard_frame",
     "psfm_shard_solve_control_chain_async", "psfm_shard_solve_poll", "psfm_shard_solve_local", "psfm_shard_solve_redo_local", "psfm_connect_batch", "psfm_solver_launches", "psfm_ctx_set_resident_budget", "psfm_resident_capacity", "psfm_load_flo_stack",
-    "psfm_path_consistency_eval",
+    "psfm_path_consistency_eval", "psfm_sort_records",
     "psfm_shard_peer_area", "psfm_shard_peer_epoch", "psfm_shard_peer_open", "psfm_shard_peer_connect", "psfm_shard_solve_blocks", "psfm_shard_solve_peer",
 ]
 
@@ -81,6 +81,7 @@ def lib():
     L.psfm_grid_sample.argtypes = [vp, vp, i32, i32, i32, vp, i64, vp, vp]
     L.psfm_optimize_location.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, ctypes.POINTER(SolveStats), vp]
     L.psfm_path_consistency_eval.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp]
+    L.psfm_sort_records.argtypes = [vp, vp, vp, i64, i32, vp]
     L.psfm_track.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, ctypes.POINTER(TrackInfo), vp]
     L.psfm_connect.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp, ctypes.POINTER(TrackInfo), vp]
     L.psfm_connect_batch.argtypes = [ctypes.POINTER(vp), i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
