@@ -642,9 +642,24 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_compact_segments_kernel(
     for (int w = 0; w < PSFM_BLOCK / PSFM_WAVE; ++w) dst += s_part[w];
     const int count = b < nblk ? seg_info[b].x : min(ctr->spill_cnt, spill_cap);
     const long long src = (long long)b * seg_cap;
-    for (int i = tid; i < count; i += PSFM_BLOCK) {
-        psfm_put_key(keys, dst + i, fin_keys[src + i], fmt);
-        lanes[dst + i] = fin_lanes[src + i];
+    // four records per thread in flight (a segment holds ~2 000 at the headline shape: two rounds instead of eight)
+    for (int i0 = 0; i0 < count; i0 += 4 * PSFM_BLOCK) {
+        unsigned long long k[4];
+        int l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PSFM_BLOCK + tid;
+            k[u] = i < count ? fin_keys[src + i] : 0ull;
+            l[u] = i < count ? fin_lanes[src + i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PSFM_BLOCK + tid;
+            if (i < count) {
+                psfm_put_key(keys, dst + i, k[u], fmt);
+                lanes[dst + i] = l[u];
+            }
+        }
     }
 }
 

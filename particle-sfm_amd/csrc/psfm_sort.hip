@@ -61,14 +61,17 @@ __device__ __forceinline__ unsigned long long ps_match8(unsigned d)
 // over the tiles of the group -> rows of cnt; their sum -> the group's row of grp.  (One block per TILE + a launch that turns 32 rows
 // into prefixes and a group row: 4.7 + 4.3 us.)
 #define PS_HWAVES 2
+#ifndef PS_HREP
+#define PS_HREP 4                             // copies of a tile's counter row (a power of two)
+#endif
 #define PS_HBLOCK (PS_GROUP * PS_HWAVES * PSFM_WAVE)
 #define PS_HITEMS (PS_TILE / (PS_HWAVES * PSFM_WAVE))
 __global__ __launch_bounds__(PS_HBLOCK) void psfm_sort_hist_kernel(const unsigned* __restrict__ keys, int64_t n, int shift,
                                                                    unsigned* __restrict__ cnt, unsigned* __restrict__ grp, int nb)
 {
-    __shared__ unsigned s_h[PS_GROUP][PS_DIGITS];
+    __shared__ unsigned s_h[PS_GROUP][PS_HREP][PS_DIGITS];
     const int tid = threadIdx.x, lane = tid & (PSFM_WAVE - 1), wave = tid / PSFM_WAVE;
-    for (int q = tid; q < PS_GROUP * PS_DIGITS; q += PS_HBLOCK) (&s_h[0][0])[q] = 0u;
+    for (int q = tid; q < PS_GROUP * PS_HREP * PS_DIGITS; q += PS_HBLOCK) (&s_h[0][0][0])[q] = 0u;
     const int t = wave / PS_HWAVES, part = wave % PS_HWAVES;      // this wave's tile of the group, and which part of it
     const int b = blockIdx.x * PS_GROUP + t;
     const int64_t tile0 = (int64_t)b * PS_TILE;
@@ -83,18 +86,31 @@ __global__ __launch_bounds__(PS_HBLOCK) void psfm_sort_hist_kernel(const unsigne
     if (PS_WHATIF & 8) { unsigned x = 0; for (int i = 0; i < PS_HITEMS; ++i) x ^= k[i]; if (x == 0x12345u) cnt[tid] = x; return; }
 #pragma unroll
     for (int i = 0; i < PS_HITEMS; ++i) {
-        if (PS_WHATIF & 1) { if (k[i] == 0x12345u) s_h[t][0] = 1; continue; }
+        if (PS_WHATIF & 1) { if (k[i] == 0x12345u) s_h[t][0][0] = 1; continue; }
         const int off = (part * PS_HITEMS + i) * PSFM_WAVE + lane;
-        // one LDS add per key, nobody waits for it: lanes that meet on a counter cost a cycle each, less than matching them first
-        // would (wave-wide matching + one add per digit and round: 8.8 us for a kernel that takes 4.9 this way)
-        if (off < nv) atomicAdd(&s_h[t][(k[i] >> shift) & 255u], 1u);
+        // one LDS add per key, nobody waits for it.  Lanes that meet on a counter are served one after the other: the records' top
+        // digit is skewed (a quarter of them die in the last frame) and made this kernel 13 us on real keys against 5.7 on random ones
+        // -> PS_HREP copies of the row, picked by lane, and one add for a round whose keys all agree.  (Matching the lanes by digit
+        // first and adding once per digit -- the scatter kernel's way -- is 65 instructions per key on the quarter of the CUs this
+        // launch occupies.)
+        const bool ok = off < nv;
+        const unsigned d = (k[i] >> shift) & 255u;
+        const unsigned long long valid = __ballot(ok);
+        const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+        if (__ballot(ok && d == d0) == valid) {
+            if (lane == 0 && valid) atomicAdd(&s_h[t][0][d0], (unsigned)__popcll(valid));
+        } else if (ok) {
+            atomicAdd(&s_h[t][lane & (PS_HREP - 1)][d], 1u);
+        }
     }
     __syncthreads();
     if (tid < PS_DIGITS) {
         unsigned run = 0;
 #pragma unroll
         for (int q = 0; q < PS_GROUP; ++q) {
-            const unsigned c = s_h[q][tid];
+            unsigned c = 0;
+#pragma unroll
+            for (int rep = 0; rep < PS_HREP; ++rep) c += s_h[q][rep][tid];
             if (blockIdx.x * PS_GROUP + q < nb) cnt[(int64_t)(blockIdx.x * PS_GROUP + q) * PS_DIGITS + tid] = run;
             run += c;
         }
