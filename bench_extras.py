@@ -702,6 +702,8 @@ def end_to_end(frames=N_FRAMES, workdir=None):
                 "write_s": tm["write_s"], "ingest_GBs": gb / tm["ingest_s"], "write_GBs": size / 1e9 / tm["write_s"],
                 "trajectory_points_per_s_end_to_end": tm["n_points"] / tm["total_s"], "points": tm["n_points"], "trajectories": tm["n_traj"]}
     finally:
+        from point_trajectory.trajectory import wait_for_reclaims
+        wait_for_reclaims()
         shutil.rmtree(work, ignore_errors=True)
 
 

@@ -169,11 +169,46 @@ def save_track_npy(path, trajectories, layout="reference"):
                 reference_pickle.dump(fp, trajectories)      # the reference's object graph as opcodes, straight from the CSR
             else:
                 pickle.dump(arr, fp, protocol=5)
-        os.replace(tmp, target)
+        _replace_deferring_reclaim(tmp, target)
     except BaseException:
         if os.path.exists(tmp):
             os.unlink(tmp)
         raise
+
+
+_reclaims = []      # helper threads that drop replaced files (joined by wait_for_reclaims / at interpreter exit: they are not daemons)
+
+
+def _replace_deferring_reclaim(tmp, target):
+    """os.replace(tmp, target), without waiting for the kernel to give back the pages of the file it replaces: rename() frees the old
+    inode's page cache before it returns (0.94 GB of track.npy on tmpfs: 50-70 ms of the stage's 0.29 s when it runs over an
+    existing output, scripts/micro/e2e_overwrite.py).  A second link keeps the old inode alive across the rename; a helper thread
+    drops it.  File systems without hard links take the plain rename."""
+    import threading
+    doomed = None
+    if os.path.exists(target):
+        doomed = "%s.old-%d-%d" % (target, os.getpid(), len(_reclaims))
+        try:
+            os.link(target, doomed)
+        except OSError:
+            doomed = None
+    os.replace(tmp, target)
+    if doomed is not None:
+        def drop():
+            try:
+                os.unlink(doomed)
+            except OSError:
+                pass
+        th = threading.Thread(target=drop, name="psfm-reclaim")
+        th.start()
+        _reclaims[:] = [t for t in _reclaims if t.is_alive()] + [th]
+
+
+def wait_for_reclaims():
+    """Blocks until the files replaced by save_track_npy are gone (tests; callers that are about to remove the directory)."""
+    for t in list(_reclaims):
+        t.join()
+    del _reclaims[:]
 
 
 def load_track_npy(path):

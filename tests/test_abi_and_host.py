@@ -547,3 +547,31 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "1", "--warmup", "0"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode != 0 and "--gpus 4 but the job has 1 rank" in r.stdout and '"metric"' not in r.stdout
+
+
+def test_saving_over_an_existing_track_npy_replaces_it_and_leaves_nothing_behind(tmp_path):
+    """save_track_npy over an existing output: the new file is moved over the old one (readers see one or the other, never a
+    truncated file), the old file's pages are given back on a helper thread (a second link keeps the inode alive across the
+    rename) -- and once that thread is through, the directory holds the one file."""
+    import os
+    from point_trajectory.optimize.build import particlesfm
+    from point_trajectory.trajectory import save_track_npy, load_track_npy, wait_for_reclaims
+    rng = np.random.default_rng(5)
+
+    def make(n):
+        length = rng.integers(1, 30, n).astype(np.int32)
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum(length)
+        return particlesfm.TrajectorySet._from_csr(np.arange(n, dtype=np.int64), rng.integers(0, 50, n).astype(np.int32), length, off,
+                                                   rng.normal(size=(int(off[-1]), 2)))
+    path = str(tmp_path / "track.npy")
+    first, second, third = make(2000), make(3100), make(10)
+    save_track_npy(path, first)
+    old_inode = os.stat(path).st_ino
+    mapped = load_track_npy(path)                  # a set read back from the file that is about to be replaced stays readable
+    save_track_npy(path, second)
+    save_track_npy(path, third)
+    wait_for_reclaims()
+    assert sorted(os.listdir(tmp_path)) == ["track.npy"] and os.stat(path).st_ino != old_inode
+    assert len(load_track_npy(path).trajs) == 10
+    assert len(mapped.trajs) == 2000
