@@ -265,20 +265,28 @@ __global__ __launch_bounds__(PSFM_PLAN_BLOCK) void psfm_group_plan_kernel(int* _
     if (tid == 0) *off_n = total;      // off[n] = all points
 }
 
-// what the gather knows of its track `id`: from the plan (and stored), or from the decoded arrays
+// what the gather knows of its track `id`, in two steps.  First what its READS need -- birth and length, from the key alone (or the
+// decoded arrays); then, with the first chunk's loads already in flight, what its WRITES need -- the offset, two dependent look-ups in
+// the plan -- and the three values stored for psfm_result_*.
 __device__ __forceinline__ void psfm_track_header(const PsfmPlan& pl, const int* __restrict__ birth, const int* __restrict__ len,
-                                                  const int64_t* __restrict__ off, int64_t id, int* b, int* l, int64_t* o, int* idx)
+                                                  int64_t id, int* b, int* l, int* idx)
 {
     if (pl.gstart) {
         int last;
         psfm_key_fields(pl.keys, id, pl.use32, pl.shift_b, pl.shift_d, &last, b, idx);
-        const int g = last * (last + 1) / 2 + *b;
         *l = last - *b + 1;
-        *o = pl.goff[g] + (id - (int64_t)pl.gstart[g]) * (int64_t)*l;
-        pl.birth_w[id] = *b; pl.len_w[id] = *l; pl.off_w[id] = *o;
     } else {
-        *b = birth[id]; *l = len[id]; *o = off[id]; *idx = -1;
+        *b = birth[id]; *l = len[id]; *idx = -1;
     }
+}
+__device__ __forceinline__ int64_t psfm_track_offset(const PsfmPlan& pl, const int64_t* __restrict__ off, int64_t id, int b, int l)
+{
+    if (!pl.gstart) return off[id];
+    const int last = b + l - 1;
+    const int g = last * (last + 1) / 2 + b;
+    const int64_t o = pl.goff[g] + (id - (int64_t)pl.gstart[g]) * (int64_t)l;
+    pl.birth_w[id] = b; pl.len_w[id] = l; pl.off_w[id] = o;
+    return o;
 }
 
 // Transpose gather: a block owns TILE_J consecutive ids and walks time in chunks of TILE_K steps.
@@ -301,18 +309,19 @@ __device__ __forceinline__ void psfm_gather_body(const double2* __restrict__ log
     __shared__ int s_maxlen;
     const int tid = threadIdx.x;
     const int64_t id0 = (int64_t)blockIdx.x * TILE_J;
+    int hb = 0, hl = 0;
     if (tid == 0) s_maxlen = 0;
     __syncthreads();
     if (tid < TILE_J) {
         const int64_t id = id0 + tid;
         const bool ok = id < n;
-        int b = 0, l = 0, idx; int64_t o = 0;
-        const int my_lane = ok ? lanes[id] : 0;       // (in flight while the header's dependent loads run)
-        if (ok) psfm_track_header(pl, birth, len, off, id, &b, &l, &o, &idx);
+        int b = 0, l = 0, idx;
+        const int my_lane = ok ? lanes[id] : 0;
+        if (ok) psfm_track_header(pl, birth, len, id, &b, &l, &idx);
+        hb = b; hl = l;
         s_lane[tid] = my_lane;
         s_birth[tid] = b;
         s_len[tid] = l;
-        s_off[tid] = o;
         if (ok) atomicMax(&s_maxlen, l);
     }
     __syncthreads();
@@ -331,6 +340,7 @@ __device__ __forceinline__ void psfm_gather_body(const double2* __restrict__ log
         const int t = q + u * (PSFM_BLOCK / TILE_J);
         r[u] = t < lj ? log[(int64_t)(bj + t) * cap + col] : make_double2(0.0, 0.0);
     }
+    if (tid < TILE_J) s_off[tid] = id0 + tid < n ? psfm_track_offset(pl, off, id0 + tid, hb, hl) : 0;   // (seen behind the loop's first barrier)
     for (int k0 = 0; k0 < maxlen; k0 += TILE_K) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) tile[j][q + u * (PSFM_BLOCK / TILE_J)] = r[u];
@@ -382,18 +392,19 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_delta_kernel(const flo
     __shared__ int s_maxlen;
     const int tid = threadIdx.x;
     const int64_t id0 = (int64_t)blockIdx.x * TILE_J;
+    int hb = 0, hl = 0;
     if (tid == 0) s_maxlen = 0;
     __syncthreads();
     if (tid < TILE_J) {
         const int64_t id = id0 + tid;
         const bool ok = id < n;
-        int b = 0, l = 0, idx = -1; int64_t o = 0;
-        const int my_lane = ok ? lanes[id] : 0;       // (in flight while the header's dependent loads run)
-        if (ok) psfm_track_header(pl, birth, len, off, id, &b, &l, &o, &idx);
+        int b = 0, l = 0, idx = -1;
+        const int my_lane = ok ? lanes[id] : 0;
+        if (ok) psfm_track_header(pl, birth, len, id, &b, &l, &idx);
+        hb = b; hl = l;
         s_lane[tid] = my_lane;
         s_birth[tid] = b;
         s_len[tid] = l;
-        s_off[tid] = o;
         if (ok) {
             atomicMax(&s_maxlen, l);
             if (idx < 0) {
@@ -419,6 +430,7 @@ __global__ __launch_bounds__(PSFM_BLOCK) void psfm_gather_delta_kernel(const flo
         const int t = q + u * (PSFM_BLOCK / TILE_J);
         r[u] = (t >= 1 && t < lj) ? dlog[(int64_t)(bj + t - 1) * cap + col] : make_float2(0.f, 0.f);
     }
+    if (tid < TILE_J) s_off[tid] = id0 + tid < n ? psfm_track_offset(pl, off, id0 + tid, hb, hl) : 0;   // (seen behind the loop's first barrier)
     for (int k0 = 0; k0 < maxlen; k0 += TILE_K) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) dtile[j][q + u * (PSFM_BLOCK / TILE_J)] = r[u];
